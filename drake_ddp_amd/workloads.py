@@ -1,0 +1,109 @@
+"""Synthetic workloads for the five BASELINE.json configs.
+
+Each ``*_problem()`` returns the solver parameters of one config as a plain
+dict; each ``*_batch_x0()`` the seeded batch of initial states.  Costs follow
+the example scripts of the reference (cited per function); the dynamics are
+the build-owned models named by ``model_id`` (drake_ddp_amd/models.py).
+Pure NumPy, importable without a GPU.
+"""
+import numpy as np
+
+PENDULUM, ACROBOT, CARTPOLE, CARTPOLE_WALL, SYNTH36 = 0, 1, 2, 3, 4
+SYNTH_TARGET_VEL = 1.0
+
+
+def pendulum_problem():
+    """C1/C2: /root/reference/pendulum.py:18-34 (T=2, dt=1e-2 -> N=200), cost
+    passed as dt*Q, dt*R, Qf (:93-94); defaults beta=.95, delta=1e-2, gamma=0 (:85-86)."""
+    dt = 1e-2
+    return dict(name="pendulum", model_id=PENDULUM, dt=dt, N=int(2.0 / dt),
+                x_nom=np.array([np.pi, 0.0]),
+                Q=dt * 0.01 * np.diag([0.0, 1.0]), R=dt * 0.01 * np.eye(1), Qf=100.0 * np.eye(2),
+                delta=1e-2, beta=0.95, gamma=0.0)
+
+
+def pendulum_batch_x0(B, seed=0):
+    """C2: theta~U(-pi,pi), omega~U(-1,1), numpy default_rng(seed)."""
+    rng = np.random.default_rng(seed)
+    th = rng.uniform(-np.pi, np.pi, B)
+    om = rng.uniform(-1.0, 1.0, B)
+    return np.stack([th, om], axis=1)
+
+
+def acrobot_problem(N=40):
+    """C3: cost of /root/reference/acrobot.py:40-45,123-125, beta=0.5 (:118-120),
+    dt=0.004 (:20); horizon shortened to N=40 by the config."""
+    dt = 0.004
+    return dict(name="acrobot", model_id=ACROBOT, dt=dt, N=N,
+                x_nom=np.array([np.pi, 0.0, 0.0, 0.0]),
+                Q=dt * 0.01 * np.diag([0.0, 0.0, 1.0, 1.0]), R=dt * 0.01 * np.eye(1),
+                Qf=100.0 * np.eye(4), delta=1e-2, beta=0.5, gamma=0.0)
+
+
+def acrobot_batch_x0(B, seed=1):
+    return np.random.default_rng(seed).uniform(-0.1, 0.1, (B, 4))
+
+
+def cartpole_problem(N=100):
+    """Plain cart-pole: /root/reference/cart_pole.py:21-22,44-46, beta=0.9 (:106-108)."""
+    dt = 1e-2
+    return dict(name="cart_pole", model_id=CARTPOLE, dt=dt, N=N,
+                x_nom=np.array([0.0, np.pi, 0.0, 0.0]),
+                Q=dt * np.diag([10.0, 10.0, 0.1, 0.1]), R=dt * 0.001 * np.eye(1),
+                Qf=np.diag([100.0, 100.0, 10.0, 10.0]), delta=1e-2, beta=0.9, gamma=0.0)
+
+
+def cartpole_wall_problem(N=200):
+    """C4: cost of /root/reference/cart_pole_with_wall.py:35-43,151-154, beta=0.5 (:148),
+    dt=1e-2 (:23); config doubles the script's N=100 to 200."""
+    dt = 1e-2
+    return dict(name="cart_pole_with_wall", model_id=CARTPOLE_WALL, dt=dt, N=N,
+                x_nom=np.array([0.0, np.pi, 0.0, 0.0]),
+                Q=dt * np.diag([0.1, 1.0, 0.01, 0.01]), R=dt * 0.001 * np.eye(1),
+                Qf=np.diag([200.0, 200.0, 10.0, 10.0]), delta=1e-2, beta=0.5, gamma=0.0)
+
+
+def cartpole_wall_batch_x0(B, seed=2):
+    d = np.random.default_rng(seed).uniform(-0.2, 0.2, B)
+    x0 = np.zeros((B, 4))
+    x0[:, 1] = np.pi + 0.5 + d
+    return x0
+
+
+def synth36_problem(N=40):
+    """C5 (shape only): diagonal Q/R/Qf patterned on /root/reference/mini_cheetah.py:60-69
+    for 6 'base' + 12 'leg' dofs, beta=.5, delta=1e-2 (:168-169), dt=4e-3 (:23)."""
+    dt = 4e-3
+    qb = np.ones(6)
+    qb[0:3] += 2.0
+    vb = np.ones(6)
+    ql = 0.0 * np.ones(12)
+    vl = 0.01 * np.ones(12)
+    Q = np.diag(np.hstack([qb, ql, 0.01 * vb, vl]))
+    R = 0.01 * np.eye(12)
+    Qf = np.diag(np.hstack([5 * qb, 0.1 + ql, vb, vl]))
+    x_nom = np.zeros(36)
+    x_nom[0] += SYNTH_TARGET_VEL * N * dt      # 'base x position' target (mini_cheetah.py:55-57)
+    x_nom[18] += SYNTH_TARGET_VEL              # 'base x velocity' target
+    return dict(name="synth36", model_id=SYNTH36, dt=dt, N=N, x_nom=x_nom,
+                Q=dt * Q, R=dt * R, Qf=Qf, delta=1e-2, beta=0.5, gamma=0.0)
+
+
+def synth36_batch_x0(B, seed=3):
+    rng = np.random.default_rng(seed)
+    x0 = np.zeros((B, 36))
+    x0[:, :18] = rng.uniform(-0.1, 0.1, (B, 18))
+    return x0
+
+
+def synth36_u_guess(N):
+    """Constant initial tape (the 'u_stand' analogue of mini_cheetah.py:47-49,177)."""
+    return np.full((12, N - 1), 0.05)
+
+
+def mpc_shift(x, u, replan):
+    """Warm start of the MPC loop (acrobot.py:147-152, mini_cheetah.py:193-198):
+    drop the first `replan` controls, repeat the last one; restart at x[:, replan].
+    Works on (..., m, N-1)/(..., n, N) batched arrays."""
+    tail = np.repeat(u[..., -1:], replan, axis=-1)
+    return x[..., replan].copy(), np.concatenate([u[..., replan:], tail], axis=-1)

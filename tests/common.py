@@ -1,0 +1,38 @@
+"""Shared helpers for the parity tests: golden loading and oracle construction."""
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    g = {k: z[k] for k in z.files}
+    prob = {k[2:]: g[k] for k in g if k.startswith("p_")}
+    for k in ("model_id", "N"):
+        prob[k] = int(prob[k])
+    for k in ("dt", "delta", "beta", "gamma"):
+        prob[k] = float(prob[k])
+    return g, prob
+
+
+def golden_keypoint(g):
+    if "kp_cfg_method" not in g:
+        return None
+    nums = g["kp_cfg_nums"]
+    return (str(g["kp_cfg_method"]), int(nums[0]), int(nums[1]), float(nums[2]), float(nums[3]))
+
+
+def make_oracle(prob, keypoint=None, jacobian="ad", fd_step=1e-5):
+    from oracle import models_np as M
+    from oracle.ilqr_np import OracleILQR, KeypointCfg
+    model = M.Model(prob["model_id"], prob["dt"], prob.get("params"))
+    kp = KeypointCfg(*keypoint) if keypoint is not None else None
+    return OracleILQR(model, prob["N"], delta=prob["delta"], beta=prob["beta"],
+                      gamma=prob["gamma"], keypoint=kp, jacobian=jacobian, fd_step=fd_step)
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return float(np.max(np.abs(a - b)) / max(1e-300, np.max(np.abs(b))))
