@@ -1,0 +1,125 @@
+"""ctypes binding of libmi_ilqr.so (include/mi_ilqr.h).  Plumbing only.
+
+The library is the product: if it is missing or fails to load this module raises
+— there is no Python/NumPy fallback for any compute entry.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmi_ilqr.so")
+
+MAX_PARAMS = 16
+ABI_VERSION = 1
+
+# enums (include/mi_ilqr.h)
+OK, E_BAD_SHAPE, E_BAD_METHOD, E_LINESEARCH, E_HIP, E_NO_DEVICE, E_BAD_ARG, E_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6, -7
+KP_SET_INTERVAL, KP_ADAPTIVE_JERK, KP_ITERATIVE_ERROR = 0, 1, 2
+JAC_FD_CENTRAL, JAC_AUTODIFF = 0, 1
+STATUS_CONVERGED, STATUS_MAX_ITERS, STATUS_LINESEARCH_FAILED = 0, 1, 2
+F_X_BAR, F_U_BAR, F_K, F_KAPPA, F_DV, F_FX, F_FU, F_COST, F_X0, F_HIST, F_X_TRIAL, F_U_TRIAL, F_TRIAL_COST = range(13)
+I_ITERS, I_STATUS, I_LS_TRIALS, I_KP_COUNT, I_KP_LIST = 100, 101, 102, 103, 104
+
+EXPORTS = [
+    "mi_ilqr_abi_version", "mi_ilqr_strerror", "mi_ilqr_model_info", "mi_ilqr_create", "mi_ilqr_destroy",
+    "mi_ilqr_set_cost", "mi_ilqr_set_initial", "mi_ilqr_reset", "mi_ilqr_rearm_initial_guess",
+    "mi_ilqr_solve", "mi_ilqr_solve_async", "mi_ilqr_collect_stats",
+    "mi_ilqr_rollout", "mi_ilqr_forward", "mi_ilqr_linearize", "mi_ilqr_backward", "mi_ilqr_mpc_shift",
+    "mi_ilqr_get", "mi_ilqr_get_int", "mi_ilqr_set", "mi_ilqr_device_ptr", "mi_ilqr_get_stream",
+    "mi_ilqr_synchronize", "mi_ilqr_bytes_per_iteration", "mi_ilqr_lds_bytes",
+]
+
+
+class Desc(C.Structure):
+    _fields_ = [
+        ("n", C.c_int32), ("m", C.c_int32), ("N", C.c_int32), ("B", C.c_int32),
+        ("model_id", C.c_int32), ("n_params", C.c_int32),
+        ("model_params", C.c_double * MAX_PARAMS),
+        ("dt", C.c_double), ("delta", C.c_double), ("beta", C.c_double), ("gamma", C.c_double),
+        ("keypoint_method", C.c_int32), ("minN", C.c_int32), ("maxN", C.c_int32),
+        ("jerk_threshold", C.c_double), ("iterative_error_threshold", C.c_double),
+        ("jacobian_mode", C.c_int32), ("fd_step", C.c_double),
+        ("max_iters", C.c_int32), ("hist_cap", C.c_int32), ("device_id", C.c_int32),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("total_iters", C.c_int64), ("total_ls_trials", C.c_int64),
+        ("n_converged", C.c_int32), ("n_max_iters", C.c_int32), ("n_ls_failed", C.c_int32),
+        ("max_iters_seen", C.c_int32),
+        ("best_cost", C.c_double), ("best_index", C.c_int32), ("kernel_ms", C.c_float),
+        ("algorithmic_bytes", C.c_double),
+    ]
+
+
+_lib = None
+
+
+def load():
+    """Load libmi_ilqr.so; raises ImportError loudly when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is not built. Run `python -m drake_ddp_amd.build` (hipcc, gfx950). "
+            "There is no CPU fallback for the iLQR hot path.")
+    lib = C.CDLL(LIB_PATH)
+    H = C.c_void_p
+    dp = C.POINTER(C.c_double)
+    lib.mi_ilqr_abi_version.restype = C.c_int
+    lib.mi_ilqr_strerror.restype = C.c_char_p
+    lib.mi_ilqr_strerror.argtypes = [C.c_int]
+    lib.mi_ilqr_model_info.argtypes = [C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), dp]
+    lib.mi_ilqr_create.argtypes = [C.POINTER(Desc), C.POINTER(H)]
+    lib.mi_ilqr_destroy.argtypes = [H]
+    lib.mi_ilqr_destroy.restype = None
+    lib.mi_ilqr_set_cost.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.mi_ilqr_set_initial.argtypes = [H, C.c_void_p, C.c_void_p]
+    for name in ("mi_ilqr_reset", "mi_ilqr_rearm_initial_guess", "mi_ilqr_solve_async", "mi_ilqr_linearize",
+                 "mi_ilqr_backward", "mi_ilqr_synchronize"):
+        getattr(lib, name).argtypes = [H]
+    lib.mi_ilqr_solve.argtypes = [H, C.POINTER(Stats)]
+    lib.mi_ilqr_collect_stats.argtypes = [H, C.POINTER(Stats)]
+    lib.mi_ilqr_rollout.argtypes = [H, C.c_void_p]
+    lib.mi_ilqr_forward.argtypes = [H, C.c_void_p]
+    lib.mi_ilqr_mpc_shift.argtypes = [H, C.c_int32]
+    lib.mi_ilqr_get.argtypes = [H, C.c_int, C.c_void_p, C.c_size_t]
+    lib.mi_ilqr_get_int.argtypes = [H, C.c_int, C.c_void_p, C.c_size_t]
+    lib.mi_ilqr_set.argtypes = [H, C.c_int, C.c_void_p, C.c_size_t]
+    lib.mi_ilqr_device_ptr.argtypes = [H, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    lib.mi_ilqr_get_stream.argtypes = [H, C.POINTER(C.c_void_p)]
+    lib.mi_ilqr_bytes_per_iteration.restype = C.c_double
+    lib.mi_ilqr_bytes_per_iteration.argtypes = [C.c_int32] * 4
+    lib.mi_ilqr_lds_bytes.restype = C.c_size_t
+    lib.mi_ilqr_lds_bytes.argtypes = [C.POINTER(Desc)]
+    if lib.mi_ilqr_abi_version() != ABI_VERSION:
+        raise ImportError("libmi_ilqr.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+class MiIlqrError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        msg = load().mi_ilqr_strerror(code).decode()
+        super().__init__(f"{where}: {msg} (code {code})")
+
+
+def check(code, where):
+    if code != OK:
+        raise MiIlqrError(code, where)
+
+
+def as_f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and a.shape != tuple(shape):
+        raise AssertionError(f"expected shape {tuple(shape)}, got {a.shape}")
+    return a
+
+
+def ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None

@@ -1,0 +1,56 @@
+// Scalar abstraction for the device dynamics: the same templated model code runs
+// on plain fp64 (rollouts, finite differences) and on Dual1 (one-directional
+// forward-mode derivative, the device analogue of Drake's AutoDiffXd used at
+// /root/reference/ilqr.py:253-270, one seeded column per lane).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace mi {
+
+struct Dual1 {
+  double v, d;
+  __host__ __device__ Dual1() {}
+  __host__ __device__ Dual1(double v_) : v(v_), d(0.0) {}
+  __host__ __device__ Dual1(double v_, double d_) : v(v_), d(d_) {}
+};
+
+__host__ __device__ inline Dual1 operator+(Dual1 a, Dual1 b) { return {a.v + b.v, a.d + b.d}; }
+__host__ __device__ inline Dual1 operator-(Dual1 a, Dual1 b) { return {a.v - b.v, a.d - b.d}; }
+__host__ __device__ inline Dual1 operator-(Dual1 a) { return {-a.v, -a.d}; }
+__host__ __device__ inline Dual1 operator*(Dual1 a, Dual1 b) { return {a.v * b.v, a.d * b.v + b.d * a.v}; }
+__host__ __device__ inline Dual1 operator/(Dual1 a, Dual1 b) {
+  const double q = a.v / b.v;
+  return {q, (a.d - q * b.d) / b.v};
+}
+__host__ __device__ inline Dual1 operator+(Dual1 a, double b) { return {a.v + b, a.d}; }
+__host__ __device__ inline Dual1 operator+(double a, Dual1 b) { return {a + b.v, b.d}; }
+__host__ __device__ inline Dual1 operator-(Dual1 a, double b) { return {a.v - b, a.d}; }
+__host__ __device__ inline Dual1 operator-(double a, Dual1 b) { return {a - b.v, -b.d}; }
+__host__ __device__ inline Dual1 operator*(Dual1 a, double b) { return {a.v * b, a.d * b}; }
+__host__ __device__ inline Dual1 operator*(double a, Dual1 b) { return {a * b.v, a * b.d}; }
+__host__ __device__ inline Dual1 operator/(Dual1 a, double b) { return {a.v / b, a.d / b}; }
+__host__ __device__ inline Dual1 operator/(double a, Dual1 b) {
+  const double q = a / b.v;
+  return {q, (-q * b.d) / b.v};
+}
+
+__host__ __device__ inline double value_of(double a) { return a; }
+__host__ __device__ inline double value_of(Dual1 a) { return a.v; }
+
+__device__ inline double mi_sin(double a) { return sin(a); }
+__device__ inline double mi_cos(double a) { return cos(a); }
+__device__ inline double mi_exp(double a) { return exp(a); }
+__device__ inline double mi_log1p(double a) { return log1p(a); }
+__device__ inline Dual1 mi_sin(Dual1 a) { double s, c; sincos(a.v, &s, &c); return {s, c * a.d}; }
+__device__ inline Dual1 mi_cos(Dual1 a) { double s, c; sincos(a.v, &s, &c); return {c, -s * a.d}; }
+__device__ inline Dual1 mi_exp(Dual1 a) { const double e = exp(a.v); return {e, e * a.d}; }
+__device__ inline Dual1 mi_log1p(Dual1 a) { return {log1p(a.v), a.d / (1.0 + a.v)}; }
+
+// log(1+exp(z)), overflow-safe; branch on the VALUE like oracle/dual.py:softplus.
+template <class T>
+__device__ inline T mi_softplus(T z) {
+  if (value_of(z) > 0.0) return z + mi_log1p(mi_exp(-z));
+  return mi_log1p(mi_exp(z));
+}
+
+}  // namespace mi

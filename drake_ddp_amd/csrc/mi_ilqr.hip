@@ -1,0 +1,541 @@
+// libmi_ilqr.so — host side of the C ABI declared in include/mi_ilqr.h.
+//
+// Owns the device-resident solver state of a batch (the persistent attributes of
+// the reference class, /root/reference/ilqr.py:61-91, with a leading batch axis),
+// dispatches the gfx950 kernels and moves data across the boundary.  No compute
+// happens on the host: without a usable device every compute entry fails with
+// MI_ILQR_E_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/mi_ilqr.h"
+#include "ilqr_small.hpp"
+
+using namespace mi;
+
+struct mi_ilqr {
+  mi_ilqr_desc d;
+  int n, m, N, B;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // double fields
+  double *x_bar = nullptr, *u_bar = nullptr, *K = nullptr, *kappa = nullptr, *dV = nullptr, *fx = nullptr, *fu = nullptr;
+  double *x0 = nullptr, *u_guess = nullptr, *cost = nullptr, *hist = nullptr;
+  double *x_trial = nullptr, *u_trial = nullptr, *trial_cost = nullptr, *stage_in = nullptr, *costmat = nullptr;
+  int32_t *iters = nullptr, *status = nullptr, *ls_trials = nullptr, *kp_count = nullptr, *kp_list = nullptr;
+  bool cold = true;        // persistent state is known to be all zero (fresh object / after reset)
+  bool u_pending = false;  // SetInitialGuess input waiting in u_guess
+  size_t lds = 0;
+  float last_ms = 0.f;
+};
+
+namespace {
+
+#define HIPCHK(expr)                                                                      \
+  do {                                                                                    \
+    hipError_t e_ = (expr);                                                               \
+    if (e_ != hipSuccess) {                                                               \
+      std::fprintf(stderr, "mi_ilqr: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return MI_ILQR_E_HIP;                                                               \
+    }                                                                                     \
+  } while (0)
+
+struct ModelInfo { int n, m, n_params; double defaults[MI_ILQR_MAX_PARAMS]; };
+
+const ModelInfo* model_info(int id) {
+  static const ModelInfo table[] = {
+      {2, 1, 3, {0.25, 0.1, 4.905}},
+      {4, 1, 10, {1.0, 1.0, 1.0, 0.5, 1.0, 0.083, 0.33, 0.1, 0.1, 9.81}},
+      {4, 1, 4, {10.0, 1.0, 0.5, 9.81}},
+      {4, 1, 8, {10.0, 1.0, 0.5, 9.81, -0.45, 0.05, 2000.0, 0.01}},
+      {36, 12, 4, {4.0, 0.5, 6.0, 0.1}},
+  };
+  if (id < 0 || id > 4) return nullptr;
+  return &table[id];
+}
+
+size_t small_lds_bytes(int model_id, int N) {
+  switch (model_id) {
+    case MI_MODEL_PENDULUM: return ws_bytes<2, 1>(N);
+    case MI_MODEL_ACROBOT:
+    case MI_MODEL_CARTPOLE:
+    case MI_MODEL_CARTPOLE_WALL: return ws_bytes<4, 1>(N);
+    default: return 0;
+  }
+}
+
+constexpr size_t kMaxLds = 160 * 1024;
+
+KArgs make_args(const mi_ilqr* h) {
+  KArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.x_bar = h->x_bar; a.u_bar = h->u_bar; a.K = h->K; a.kappa = h->kappa; a.dV = h->dV; a.fx = h->fx; a.fu = h->fu;
+  a.x0 = h->x0; a.u_guess = h->u_guess; a.cost = h->cost; a.hist = h->hist;
+  a.x_trial = h->x_trial; a.u_trial = h->u_trial; a.trial_cost = h->trial_cost; a.stage_in = h->stage_in;
+  a.costmat = h->costmat;
+  a.iters = h->iters; a.status = h->status; a.ls_trials = h->ls_trials; a.kp_count = h->kp_count; a.kp_list = h->kp_list;
+  for (int i = 0; i < MI_ILQR_MAX_PARAMS; ++i) a.params[i] = h->d.model_params[i];
+  a.dt = h->d.dt; a.delta = h->d.delta; a.beta = h->d.beta; a.gamma = h->d.gamma;
+  a.jerk_thr = h->d.jerk_threshold; a.err_thr = h->d.iterative_error_threshold; a.fd_h = h->d.fd_step;
+  a.N = h->N; a.B = h->B; a.kp_method = h->d.keypoint_method; a.minN = h->d.minN; a.maxN = h->d.maxN;
+  a.max_iters = h->d.max_iters; a.hist_cap = h->d.hist_cap;
+  a.cold = h->cold ? 1 : 0;
+  a.u_pending = h->u_pending ? 1 : 0;
+  return a;
+}
+
+template <class M, int JAC, int MODE>
+int launch_one(mi_ilqr* h, const KArgs& a) {
+  auto kern = ilqr_small_kernel<M, JAC, MODE>;
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
+  HIPCHK(hipEventRecord(h->ev0, h->stream));
+  hipLaunchKernelGGL(kern, dim3(h->B), dim3(64), h->lds, h->stream, a);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(h->ev1, h->stream));
+  return MI_ILQR_OK;
+}
+
+template <class M, int JAC>
+int launch_mode(mi_ilqr* h, int mode, const KArgs& a) {
+  switch (mode) {
+    case MODE_SOLVE: return launch_one<M, JAC, MODE_SOLVE>(h, a);
+    case MODE_ROLLOUT: return launch_one<M, JAC, MODE_ROLLOUT>(h, a);
+    case MODE_FORWARD: return launch_one<M, JAC, MODE_FORWARD>(h, a);
+    case MODE_LINEARIZE: return launch_one<M, JAC, MODE_LINEARIZE>(h, a);
+    case MODE_BACKWARD: return launch_one<M, JAC, MODE_BACKWARD>(h, a);
+  }
+  return MI_ILQR_E_BAD_ARG;
+}
+
+template <class M>
+int launch_jac(mi_ilqr* h, int mode, const KArgs& a) {
+  if (h->d.jacobian_mode == MI_JAC_AUTODIFF) return launch_mode<M, MI_JAC_AUTODIFF>(h, mode, a);
+  return launch_mode<M, MI_JAC_FD_CENTRAL>(h, mode, a);
+}
+
+// Launch `mode` for the handle's model; afterwards the persistent state is no
+// longer known-zero for the fields the mode writes, and u_bar is materialized.
+int launch(mi_ilqr* h, int mode) {
+  HIPCHK(hipSetDevice(h->d.device_id));
+  const KArgs a = make_args(h);
+  int rc;
+  switch (h->d.model_id) {
+    case MI_MODEL_PENDULUM: rc = launch_jac<Pendulum>(h, mode, a); break;
+    case MI_MODEL_ACROBOT: rc = launch_jac<Acrobot>(h, mode, a); break;
+    case MI_MODEL_CARTPOLE: rc = launch_jac<CartPole>(h, mode, a); break;
+    case MI_MODEL_CARTPOLE_WALL: rc = launch_jac<CartPoleWall>(h, mode, a); break;
+    default: return MI_ILQR_E_UNSUPPORTED;
+  }
+  return rc;
+}
+
+// When the state is lazily-zero (cold) but a kernel is about to write only part
+// of it, materialize the zeros first.
+int materialize_zero_state(mi_ilqr* h) {
+  if (!h->cold) return MI_ILQR_OK;
+  const size_t n = h->n, m = h->m, N = h->N, B = h->B;
+  HIPCHK(hipMemsetAsync(h->x_bar, 0, B * n * N * 8, h->stream));
+  HIPCHK(hipMemsetAsync(h->K, 0, B * m * n * (N - 1) * 8, h->stream));
+  HIPCHK(hipMemsetAsync(h->kappa, 0, B * m * (N - 1) * 8, h->stream));
+  HIPCHK(hipMemsetAsync(h->dV, 0, B * (N - 1) * 8, h->stream));
+  HIPCHK(hipMemsetAsync(h->fx, 0, B * n * n * (N - 1) * 8, h->stream));
+  HIPCHK(hipMemsetAsync(h->fu, 0, B * n * m * (N - 1) * 8, h->stream));
+  h->cold = false;
+  return MI_ILQR_OK;
+}
+
+int materialize_u(mi_ilqr* h) {
+  if (!h->u_pending) return MI_ILQR_OK;
+  HIPCHK(hipMemcpyAsync(h->u_bar, h->u_guess, (size_t)h->B * h->m * (h->N - 1) * 8, hipMemcpyDeviceToDevice, h->stream));
+  h->u_pending = false;
+  return MI_ILQR_OK;
+}
+
+__global__ void mpc_shift_kernel(const double* x_bar, const double* u_bar, double* x0, double* u_guess,
+                                 int B, int n, int m, int N, int r) {
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) x0[(size_t)b * n + i] = x_bar[((size_t)b * n + i) * N + r];
+  const int M1 = N - 1;
+  for (int idx = threadIdx.x; idx < m * M1; idx += blockDim.x) {
+    const int k = idx / M1, t = idx - k * M1;
+    const int src = (t + r < M1) ? t + r : M1 - 1;
+    u_guess[((size_t)b * m + k) * M1 + t] = u_bar[((size_t)b * m + k) * M1 + src];
+  }
+}
+
+struct Field { void* ptr; size_t bytes; bool is_int; };
+
+Field field_of(mi_ilqr* h, int which) {
+  const size_t n = h->n, m = h->m, N = h->N, B = h->B;
+  switch (which) {
+    case MI_F_X_BAR: return {h->x_bar, B * n * N * 8, false};
+    case MI_F_U_BAR: return {h->u_bar, B * m * (N - 1) * 8, false};
+    case MI_F_K: return {h->K, B * m * n * (N - 1) * 8, false};
+    case MI_F_KAPPA: return {h->kappa, B * m * (N - 1) * 8, false};
+    case MI_F_DV: return {h->dV, B * (N - 1) * 8, false};
+    case MI_F_FX: return {h->fx, B * n * n * (N - 1) * 8, false};
+    case MI_F_FU: return {h->fu, B * n * m * (N - 1) * 8, false};
+    case MI_F_COST: return {h->cost, B * 8, false};
+    case MI_F_X0: return {h->x0, B * n * 8, false};
+    case MI_F_HIST: return {h->hist, B * (size_t)h->d.hist_cap * 4 * 8, false};
+    case MI_F_X_TRIAL: return {h->x_trial, B * n * N * 8, false};
+    case MI_F_U_TRIAL: return {h->u_trial, B * m * (N - 1) * 8, false};
+    case MI_F_TRIAL_COST: return {h->trial_cost, B * 2 * 8, false};
+    case MI_I_ITERS: return {h->iters, B * 4, true};
+    case MI_I_STATUS: return {h->status, B * 4, true};
+    case MI_I_LS_TRIALS: return {h->ls_trials, B * 4, true};
+    case MI_I_KP_COUNT: return {h->kp_count, B * 4, true};
+    case MI_I_KP_LIST: return {h->kp_list, B * (N - 1) * 4, true};
+  }
+  return {nullptr, 0, false};
+}
+
+bool is_state_field(int which) {
+  return which == MI_F_X_BAR || which == MI_F_K || which == MI_F_KAPPA || which == MI_F_DV || which == MI_F_FX || which == MI_F_FU;
+}
+
+double bytes_per_iteration(int n, int m, int N, int ls) {
+  const double roll = 2.0 * n * N + (3.0 * m + (double)m * n) * (N - 1) + n + 1;
+  const double deriv = (N - 1.0) * ((n + m) + ((double)n * n + (double)n * m));
+  const double back = (N - 1.0) * ((n + m) + ((double)n * n + (double)n * m) + ((double)m * n + m + 1)) + n;
+  return 8.0 * (ls * roll + deriv + back);
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi_ilqr_abi_version(void) { return MI_ILQR_ABI_VERSION; }
+
+const char* mi_ilqr_strerror(int code) {
+  switch (code) {
+    case MI_ILQR_OK: return "ok";
+    case MI_ILQR_E_BAD_SHAPE: return "bad shape";
+    case MI_ILQR_E_BAD_METHOD: return "unknown interpolation method";
+    case MI_ILQR_E_LINESEARCH: return "linesearch failed";
+    case MI_ILQR_E_HIP: return "HIP runtime error";
+    case MI_ILQR_E_NO_DEVICE: return "no usable gfx950 device (there is no CPU fallback)";
+    case MI_ILQR_E_BAD_ARG: return "bad argument";
+    case MI_ILQR_E_UNSUPPORTED: return "model/size combination not supported by any kernel";
+  }
+  return "unknown error";
+}
+
+int mi_ilqr_model_info(int model_id, int32_t* n, int32_t* m, int32_t* n_params, double* default_params) {
+  const ModelInfo* mi_ = model_info(model_id);
+  if (!mi_) return MI_ILQR_E_BAD_ARG;
+  if (n) *n = mi_->n;
+  if (m) *m = mi_->m;
+  if (n_params) *n_params = mi_->n_params;
+  if (default_params) for (int i = 0; i < MI_ILQR_MAX_PARAMS; ++i) default_params[i] = i < mi_->n_params ? mi_->defaults[i] : 0.0;
+  return MI_ILQR_OK;
+}
+
+double mi_ilqr_bytes_per_iteration(int32_t n, int32_t m, int32_t N, int32_t ls) { return bytes_per_iteration(n, m, N, ls); }
+
+size_t mi_ilqr_lds_bytes(const mi_ilqr_desc* d) {
+  if (!d) return 0;
+  return small_lds_bytes(d->model_id, d->N);
+}
+
+int mi_ilqr_create(const mi_ilqr_desc* desc, mi_ilqr_t** out) {
+  if (!desc || !out) return MI_ILQR_E_BAD_ARG;
+  *out = nullptr;
+  const ModelInfo* info = model_info(desc->model_id);
+  if (!info) return MI_ILQR_E_BAD_ARG;
+  if (desc->n != info->n || desc->m != info->m) return MI_ILQR_E_BAD_SHAPE;
+  if (desc->N < 4 || desc->B < 1) return MI_ILQR_E_BAD_SHAPE;
+  if (desc->keypoint_method < MI_KP_SET_INTERVAL || desc->keypoint_method > MI_KP_ITERATIVE_ERROR) return MI_ILQR_E_BAD_METHOD;
+  if (desc->minN < 1) return MI_ILQR_E_BAD_ARG;
+  if (desc->jacobian_mode != MI_JAC_FD_CENTRAL && desc->jacobian_mode != MI_JAC_AUTODIFF) return MI_ILQR_E_BAD_ARG;
+  if (desc->jacobian_mode == MI_JAC_FD_CENTRAL && !(desc->fd_step > 0.0)) return MI_ILQR_E_BAD_ARG;
+
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return MI_ILQR_E_NO_DEVICE;
+  if (desc->device_id < 0 || desc->device_id >= ndev) return MI_ILQR_E_NO_DEVICE;
+  HIPCHK(hipSetDevice(desc->device_id));
+
+  const size_t lds = small_lds_bytes(desc->model_id, desc->N);
+  if (lds == 0 || lds > kMaxLds) return MI_ILQR_E_UNSUPPORTED;
+
+  mi_ilqr* h = new (std::nothrow) mi_ilqr();
+  if (!h) return MI_ILQR_E_BAD_ARG;
+  h->d = *desc;
+  if (h->d.max_iters <= 0) h->d.max_iters = 1000;
+  if (h->d.hist_cap <= 0) h->d.hist_cap = 64;
+  h->n = desc->n; h->m = desc->m; h->N = desc->N; h->B = desc->B;
+  h->lds = lds;
+  const size_t n = h->n, m = h->m, N = h->N, B = h->B;
+
+#define ALLOC(p, count, T)                                             \
+  do {                                                                 \
+    if (hipMalloc(reinterpret_cast<void**>(&(p)), (count) * sizeof(T)) != hipSuccess) { mi_ilqr_destroy(h); return MI_ILQR_E_HIP; } \
+    if (hipMemset((p), 0, (count) * sizeof(T)) != hipSuccess) { mi_ilqr_destroy(h); return MI_ILQR_E_HIP; } \
+  } while (0)
+  ALLOC(h->x_bar, B * n * N, double);
+  ALLOC(h->u_bar, B * m * (N - 1), double);
+  ALLOC(h->K, B * m * n * (N - 1), double);
+  ALLOC(h->kappa, B * m * (N - 1), double);
+  ALLOC(h->dV, B * (N - 1), double);
+  ALLOC(h->fx, B * n * n * (N - 1), double);
+  ALLOC(h->fu, B * n * m * (N - 1), double);
+  ALLOC(h->x0, B * n, double);
+  ALLOC(h->u_guess, B * m * (N - 1), double);
+  ALLOC(h->cost, B, double);
+  ALLOC(h->hist, B * (size_t)h->d.hist_cap * 4, double);
+  ALLOC(h->x_trial, B * n * N, double);
+  ALLOC(h->u_trial, B * m * (N - 1), double);
+  ALLOC(h->trial_cost, B * 2, double);
+  ALLOC(h->stage_in, B, double);
+  ALLOC(h->costmat, 2 * n * n + m * m + n, double);
+  ALLOC(h->iters, B, int32_t);
+  ALLOC(h->status, B, int32_t);
+  ALLOC(h->ls_trials, B, int32_t);
+  ALLOC(h->kp_count, B, int32_t);
+  ALLOC(h->kp_list, B * (N - 1), int32_t);
+#undef ALLOC
+  // defaults Q=I, R=I, Qf=I, x_nom=0 (ilqr.py:61-67)
+  {
+    std::vector<double> cm(2 * n * n + m * m + n, 0.0);
+    for (size_t i = 0; i < n; ++i) { cm[i * n + i] = 1.0; cm[n * n + m * m + i * n + i] = 1.0; }
+    for (size_t i = 0; i < m; ++i) cm[n * n + i * m + i] = 1.0;
+    if (hipMemcpy(h->costmat, cm.data(), cm.size() * 8, hipMemcpyHostToDevice) != hipSuccess) { mi_ilqr_destroy(h); return MI_ILQR_E_HIP; }
+  }
+  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
+    mi_ilqr_destroy(h);
+    return MI_ILQR_E_HIP;
+  }
+  h->cold = true;
+  h->u_pending = false;
+  *out = h;
+  return MI_ILQR_OK;
+}
+
+void mi_ilqr_destroy(mi_ilqr_t* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->d.device_id);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  void* ptrs[] = {h->x_bar, h->u_bar, h->K, h->kappa, h->dV, h->fx, h->fu, h->x0, h->u_guess, h->cost, h->hist,
+                  h->x_trial, h->u_trial, h->trial_cost, h->stage_in, h->costmat, h->iters, h->status, h->ls_trials,
+                  h->kp_count, h->kp_list};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int mi_ilqr_set_cost(mi_ilqr_t* h, const double* Q, const double* R, const double* Qf, const double* x_nom) {
+  if (!h) return MI_ILQR_E_BAD_ARG;
+  HIPCHK(hipSetDevice(h->d.device_id));
+  const size_t n = h->n, m = h->m;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (Q) HIPCHK(hipMemcpy(h->costmat, Q, n * n * 8, hipMemcpyHostToDevice));
+  if (R) HIPCHK(hipMemcpy(h->costmat + n * n, R, m * m * 8, hipMemcpyHostToDevice));
+  if (Qf) HIPCHK(hipMemcpy(h->costmat + n * n + m * m, Qf, n * n * 8, hipMemcpyHostToDevice));
+  if (x_nom) HIPCHK(hipMemcpy(h->costmat + 2 * n * n + m * m, x_nom, n * 8, hipMemcpyHostToDevice));
+  return MI_ILQR_OK;
+}
+
+int mi_ilqr_set_initial(mi_ilqr_t* h, const double* x0, const double* u_guess) {
+  if (!h) return MI_ILQR_E_BAD_ARG;
+  HIPCHK(hipSetDevice(h->d.device_id));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (x0) HIPCHK(hipMemcpy(h->x0, x0, (size_t)h->B * h->n * 8, hipMemcpyHostToDevice));
+  if (u_guess) {
+    HIPCHK(hipMemcpy(h->u_guess, u_guess, (size_t)h->B * h->m * (h->N - 1) * 8, hipMemcpyHostToDevice));
+    h->u_pending = true;
+  }
+  return MI_ILQR_OK;
+}
+
+int mi_ilqr_reset(mi_ilqr_t* h) {
+  if (!h) return MI_ILQR_E_BAD_ARG;
+  h->cold = true;          // zeros are materialized lazily (the kernels skip the HBM read)
+  return MI_ILQR_OK;
+}
+
+int mi_ilqr_rearm_initial_guess(mi_ilqr_t* h) {
+  if (!h) return MI_ILQR_E_BAD_ARG;
+  h->u_pending = true;     // next kernel takes u_bar from the resident u_guess again
+  return MI_ILQR_OK;
+}
+
+int mi_ilqr_synchronize(mi_ilqr_t* h) {
+  if (!h) return MI_ILQR_E_BAD_ARG;
+  HIPCHK(hipSetDevice(h->d.device_id));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return MI_ILQR_OK;
+}
+
+int mi_ilqr_solve_async(mi_ilqr_t* h) {
+  if (!h) return MI_ILQR_E_BAD_ARG;
+  int rc = launch(h, MODE_SOLVE);
+  if (rc != MI_ILQR_OK) return rc;
+  h->cold = false;
+  h->u_pending = false;
+  return MI_ILQR_OK;
+}
+
+int mi_ilqr_collect_stats(mi_ilqr_t* h, mi_ilqr_stats* st) {
+  if (!h || !st) return MI_ILQR_E_BAD_ARG;
+  HIPCHK(hipSetDevice(h->d.device_id));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  const int B = h->B;
+  std::vector<int32_t> iters(B), status(B), ls(B);
+  std::vector<double> cost(B);
+  HIPCHK(hipMemcpy(iters.data(), h->iters, B * 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(status.data(), h->status, B * 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(ls.data(), h->ls_trials, B * 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(cost.data(), h->cost, B * 8, hipMemcpyDeviceToHost));
+  std::memset(st, 0, sizeof(*st));
+  st->best_cost = INFINITY;
+  st->best_index = -1;
+  for (int b = 0; b < B; ++b) {
+    st->total_iters += iters[b];
+    st->total_ls_trials += ls[b];
+    if (iters[b] > st->max_iters_seen) st->max_iters_seen = iters[b];
+    if (status[b] == MI_STATUS_CONVERGED) {
+      st->n_converged++;
+      if (cost[b] < st->best_cost) { st->best_cost = cost[b]; st->best_index = b; }
+    } else if (status[b] == MI_STATUS_MAX_ITERS) st->n_max_iters++;
+    else st->n_ls_failed++;
+  }
+  float ms = 0.f;
+  if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) st->kernel_ms = ms;
+  // bytes_iter is affine in ls: sum over iterations = ls_total*roll + iters*(deriv+back)
+  const double per_ls = bytes_per_iteration(h->n, h->m, h->N, 1) - bytes_per_iteration(h->n, h->m, h->N, 0);
+  const double fixed = bytes_per_iteration(h->n, h->m, h->N, 0);
+  st->algorithmic_bytes = per_ls * (double)st->total_ls_trials + fixed * (double)st->total_iters;
+  return MI_ILQR_OK;
+}
+
+int mi_ilqr_solve(mi_ilqr_t* h, mi_ilqr_stats* stats) {
+  int rc = mi_ilqr_solve_async(h);
+  if (rc != MI_ILQR_OK) return rc;
+  if (stats) return mi_ilqr_collect_stats(h, stats);
+  return mi_ilqr_synchronize(h);
+}
+
+static int upload_stage_in(mi_ilqr* h, const double* v) {
+  if (!v) return MI_ILQR_E_BAD_ARG;
+  HIPCHK(hipSetDevice(h->d.device_id));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipMemcpy(h->stage_in, v, (size_t)h->B * 8, hipMemcpyHostToDevice));
+  return MI_ILQR_OK;
+}
+
+int mi_ilqr_rollout(mi_ilqr_t* h, const double* eps) {
+  if (!h) return MI_ILQR_E_BAD_ARG;
+  int rc = upload_stage_in(h, eps);
+  if (rc != MI_ILQR_OK) return rc;
+  rc = launch(h, MODE_ROLLOUT);          // reads only; cold/u_pending stay as they are
+  if (rc != MI_ILQR_OK) return rc;
+  return mi_ilqr_synchronize(h);
+}
+
+int mi_ilqr_forward(mi_ilqr_t* h, const double* L_last) {
+  if (!h) return MI_ILQR_E_BAD_ARG;
+  int rc = upload_stage_in(h, L_last);
+  if (rc != MI_ILQR_OK) return rc;
+  if ((rc = materialize_zero_state(h)) != MI_ILQR_OK) return rc;   // forward leaves K/kappa/dV untouched
+  rc = launch(h, MODE_FORWARD);
+  if (rc != MI_ILQR_OK) return rc;
+  h->u_pending = false;
+  return mi_ilqr_synchronize(h);
+}
+
+int mi_ilqr_linearize(mi_ilqr_t* h) {
+  if (!h) return MI_ILQR_E_BAD_ARG;
+  int rc;
+  if ((rc = materialize_zero_state(h)) != MI_ILQR_OK) return rc;
+  if ((rc = materialize_u(h)) != MI_ILQR_OK) return rc;
+  rc = launch(h, MODE_LINEARIZE);
+  if (rc != MI_ILQR_OK) return rc;
+  return mi_ilqr_synchronize(h);
+}
+
+int mi_ilqr_backward(mi_ilqr_t* h) {
+  if (!h) return MI_ILQR_E_BAD_ARG;
+  int rc;
+  if ((rc = materialize_zero_state(h)) != MI_ILQR_OK) return rc;
+  if ((rc = materialize_u(h)) != MI_ILQR_OK) return rc;
+  rc = launch(h, MODE_BACKWARD);
+  if (rc != MI_ILQR_OK) return rc;
+  return mi_ilqr_synchronize(h);
+}
+
+int mi_ilqr_mpc_shift(mi_ilqr_t* h, int32_t replan_steps) {
+  if (!h) return MI_ILQR_E_BAD_ARG;
+  if (replan_steps < 1 || replan_steps >= h->N - 1) return MI_ILQR_E_BAD_ARG;
+  HIPCHK(hipSetDevice(h->d.device_id));
+  int rc;
+  if ((rc = materialize_zero_state(h)) != MI_ILQR_OK) return rc;
+  if ((rc = materialize_u(h)) != MI_ILQR_OK) return rc;
+  hipLaunchKernelGGL(mpc_shift_kernel, dim3(h->B), dim3(64), 0, h->stream, h->x_bar, h->u_bar, h->x0, h->u_guess,
+                     h->B, h->n, h->m, h->N, (int)replan_steps);
+  HIPCHK(hipGetLastError());
+  h->u_pending = true;
+  return MI_ILQR_OK;
+}
+
+int mi_ilqr_get(mi_ilqr_t* h, int which, double* dst, size_t bytes) {
+  if (!h || !dst) return MI_ILQR_E_BAD_ARG;
+  Field f = field_of(h, which);
+  if (!f.ptr || f.is_int) return MI_ILQR_E_BAD_ARG;
+  if (bytes != f.bytes) return MI_ILQR_E_BAD_SHAPE;
+  HIPCHK(hipSetDevice(h->d.device_id));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (h->cold && is_state_field(which)) { std::memset(dst, 0, bytes); return MI_ILQR_OK; }
+  if (h->u_pending && which == MI_F_U_BAR) { HIPCHK(hipMemcpy(dst, h->u_guess, bytes, hipMemcpyDeviceToHost)); return MI_ILQR_OK; }
+  HIPCHK(hipMemcpy(dst, f.ptr, bytes, hipMemcpyDeviceToHost));
+  return MI_ILQR_OK;
+}
+
+int mi_ilqr_get_int(mi_ilqr_t* h, int which, int32_t* dst, size_t bytes) {
+  if (!h || !dst) return MI_ILQR_E_BAD_ARG;
+  Field f = field_of(h, which);
+  if (!f.ptr || !f.is_int) return MI_ILQR_E_BAD_ARG;
+  if (bytes != f.bytes) return MI_ILQR_E_BAD_SHAPE;
+  HIPCHK(hipSetDevice(h->d.device_id));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipMemcpy(dst, f.ptr, bytes, hipMemcpyDeviceToHost));
+  return MI_ILQR_OK;
+}
+
+int mi_ilqr_set(mi_ilqr_t* h, int which, const double* src, size_t bytes) {
+  if (!h || !src) return MI_ILQR_E_BAD_ARG;
+  Field f = field_of(h, which);
+  if (!f.ptr || f.is_int) return MI_ILQR_E_BAD_ARG;
+  if (bytes != f.bytes) return MI_ILQR_E_BAD_SHAPE;
+  HIPCHK(hipSetDevice(h->d.device_id));
+  if (is_state_field(which)) { int rc = materialize_zero_state(h); if (rc != MI_ILQR_OK) return rc; }
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipMemcpy(f.ptr, src, bytes, hipMemcpyHostToDevice));
+  if (which == MI_F_U_BAR) h->u_pending = false;
+  return MI_ILQR_OK;
+}
+
+int mi_ilqr_device_ptr(mi_ilqr_t* h, int which, void** ptr, size_t* bytes) {
+  if (!h || !ptr) return MI_ILQR_E_BAD_ARG;
+  Field f = field_of(h, which);
+  if (!f.ptr) return MI_ILQR_E_BAD_ARG;
+  *ptr = f.ptr;
+  if (bytes) *bytes = f.bytes;
+  return MI_ILQR_OK;
+}
+
+int mi_ilqr_get_stream(mi_ilqr_t* h, void** hip_stream) {
+  if (!h || !hip_stream) return MI_ILQR_E_BAD_ARG;
+  *hip_stream = reinterpret_cast<void*>(h->stream);
+  return MI_ILQR_OK;
+}
+
+}  // extern "C"

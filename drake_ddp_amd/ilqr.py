@@ -1,0 +1,312 @@
+"""Host-side mirror of the reference solver class over the C ABI.
+
+``IterativeLinearQuadraticRegulator`` keeps the class surface of
+/root/reference/ilqr.py:12-733 (same constructor signature, setters, ``Solve``
+return tuple, ``SaveSolution`` npz keys, attribute names and shapes) so the
+solver section of any example script can import it as a drop-in; the `system`
+argument is a model descriptor (drake_ddp_amd.models.ModelSystem).  All compute
+is in libmi_ilqr.so (HIP, gfx950) — this file only moves arrays across the
+boundary.  ``BatchedIterativeLQR`` is the same surface with a leading batch axis.
+"""
+import ctypes as C
+import time
+
+import numpy as np
+
+from . import _capi
+from . import utils_derivs_interpolation
+from .models import ModelSystem
+
+_KP_IDS = {"setInterval": _capi.KP_SET_INTERVAL, "adaptiveJerk": _capi.KP_ADAPTIVE_JERK,
+           "iterativeError": _capi.KP_ITERATIVE_ERROR}
+_JAC_IDS = {"fd": _capi.JAC_FD_CENTRAL, "fd_central": _capi.JAC_FD_CENTRAL,
+            "autodiff": _capi.JAC_AUTODIFF, "ad": _capi.JAC_AUTODIFF}
+
+
+def shard_range(B, rank, world):
+    """Contiguous block of problems owned by `rank`."""
+    base, rem = divmod(B, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class BatchedIterativeLQR:
+    """B independent iLQR problems sharing model, horizon and cost, solved on one GPU.
+
+    Same method names as the reference class; array arguments/attributes carry a
+    leading batch axis: x0 (B,n), u_guess (B,m,N-1) [or (m,N-1), broadcast],
+    x_bar (B,n,N), u_bar (B,m,N-1), K (B,m,n,N-1), kappa (B,m,N-1) ...
+    """
+
+    def __init__(self, system, num_timesteps, batch, input_port_index=0, delta=1e-2, beta=0.95, gamma=0.0,
+                 derivs_keypoint_method=None, jacobian_mode="fd", fd_step=1e-5, device=0,
+                 max_iters=1000, hist_cap=64):
+        assert isinstance(system, ModelSystem), \
+            "system must be a drake_ddp_amd.models.ModelSystem (Drake systems cannot run on the GPU)"
+        assert system.IsDifferenceEquationSystem()[0], "must be a discrete-time system"   # ilqr.py:37
+        self._lib = _capi.load()
+        self.system = system
+        self.N = int(num_timesteps)
+        self.B = int(batch)
+        self.delta, self.beta, self.gamma = delta, beta, gamma
+        self.n, self.m = system.n, system.m
+        # ilqr.py:97-100: default = derivatives at every time step
+        if derivs_keypoint_method is None:
+            derivs_keypoint_method = utils_derivs_interpolation.derivs_interpolation('setInterval', 1, 0, 0, 0)
+        self.derivs_interpolation = derivs_keypoint_method
+        if derivs_keypoint_method.keypoint_method not in _KP_IDS:
+            raise Exception('unknown interpolation method')                               # ilqr.py:404
+        d = _capi.Desc()
+        d.n, d.m, d.N, d.B = self.n, self.m, self.N, self.B
+        d.model_id = system.model_id
+        d.n_params = system.params.size
+        for i, v in enumerate(system.params):
+            d.model_params[i] = float(v)
+        d.dt = system.dt
+        d.delta, d.beta, d.gamma = float(delta), float(beta), float(gamma)
+        d.keypoint_method = _KP_IDS[derivs_keypoint_method.keypoint_method]
+        d.minN, d.maxN = int(derivs_keypoint_method.minN), int(derivs_keypoint_method.maxN)
+        d.jerk_threshold = float(derivs_keypoint_method.jerk_threshold)
+        d.iterative_error_threshold = float(derivs_keypoint_method.iterative_error_threshold)
+        d.jacobian_mode = _JAC_IDS[jacobian_mode]
+        d.fd_step = float(fd_step)
+        d.max_iters, d.hist_cap, d.device_id = int(max_iters), int(hist_cap), int(device)
+        self._desc = d
+        self.hist_cap = int(hist_cap)
+        h = C.c_void_p()
+        _capi.check(self._lib.mi_ilqr_create(C.byref(d), C.byref(h)), "mi_ilqr_create")
+        self._h = h
+        # reference defaults (ilqr.py:61-67); NOTE x_nom is undefined until SetTargetState (F12)
+        self.x0 = np.zeros((self.B, self.n))
+        self.Q, self.R, self.Qf = np.eye(self.n), np.eye(self.m), np.eye(self.n)
+        self._u_guess = None
+        self.stats = None
+        self.time_getDerivs = self.time_backwardsPass = self.time_fp = 0.0
+        self.solve_wall_s = 0.0
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.mi_ilqr_destroy(h)
+
+    # ------------------------------------------------------------- setters (ilqr.py:102-159)
+    def SetInitialState(self, x0):
+        self.x0 = x0
+
+    def SetTargetState(self, x_nom):
+        self.x_nom = np.asarray(x_nom).reshape((self.n,))
+
+    def SetRunningCost(self, Q, R):
+        assert Q.shape == (self.n, self.n)
+        assert R.shape == (self.m, self.m)
+        self.Q = Q
+        self.R = R
+
+    def SetTerminalCost(self, Qf):
+        assert Qf.shape == (self.n, self.n)
+        self.Qf = Qf
+
+    def SetInitialGuess(self, u_guess):
+        assert u_guess.shape in ((self.m, self.N - 1), (self.B, self.m, self.N - 1))
+        self._u_guess = u_guess        # aliased like the reference; copied in at Solve()
+
+    def SetControlLimits(self, u_min, u_max):
+        pass                           # no-op stub in the reference too (ilqr.py:158-159)
+
+    # ------------------------------------------------------------- boundary traffic
+    def _push_problem(self):
+        x_nom = self.x_nom             # AttributeError if SetTargetState was never called, as in the reference
+        Q, R, Qf = (_capi.as_f64(a) for a in (self.Q, self.R, self.Qf))
+        xn = _capi.as_f64(x_nom, (self.n,))
+        _capi.check(self._lib.mi_ilqr_set_cost(self._h, _capi.ptr(Q), _capi.ptr(R), _capi.ptr(Qf), _capi.ptr(xn)),
+                    "mi_ilqr_set_cost")
+        x0 = np.broadcast_to(np.asarray(self.x0, dtype=np.float64).reshape(-1, self.n), (self.B, self.n))
+        x0 = np.ascontiguousarray(x0)
+        ug = None
+        if self._u_guess is not None:
+            ug = np.ascontiguousarray(np.broadcast_to(np.asarray(self._u_guess, dtype=np.float64),
+                                                      (self.B, self.m, self.N - 1)))
+            self._u_guess = None       # u_bar is rebound by the forward pass (ilqr.py:375)
+        _capi.check(self._lib.mi_ilqr_set_initial(self._h, _capi.ptr(x0), _capi.ptr(ug)), "mi_ilqr_set_initial")
+
+    def _get(self, which, shape):
+        out = np.empty(shape, dtype=np.float64)
+        _capi.check(self._lib.mi_ilqr_get(self._h, which, _capi.ptr(out), out.nbytes), "mi_ilqr_get")
+        return out
+
+    def _get_int(self, which, shape):
+        out = np.empty(shape, dtype=np.int32)
+        _capi.check(self._lib.mi_ilqr_get_int(self._h, which, _capi.ptr(out), out.nbytes), "mi_ilqr_get_int")
+        return out
+
+    def _set(self, which, arr, shape):
+        arr = _capi.as_f64(arr, shape)
+        _capi.check(self._lib.mi_ilqr_set(self._h, which, _capi.ptr(arr), arr.nbytes), "mi_ilqr_set")
+
+    # state attributes with the reference's names (batched)
+    x_bar = property(lambda s: s._get(_capi.F_X_BAR, (s.B, s.n, s.N)))
+    u_bar = property(lambda s: s._get(_capi.F_U_BAR, (s.B, s.m, s.N - 1)))
+    K = property(lambda s: s._get(_capi.F_K, (s.B, s.m, s.n, s.N - 1)))
+    kappa = property(lambda s: s._get(_capi.F_KAPPA, (s.B, s.m, s.N - 1)))
+    dV_coeff = property(lambda s: s._get(_capi.F_DV, (s.B, s.N - 1)))
+    fx = property(lambda s: s._get(_capi.F_FX, (s.B, s.n, s.n, s.N - 1)))
+    fu = property(lambda s: s._get(_capi.F_FU, (s.B, s.n, s.m, s.N - 1)))
+    cost = property(lambda s: s._get(_capi.F_COST, (s.B,)))
+    history = property(lambda s: s._get(_capi.F_HIST, (s.B, s.hist_cap, 4)))
+    iterations = property(lambda s: s._get_int(_capi.I_ITERS, (s.B,)))
+    status = property(lambda s: s._get_int(_capi.I_STATUS, (s.B,)))
+    ls_trials = property(lambda s: s._get_int(_capi.I_LS_TRIALS, (s.B,)))
+    keypoint_count = property(lambda s: s._get_int(_capi.I_KP_COUNT, (s.B,)))
+    keypoint_list = property(lambda s: s._get_int(_capi.I_KP_LIST, (s.B, s.N - 1)))
+
+    @property
+    def percentage_derivs(self):
+        return self.keypoint_count / (self.N - 1) * 100.0          # ilqr.py:406
+
+    def set_state(self, **fields):
+        """Overwrite persistent state arrays (stage-level tests / checkpoint restore)."""
+        table = {"x_bar": (_capi.F_X_BAR, (self.B, self.n, self.N)), "u_bar": (_capi.F_U_BAR, (self.B, self.m, self.N - 1)),
+                 "K": (_capi.F_K, (self.B, self.m, self.n, self.N - 1)), "kappa": (_capi.F_KAPPA, (self.B, self.m, self.N - 1)),
+                 "dV_coeff": (_capi.F_DV, (self.B, self.N - 1)), "fx": (_capi.F_FX, (self.B, self.n, self.n, self.N - 1)),
+                 "fu": (_capi.F_FU, (self.B, self.n, self.m, self.N - 1))}
+        for k, v in fields.items():
+            self._set(table[k][0], v, table[k][1])
+
+    def Reset(self):
+        """Forget warm-start state: equivalent to constructing a new solver (ilqr.py:70-83)."""
+        _capi.check(self._lib.mi_ilqr_reset(self._h), "mi_ilqr_reset")
+
+    # ------------------------------------------------------------- Solve (ilqr.py:669-710)
+    def Solve(self):
+        st = time.time()
+        self._push_problem()
+        stats = _capi.Stats()
+        _capi.check(self._lib.mi_ilqr_solve(self._h, C.byref(stats)), "mi_ilqr_solve")
+        self.stats = stats
+        self.solve_wall_s = time.time() - st
+        return self.x_bar, self.u_bar, self.solve_wall_s, self.cost
+
+    def solve_resident(self):
+        """Solve again from the inputs already resident on the device (no host traffic
+        except the aggregate stats): used by bench.py and the on-device MPC loop."""
+        stats = _capi.Stats()
+        _capi.check(self._lib.mi_ilqr_solve(self._h, C.byref(stats)), "mi_ilqr_solve")
+        self.stats = stats
+        return stats
+
+    def rearm(self, cold=True):
+        if cold:
+            _capi.check(self._lib.mi_ilqr_reset(self._h), "mi_ilqr_reset")
+        _capi.check(self._lib.mi_ilqr_rearm_initial_guess(self._h), "mi_ilqr_rearm_initial_guess")
+
+    def MPCShift(self, replan_steps):
+        """On-device warm start of the receding-horizon loop (acrobot.py:147-152)."""
+        _capi.check(self._lib.mi_ilqr_mpc_shift(self._h, int(replan_steps)), "mi_ilqr_mpc_shift")
+
+    def SetTargetStateResident(self, x_nom):
+        """Moving target between resident re-solves (mini_cheetah.py:151-156)."""
+        self.SetTargetState(x_nom)
+        xn = _capi.as_f64(self.x_nom, (self.n,))
+        _capi.check(self._lib.mi_ilqr_set_cost(self._h, None, None, None, _capi.ptr(xn)), "mi_ilqr_set_cost")
+
+    # ------------------------------------------------------------- stage-level entries
+    def stage_rollout(self, eps):
+        self._push_problem()
+        eps = np.ascontiguousarray(np.broadcast_to(np.asarray(eps, dtype=np.float64), (self.B,)))
+        _capi.check(self._lib.mi_ilqr_rollout(self._h, _capi.ptr(eps)), "mi_ilqr_rollout")
+        tc = self._get(_capi.F_TRIAL_COST, (self.B, 2))
+        return (self._get(_capi.F_X_TRIAL, (self.B, self.n, self.N)),
+                self._get(_capi.F_U_TRIAL, (self.B, self.m, self.N - 1)), tc[:, 0], tc[:, 1])
+
+    def stage_forward(self, L_last):
+        self._push_problem()
+        L_last = np.ascontiguousarray(np.broadcast_to(np.asarray(L_last, dtype=np.float64), (self.B,)))
+        _capi.check(self._lib.mi_ilqr_forward(self._h, _capi.ptr(L_last)), "mi_ilqr_forward")
+        h = self.history[:, 0, :]
+        return h[:, 0], h[:, 1], h[:, 2].astype(int)
+
+    def stage_linearize(self):
+        self._push_problem()
+        _capi.check(self._lib.mi_ilqr_linearize(self._h), "mi_ilqr_linearize")
+
+    def stage_backward(self):
+        self._push_problem()
+        _capi.check(self._lib.mi_ilqr_backward(self._h), "mi_ilqr_backward")
+
+    # ------------------------------------------------------------- multi-GPU helper
+    def best_cost_allreduce(self):
+        """min over all ranks of the best converged cost — the ONE collective of the
+        path: a single RCCL all-reduce(min) per batched solve, off
+        the per-iteration path.  No-op without an initialized process group."""
+        import torch
+        import torch.distributed as dist
+        best = float(self.stats.best_cost) if self.stats is not None else float(np.min(self.cost))
+        if not (dist.is_available() and dist.is_initialized()):
+            return best
+        dev = torch.device("cuda", self._desc.device_id) if dist.get_backend() == "nccl" else torch.device("cpu")
+        t = torch.tensor([best], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return float(t.item())
+
+
+class IterativeLinearQuadraticRegulator(BatchedIterativeLQR):
+    """Drop-in for the reference class (single problem): same constructor signature
+    (ilqr.py:21-22), same setters, Solve() -> (x_bar (n,N), u_bar (m,N-1), solve_time,
+    cost), SaveSolution(fname)."""
+
+    def __init__(self, system, num_timesteps, input_port_index=0, delta=1e-2, beta=0.95, gamma=0.0,
+                 derivs_keypoint_method=None, **device_options):
+        self.verbose = device_options.pop("verbose", True)
+        super().__init__(system, num_timesteps, 1, input_port_index=input_port_index, delta=delta, beta=beta,
+                         gamma=gamma, derivs_keypoint_method=derivs_keypoint_method, **device_options)
+        self.x0 = np.zeros(self.n)
+
+    def SetInitialGuess(self, u_guess):
+        assert u_guess.shape == (self.m, self.N - 1)          # ilqr.py:155
+        self._u_guess = u_guess
+
+    x_bar = property(lambda s: s._get(_capi.F_X_BAR, (s.n, s.N)))
+    u_bar = property(lambda s: s._get(_capi.F_U_BAR, (s.m, s.N - 1)))
+    K = property(lambda s: s._get(_capi.F_K, (s.m, s.n, s.N - 1)))
+    kappa = property(lambda s: s._get(_capi.F_KAPPA, (s.m, s.N - 1)))
+    dV_coeff = property(lambda s: s._get(_capi.F_DV, (s.N - 1,)))
+    fx = property(lambda s: s._get(_capi.F_FX, (s.n, s.n, s.N - 1)))
+    fu = property(lambda s: s._get(_capi.F_FU, (s.n, s.m, s.N - 1)))
+
+    @property
+    def percentage_derivs(self):
+        return float(self.keypoint_count[0]) / (self.N - 1) * 100.0
+
+    def Solve(self):
+        st = time.time()
+        self._push_problem()
+        stats = _capi.Stats()
+        _capi.check(self._lib.mi_ilqr_solve(self._h, C.byref(stats)), "mi_ilqr_solve")
+        self.stats = stats
+        total_time = time.time() - st
+        self.solve_wall_s = total_time
+        iters = int(self.iterations[0])
+        hist = self.history[0]
+        status = int(self.status[0])
+        if self.verbose:
+            # same table as ilqr.py:685-704; the fused kernel has no per-stage clocks, so the
+            # per-iteration time columns carry the kernel time divided by the iteration count
+            print("----------------------------------------------------------------------------------------------------------------------------------")
+            print("|    iter    |    cost    |    eps    |    ls    | derivs time | derivs '%'  | bp time  | fp time  |   iter time    |    time    |")
+            print("----------------------------------------------------------------------------------------------------------------------------------")
+            per_iter = stats.kernel_ms * 1e-3 / max(iters, 1)
+            for i in range(min(iters, self.hist_cap)):
+                L_new, eps, ls, pct = hist[i]
+                print(f"{i + 1:^14}{L_new:11.4f}  {eps:^12.4f}{int(ls):^11}   {0.0:1.5f}         {pct:.1f}       "
+                      f"{0.0:1.5f}    {0.0:1.5f}      {per_iter:1.5f}          {per_iter * (i + 1):4.2f}")
+        if status == _capi.STATUS_LINESEARCH_FAILED:
+            raise RuntimeError("linesearch failed after %s iterations" % int(self.ls_trials[0]))   # ilqr.py:337
+        return self.x_bar, self.u_bar, total_time, float(self.cost[0])
+
+    def SaveSolution(self, fname):
+        """ilqr.py:712-733: npz with t, x_bar (last step dropped), u_bar, K."""
+        dt = self.system.GetSubsystemByName("plant").time_step()
+        T = (self.N - 1) * dt
+        t = np.arange(0, T, dt)
+        x_bar = self.x_bar[:, :-1]
+        np.savez(fname, t=t, x_bar=x_bar, u_bar=self.u_bar, K=self.K)

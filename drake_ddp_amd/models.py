@@ -1,0 +1,85 @@
+"""Model descriptors: what the `system` argument of the reference class
+(/root/reference/ilqr.py:21) becomes.  A Drake System cannot execute on the GPU
+(SURVEY.md §8b), so the solver is handed a descriptor naming one of the device
+dynamics functions (drake_ddp_amd/csrc/models.hpp) plus its parameters and time
+step.  The descriptor answers the Drake calls the example scripts make on their
+plant around the solver (IsDifferenceEquationSystem, time_step, ...)."""
+import numpy as np
+
+from . import _capi
+
+PENDULUM, ACROBOT, CARTPOLE, CARTPOLE_WALL, SYNTH36 = 0, 1, 2, 3, 4
+_DIMS = {PENDULUM: (2, 1), ACROBOT: (4, 1), CARTPOLE: (4, 1), CARTPOLE_WALL: (4, 1), SYNTH36: (36, 12)}
+_DEFAULTS = {
+    PENDULUM: [0.25, 0.1, 4.905],
+    ACROBOT: [1.0, 1.0, 1.0, 0.5, 1.0, 0.083, 0.33, 0.1, 0.1, 9.81],
+    CARTPOLE: [10.0, 1.0, 0.5, 9.81],
+    CARTPOLE_WALL: [10.0, 1.0, 0.5, 9.81, -0.45, 0.05, 2000.0, 0.01],
+    SYNTH36: [4.0, 0.5, 6.0, 0.1],
+}
+_NAMES = {"pendulum": PENDULUM, "acrobot": ACROBOT, "cart_pole": CARTPOLE,
+          "cart_pole_with_wall": CARTPOLE_WALL, "synth36": SYNTH36}
+
+
+class _InputPort:
+    def __init__(self, m):
+        self._m = m
+
+    def size(self):
+        return self._m
+
+    def get_index(self):
+        return 0
+
+
+class ModelSystem:
+    """Discrete-time model x+ = f(x,u) evaluated on the device."""
+
+    def __init__(self, model, dt, params=None):
+        self.model_id = _NAMES[model] if isinstance(model, str) else int(model)
+        if self.model_id not in _DIMS:
+            raise ValueError(f"unknown model {model!r}")
+        self.n, self.m = _DIMS[self.model_id]
+        self.dt = float(dt)
+        self.params = np.array(_DEFAULTS[self.model_id] if params is None else params, dtype=np.float64)
+        if self.params.size > _capi.MAX_PARAMS:
+            raise ValueError("too many model parameters")
+
+    # --- the Drake calls made on the plant by the reference ctor / scripts ---
+    def IsDifferenceEquationSystem(self):          # ilqr.py:37
+        return (True, self.dt)
+
+    def time_step(self):                            # ilqr.py:725
+        return self.dt
+
+    def GetSubsystemByName(self, name):             # ilqr.py:725
+        return self
+
+    def get_input_port(self, index=0):              # ilqr.py:43
+        return _InputPort(self.m)
+
+    def get_actuation_input_port(self):             # pendulum.py:76
+        return _InputPort(self.m)
+
+    def num_multibody_states(self):                 # mini_cheetah.py:183
+        return self.n
+
+
+def Pendulum(dt=1e-2, **kw):
+    return ModelSystem(PENDULUM, dt, **kw)
+
+
+def Acrobot(dt=0.004, **kw):
+    return ModelSystem(ACROBOT, dt, **kw)
+
+
+def CartPole(dt=1e-2, **kw):
+    return ModelSystem(CARTPOLE, dt, **kw)
+
+
+def CartPoleWithWall(dt=1e-2, **kw):
+    return ModelSystem(CARTPOLE_WALL, dt, **kw)
+
+
+def Synth36(dt=4e-3, **kw):
+    return ModelSystem(SYNTH36, dt, **kw)

@@ -1,0 +1,192 @@
+/*
+ * mi_ilqr.h — C ABI of libmi_ilqr.so: the MI355X-native batched iLQR/DDP hot path.
+ *
+ * This is the drop-in boundary for the path BASELINE.json:north_star names: the
+ * body of IterativeLinearQuadraticRegulator.Solve() in the reference
+ * (/root/reference/ilqr.py:669-710) and the stages it calls, for a BATCH of B
+ * independent problems that share model, horizon and cost matrices.  Each entry
+ * point cites the reference interface it replaces.  Plain pointers and sizes
+ * only; all `double*` arguments are HOST memory unless the name says `device`;
+ * the library copies in/out and never keeps or frees caller memory.
+ *
+ * Array layout is the reference's, per problem (time on the LAST
+ * axis, C order), with a leading batch axis:
+ *     x_bar (B,n,N)   u_bar (B,m,N-1)   K (B,m,n,N-1)   kappa (B,m,N-1)
+ *     fx (B,n,n,N-1)  fu (B,n,m,N-1)    dV_coeff (B,N-1)
+ *
+ * Threading: a handle is not thread-safe (the reference class is not either:
+ * it mutates self.context, ilqr.py:223-229); distinct handles are independent.
+ * One handle = one GPU = one HIP stream.  Multi-GPU = one process per GPU, each
+ * with its own handle over its shard of the batch (no data-path collective).
+ *
+ * There is NO CPU fallback: every compute entry returns MI_ILQR_E_NO_DEVICE when
+ * no gfx950 device is usable.
+ */
+#ifndef MI_ILQR_H
+#define MI_ILQR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_ILQR_ABI_VERSION 1
+#define MI_ILQR_MAX_PARAMS 16
+
+/* Error codes (0 = OK).  The Python wrapper maps them onto the exception types
+ * the reference raises (SURVEY.md §8b "Error convention"). */
+enum {
+  MI_ILQR_OK = 0,
+  MI_ILQR_E_BAD_SHAPE = -1,      /* reference: assert on shapes, ilqr.py:130-131,145,155 */
+  MI_ILQR_E_BAD_METHOD = -2,     /* reference: Exception('unknown interpolation method'), ilqr.py:404 */
+  MI_ILQR_E_LINESEARCH = -3,     /* reference: RuntimeError("linesearch failed ..."), ilqr.py:337 */
+  MI_ILQR_E_HIP = -4,
+  MI_ILQR_E_NO_DEVICE = -5,
+  MI_ILQR_E_BAD_ARG = -6,
+  MI_ILQR_E_UNSUPPORTED = -7     /* model / size combination no kernel covers */
+};
+
+/* Device dynamics models (the `system` argument of ilqr.py:21 becomes a model
+ * descriptor; Drake systems cannot run on the GPU — SURVEY.md §8b).  Parameter
+ * vectors are documented in drake_ddp_amd/csrc/models.hpp. */
+enum {
+  MI_MODEL_PENDULUM = 0,       /* n=2  m=1  */
+  MI_MODEL_ACROBOT = 1,        /* n=4  m=1  */
+  MI_MODEL_CARTPOLE = 2,       /* n=4  m=1  */
+  MI_MODEL_CARTPOLE_WALL = 3,  /* n=4  m=1  */
+  MI_MODEL_SYNTH36 = 4         /* n=36 m=12 */
+};
+
+/* utils_derivs_interpolation.derivs_interpolation.keypoint_method
+ * (/root/reference/utils_derivs_interpolation.py:4-9; strings at ilqr.py:396-400). */
+enum { MI_KP_SET_INTERVAL = 0, MI_KP_ADAPTIVE_JERK = 1, MI_KP_ITERATIVE_ERROR = 2 };
+
+/* How fx/fu are obtained (replaces _calc_dynamics_partials, ilqr.py:233-272). */
+enum { MI_JAC_FD_CENTRAL = 0, MI_JAC_AUTODIFF = 1 };
+
+/* Per-problem status written by solve/forward. */
+enum { MI_STATUS_CONVERGED = 0, MI_STATUS_MAX_ITERS = 1, MI_STATUS_LINESEARCH_FAILED = 2 };
+
+/* Selector for mi_ilqr_get / mi_ilqr_set / mi_ilqr_device_ptr. */
+enum {
+  MI_F_X_BAR = 0, MI_F_U_BAR = 1, MI_F_K = 2, MI_F_KAPPA = 3, MI_F_DV = 4, MI_F_FX = 5, MI_F_FU = 6,
+  MI_F_COST = 7,        /* (B,)   total cost L of x_bar/u_bar                          */
+  MI_F_X0 = 8,          /* (B,n)                                                        */
+  MI_F_HIST = 9,        /* (B,hist_cap,4) rows (L, eps, ls_trials, percentage_derivs)   */
+  MI_F_X_TRIAL = 10,    /* (B,n,N)   last mi_ilqr_rollout trajectory                    */
+  MI_F_U_TRIAL = 11,    /* (B,m,N-1)                                                    */
+  MI_F_TRIAL_COST = 12, /* (B,2) (L, expected_improvement) of the last rollout          */
+  /* int32 fields (mi_ilqr_get_int) */
+  MI_I_ITERS = 100,     /* (B,) iterations of the last solve                            */
+  MI_I_STATUS = 101,    /* (B,)                                                         */
+  MI_I_LS_TRIALS = 102, /* (B,) reference-equivalent line-search trials, summed         */
+  MI_I_KP_COUNT = 103,  /* (B,) key-points used by the last linearization               */
+  MI_I_KP_LIST = 104    /* (B,N-1) the key-point indices, first KP_COUNT valid          */
+};
+
+typedef struct mi_ilqr mi_ilqr_t;
+
+/* Everything IterativeLinearQuadraticRegulator.__init__ takes (ilqr.py:21-22,
+ * 51-58, 97-100), plus the batch size and the model descriptor. */
+typedef struct {
+  int32_t n, m;            /* must equal the model's dimensions (ilqr.py:57-58) */
+  int32_t N;               /* num_timesteps (ilqr.py:51) */
+  int32_t B;               /* problems in this handle's shard */
+  int32_t model_id;
+  int32_t n_params;
+  double model_params[MI_ILQR_MAX_PARAMS];
+  double dt;
+  double delta, beta, gamma;                 /* ilqr.py:52-54 */
+  int32_t keypoint_method, minN, maxN;       /* derivs_interpolation fields */
+  double jerk_threshold, iterative_error_threshold;
+  int32_t jacobian_mode;
+  double fd_step;                            /* absolute central-difference step */
+  int32_t max_iters;                         /* safety cap (reference has none); <=0 -> 1000 */
+  int32_t hist_cap;                          /* per-problem iteration rows kept; <=0 -> 64 */
+  int32_t device_id;                         /* HIP device ordinal */
+} mi_ilqr_desc;
+
+typedef struct {
+  int64_t total_iters;        /* sum_b iterations */
+  int64_t total_ls_trials;    /* sum_b sum_i ls_{b,i} (reference-equivalent trials) */
+  int32_t n_converged, n_max_iters, n_ls_failed;
+  int32_t max_iters_seen;
+  double best_cost;           /* min_b L_b over converged problems */
+  int32_t best_index;
+  float kernel_ms;            /* HIP-event time of the solve kernel(s) on the handle's stream */
+  double algorithmic_bytes;   /* sum_b sum_i bytes_iter(ls_{b,i}) — SURVEY.md §8d formula */
+} mi_ilqr_stats;
+
+int mi_ilqr_abi_version(void);
+const char* mi_ilqr_strerror(int code);
+
+/* Model registry: dimensions and default parameters of a model id. */
+int mi_ilqr_model_info(int model_id, int32_t* n, int32_t* m, int32_t* n_params, double* default_params);
+
+/* ilqr.py:21-100 — allocate the solver state on the device, zeroed (ilqr.py:70-83). */
+int mi_ilqr_create(const mi_ilqr_desc* desc, mi_ilqr_t** out);
+void mi_ilqr_destroy(mi_ilqr_t* h);
+
+/* SetRunningCost / SetTerminalCost / SetTargetState (ilqr.py:111-146): Q (n,n), R (m,m),
+ * Qf (n,n), x_nom (n), shared by the batch.  Any pointer may be NULL = keep. */
+int mi_ilqr_set_cost(mi_ilqr_t* h, const double* Q, const double* R, const double* Qf, const double* x_nom);
+
+/* SetInitialState / SetInitialGuess (ilqr.py:102-109,148-156): x0 (B,n), u_guess (B,m,N-1).
+ * u_guess becomes u_bar (the reference aliases it, ilqr.py:156).  NULL = keep. */
+int mi_ilqr_set_initial(mi_ilqr_t* h, const double* x0, const double* u_guess);
+
+/* Zero the persistent solver state (x_bar,K,kappa,dV,fx,fu) = a freshly constructed
+ * reference object (ilqr.py:70-83).  Without it the state persists across solves (F10). */
+int mi_ilqr_reset(mi_ilqr_t* h);
+
+/* Benchmark/MPC helper: make the resident u_guess (last mi_ilqr_set_initial or
+ * mi_ilqr_mpc_shift) the initial guess of the next solve again, without host traffic. */
+int mi_ilqr_rearm_initial_guess(mi_ilqr_t* h);
+
+/* Solve (ilqr.py:669-710) for every problem of the batch, on the device, to convergence.
+ * Blocking, like the reference call; `stats` may be NULL.  _solve_async only enqueues the
+ * kernel on the handle's stream; _collect_stats synchronizes and aggregates. */
+int mi_ilqr_solve(mi_ilqr_t* h, mi_ilqr_stats* stats);
+int mi_ilqr_solve_async(mi_ilqr_t* h);
+int mi_ilqr_collect_stats(mi_ilqr_t* h, mi_ilqr_stats* stats);
+
+/* Stage-level entries (parity tests).
+ * rollout : one line-search trial per problem with the given eps (ilqr.py:306-327)
+ *           -> MI_F_X_TRIAL / MI_F_U_TRIAL / MI_F_TRIAL_COST.
+ * forward : _forward_pass (ilqr.py:339-378): line search against L_last (B,; +inf allowed),
+ *           linearization at the accepted trajectory, commit to x_bar/u_bar -> MI_F_COST,
+ *           HIST row 0 holds (L, eps, ls, pct).
+ * linearize: _get_derivatives (ilqr.py:380-415) at the current x_bar/u_bar.
+ * backward: _backward_pass (ilqr.py:623-667). */
+int mi_ilqr_rollout(mi_ilqr_t* h, const double* eps);
+int mi_ilqr_forward(mi_ilqr_t* h, const double* L_last);
+int mi_ilqr_linearize(mi_ilqr_t* h);
+int mi_ilqr_backward(mi_ilqr_t* h);
+
+/* MPC warm start on the device (acrobot.py:147-152, mini_cheetah.py:193-198):
+ * x0 <- x_bar[:, replan_steps]; u_bar <- [u_bar[:, replan_steps:], repeat(u_bar[:, -1])]. */
+int mi_ilqr_mpc_shift(mi_ilqr_t* h, int32_t replan_steps);
+
+/* Copy a field out / in (host memory; `bytes` must equal the field size). */
+int mi_ilqr_get(mi_ilqr_t* h, int which, double* dst, size_t bytes);
+int mi_ilqr_get_int(mi_ilqr_t* h, int which, int32_t* dst, size_t bytes);
+int mi_ilqr_set(mi_ilqr_t* h, int which, const double* src, size_t bytes);
+
+/* Raw device pointer of a double field (for zero-copy consumers, e.g. a torch tensor
+ * view feeding the RCCL best-cost reduction), and the handle's stream. */
+int mi_ilqr_device_ptr(mi_ilqr_t* h, int which, void** ptr, size_t* bytes);
+int mi_ilqr_get_stream(mi_ilqr_t* h, void** hip_stream);
+int mi_ilqr_synchronize(mi_ilqr_t* h);
+
+/* Algorithmic bytes of one iteration of one problem with `ls` line-search trials. */
+double mi_ilqr_bytes_per_iteration(int32_t n, int32_t m, int32_t N, int32_t ls);
+
+/* LDS bytes one problem occupies in the wave-per-problem kernels (0 if unsupported). */
+size_t mi_ilqr_lds_bytes(const mi_ilqr_desc* desc);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_ILQR_H */
