@@ -1,0 +1,177 @@
+#!/usr/bin/env python
+"""bench.py — iLQR iterations/s of the batched HIP solver on BASELINE.json's config C2
+(pendulum swing-up n=2 m=1 N=200, B=1024 seeded initial states per GPU, fp64).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is ONE batched Solve() from a cold start (fresh solver state, the resident
+u_guess re-armed) of this rank's shard; inputs are resident in HBM before the timed
+region.  value = (sum over ranks and steps of iLQR iterations) / (max-over-ranks wall).
+Prints exactly one JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(prob, x0, sample, budget_s=25.0):
+    """Oracle (NumPy port of the reference algorithm) on the host, single thread, on a
+    bounded sample of the same workload.  Reported beside the GPU number; never `value`."""
+    from oracle import models_np as M
+    from oracle.ilqr_np import OracleILQR
+    N = prob["N"]
+    iters = 0
+    done = 0
+    t0 = time.perf_counter()
+    for b in range(sample):
+        o = OracleILQR(M.Model(prob["model_id"], prob["dt"]), N, prob["delta"], prob["beta"], prob["gamma"],
+                       jacobian="fd", fd_step=1e-5)
+        o.set_problem(x0[b], prob["x_nom"], prob["Q"], prob["R"], prob["Qf"], np.zeros((1, N - 1)))
+        _, _, _, hist = o.solve()
+        iters += len(hist)
+        done += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": iters / dt, "unit": "iterations/s", "cores": 1, "kind": "port",
+            "sample": f"first {done} of the {len(x0)} C2 problems, {iters} iterations, NumPy oracle (oracle/ilqr_np.py), 1 thread",
+            "ms_per_solve": 1e3 * dt / max(done, 1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1024, help="problems per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=48)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the hot path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from drake_ddp_amd import workloads as W
+    from drake_ddp_amd.ilqr import BatchedIterativeLQR
+    from drake_ddp_amd.models import ModelSystem
+
+    prob = W.pendulum_problem()
+    B = args.batch
+    N = prob["N"]
+    x0_all = W.pendulum_batch_x0(B * world, seed=0)       # global batch; rank r owns a contiguous block
+    x0 = x0_all[rank * B:(rank + 1) * B]
+
+    s = BatchedIterativeLQR(ModelSystem(prob["model_id"], prob["dt"]), N, B, delta=prob["delta"], beta=prob["beta"],
+                            gamma=prob["gamma"], jacobian_mode="fd", fd_step=1e-5, device=local_rank)
+    s.SetTargetState(prob["x_nom"])
+    s.SetRunningCost(prob["Q"], prob["R"])
+    s.SetTerminalCost(prob["Qf"])
+    s.SetInitialState(x0)
+    s.SetInitialGuess(np.zeros((1, N - 1)))
+    s._push_problem()                                      # inputs resident in HBM from here on
+
+    def step():
+        s.rearm(cold=True)
+        st = s.solve_resident()
+        if world > 1:
+            s.best_cost_allreduce()                        # the path's one collective (RCCL min)
+        return st
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    iters = 0
+    ls_trials = 0
+    kernel_ms = 0.0
+    alg_bytes = 0.0
+    last = None
+    for _ in range(args.steps):
+        last = step()
+        iters += last.total_iters
+        ls_trials += last.total_ls_trials
+        kernel_ms += last.kernel_ms
+        alg_bytes += last.algorithmic_bytes
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    tot = torch.tensor([elapsed, float(iters), kernel_ms, alg_bytes], dtype=torch.float64, device="cuda")
+    if world > 1:
+        mx = tot.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = tot.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        elapsed = float(mx[0])
+        iters_all = float(sm[1])
+    else:
+        iters_all = float(iters)
+
+    if rank == 0:
+        k_ms = kernel_ms / args.steps                       # avg launch duration of the dominant kernel (HIP events)
+        bytes_per_launch = alg_bytes / args.steps
+        achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9
+        out = {
+            "metric": "iLQR iterations/sec (batch, whole node)",
+            "value": iters_all / elapsed,
+            "unit": "iterations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_solve": 1e3 * elapsed / args.steps,
+            "us_per_solve_per_problem": 1e6 * elapsed / args.steps / B,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "C2 pendulum swing-up n=2 m=1 N=200, batch=1024 random initial states per GPU "
+                                   "(rng seed 0), fp64, central-FD Jacobians h=1e-5, cold-start Solve per step",
+                       "batch_per_gpu": B, "global_batch": B * world, "N": N, "n": 2, "m": 1,
+                       "parallelism": f"batch-shard x{world}"},
+            "iterations_per_step_rank0": iters / args.steps,
+            "max_iterations_per_problem": int(last.max_iters_seen),
+            "converged_rank0": int(last.n_converged),
+            "ls_trials_per_step_rank0": ls_trials / args.steps,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "ilqr_small_kernel<Pendulum,FD,SOLVE>", "kernel_ms": k_ms,
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "note": "dependency-latency-bound: 2(N-1) sequential steps per iteration; state is LDS-resident"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(prob, x0_all, min(args.cpu_sample, B))
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -28,7 +28,7 @@ EXPORTS = [
     "mi_ilqr_solve", "mi_ilqr_solve_async", "mi_ilqr_collect_stats",
     "mi_ilqr_rollout", "mi_ilqr_forward", "mi_ilqr_linearize", "mi_ilqr_backward", "mi_ilqr_mpc_shift",
     "mi_ilqr_get", "mi_ilqr_get_int", "mi_ilqr_set", "mi_ilqr_device_ptr", "mi_ilqr_get_stream",
-    "mi_ilqr_synchronize", "mi_ilqr_bytes_per_iteration", "mi_ilqr_lds_bytes",
+    "mi_ilqr_synchronize", "mi_ilqr_last_kernel_ms", "mi_ilqr_get_cycles", "mi_ilqr_bytes_per_iteration", "mi_ilqr_lds_bytes",
 ]
 
 
@@ -92,6 +92,8 @@ def load():
     lib.mi_ilqr_set.argtypes = [H, C.c_int, C.c_void_p, C.c_size_t]
     lib.mi_ilqr_device_ptr.argtypes = [H, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     lib.mi_ilqr_get_stream.argtypes = [H, C.POINTER(C.c_void_p)]
+    lib.mi_ilqr_last_kernel_ms.argtypes = [H, C.POINTER(C.c_float)]
+    lib.mi_ilqr_get_cycles.argtypes = [H, C.c_void_p, C.c_size_t]
     lib.mi_ilqr_bytes_per_iteration.restype = C.c_double
     lib.mi_ilqr_bytes_per_iteration.argtypes = [C.c_int32] * 4
     lib.mi_ilqr_lds_bytes.restype = C.c_size_t

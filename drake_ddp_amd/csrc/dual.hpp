@@ -5,6 +5,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "fastmath.hpp"
+
 namespace mi {
 
 struct Dual1 {
@@ -37,12 +39,14 @@ __host__ __device__ inline Dual1 operator/(double a, Dual1 b) {
 __host__ __device__ inline double value_of(double a) { return a; }
 __host__ __device__ inline double value_of(Dual1 a) { return a.v; }
 
-__device__ inline double mi_sin(double a) { return sin(a); }
-__device__ inline double mi_cos(double a) { return cos(a); }
+__device__ inline double mi_sin(double a) { return fast_sin(a); }
+__device__ inline double mi_cos(double a) { return fast_cos(a); }
+__device__ inline double mi_rcp(double a) { return fast_rcp(a); }
+__device__ inline Dual1 mi_rcp(Dual1 a) { const double r = fast_rcp(a.v); return {r, -(r * r) * a.d}; }
 __device__ inline double mi_exp(double a) { return exp(a); }
 __device__ inline double mi_log1p(double a) { return log1p(a); }
-__device__ inline Dual1 mi_sin(Dual1 a) { double s, c; sincos(a.v, &s, &c); return {s, c * a.d}; }
-__device__ inline Dual1 mi_cos(Dual1 a) { double s, c; sincos(a.v, &s, &c); return {c, -s * a.d}; }
+__device__ inline Dual1 mi_sin(Dual1 a) { return {fast_sin(a.v), fast_cos(a.v) * a.d}; }
+__device__ inline Dual1 mi_cos(Dual1 a) { return {fast_cos(a.v), -fast_sin(a.v) * a.d}; }
 __device__ inline Dual1 mi_exp(Dual1 a) { const double e = exp(a.v); return {e, e * a.d}; }
 __device__ inline Dual1 mi_log1p(Dual1 a) { return {log1p(a.v), a.d / (1.0 + a.v)}; }
 

@@ -24,6 +24,7 @@
 #include <stdint.h>
 
 #include "../../include/mi_ilqr.h"
+#include "fastmath.hpp"
 #include "models.hpp"
 
 namespace mi {
@@ -41,6 +42,7 @@ struct KArgs {
   const double* stage_in;  // (B,) eps (ROLLOUT) or L_last (FORWARD)
   const double* costmat;   // Q[n*n] R[m*m] Qf[n*n] x_nom[n]
   int32_t *iters, *status, *ls_trials, *kp_count, *kp_list;
+  long long* prof;         // (B,4) shader-clock cycles: line search, linearization, backward pass, whole solve
   double params[MI_ILQR_MAX_PARAMS];
   double dt, delta, beta, gamma, jerk_thr, err_thr, fd_h;
   int32_t N, B, kp_method, minN, maxN, max_iters, hist_cap;
@@ -58,38 +60,56 @@ __device__ __forceinline__ double bcast_lane0(double v) {
 
 __device__ __forceinline__ void wave_sync() { __syncthreads(); }
 
-// Per-problem workspace carved out of dynamic LDS.  Strides: SN = N for state
-// trajectories, SM = N-1 for everything indexed by control step.
+// ---------------------------------------------------------------------------
+// LDS layout: array-of-records, ONE record per time step, so that everything a
+// sequential step touches is reachable from a single per-step pointer with
+// compile-time (immediate) offsets — no per-access address arithmetic in the
+// latency-critical loops, and adjacent fields fuse into ds_read2/ds_read_b128.
+//   G_t  nominal trajectory + gains : x_bar[n] | K[m][n] | u_bar[m] | kappa[m], dV
+//   T_t  trial trajectory           : x[n] | u[m]
+//   J_t  dynamics partials          : fx[n][n] | fu[n][m]
+// (HBM keeps the reference's time-last layout; the staging copy transposes.)
+// Each array has one pad record before index 0 and after the last index so the
+// one-step-ahead software prefetch never needs a clamp.
+// ---------------------------------------------------------------------------
+template <int n, int m>
+struct Lay {
+  static constexpr int even(int v) { return (v + 1) & ~1; }
+  static constexpr int XB = 0;
+  static constexpr int KK = even(n);
+  static constexpr int UB = KK + even(m * n);
+  static constexpr int KAP = UB + even(m);
+  static constexpr int DV = KAP + m;
+  static constexpr int GS = even(DV + 1);
+  static constexpr int XN = 0, UN = even(n), TS = even(UN + m);
+  static constexpr int FX = 0, FU = even(n * n), JS = even(FU + n * m);
+  static constexpr int DUMP_DOUBLES = 64 * 2 + (GS > JS ? GS : JS);   // 16 B per lane + one record of slack
+};
+
 struct WS {
-  double *xb, *xn, *ub, *un, *K, *kap, *fx, *fu, *dV;
+  double *G, *T, *J;       // point at record index 0 (pad record lives at index -1)
+  double* dump;            // per-lane sink for predicated-off stores (lane*16 B)
   int *kp, *aux, *need, *binA, *binB;
-  int N, SN, SM;
+  int N;
 };
 
 template <int n, int m>
-__host__ __device__ constexpr size_t ws_doubles(int N) {
-  return (size_t)2 * n * N + (size_t)(2 * m + m * n + m + n * n + n * m + 1) * (N - 1);
-}
-template <int n, int m>
 __host__ __device__ constexpr size_t ws_bytes(int N) {
-  // doubles + kp[N] + aux[N] + need[N] + binA[2N] + binB[2N] ints
-  return ws_doubles<n, m>(N) * 8 + (size_t)7 * N * 4 + 16;
+  using L = Lay<n, m>;
+  return ((size_t)(N + 2) * L::GS + (size_t)(N + 2) * L::TS + (size_t)(N + 2) * L::JS + L::DUMP_DOUBLES) * 8 +
+         (size_t)7 * N * 4 + 16;
 }
 
 template <int n, int m>
 __device__ inline WS carve(char* base, int N) {
+  using L = Lay<n, m>;
   WS w;
-  w.N = N; w.SN = N; w.SM = N - 1;
+  w.N = N;
   double* p = reinterpret_cast<double*>(base);
-  w.xb = p; p += n * N;
-  w.xn = p; p += n * N;
-  w.ub = p; p += m * (N - 1);
-  w.un = p; p += m * (N - 1);
-  w.K = p; p += m * n * (N - 1);
-  w.kap = p; p += m * (N - 1);
-  w.fx = p; p += n * n * (N - 1);
-  w.fu = p; p += n * m * (N - 1);
-  w.dV = p; p += (N - 1);
+  w.G = p + L::GS; p += (size_t)(N + 2) * L::GS;
+  w.T = p + L::TS; p += (size_t)(N + 2) * L::TS;
+  w.J = p + L::JS; p += (size_t)(N + 2) * L::JS;
+  w.dump = p; p += L::DUMP_DOUBLES;
   int* q = reinterpret_cast<int*>(p);
   w.kp = q; q += N;
   w.aux = q; q += N;
@@ -99,12 +119,25 @@ __device__ inline WS carve(char* base, int N) {
   return w;
 }
 
-__device__ inline void copy_in(double* dst, const double* src, int count, bool zero) {
-  if (zero) { for (int i = threadIdx.x; i < count; i += 64) dst[i] = 0.0; }
-  else { for (int i = threadIdx.x; i < count; i += 64) dst[i] = src[i]; }
+// HBM (rows,len) time-last  ->  LDS records rec[t*RS + off + row]   (and back)
+__device__ inline void stage_in(double* recs, int RS, int off, const double* src, int rows, int len, bool zero) {
+  for (int r = 0; r < rows; ++r) {
+    double* d = recs + off + r;
+    const double* s = src + (size_t)r * len;
+    if (zero) { for (int t = threadIdx.x; t < len; t += 64) d[t * RS] = 0.0; }
+    else {
+#pragma unroll 4
+      for (int t = threadIdx.x; t < len; t += 64) d[t * RS] = s[t];
+    }
+  }
 }
-__device__ inline void copy_out(double* dst, const double* src, int count) {
-  for (int i = threadIdx.x; i < count; i += 64) dst[i] = src[i];
+__device__ inline void stage_out(double* dst, const double* recs, int RS, int off, int rows, int len) {
+  for (int r = 0; r < rows; ++r) {
+    const double* s = recs + off + r;
+    double* d = dst + (size_t)r * len;
+#pragma unroll 4
+    for (int t = threadIdx.x; t < len; t += 64) d[t] = s[t * RS];
+  }
 }
 
 template <class M>
@@ -135,104 +168,110 @@ struct Consts {
 };
 
 // ---------------------------------------------------------------------------
-// One line-search trial (ilqr.py:306-327) for this lane's eps.  Reads the
-// nominal trajectory and gains from LDS (wave-uniform addresses -> broadcast
-// reads, software-prefetched one step ahead so the LDS latency is off the x
-// dependency chain); lane 0 optionally stores the trajectory into xn/un.
+// One line-search trial (ilqr.py:306-327) for this lane's eps.  G records are
+// read at wave-uniform addresses (LDS broadcast), one step ahead of use, into
+// two alternating register sets (manual 2x unroll: no register rotation moves).
+// Lane 0 stores its trajectory into the T records; the other lanes' stores go
+// to a per-lane dump slot so the loop carries no exec-mask branches.
 // ---------------------------------------------------------------------------
+template <class M>
+struct GRegs {
+  double xb[M::n], K[M::m][M::n], ub[M::m], kap[M::m], dv;
+  __device__ __forceinline__ void load(const double* g) {
+    using L = Lay<M::n, M::m>;
+#pragma unroll
+    for (int i = 0; i < M::n; ++i) xb[i] = g[L::XB + i];
+#pragma unroll
+    for (int k = 0; k < M::m; ++k) {
+#pragma unroll
+      for (int j = 0; j < M::n; ++j) K[k][j] = g[L::KK + k * M::n + j];
+      ub[k] = g[L::UB + k];
+      kap[k] = g[L::KAP + k];
+    }
+    dv = g[L::DV];
+  }
+};
+
+template <class M>
+__device__ __forceinline__ void rollout_step(const GRegs<M>& r, const Consts<M>& c, const KArgs& a, double eps,
+                                             double ce, double (&x)[M::n], double& L, double& expd, double* tw) {
+  constexpr int n = M::n, m = M::m;
+  using Ly = Lay<n, m>;
+  // u_t = u_bar_t - eps*kappa_t - K_t (x_t - x_bar_t)          (ilqr.py:313)
+  double u[m];
+#pragma unroll
+  for (int k = 0; k < m; ++k) {
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < n; ++j) acc += r.K[k][j] * (x[j] - r.xb[j]);
+    u[k] = (r.ub[k] - eps * r.kap[k]) - acc;
+  }
+  double xnext[n];
+  M::template step<double>(x, u, xnext, a.params, a.dt);        // ilqr.py:316
+  // stage cost (no 1/2 factor, ilqr.py:325) and expected improvement (:326)
+  double dx[n];
+#pragma unroll
+  for (int i = 0; i < n; ++i) dx[i] = x[i] - c.xnom[i];
+  double q = 0.0;
+#pragma unroll
+  for (int i = 0; i < n; ++i) {
+    double s = 0.0;
+#pragma unroll
+    for (int j = 0; j < n; ++j) s += c.Q[i][j] * dx[j];
+    q += dx[i] * s;
+  }
+  double ru = 0.0;
+#pragma unroll
+  for (int i = 0; i < m; ++i) {
+    double s = 0.0;
+#pragma unroll
+    for (int j = 0; j < m; ++j) s += c.R[i][j] * u[j];
+    ru += u[i] * s;
+  }
+  L += q + ru;
+  expd += ce * r.dv;
+  // T_t.u = u_t ; T_{t+1}.x = x_{t+1}
+#pragma unroll
+  for (int k = 0; k < m; ++k) tw[Ly::UN + k] = u[k];
+#pragma unroll
+  for (int i = 0; i < n; ++i) tw[Ly::TS + Ly::XN + i] = xnext[i];
+#pragma unroll
+  for (int i = 0; i < n; ++i) x[i] = xnext[i];
+}
+
 template <class M>
 __device__ inline void rollout(const WS& w, const Consts<M>& c, const KArgs& a, const double* x0r,
                                double eps, bool store, double& L_out, double& exp_out) {
   constexpr int n = M::n, m = M::m;
-  const int N = w.N, SN = w.SN, SM = w.SM;
+  using Ly = Lay<n, m>;
+  const int N = w.N;
   double x[n];
 #pragma unroll
   for (int i = 0; i < n; ++i) x[i] = x0r[i];
-  if (store) {
+  // store==true (lane 0): walk the T records; otherwise park on this lane's dump slot
+  double* tw = store ? w.T : (w.dump + 2 * threadIdx.x);
+  const int tstep = store ? Ly::TS : 0;
 #pragma unroll
-    for (int i = 0; i < n; ++i) w.xn[i * SN] = x[i];
-  }
+  for (int i = 0; i < n; ++i) tw[Ly::XN + i] = x[i];
   double L = 0.0, expd = 0.0;
   const double ce = -eps * (1.0 - eps / 2.0);
 
-  double ub[m], kp[m], Kt[m][n], xb[n], dv;
-  // prefetch t = 0
-#pragma unroll
-  for (int k = 0; k < m; ++k) {
-    ub[k] = w.ub[k * SM]; kp[k] = w.kap[k * SM];
-#pragma unroll
-    for (int j = 0; j < n; ++j) Kt[k][j] = w.K[(k * n + j) * SM];
+  const double* g = w.G;
+  GRegs<M> A, B;
+  A.load(g);
+  int t = 0;
+  for (; t + 1 < N - 1; t += 2) {
+    B.load(g + Ly::GS);
+    __builtin_amdgcn_sched_barrier(0);      // keep the prefetch a full step ahead of its first use
+    rollout_step<M>(A, c, a, eps, ce, x, L, expd, tw);
+    tw += tstep;
+    A.load(g + 2 * Ly::GS);                 // t+2 <= N-1: a real record (or the pad at N)
+    __builtin_amdgcn_sched_barrier(0);
+    rollout_step<M>(B, c, a, eps, ce, x, L, expd, tw);
+    tw += tstep;
+    g += 2 * Ly::GS;
   }
-#pragma unroll
-  for (int i = 0; i < n; ++i) xb[i] = w.xb[i * SN];
-  dv = w.dV[0];
-
-  for (int t = 0; t < N - 1; ++t) {
-    double ub_c[m], kp_c[m], K_c[m][n], xb_c[n];
-    const double dv_c = dv;
-#pragma unroll
-    for (int k = 0; k < m; ++k) {
-      ub_c[k] = ub[k]; kp_c[k] = kp[k];
-#pragma unroll
-      for (int j = 0; j < n; ++j) K_c[k][j] = Kt[k][j];
-    }
-#pragma unroll
-    for (int i = 0; i < n; ++i) xb_c[i] = xb[i];
-    const int tn = (t + 1 < N - 1) ? t + 1 : t;   // clamp: last prefetch re-reads t
-#pragma unroll
-    for (int k = 0; k < m; ++k) {
-      ub[k] = w.ub[k * SM + tn]; kp[k] = w.kap[k * SM + tn];
-#pragma unroll
-      for (int j = 0; j < n; ++j) Kt[k][j] = w.K[(k * n + j) * SM + tn];
-    }
-#pragma unroll
-    for (int i = 0; i < n; ++i) xb[i] = w.xb[i * SN + tn];
-    dv = w.dV[tn];
-
-    // u_t = u_bar_t - eps*kappa_t - K_t (x_t - x_bar_t)          (ilqr.py:313)
-    double u[m];
-#pragma unroll
-    for (int k = 0; k < m; ++k) {
-      double acc = 0.0;
-#pragma unroll
-      for (int j = 0; j < n; ++j) acc += K_c[k][j] * (x[j] - xb_c[j]);
-      u[k] = (ub_c[k] - eps * kp_c[k]) - acc;
-    }
-    double xnext[n];
-    M::template step<double>(x, u, xnext, a.params, a.dt);        // ilqr.py:316
-
-    // stage cost (no 1/2 factor, ilqr.py:325) and expected improvement (:326)
-    double dx[n];
-#pragma unroll
-    for (int i = 0; i < n; ++i) dx[i] = x[i] - c.xnom[i];
-    double q = 0.0;
-#pragma unroll
-    for (int i = 0; i < n; ++i) {
-      double r = 0.0;
-#pragma unroll
-      for (int j = 0; j < n; ++j) r += c.Q[i][j] * dx[j];
-      q += dx[i] * r;
-    }
-    double ru = 0.0;
-#pragma unroll
-    for (int i = 0; i < m; ++i) {
-      double r = 0.0;
-#pragma unroll
-      for (int j = 0; j < m; ++j) r += c.R[i][j] * u[j];
-      ru += u[i] * r;
-    }
-    L += q + ru;
-    expd += ce * dv_c;
-
-    if (store) {
-#pragma unroll
-      for (int k = 0; k < m; ++k) w.un[k * SM + t] = u[k];
-#pragma unroll
-      for (int i = 0; i < n; ++i) w.xn[i * SN + t + 1] = xnext[i];
-    }
-#pragma unroll
-    for (int i = 0; i < n; ++i) x[i] = xnext[i];
-  }
+  if (t < N - 1) rollout_step<M>(A, c, a, eps, ce, x, L, expd, tw);
   // terminal cost (ilqr.py:327)
   {
     double dx[n];
@@ -241,10 +280,10 @@ __device__ inline void rollout(const WS& w, const Consts<M>& c, const KArgs& a, 
     double q = 0.0;
 #pragma unroll
     for (int i = 0; i < n; ++i) {
-      double r = 0.0;
+      double s = 0.0;
 #pragma unroll
-      for (int j = 0; j < n; ++j) r += c.Qf[i][j] * dx[j];
-      q += dx[i] * r;
+      for (int j = 0; j < n; ++j) s += c.Qf[i][j] * dx[j];
+      q += dx[i] * s;
     }
     L += q;
   }
@@ -254,8 +293,8 @@ __device__ inline void rollout(const WS& w, const Consts<M>& c, const KArgs& a, 
 
 // ---------------------------------------------------------------------------
 // Speculative parallel line search (ilqr.py:300-337).  Returns true on accept;
-// xn/un then hold the accepted trajectory.  `trials` is the reference-equivalent
-// sequential trial count (accepted candidate index + 1).
+// the T records then hold the accepted trajectory.  `trials` is the
+// reference-equivalent sequential trial count (accepted candidate index + 1).
 // ---------------------------------------------------------------------------
 template <class M>
 __device__ inline bool linesearch(const WS& w, const Consts<M>& c, const KArgs& a, const double* x0r,
@@ -296,34 +335,51 @@ __device__ inline bool linesearch(const WS& w, const Consts<M>& c, const KArgs& 
   }
 }
 
+// Commit the accepted trial: x_bar <- x, u_bar <- u (ilqr.py:375-376).
+template <int n, int m>
+__device__ inline void commit_trial(const WS& w) {
+  using Ly = Lay<n, m>;
+  for (int t = threadIdx.x; t < w.N; t += 64) {
+    const double* s = w.T + t * Ly::TS;
+    double* d = w.G + t * Ly::GS;
+#pragma unroll
+    for (int i = 0; i < n; ++i) d[Ly::XB + i] = s[Ly::XN + i];
+    if (t < w.N - 1) {
+#pragma unroll
+      for (int k = 0; k < m; ++k) d[Ly::UB + k] = s[Ly::UN + k];
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
-// Dynamics partials at the listed time steps (replaces _calc_dynamics_partials,
-// ilqr.py:233-272): items (list entry, column) over lanes.
+// Dynamics partials at the listed time steps of the NOMINAL trajectory in G
+// (replaces _calc_dynamics_partials, ilqr.py:233-272): (list entry, column)
+// items over lanes.
 // ---------------------------------------------------------------------------
 template <class M, int JAC>
-__device__ inline void jac_at(const WS& w, const KArgs& a, const double* xs, const double* us,
-                              const int* list, int count) {
+__device__ inline void jac_at(const WS& w, const KArgs& a, const int* list, int count) {
   constexpr int n = M::n, m = M::m, nc = n + m;
-  const int SN = w.SN, SM = w.SM;
+  using Ly = Lay<n, m>;
   const double h = a.fd_h, inv2h = 1.0 / (2.0 * h);
   for (int it = threadIdx.x; it < count * nc; it += 64) {
     const int ki = it / nc, col = it - ki * nc;
     const int t = list[ki];
+    const double* g = w.G + t * Ly::GS;
     double x[n], u[m], d[n];
 #pragma unroll
-    for (int i = 0; i < n; ++i) x[i] = xs[i * SN + t];
+    for (int i = 0; i < n; ++i) x[i] = g[Ly::XB + i];
 #pragma unroll
-    for (int k = 0; k < m; ++k) u[k] = us[k * SM + t];
+    for (int k = 0; k < m; ++k) u[k] = g[Ly::UB + k];
     if (JAC == MI_JAC_FD_CENTRAL) {
-      double xp[n], up[m], xm[n], um[m], fp[n], fm[n];
+      double xp[n], up[m], xm[n], um[m], fp[n], fm_[n];
 #pragma unroll
       for (int i = 0; i < n; ++i) { xp[i] = (col == i) ? x[i] + h : x[i]; xm[i] = (col == i) ? x[i] - h : x[i]; }
 #pragma unroll
       for (int k = 0; k < m; ++k) { up[k] = (col == n + k) ? u[k] + h : u[k]; um[k] = (col == n + k) ? u[k] - h : u[k]; }
       M::template step<double>(xp, up, fp, a.params, a.dt);
-      M::template step<double>(xm, um, fm, a.params, a.dt);
+      M::template step<double>(xm, um, fm_, a.params, a.dt);
 #pragma unroll
-      for (int i = 0; i < n; ++i) d[i] = (fp[i] - fm[i]) * inv2h;
+      for (int i = 0; i < n; ++i) d[i] = (fp[i] - fm_[i]) * inv2h;
     } else {
       Dual1 xd[n], ud[m], fd[n];
 #pragma unroll
@@ -334,12 +390,13 @@ __device__ inline void jac_at(const WS& w, const KArgs& a, const double* xs, con
 #pragma unroll
       for (int i = 0; i < n; ++i) d[i] = fd[i].d;
     }
+    double* j = w.J + t * Ly::JS;
     if (col < n) {
 #pragma unroll
-      for (int i = 0; i < n; ++i) w.fx[(i * n + col) * SM + t] = d[i];
+      for (int i = 0; i < n; ++i) j[Ly::FX + i * n + col] = d[i];
     } else {
 #pragma unroll
-      for (int i = 0; i < n; ++i) w.fu[(i * m + (col - n)) * SM + t] = d[i];
+      for (int i = 0; i < n; ++i) j[Ly::FU + i * m + (col - n)] = d[i];
     }
   }
 }
@@ -375,9 +432,10 @@ __device__ inline int keypoints_set_interval(const WS& w, int minN) {
 // get_keypoints_adaptive_jerk + calc_jerk_profile (ilqr.py:434-486).  The jerk
 // test is evaluated for 64 time steps at once; the counter automaton then walks
 // the ballot mask with scalar code.
-template <int n>
-__device__ inline int keypoints_adaptive_jerk(const WS& w, const KArgs& a, const double* xs) {
-  const int N = w.N, SN = w.SN, lane = threadIdx.x;
+template <int n, int m>
+__device__ inline int keypoints_adaptive_jerk(const WS& w, const KArgs& a) {
+  using Ly = Lay<n, m>;
+  const int N = w.N, lane = threadIdx.x;
   constexpr int dof = n / 2;
   int nk = 0, since = 0, last = 0;
   if (lane == 0) w.kp[0] = 0;
@@ -386,10 +444,11 @@ __device__ inline int keypoints_adaptive_jerk(const WS& w, const KArgs& a, const
     const int t = t0 + lane;
     bool trig = false;
     if (t < N - 3) {
+      const double* g = w.G + t * Ly::GS + Ly::XB;
 #pragma unroll
       for (int i = 0; i < dof; ++i) {
-        const double* v = xs + (i + dof) * SN + t;
-        const double jerk = (v[2] - v[1]) - (v[1] - v[0]);   // signed, no abs (:481-484)
+        const double v0 = g[i + dof], v1 = g[Ly::GS + i + dof], v2 = g[2 * Ly::GS + i + dof];
+        const double jerk = (v2 - v1) - (v1 - v0);           // signed, no abs (:481-484)
         trig = trig || (jerk > a.jerk_thr);
       }
     }
@@ -413,11 +472,12 @@ __device__ inline int keypoints_adaptive_jerk(const WS& w, const KArgs& a, const
 
 // get_keypoints_iterative_error + check_one_matrix_error (ilqr.py:488-593):
 // level-synchronous bisection, one lane per bin; Jacobians are evaluated (and
-// written into fx/fu) only where the reference would evaluate them.
+// written into J) only where the reference would evaluate them.
 template <class M, int JAC>
-__device__ inline int keypoints_iterative_error(const WS& w, const KArgs& a, const double* xs, const double* us) {
+__device__ inline int keypoints_iterative_error(const WS& w, const KArgs& a) {
   constexpr int n = M::n;
-  const int N = w.N, SM = w.SM, lane = threadIdx.x;
+  using Ly = Lay<M::n, M::m>;
+  const int N = w.N, lane = threadIdx.x;
   int* done = w.aux;             // 0/1 per time step: derivative evaluated (deriv_calculated_at_index)
   int* need = w.need;            // scratch flags: indices a level wants evaluated
   for (int t = lane; t < N; t += 64) done[t] = 0;
@@ -438,7 +498,7 @@ __device__ inline int keypoints_iterative_error(const WS& w, const KArgs& a, con
     wave_sync();
     const int cnt = compact(N, w.kp, [&](int t) { return need[t] && !done[t]; });
     wave_sync();
-    jac_at<M, JAC>(w, a, xs, us, w.kp, cnt);
+    jac_at<M, JAC>(w, a, w.kp, cnt);
     for (int i = lane; i < cnt; i += 64) done[w.kp[i]] = 1;
     wave_sync();
     // evaluate bins; bad ones are split (order within a level is irrelevant to the result)
@@ -450,10 +510,14 @@ __device__ inline int keypoints_iterative_error(const WS& w, const KArgs& a, con
       if (i < nb) {
         s = bins[2 * i]; e = bins[2 * i + 1]; mid = (s + e) / 2;
         if (e - s > a.minN) {
+          const double* js = w.J + s * Ly::JS + Ly::FX;
+          const double* je = w.J + e * Ly::JS + Ly::FX;
+          const double* jm = w.J + mid * Ly::JS + Ly::FX;
           double sum = 0.0;
+#pragma unroll
           for (int r = 0; r < n * n; ++r) {
-            const double lin = (w.fx[r * SM + e] + w.fx[r * SM + s]) / 2.0;
-            const double df = lin - w.fx[r * SM + mid];
+            const double lin = (je[r] + js[r]) / 2.0;
+            const double df = lin - jm[r];
             sum += df * df;
           }
           bad = (sum / (2.0 * n)) > a.err_thr;       // divisor 2n, fx only (:583-591)
@@ -478,37 +542,37 @@ __device__ inline int keypoints_iterative_error(const WS& w, const KArgs& a, con
 // interior points only (the end points are reproduced exactly by the formula).
 template <int n, int m>
 __device__ inline void interpolate(const WS& w, int nk) {
-  const int SM = w.SM;
+  using Ly = Lay<n, m>;
+  constexpr int cnt = n * n + n * m;
   for (int i = threadIdx.x; i < nk - 1; i += 64) {
     const int s = w.kp[i], e = w.kp[i + 1];
     if (e - s < 2) continue;
     const double len = (double)(e - s);
-    for (int r = 0; r < n * n; ++r) {
-      const double fs = w.fx[r * SM + s], fe = w.fx[r * SM + e];
-      for (int j = s + 1; j < e; ++j) w.fx[r * SM + j] = fs + (fe - fs) * (double)(j - s) / len;
-    }
-    for (int r = 0; r < n * m; ++r) {
-      const double fs = w.fu[r * SM + s], fe = w.fu[r * SM + e];
-      for (int j = s + 1; j < e; ++j) w.fu[r * SM + j] = fs + (fe - fs) * (double)(j - s) / len;
+    const double* js = w.J + s * Ly::JS;
+    const double* je = w.J + e * Ly::JS;
+    for (int r = 0; r < cnt; ++r) {
+      const int off = r < n * n ? Ly::FX + r : Ly::FU + (r - n * n);
+      const double fs = js[off], fe = je[off];
+      for (int j = s + 1; j < e; ++j) w.J[j * Ly::JS + off] = fs + (fe - fs) * (double)(j - s) / len;
     }
   }
 }
 
-// _get_derivatives (ilqr.py:380-415) at trajectory (xs,us).  Returns key-point count.
+// _get_derivatives (ilqr.py:380-415) at the nominal trajectory in G.  Returns key-point count.
 template <class M, int JAC>
-__device__ inline int linearize(const WS& w, const KArgs& a, const double* xs, const double* us) {
+__device__ inline int linearize(const WS& w, const KArgs& a) {
   constexpr int n = M::n, m = M::m;
   int nk;
   if (a.kp_method == MI_KP_SET_INTERVAL) {
     nk = keypoints_set_interval(w, a.minN);
     wave_sync();
-    jac_at<M, JAC>(w, a, xs, us, w.kp, nk);
+    jac_at<M, JAC>(w, a, w.kp, nk);
   } else if (a.kp_method == MI_KP_ADAPTIVE_JERK) {
-    nk = keypoints_adaptive_jerk<n>(w, a, xs);
+    nk = keypoints_adaptive_jerk<n, m>(w, a);
     wave_sync();
-    jac_at<M, JAC>(w, a, xs, us, w.kp, nk);
+    jac_at<M, JAC>(w, a, w.kp, nk);
   } else {
-    nk = keypoints_iterative_error<M, JAC>(w, a, xs, us);
+    nk = keypoints_iterative_error<M, JAC>(w, a);
   }
   wave_sync();
   if (!(a.kp_method == MI_KP_SET_INTERVAL && a.minN == 1)) {   // ilqr.py:414
@@ -519,13 +583,12 @@ __device__ inline int linearize(const WS& w, const KArgs& a, const double* xs, c
 }
 
 template <int m>
-__device__ inline void invert_small(const double (&A)[m][m], double (&Ai)[m][m]) {
+__device__ __forceinline__ void invert_small(const double (&A)[m][m], double (&Ai)[m][m]) {
   static_assert(m >= 1 && m <= 2, "wave-per-problem path covers m <= 2");
   if constexpr (m == 1) {
-    Ai[0][0] = 1.0 / A[0][0];
+    Ai[0][0] = fast_rcp(A[0][0]);
   } else {
-    const double det = A[0][0] * A[1][1] - A[0][1] * A[1][0];
-    const double id = 1.0 / det;
+    const double id = fast_rcp(A[0][0] * A[1][1] - A[0][1] * A[1][0]);
     Ai[0][0] = A[1][1] * id; Ai[0][1] = -A[0][1] * id;
     Ai[1][0] = -A[1][0] * id; Ai[1][1] = A[0][0] * id;
   }
@@ -534,180 +597,202 @@ __device__ inline void invert_small(const double (&A)[m][m], double (&Ai)[m][m])
 // ---------------------------------------------------------------------------
 // Backward Riccati pass (ilqr.py:623-667) with the quadratic cost expansion
 // (:161-206) fused in.  Wave-uniform: every lane carries the same Vx/Vxx in
-// registers; LDS reads are broadcasts, prefetched one step ahead.
+// registers; G/J records are broadcast-read one step ahead into alternating
+// register sets; lane 0 writes the gains back into the G record.
 // ---------------------------------------------------------------------------
 template <class M>
-__device__ inline void backward(const WS& w, const Consts<M>& c) {
-  constexpr int n = M::n, m = M::m;
-  const int N = w.N, SN = w.SN, SM = w.SM;
-  const bool writer = threadIdx.x == 0;
-  double Vx[n], Vxx[n][n];
-  {
-    double xT[n];
+struct BRegs {
+  double x[M::n], u[M::m], fx[M::n][M::n], fu[M::n][M::m];
+  __device__ __forceinline__ void load(const double* g, const double* j) {
+    using L = Lay<M::n, M::m>;
 #pragma unroll
-    for (int i = 0; i < n; ++i) xT[i] = w.xb[i * SN + N - 1];
+    for (int i = 0; i < M::n; ++i) {
+      x[i] = g[L::XB + i];
 #pragma unroll
-    for (int i = 0; i < n; ++i) {
-      double s = 0.0;
+      for (int c = 0; c < M::n; ++c) fx[i][c] = j[L::FX + i * M::n + c];
 #pragma unroll
-      for (int j = 0; j < n; ++j) { s += (2.0 * c.Qf[i][j]) * xT[j]; Vxx[i][j] = 2.0 * c.Qf[i][j]; }
-      Vx[i] = s - c.qfn[i];                                   // ilqr.py:203-204
+      for (int k = 0; k < M::m; ++k) fu[i][k] = j[L::FU + i * M::m + k];
     }
+#pragma unroll
+    for (int k = 0; k < M::m; ++k) u[k] = g[L::UB + k];
   }
-  double x[n], u[m], fx[n][n], fu[n][m];
-  auto fetch = [&](int t) {
-#pragma unroll
-    for (int i = 0; i < n; ++i) {
-      x[i] = w.xb[i * SN + t];
-#pragma unroll
-      for (int j = 0; j < n; ++j) fx[i][j] = w.fx[(i * n + j) * SM + t];
-#pragma unroll
-      for (int k = 0; k < m; ++k) fu[i][k] = w.fu[(i * m + k) * SM + t];
-    }
-#pragma unroll
-    for (int k = 0; k < m; ++k) u[k] = w.ub[k * SM + t];
-  };
-  fetch(N - 2);
-  for (int t = N - 2; t >= 0; --t) {
-    double xc[n], uc[m], fxc[n][n], fuc[n][m];
-#pragma unroll
-    for (int i = 0; i < n; ++i) {
-      xc[i] = x[i];
-#pragma unroll
-      for (int j = 0; j < n; ++j) fxc[i][j] = fx[i][j];
-#pragma unroll
-      for (int k = 0; k < m; ++k) fuc[i][k] = fu[i][k];
-    }
-#pragma unroll
-    for (int k = 0; k < m; ++k) uc[k] = u[k];
-    fetch(t > 0 ? t - 1 : 0);
+};
 
-    // cost partials (ilqr.py:180-184): lx = 2Qx - 2x_nom^T Q, lu = 2Ru, lxx = 2Q, luu = 2R, lux = 0
-    double Qx[n], Qu[m], Qxx[n][n], Quu[m][m], Qux[m][n];
+template <class M>
+__device__ __forceinline__ void backward_step(const BRegs<M>& r, const Consts<M>& c, const double (&Q2)[M::n][M::n],
+                                              const double (&R2)[M::m][M::m], double (&Vx)[M::n],
+                                              double (&Vxx)[M::n][M::n], double* gw) {
+  constexpr int n = M::n, m = M::m;
+  using Ly = Lay<n, m>;
+  // cost partials (ilqr.py:180-184): lx = 2Qx - 2x_nom^T Q, lu = 2Ru, lxx = 2Q, luu = 2R, lux = 0
+  double Qx[n], Qu[m], Qxx[n][n], Quu[m][m], Qux[m][n];
 #pragma unroll
-    for (int i = 0; i < n; ++i) {
-      double s = 0.0;
+  for (int i = 0; i < n; ++i) {
+    double s = -c.qn[i];
 #pragma unroll
-      for (int j = 0; j < n; ++j) s += (2.0 * c.Q[i][j]) * xc[j];
-      double g = 0.0;
+    for (int j = 0; j < n; ++j) s += Q2[i][j] * r.x[j];
 #pragma unroll
-      for (int k = 0; k < n; ++k) g += fxc[k][i] * Vx[k];
-      Qx[i] = (s - c.qn[i]) + g;                              // :651
-    }
+    for (int k = 0; k < n; ++k) s += r.fx[k][i] * Vx[k];
+    Qx[i] = s;                                              // :651
+  }
 #pragma unroll
-    for (int a_ = 0; a_ < m; ++a_) {
-      double s = 0.0;
+  for (int a_ = 0; a_ < m; ++a_) {
+    double s = 0.0;
 #pragma unroll
-      for (int j = 0; j < m; ++j) s += (2.0 * c.R[a_][j]) * uc[j];
-      double g = 0.0;
+    for (int j = 0; j < m; ++j) s += R2[a_][j] * r.u[j];
 #pragma unroll
-      for (int k = 0; k < n; ++k) g += fuc[k][a_] * Vx[k];
-      Qu[a_] = s + g;                                         // :652
-    }
-    // A = fx^T Vxx (n x n), Bm = fu^T Vxx (m x n)  — the reference's association (fx.T@Vxx)@fx
-    double A[n][n], Bm[m][n];
+    for (int k = 0; k < n; ++k) s += r.fu[k][a_] * Vx[k];
+    Qu[a_] = s;                                             // :652
+  }
+  // A = fx^T Vxx (n x n), Bm = fu^T Vxx (m x n)  — the reference's association (fx.T@Vxx)@fx
+  double A[n][n], Bm[m][n];
 #pragma unroll
-    for (int i = 0; i < n; ++i)
-#pragma unroll
-      for (int j = 0; j < n; ++j) {
-        double s = 0.0;
-#pragma unroll
-        for (int k = 0; k < n; ++k) s += fxc[k][i] * Vxx[k][j];
-        A[i][j] = s;
-      }
-#pragma unroll
-    for (int a_ = 0; a_ < m; ++a_)
-#pragma unroll
-      for (int j = 0; j < n; ++j) {
-        double s = 0.0;
-#pragma unroll
-        for (int k = 0; k < n; ++k) s += fuc[k][a_] * Vxx[k][j];
-        Bm[a_][j] = s;
-      }
-#pragma unroll
-    for (int i = 0; i < n; ++i)
-#pragma unroll
-      for (int j = 0; j < n; ++j) {
-        double s = 0.0;
-#pragma unroll
-        for (int k = 0; k < n; ++k) s += A[i][k] * fxc[k][j];
-        Qxx[i][j] = 2.0 * c.Q[i][j] + s;                      // :653
-      }
-#pragma unroll
-    for (int a_ = 0; a_ < m; ++a_) {
-#pragma unroll
-      for (int b_ = 0; b_ < m; ++b_) {
-        double s = 0.0;
-#pragma unroll
-        for (int k = 0; k < n; ++k) s += Bm[a_][k] * fuc[k][b_];
-        Quu[a_][b_] = 2.0 * c.R[a_][b_] + s;                  // :654
-      }
-#pragma unroll
-      for (int j = 0; j < n; ++j) {
-        double s = 0.0;
-#pragma unroll
-        for (int k = 0; k < n; ++k) s += Bm[a_][k] * fxc[k][j];
-        Qux[a_][j] = s;                                       // :656 (lux = 0)
-      }
-    }
-    double Qi[m][m];
-    invert_small<m>(Quu, Qi);                                 // :655 explicit inverse
-    double kap[m], Kg[m][n], QuQi[m];
-#pragma unroll
-    for (int a_ = 0; a_ < m; ++a_) {
-      double s = 0.0, r = 0.0;
-#pragma unroll
-      for (int b_ = 0; b_ < m; ++b_) { s += Qi[a_][b_] * Qu[b_]; r += Qu[b_] * Qi[b_][a_]; }
-      kap[a_] = s;                                            // :659
-      QuQi[a_] = r;                                           // Qu^T Quu_inv
-#pragma unroll
-      for (int j = 0; j < n; ++j) {
-        double g = 0.0;
-#pragma unroll
-        for (int b_ = 0; b_ < m; ++b_) g += Qi[a_][b_] * Qux[b_][j];
-        Kg[a_][j] = g;                                        // :660
-      }
-    }
-    double dv = 0.0;
-#pragma unroll
-    for (int a_ = 0; a_ < m; ++a_) dv += QuQi[a_] * Qu[a_];   // :663
-    if (writer) {
-#pragma unroll
-      for (int a_ = 0; a_ < m; ++a_) {
-        w.kap[a_ * SM + t] = kap[a_];
-#pragma unroll
-        for (int j = 0; j < n; ++j) w.K[(a_ * n + j) * SM + t] = Kg[a_][j];
-      }
-      w.dV[t] = dv;
-    }
-    // Vx = Qx - Qu^T Quu_inv Qux ; Vxx = Qxx - Qux^T Quu_inv Qux   (:666-667; no symmetrization)
+  for (int i = 0; i < n; ++i)
 #pragma unroll
     for (int j = 0; j < n; ++j) {
       double s = 0.0;
 #pragma unroll
-      for (int a_ = 0; a_ < m; ++a_) s += QuQi[a_] * Qux[a_][j];
-      Vx[j] = Qx[j] - s;
+      for (int k = 0; k < n; ++k) s += r.fx[k][i] * Vxx[k][j];
+      A[i][j] = s;
     }
-    double QuxTQi[n][m];
 #pragma unroll
-    for (int i = 0; i < n; ++i)
+  for (int a_ = 0; a_ < m; ++a_)
 #pragma unroll
-      for (int b_ = 0; b_ < m; ++b_) {
-        double s = 0.0;
+    for (int j = 0; j < n; ++j) {
+      double s = 0.0;
 #pragma unroll
-        for (int a_ = 0; a_ < m; ++a_) s += Qux[a_][i] * Qi[a_][b_];
-        QuxTQi[i][b_] = s;
-      }
+      for (int k = 0; k < n; ++k) s += r.fu[k][a_] * Vxx[k][j];
+      Bm[a_][j] = s;
+    }
 #pragma unroll
-    for (int i = 0; i < n; ++i)
+  for (int i = 0; i < n; ++i)
 #pragma unroll
-      for (int j = 0; j < n; ++j) {
-        double s = 0.0;
+    for (int j = 0; j < n; ++j) {
+      double s = Q2[i][j];
 #pragma unroll
-        for (int b_ = 0; b_ < m; ++b_) s += QuxTQi[i][b_] * Qux[b_][j];
-        Vxx[i][j] = Qxx[i][j] - s;
-      }
+      for (int k = 0; k < n; ++k) s += A[i][k] * r.fx[k][j];
+      Qxx[i][j] = s;                                        // :653
+    }
+#pragma unroll
+  for (int a_ = 0; a_ < m; ++a_) {
+#pragma unroll
+    for (int b_ = 0; b_ < m; ++b_) {
+      double s = R2[a_][b_];
+#pragma unroll
+      for (int k = 0; k < n; ++k) s += Bm[a_][k] * r.fu[k][b_];
+      Quu[a_][b_] = s;                                      // :654
+    }
+#pragma unroll
+    for (int j = 0; j < n; ++j) {
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < n; ++k) s += Bm[a_][k] * r.fx[k][j];
+      Qux[a_][j] = s;                                       // :656 (lux = 0)
+    }
   }
+  double Qi[m][m];
+  invert_small<m>(Quu, Qi);                                 // :655 explicit inverse
+  double kap[m], Kg[m][n], QuQi[m];
+#pragma unroll
+  for (int a_ = 0; a_ < m; ++a_) {
+    double s = 0.0, q = 0.0;
+#pragma unroll
+    for (int b_ = 0; b_ < m; ++b_) { s += Qi[a_][b_] * Qu[b_]; q += Qu[b_] * Qi[b_][a_]; }
+    kap[a_] = s;                                            // :659
+    QuQi[a_] = q;                                           // Qu^T Quu_inv
+#pragma unroll
+    for (int j = 0; j < n; ++j) {
+      double g = 0.0;
+#pragma unroll
+      for (int b_ = 0; b_ < m; ++b_) g += Qi[a_][b_] * Qux[b_][j];
+      Kg[a_][j] = g;                                        // :660
+    }
+  }
+  double dv = 0.0;
+#pragma unroll
+  for (int a_ = 0; a_ < m; ++a_) dv += QuQi[a_] * Qu[a_];   // :663
+#pragma unroll
+  for (int a_ = 0; a_ < m; ++a_) {
+    gw[Ly::KAP + a_] = kap[a_];
+#pragma unroll
+    for (int j = 0; j < n; ++j) gw[Ly::KK + a_ * n + j] = Kg[a_][j];
+  }
+  gw[Ly::DV] = dv;
+  // Vx = Qx - Qu^T Quu_inv Qux ; Vxx = Qxx - Qux^T Quu_inv Qux   (:666-667; no symmetrization)
+#pragma unroll
+  for (int j = 0; j < n; ++j) {
+    double s = Qx[j];
+#pragma unroll
+    for (int a_ = 0; a_ < m; ++a_) s -= QuQi[a_] * Qux[a_][j];
+    Vx[j] = s;
+  }
+  double QuxTQi[n][m];
+#pragma unroll
+  for (int i = 0; i < n; ++i)
+#pragma unroll
+    for (int b_ = 0; b_ < m; ++b_) {
+      double s = 0.0;
+#pragma unroll
+      for (int a_ = 0; a_ < m; ++a_) s += Qux[a_][i] * Qi[a_][b_];
+      QuxTQi[i][b_] = s;
+    }
+#pragma unroll
+  for (int i = 0; i < n; ++i)
+#pragma unroll
+    for (int j = 0; j < n; ++j) {
+      double s = Qxx[i][j];
+#pragma unroll
+      for (int b_ = 0; b_ < m; ++b_) s -= QuxTQi[i][b_] * Qux[b_][j];
+      Vxx[i][j] = s;
+    }
+}
+
+template <class M>
+__device__ inline void backward(const WS& w, const Consts<M>& c) {
+  constexpr int n = M::n, m = M::m;
+  using Ly = Lay<n, m>;
+  const int N = w.N;
+  double Q2[n][n], R2[m][m];
+#pragma unroll
+  for (int i = 0; i < n; ++i)
+#pragma unroll
+    for (int j = 0; j < n; ++j) Q2[i][j] = 2.0 * c.Q[i][j];
+#pragma unroll
+  for (int i = 0; i < m; ++i)
+#pragma unroll
+    for (int j = 0; j < m; ++j) R2[i][j] = 2.0 * c.R[i][j];
+  double Vx[n], Vxx[n][n];
+  {
+    const double* gT = w.G + (N - 1) * Ly::GS;
+#pragma unroll
+    for (int i = 0; i < n; ++i) {
+      double s = 0.0;
+#pragma unroll
+      for (int j = 0; j < n; ++j) { s += (2.0 * c.Qf[i][j]) * gT[Ly::XB + j]; Vxx[i][j] = 2.0 * c.Qf[i][j]; }
+      Vx[i] = s - c.qfn[i];                                 // ilqr.py:203-204
+    }
+  }
+  const bool writer = threadIdx.x == 0;
+  const double* g = w.G + (N - 2) * Ly::GS;
+  const double* j = w.J + (N - 2) * Ly::JS;
+  double* gw = writer ? const_cast<double*>(g) : (w.dump + 2 * threadIdx.x);
+  const int gstep = writer ? Ly::GS : 0;
+  BRegs<M> A, B;
+  A.load(g, j);
+  int t = N - 2;
+  for (; t >= 1; t -= 2) {
+    B.load(g - Ly::GS, j - Ly::JS);
+    __builtin_amdgcn_sched_barrier(0);                   // keep the prefetch a full step ahead
+    backward_step<M>(A, c, Q2, R2, Vx, Vxx, gw);
+    gw -= gstep;
+    A.load(g - 2 * Ly::GS, j - 2 * Ly::JS);              // t-2 >= -1: the leading pad record
+    __builtin_amdgcn_sched_barrier(0);
+    backward_step<M>(B, c, Q2, R2, Vx, Vxx, gw);
+    gw -= gstep;
+    g -= 2 * Ly::GS;
+    j -= 2 * Ly::JS;
+  }
+  if (t == 0) backward_step<M>(A, c, Q2, R2, Vx, Vxx, gw);
 }
 
 // ---------------------------------------------------------------------------
@@ -716,6 +801,7 @@ __device__ inline void backward(const WS& w, const Consts<M>& c) {
 template <class M, int JAC, int MODE>
 __global__ void __launch_bounds__(64) ilqr_small_kernel(const KArgs a) {
   constexpr int n = M::n, m = M::m;
+  using Ly = Lay<n, m>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = blockIdx.x;
   const int lane = threadIdx.x;
@@ -725,13 +811,13 @@ __global__ void __launch_bounds__(64) ilqr_small_kernel(const KArgs a) {
   const size_t oFx = (size_t)b * n * n * (N - 1), oFu = (size_t)b * n * m * (N - 1), oT = (size_t)b * (N - 1);
 
   const bool cold = a.cold != 0;
-  copy_in(w.xb, a.x_bar + oX, n * N, cold);
-  copy_in(w.ub, (a.u_pending ? a.u_guess : a.u_bar) + oU, m * (N - 1), false);
-  copy_in(w.K, a.K + oK, m * n * (N - 1), cold);
-  copy_in(w.kap, a.kappa + oU, m * (N - 1), cold);
-  copy_in(w.dV, a.dV + oT, N - 1, cold);
-  copy_in(w.fx, a.fx + oFx, n * n * (N - 1), cold);
-  copy_in(w.fu, a.fu + oFu, n * m * (N - 1), cold);
+  stage_in(w.G, Ly::GS, Ly::XB, a.x_bar + oX, n, N, cold);
+  stage_in(w.G, Ly::GS, Ly::UB, (a.u_pending ? a.u_guess : a.u_bar) + oU, m, N - 1, false);
+  stage_in(w.G, Ly::GS, Ly::KK, a.K + oK, m * n, N - 1, cold);
+  stage_in(w.G, Ly::GS, Ly::KAP, a.kappa + oU, m, N - 1, cold);
+  stage_in(w.G, Ly::GS, Ly::DV, a.dV + oT, 1, N - 1, cold);
+  stage_in(w.J, Ly::JS, Ly::FX, a.fx + oFx, n * n, N - 1, cold);
+  stage_in(w.J, Ly::JS, Ly::FU, a.fu + oFu, n * m, N - 1, cold);
 
   Consts<M> c;
   c.load(a.costmat);
@@ -744,15 +830,15 @@ __global__ void __launch_bounds__(64) ilqr_small_kernel(const KArgs a) {
     double L, ex;
     rollout<M>(w, c, a, x0r, a.stage_in[b], lane == 0, L, ex);
     wave_sync();
-    copy_out(a.x_trial + oX, w.xn, n * N);
-    copy_out(a.u_trial + oU, w.un, m * (N - 1));
+    stage_out(a.x_trial + oX, w.T, Ly::TS, Ly::XN, n, N);
+    stage_out(a.u_trial + oU, w.T, Ly::TS, Ly::UN, m, N - 1);
     if (lane == 0) { a.trial_cost[2 * b] = L; a.trial_cost[2 * b + 1] = ex; }
     return;
   }
   if (MODE == MODE_LINEARIZE) {
-    const int nk = linearize<M, JAC>(w, a, w.xb, w.ub);
-    copy_out(a.fx + oFx, w.fx, n * n * (N - 1));
-    copy_out(a.fu + oFu, w.fu, n * m * (N - 1));
+    const int nk = linearize<M, JAC>(w, a);
+    stage_out(a.fx + oFx, w.J, Ly::JS, Ly::FX, n * n, N - 1);
+    stage_out(a.fu + oFu, w.J, Ly::JS, Ly::FU, n * m, N - 1);
     for (int i = lane; i < nk; i += 64) a.kp_list[(size_t)b * (N - 1) + i] = w.kp[i];
     if (lane == 0) a.kp_count[b] = nk;
     return;
@@ -760,9 +846,9 @@ __global__ void __launch_bounds__(64) ilqr_small_kernel(const KArgs a) {
   if (MODE == MODE_BACKWARD) {
     backward<M>(w, c);
     wave_sync();
-    copy_out(a.K + oK, w.K, m * n * (N - 1));
-    copy_out(a.kappa + oU, w.kap, m * (N - 1));
-    copy_out(a.dV + oT, w.dV, N - 1);
+    stage_out(a.K + oK, w.G, Ly::GS, Ly::KK, m * n, N - 1);
+    stage_out(a.kappa + oU, w.G, Ly::GS, Ly::KAP, m, N - 1);
+    stage_out(a.dV + oT, w.G, Ly::GS, Ly::DV, 1, N - 1);
     return;
   }
 
@@ -772,16 +858,25 @@ __global__ void __launch_bounds__(64) ilqr_small_kernel(const KArgs a) {
   int iters = 0, ls_total = 0, nk = 0;
   int status = MI_STATUS_CONVERGED;
   double* hist = a.hist + (size_t)b * a.hist_cap * 4;
+  // the reference's stopwatches (time_fp / time_getDerivs / time_backwardsPass, ilqr.py:364-372,696-699)
+  long long c_ls = 0, c_lin = 0, c_bp = 0;
+  const long long c_begin = clock64();
   while (improvement > a.delta) {
     if (iters >= a.max_iters) { status = MI_STATUS_MAX_ITERS; break; }
     double L_new, eps; int trials;
+    const long long c0 = clock64();
     const bool ok = linesearch<M>(w, c, a, x0r, L, L_new, eps, trials);
     ls_total += trials;
     if (!ok) { status = MI_STATUS_LINESEARCH_FAILED; break; }
     wave_sync();
-    nk = linearize<M, JAC>(w, a, w.xn, w.un);                  // at the ACCEPTED trajectory (:370)
-    { double* t_; t_ = w.xb; w.xb = w.xn; w.xn = t_; t_ = w.ub; w.ub = w.un; w.un = t_; }   // :375-376
-    if (MODE == MODE_SOLVE) { backward<M>(w, c); wave_sync(); }   // :697
+    const long long c1 = clock64();
+    commit_trial<n, m>(w);                                      // u_bar <- u, x_bar <- x (:375-376)
+    wave_sync();
+    nk = linearize<M, JAC>(w, a);                               // at the ACCEPTED trajectory (:370)
+    const long long c2 = clock64();
+    if (MODE == MODE_SOLVE) { backward<M>(w, c); wave_sync(); } // :697
+    const long long c3 = clock64();
+    c_ls += c1 - c0; c_lin += c2 - c1; c_bp += c3 - c2;
     if (lane == 0 && iters < a.hist_cap) {
       hist[4 * iters + 0] = L_new; hist[4 * iters + 1] = eps;
       hist[4 * iters + 2] = (double)trials; hist[4 * iters + 3] = (double)nk / (double)(N - 1) * 100.0;   // :406
@@ -792,18 +887,19 @@ __global__ void __launch_bounds__(64) ilqr_small_kernel(const KArgs a) {
     if (MODE == MODE_FORWARD) break;
   }
   wave_sync();
-  copy_out(a.x_bar + oX, w.xb, n * N);
-  copy_out(a.u_bar + oU, w.ub, m * (N - 1));
-  copy_out(a.fx + oFx, w.fx, n * n * (N - 1));
-  copy_out(a.fu + oFu, w.fu, n * m * (N - 1));
+  stage_out(a.x_bar + oX, w.G, Ly::GS, Ly::XB, n, N);
+  stage_out(a.u_bar + oU, w.G, Ly::GS, Ly::UB, m, N - 1);
+  stage_out(a.fx + oFx, w.J, Ly::JS, Ly::FX, n * n, N - 1);
+  stage_out(a.fu + oFu, w.J, Ly::JS, Ly::FU, n * m, N - 1);
   if (MODE == MODE_SOLVE) {
-    copy_out(a.K + oK, w.K, m * n * (N - 1));
-    copy_out(a.kappa + oU, w.kap, m * (N - 1));
-    copy_out(a.dV + oT, w.dV, N - 1);
+    stage_out(a.K + oK, w.G, Ly::GS, Ly::KK, m * n, N - 1);
+    stage_out(a.kappa + oU, w.G, Ly::GS, Ly::KAP, m, N - 1);
+    stage_out(a.dV + oT, w.G, Ly::GS, Ly::DV, 1, N - 1);
   }
   for (int i = lane; i < nk; i += 64) a.kp_list[(size_t)b * (N - 1) + i] = w.kp[i];
   if (lane == 0) {
     a.cost[b] = L; a.iters[b] = iters; a.status[b] = status; a.ls_trials[b] = ls_total; a.kp_count[b] = nk;
+    a.prof[4 * b + 0] = c_ls; a.prof[4 * b + 1] = c_lin; a.prof[4 * b + 2] = c_bp; a.prof[4 * b + 3] = clock64() - c_begin;
   }
 }
 

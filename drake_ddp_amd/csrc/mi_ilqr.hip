@@ -28,6 +28,7 @@ struct mi_ilqr {
   double *x0 = nullptr, *u_guess = nullptr, *cost = nullptr, *hist = nullptr;
   double *x_trial = nullptr, *u_trial = nullptr, *trial_cost = nullptr, *stage_in = nullptr, *costmat = nullptr;
   int32_t *iters = nullptr, *status = nullptr, *ls_trials = nullptr, *kp_count = nullptr, *kp_list = nullptr;
+  long long* prof = nullptr;
   bool cold = true;        // persistent state is known to be all zero (fresh object / after reset)
   bool u_pending = false;  // SetInitialGuess input waiting in u_guess
   size_t lds = 0;
@@ -79,6 +80,7 @@ KArgs make_args(const mi_ilqr* h) {
   a.x_trial = h->x_trial; a.u_trial = h->u_trial; a.trial_cost = h->trial_cost; a.stage_in = h->stage_in;
   a.costmat = h->costmat;
   a.iters = h->iters; a.status = h->status; a.ls_trials = h->ls_trials; a.kp_count = h->kp_count; a.kp_list = h->kp_list;
+  a.prof = h->prof;
   for (int i = 0; i < MI_ILQR_MAX_PARAMS; ++i) a.params[i] = h->d.model_params[i];
   a.dt = h->d.dt; a.delta = h->d.delta; a.beta = h->d.beta; a.gamma = h->d.gamma;
   a.jerk_thr = h->d.jerk_threshold; a.err_thr = h->d.iterative_error_threshold; a.fd_h = h->d.fd_step;
@@ -299,6 +301,7 @@ int mi_ilqr_create(const mi_ilqr_desc* desc, mi_ilqr_t** out) {
   ALLOC(h->ls_trials, B, int32_t);
   ALLOC(h->kp_count, B, int32_t);
   ALLOC(h->kp_list, B * (N - 1), int32_t);
+  ALLOC(h->prof, B * 4, long long);
 #undef ALLOC
   // defaults Q=I, R=I, Qf=I, x_nom=0 (ilqr.py:61-67)
   {
@@ -324,7 +327,7 @@ void mi_ilqr_destroy(mi_ilqr_t* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   void* ptrs[] = {h->x_bar, h->u_bar, h->K, h->kappa, h->dV, h->fx, h->fu, h->x0, h->u_guess, h->cost, h->hist,
                   h->x_trial, h->u_trial, h->trial_cost, h->stage_in, h->costmat, h->iters, h->status, h->ls_trials,
-                  h->kp_count, h->kp_list};
+                  h->kp_count, h->kp_list, h->prof};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -529,6 +532,23 @@ int mi_ilqr_device_ptr(mi_ilqr_t* h, int which, void** ptr, size_t* bytes) {
   if (!f.ptr) return MI_ILQR_E_BAD_ARG;
   *ptr = f.ptr;
   if (bytes) *bytes = f.bytes;
+  return MI_ILQR_OK;
+}
+
+int mi_ilqr_last_kernel_ms(mi_ilqr_t* h, float* ms) {
+  if (!h || !ms) return MI_ILQR_E_BAD_ARG;
+  HIPCHK(hipSetDevice(h->d.device_id));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipEventElapsedTime(ms, h->ev0, h->ev1));
+  return MI_ILQR_OK;
+}
+
+int mi_ilqr_get_cycles(mi_ilqr_t* h, int64_t* dst, size_t bytes) {
+  if (!h || !dst) return MI_ILQR_E_BAD_ARG;
+  if (bytes != (size_t)h->B * 4 * 8) return MI_ILQR_E_BAD_SHAPE;
+  HIPCHK(hipSetDevice(h->d.device_id));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipMemcpy(dst, h->prof, bytes, hipMemcpyDeviceToHost));
   return MI_ILQR_OK;
 }
 

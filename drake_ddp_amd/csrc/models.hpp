@@ -16,7 +16,8 @@ struct Pendulum {            // params [ml2, b, mgl]
   __device__ static inline void step(const T* x, const T* u, T* xn, const double* p, double dt) {
     const double ml2 = p[0], b = p[1], mgl = p[2];
     const T th = x[0], w = x[1];
-    const T acc = (u[0] - b * w - mgl * mi_sin(th)) / ml2;
+    const double inv_ml2 = 1.0 / ml2;      // loop-invariant: hoisted out of the time loops
+    const T acc = (u[0] - b * w - mgl * mi_sin(th)) * inv_ml2;
     const T wn = w + dt * acc;
     xn[0] = th + dt * wn;
     xn[1] = wn;
@@ -43,9 +44,9 @@ struct Acrobot {             // params [m1,m2,l1,lc1,lc2,Ic1,Ic2,b1,b2,g]
     const T g2 = g * m2 * lc2 * s12;
     const T r1 = -cb1 - g1 - b1 * v1;
     const T r2 = u[0] - cb2 - g2 - b2 * v2;
-    const T det = M11 * M22 - M12 * M12;
-    const T a1 = (M22 * r1 - M12 * r2) / det;
-    const T a2 = (M11 * r2 - M12 * r1) / det;
+    const T idet = mi_rcp(M11 * M22 - M12 * M12);
+    const T a1 = (M22 * r1 - M12 * r2) * idet;
+    const T a2 = (M11 * r2 - M12 * r1) * idet;
     const T v1n = v1 + dt * a1, v2n = v2 + dt * a2;
     xn[0] = q1 + dt * v1n;
     xn[1] = q2 + dt * v2n;
@@ -75,9 +76,9 @@ struct CartPoleT {           // params [mc, mp, l, g, wall_face_x, ball_radius, 
       r1 = r1 + F;
       r2 = r2 + F * l * c;
     }
-    const T det = M11 * M22 - M12 * M12;
-    const T a1 = (M22 * r1 - M12 * r2) / det;
-    const T a2 = (M11 * r2 - M12 * r1) / det;
+    const T idet = mi_rcp(M11 * M22 - M12 * M12);
+    const T a1 = (M22 * r1 - M12 * r2) * idet;
+    const T a2 = (M11 * r2 - M12 * r1) * idet;
     const T vxn = vx + dt * a1, wn = w + dt * a2;
     xn[0] = px + dt * vxn;
     xn[1] = th + dt * wn;

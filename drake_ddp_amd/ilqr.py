@@ -172,6 +172,19 @@ class BatchedIterativeLQR:
         for k, v in fields.items():
             self._set(table[k][0], v, table[k][1])
 
+    @property
+    def stage_cycles(self):
+        """(B,4) in-kernel shader-clock cycles of the last solve: line search, linearization,
+        backward pass, whole loop (device counterpart of time_fp/time_getDerivs/time_backwardsPass)."""
+        out = np.empty((self.B, 4), dtype=np.int64)
+        _capi.check(self._lib.mi_ilqr_get_cycles(self._h, _capi.ptr(out), out.nbytes), "mi_ilqr_get_cycles")
+        return out
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        _capi.check(self._lib.mi_ilqr_last_kernel_ms(self._h, C.byref(ms)), "mi_ilqr_last_kernel_ms")
+        return float(ms.value)
+
     def Reset(self):
         """Forget warm-start state: equivalent to constructing a new solver (ilqr.py:70-83)."""
         _capi.check(self._lib.mi_ilqr_reset(self._h), "mi_ilqr_reset")

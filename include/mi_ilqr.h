@@ -180,6 +180,14 @@ int mi_ilqr_device_ptr(mi_ilqr_t* h, int which, void** ptr, size_t* bytes);
 int mi_ilqr_get_stream(mi_ilqr_t* h, void** hip_stream);
 int mi_ilqr_synchronize(mi_ilqr_t* h);
 
+/* Per-problem in-kernel stopwatches of the last solve, shader-clock cycles, (B,4):
+ * line search, linearization, backward pass, whole Solve loop — the device counterpart
+ * of the reference's time_fp / time_getDerivs / time_backwardsPass (ilqr.py:364-372,696-699). */
+int mi_ilqr_get_cycles(mi_ilqr_t* h, int64_t* dst, size_t bytes);
+
+/* HIP-event duration of the most recent kernel launch on the handle's stream. */
+int mi_ilqr_last_kernel_ms(mi_ilqr_t* h, float* ms);
+
 /* Algorithmic bytes of one iteration of one problem with `ls` line-search trials. */
 double mi_ilqr_bytes_per_iteration(int32_t n, int32_t m, int32_t N, int32_t ls);
 
