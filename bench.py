@@ -24,6 +24,22 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def pmc_traffic(batch):
+    """HBM bytes per launch of the solve kernel from the committed rocprofv3 PMC passes
+    (profiles/rNN_pmc_c2.json: FETCH_SIZE and WRITE_SIZE collected in separate runs of THIS
+    command, gfx950 read correction applied).  bench.py cannot run the profiler on itself,
+    so the latest committed measurement for the same workload is reported; null otherwise."""
+    import glob
+    if batch != 1024:
+        return None, None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_c2.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as fh:
+        d = json.load(fh)
+    return d.get("hbm_bytes_per_launch_corrected"), os.path.basename(files[-1])
+
+
 def cpu_baseline(prob, x0, sample, budget_s=25.0):
     """Oracle (NumPy port of the reference algorithm) on the host, single thread, on a
     bounded sample of the same workload.  Reported beside the GPU number; never `value`."""
@@ -135,6 +151,7 @@ def main():
         k_ms = kernel_ms / args.steps                       # avg launch duration of the dominant kernel (HIP events)
         bytes_per_launch = alg_bytes / args.steps
         achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(B)
         out = {
             "metric": "iLQR iterations/sec (batch, whole node)",
             "value": iters_all / elapsed,
@@ -159,7 +176,7 @@ def main():
             "converged_rank0": int(last.n_converged),
             "ls_trials_per_step_rank0": ls_trials / args.steps,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "ilqr_small_kernel<Pendulum,FD,SOLVE>", "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "note": "dependency-latency-bound: 2(N-1) sequential steps per iteration; state is LDS-resident"},

@@ -1,0 +1,65 @@
+"""Multi-GPU plumbing: one process per GPU, each with its own handle over a
+contiguous shard of the batch.  Problems are independent, so the
+data path needs NO collective; the only exchange is the best-cost reduction at
+the end of a batched solve — one RCCL all-reduce(min) of 8 bytes (plus an
+all-gather of 16-byte {cost,index} pairs when the winner's identity is wanted).
+torch.distributed is used as plumbing only (backend "nccl" = RCCL on ROCm; "gloo"
+in the CPU tests)."""
+import numpy as np
+
+
+def shard_range(B, rank, world):
+    """Contiguous block of problems owned by `rank`; sizes differ by at most one."""
+    base, rem = divmod(B, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist if (dist.is_available() and dist.is_initialized()) else None
+
+
+def _device(device_id):
+    import torch
+    dist = _dist()
+    if dist is not None and dist.get_backend() == "nccl":
+        return torch.device("cuda", device_id)
+    return torch.device("cpu")
+
+
+def allreduce_min(value, device_id=0):
+    """min over ranks of a scalar; identity without a process group."""
+    import torch
+    dist = _dist()
+    if dist is None:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=_device(device_id))
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return float(t.item())
+
+
+def best_of_all_ranks(local_best_cost, local_best_index, shard_lo, device_id=0):
+    """(cost, global problem index, owning rank) of the best converged problem of the
+    whole batch: all-gather of one {cost, global index} pair per rank + local argmin."""
+    import torch
+    dist = _dist()
+    gidx = float(shard_lo + local_best_index) if local_best_index >= 0 else -1.0
+    if dist is None:
+        return float(local_best_cost), int(gidx), 0
+    mine = torch.tensor([float(local_best_cost), gidx], dtype=torch.float64, device=_device(device_id))
+    allp = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(allp, mine)
+    costs = np.array([float(p[0]) for p in allp])
+    r = int(np.argmin(costs))
+    return float(costs[r]), int(allp[r][1].item()), r
+
+
+def allreduce_sum(values, device_id=0):
+    """Element-wise sum over ranks of a small vector (iteration counters for the metric)."""
+    import torch
+    dist = _dist()
+    v = torch.tensor(np.asarray(values, dtype=np.float64), dtype=torch.float64, device=_device(device_id))
+    if dist is not None:
+        dist.all_reduce(v, op=dist.ReduceOp.SUM)
+    return v.cpu().numpy()

@@ -23,11 +23,7 @@ _JAC_IDS = {"fd": _capi.JAC_FD_CENTRAL, "fd_central": _capi.JAC_FD_CENTRAL,
             "autodiff": _capi.JAC_AUTODIFF, "ad": _capi.JAC_AUTODIFF}
 
 
-def shard_range(B, rank, world):
-    """Contiguous block of problems owned by `rank`."""
-    base, rem = divmod(B, world)
-    lo = rank * base + min(rank, rem)
-    return lo, lo + base + (1 if rank < rem else 0)
+from .dist import shard_range, allreduce_min  # noqa: E402,F401
 
 
 class BatchedIterativeLQR:
@@ -251,15 +247,8 @@ class BatchedIterativeLQR:
         """min over all ranks of the best converged cost — the ONE collective of the
         path: a single RCCL all-reduce(min) per batched solve, off
         the per-iteration path.  No-op without an initialized process group."""
-        import torch
-        import torch.distributed as dist
         best = float(self.stats.best_cost) if self.stats is not None else float(np.min(self.cost))
-        if not (dist.is_available() and dist.is_initialized()):
-            return best
-        dev = torch.device("cuda", self._desc.device_id) if dist.get_backend() == "nccl" else torch.device("cpu")
-        t = torch.tensor([best], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        return float(t.item())
+        return allreduce_min(best, self._desc.device_id)
 
 
 class IterativeLinearQuadraticRegulator(BatchedIterativeLQR):

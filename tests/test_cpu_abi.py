@@ -1,0 +1,126 @@
+"""CPU-side checks (no GPU): the C-ABI library loads, exports every symbol that
+include/mi_ilqr.h declares, fails loudly (no CPU fallback) without a device, and the
+host-side mirror validates arguments like the reference class does."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from drake_ddp_amd import build, _capi
+    build.build(force=False, verbose=False)
+    return _capi.load()
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "mi_ilqr.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mi_ilqr_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    from drake_ddp_amd import _capi
+    syms = header_symbols()
+    assert len(syms) >= 25
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/mi_ilqr.h but not exported"
+    assert sorted(_capi.EXPORTS) == syms       # the ctypes binding covers the whole header
+
+
+def test_abi_version_and_strerror(lib):
+    from drake_ddp_amd import _capi
+    assert lib.mi_ilqr_abi_version() == _capi.ABI_VERSION
+    assert b"linesearch failed" in lib.mi_ilqr_strerror(_capi.E_LINESEARCH)
+    assert b"no CPU fallback" in lib.mi_ilqr_strerror(_capi.E_NO_DEVICE)
+
+
+def test_model_registry_matches_python_side(lib):
+    from drake_ddp_amd import models
+    for mid, (n, m) in models._DIMS.items():
+        nn, mm, npar = C.c_int32(), C.c_int32(), C.c_int32()
+        buf = (C.c_double * 16)()
+        assert lib.mi_ilqr_model_info(mid, C.byref(nn), C.byref(mm), C.byref(npar), buf) == 0
+        assert (nn.value, mm.value) == (n, m)
+        assert list(buf)[:npar.value] == models._DEFAULTS[mid]
+    assert lib.mi_ilqr_model_info(99, None, None, None, None) != 0
+
+
+def test_bytes_per_iteration_formula(lib):
+    # SURVEY.md §8d per-unit figures
+    assert lib.mi_ilqr_bytes_per_iteration(2, 1, 200, 1) == 49424
+    assert lib.mi_ilqr_bytes_per_iteration(4, 1, 40, 1) == 22288
+    assert lib.mi_ilqr_bytes_per_iteration(4, 1, 200, 1) == 113168
+    assert lib.mi_ilqr_bytes_per_iteration(36, 12, 40, 1) == 1416704
+
+
+def test_create_validates_and_fails_loudly_without_gpu(lib):
+    import torch
+    from drake_ddp_amd import _capi
+    d = _capi.Desc()
+    d.n, d.m, d.N, d.B, d.model_id, d.minN, d.fd_step = 2, 1, 200, 4, 0, 1, 1e-5
+    h = C.c_void_p()
+    bad = _capi.Desc.from_buffer_copy(d); bad.n = 3
+    assert lib.mi_ilqr_create(C.byref(bad), C.byref(h)) == _capi.E_BAD_SHAPE
+    bad = _capi.Desc.from_buffer_copy(d); bad.keypoint_method = 7
+    assert lib.mi_ilqr_create(C.byref(bad), C.byref(h)) == _capi.E_BAD_METHOD
+    bad = _capi.Desc.from_buffer_copy(d); bad.minN = 0
+    assert lib.mi_ilqr_create(C.byref(bad), C.byref(h)) == _capi.E_BAD_ARG
+    if not torch.cuda.is_available():
+        assert lib.mi_ilqr_create(C.byref(d), C.byref(h)) == _capi.E_NO_DEVICE   # never a CPU fallback
+        assert not h.value
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "drake_ddp_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text, f
+
+
+def test_host_mirror_argument_checks():
+    """Same assertion behaviour as the reference setters (ilqr.py:130-131,145,155)."""
+    import torch
+    from drake_ddp_amd.models import ModelSystem, Pendulum
+    from drake_ddp_amd.utils_derivs_interpolation import derivs_interpolation, index_tuple
+    assert derivs_interpolation('setInterval', 1, 0, 0, 0).keypoint_method == 'setInterval'
+    assert index_tuple(1, 2).end_index == 2
+    sysm = Pendulum(1e-2)
+    assert sysm.IsDifferenceEquationSystem()[0] and sysm.GetSubsystemByName("plant").time_step() == 1e-2
+    assert isinstance(sysm, ModelSystem) and (sysm.n, sysm.m) == (2, 1)
+    if torch.cuda.is_available():
+        return
+    from drake_ddp_amd.ilqr import IterativeLinearQuadraticRegulator
+    from drake_ddp_amd._capi import MiIlqrError
+    with pytest.raises(MiIlqrError):          # constructing the solver needs the device: loud failure
+        IterativeLinearQuadraticRegulator(sysm, 200)
+
+
+def test_shard_range_partitions_exactly():
+    from drake_ddp_amd.ilqr import shard_range
+    for B in (1, 7, 64, 1024, 1025):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(B, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == B
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_mpc_shift_matches_reference_callers():
+    """acrobot.py:147-152 / mini_cheetah.py:193-198 warm start."""
+    from drake_ddp_amd.workloads import mpc_shift
+    rng = np.random.default_rng(0)
+    x, u = rng.normal(size=(4, 40)), rng.normal(size=(1, 39))
+    replan = 2
+    last_u = u[:, -1]
+    ref_guess = np.block([u[:, replan:], np.repeat(last_u[np.newaxis].T, replan, axis=1)])
+    x0, ug = mpc_shift(x, u, replan)
+    assert np.array_equal(ug, ref_guess) and np.array_equal(x0, x[:, replan])
