@@ -25,6 +25,7 @@
 
 #include "../../include/mi_ilqr.h"
 #include "fastmath.hpp"
+#include "keypoints.hpp"
 #include "models.hpp"
 
 namespace mi {
@@ -357,7 +358,7 @@ __device__ inline void commit_trial(const WS& w) {
 // items over lanes.
 // ---------------------------------------------------------------------------
 template <class M, int JAC>
-__device__ inline void jac_at(const WS& w, const KArgs& a, const int* list, int count) {
+__device__ __forceinline__ void jac_at(const WS& w, const KArgs& a, const int* list, int count) {
   constexpr int n = M::n, m = M::m, nc = n + m;
   using Ly = Lay<n, m>;
   const double h = a.fd_h, inv2h = 1.0 / (2.0 * h);
@@ -401,185 +402,28 @@ __device__ inline void jac_at(const WS& w, const KArgs& a, const int* list, int 
   }
 }
 
-// Ordered stream compaction of {t in [0,count) : pred(t)} into list; returns size.
-template <class Pred>
-__device__ inline int compact(int count, int* list, Pred pred) {
-  const int lane = threadIdx.x;
-  int total = 0;
-  for (int t0 = 0; t0 < count; t0 += 64) {
-    const int t = t0 + lane;
-    const bool p = (t < count) && pred(t);
-    const unsigned long long mask = __ballot(p);
-    const int pos = total + __popcll(mask & ((1ull << lane) - 1ull));
-    if (p) list[pos] = t;
-    total += __popcll(mask);
-  }
-  return total;
-}
-
-// get_keypoints_set_interval (ilqr.py:417-432)
-__device__ inline int keypoints_set_interval(const WS& w, int minN) {
-  const int N = w.N;
-  const int count = (N - 2) / minN + 1;            // len(arange(0, N-1, minN))
-  for (int i = threadIdx.x; i < count; i += 64) {
-    int v = i * minN;
-    if (i == count - 1 && v != N - 2) v = N - 2;   // overwrite, not append (:428-430)
-    w.kp[i] = v;
-  }
-  return count;
-}
-
-// get_keypoints_adaptive_jerk + calc_jerk_profile (ilqr.py:434-486).  The jerk
-// test is evaluated for 64 time steps at once; the counter automaton then walks
-// the ballot mask with scalar code.
-template <int n, int m>
-__device__ inline int keypoints_adaptive_jerk(const WS& w, const KArgs& a) {
-  using Ly = Lay<n, m>;
-  const int N = w.N, lane = threadIdx.x;
-  constexpr int dof = n / 2;
-  int nk = 0, since = 0, last = 0;
-  if (lane == 0) w.kp[0] = 0;
-  nk = 1;
-  for (int t0 = 0; t0 < N - 3; t0 += 64) {
-    const int t = t0 + lane;
-    bool trig = false;
-    if (t < N - 3) {
-      const double* g = w.G + t * Ly::GS + Ly::XB;
-#pragma unroll
-      for (int i = 0; i < dof; ++i) {
-        const double v0 = g[i + dof], v1 = g[Ly::GS + i + dof], v2 = g[2 * Ly::GS + i + dof];
-        const double jerk = (v2 - v1) - (v1 - v0);           // signed, no abs (:481-484)
-        trig = trig || (jerk > a.jerk_thr);
-      }
-    }
-    const unsigned long long mask = __ballot(trig);
-    const int lim = (N - 3 - t0) < 64 ? (N - 3 - t0) : 64;
-    for (int j = 0; j < lim; ++j) {
-      since += 1;
-      if (since >= a.minN && ((mask >> j) & 1ull)) {
-        if (lane == 0) w.kp[nk] = t0 + j;
-        last = t0 + j; nk += 1; since = 0;
-      }
-      if (since >= a.maxN) {
-        if (lane == 0) w.kp[nk] = t0 + j;
-        last = t0 + j; nk += 1; since = 0;
-      }
-    }
-  }
-  if (last != N - 2 && lane == 0) w.kp[nk - 1] = N - 2;      // :465-466
-  return nk;
-}
-
-// get_keypoints_iterative_error + check_one_matrix_error (ilqr.py:488-593):
-// level-synchronous bisection, one lane per bin; Jacobians are evaluated (and
-// written into J) only where the reference would evaluate them.
-template <class M, int JAC>
-__device__ inline int keypoints_iterative_error(const WS& w, const KArgs& a) {
-  constexpr int n = M::n;
-  using Ly = Lay<M::n, M::m>;
-  const int N = w.N, lane = threadIdx.x;
-  int* done = w.aux;             // 0/1 per time step: derivative evaluated (deriv_calculated_at_index)
-  int* need = w.need;            // scratch flags: indices a level wants evaluated
-  for (int t = lane; t < N; t += 64) done[t] = 0;
-  int* bins = w.binA;            // (s,e) pairs
-  int* next = w.binB;
-  int nb = 1;
-  if (lane == 0) { bins[0] = 0; bins[1] = N - 2; }
-  wave_sync();
-  // A level's bins are disjoint sub-intervals of [0,N-2] of width >= 1: at most N-1
-  // pairs = 2(N-1) ints per buffer.
-  for (;;) {
-    for (int t = lane; t < N; t += 64) need[t] = 0;
-    wave_sync();
-    for (int i = lane; i < nb; i += 64) {
-      const int s = bins[2 * i], e = bins[2 * i + 1];
-      if (e - s > a.minN) { const int mid = (s + e) / 2; need[s] = 1; need[mid] = 1; need[e] = 1; }
-    }
-    wave_sync();
-    const int cnt = compact(N, w.kp, [&](int t) { return need[t] && !done[t]; });
-    wave_sync();
-    jac_at<M, JAC>(w, a, w.kp, cnt);
-    for (int i = lane; i < cnt; i += 64) done[w.kp[i]] = 1;
-    wave_sync();
-    // evaluate bins; bad ones are split (order within a level is irrelevant to the result)
-    int nn = 0;
-    for (int i0 = 0; i0 < nb; i0 += 64) {
-      const int i = i0 + lane;
-      bool bad = false;
-      int s = 0, e = 0, mid = 0;
-      if (i < nb) {
-        s = bins[2 * i]; e = bins[2 * i + 1]; mid = (s + e) / 2;
-        if (e - s > a.minN) {
-          const double* js = w.J + s * Ly::JS + Ly::FX;
-          const double* je = w.J + e * Ly::JS + Ly::FX;
-          const double* jm = w.J + mid * Ly::JS + Ly::FX;
-          double sum = 0.0;
-#pragma unroll
-          for (int r = 0; r < n * n; ++r) {
-            const double lin = (je[r] + js[r]) / 2.0;
-            const double df = lin - jm[r];
-            sum += df * df;
-          }
-          bad = (sum / (2.0 * n)) > a.err_thr;       // divisor 2n, fx only (:583-591)
-        }
-      }
-      const unsigned long long mask = __ballot(bad);
-      const int pos = nn + __popcll(mask & ((1ull << lane) - 1ull));
-      if (bad) { next[4 * pos] = s; next[4 * pos + 1] = mid; next[4 * pos + 2] = mid; next[4 * pos + 3] = e; }
-      nn += __popcll(mask);
-    }
-    wave_sync();
-    if (nn == 0) break;
-    nb = 2 * nn;
-    int* tmp = bins; bins = next; next = tmp;
-  }
-  const int nk = compact(N - 1, w.kp, [&](int t) { return done[t] != 0; });
-  wave_sync();
-  return nk;
-}
-
-// interpolate_derivatives (ilqr.py:596-621): one lane per key-point segment,
-// interior points only (the end points are reproduced exactly by the formula).
-template <int n, int m>
-__device__ inline void interpolate(const WS& w, int nk) {
-  using Ly = Lay<n, m>;
-  constexpr int cnt = n * n + n * m;
-  for (int i = threadIdx.x; i < nk - 1; i += 64) {
-    const int s = w.kp[i], e = w.kp[i + 1];
-    if (e - s < 2) continue;
-    const double len = (double)(e - s);
-    const double* js = w.J + s * Ly::JS;
-    const double* je = w.J + e * Ly::JS;
-    for (int r = 0; r < cnt; ++r) {
-      const int off = r < n * n ? Ly::FX + r : Ly::FU + (r - n * n);
-      const double fs = js[off], fe = je[off];
-      for (int j = s + 1; j < e; ++j) w.J[j * Ly::JS + off] = fs + (fe - fs) * (double)(j - s) / len;
-    }
-  }
-}
+// Accessor over the LDS records for the shared key-point code (keypoints.hpp).
+template <int n_, int m_>
+struct SmallAcc {
+  static constexpr int n = n_, m = m_;
+  using Ly = Lay<n_, m_>;
+  double *G, *J;
+  int *kp, *aux, *need, *binA, *binB;
+  int N;
+  __device__ SmallAcc(const WS& w) : G(w.G), J(w.J), kp(w.kp), aux(w.aux), need(w.need), binA(w.binA), binB(w.binB), N(w.N) {}
+  __device__ __forceinline__ double x(int t, int i) const { return G[t * Ly::GS + Ly::XB + i]; }
+  __device__ __forceinline__ double fx(int t, int r) const { return J[t * Ly::JS + Ly::FX + r]; }
+  __device__ __forceinline__ double fu(int t, int r) const { return J[t * Ly::JS + Ly::FU + r]; }
+  __device__ __forceinline__ void set_fx(int t, int r, double v) const { J[t * Ly::JS + Ly::FX + r] = v; }
+  __device__ __forceinline__ void set_fu(int t, int r, double v) const { J[t * Ly::JS + Ly::FU + r] = v; }
+};
 
 // _get_derivatives (ilqr.py:380-415) at the nominal trajectory in G.  Returns key-point count.
 template <class M, int JAC>
 __device__ inline int linearize(const WS& w, const KArgs& a) {
-  constexpr int n = M::n, m = M::m;
-  int nk;
-  if (a.kp_method == MI_KP_SET_INTERVAL) {
-    nk = keypoints_set_interval(w, a.minN);
-    wave_sync();
-    jac_at<M, JAC>(w, a, w.kp, nk);
-  } else if (a.kp_method == MI_KP_ADAPTIVE_JERK) {
-    nk = keypoints_adaptive_jerk<n, m>(w, a);
-    wave_sync();
-    jac_at<M, JAC>(w, a, w.kp, nk);
-  } else {
-    nk = keypoints_iterative_error<M, JAC>(w, a);
-  }
-  wave_sync();
-  if (!(a.kp_method == MI_KP_SET_INTERVAL && a.minN == 1)) {   // ilqr.py:414
-    interpolate<n, m>(w, nk);
-    wave_sync();
-  }
-  return nk;
+  SmallAcc<M::n, M::m> acc(w);
+  return linearize_generic(acc, a.kp_method, a.minN, a.maxN, a.jerk_thr, a.err_thr,
+                           [&](const int* list, int count) __attribute__((always_inline)) { jac_at<M, JAC>(w, a, list, count); });
 }
 
 template <int m>

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/mi_ilqr.h"
+#include "ilqr_large.hpp"
 #include "ilqr_small.hpp"
 
 using namespace mi;
@@ -32,6 +33,7 @@ struct mi_ilqr {
   bool cold = true;        // persistent state is known to be all zero (fresh object / after reset)
   bool u_pending = false;  // SetInitialGuess input waiting in u_guess
   size_t lds = 0;
+  bool large = false;      // workgroup-per-problem path: state arrays are TIME-MAJOR in HBM
   float last_ms = 0.f;
 };
 
@@ -66,6 +68,13 @@ size_t small_lds_bytes(int model_id, int N) {
     case MI_MODEL_ACROBOT:
     case MI_MODEL_CARTPOLE:
     case MI_MODEL_CARTPOLE_WALL: return ws_bytes<4, 1>(N);
+    default: return 0;
+  }
+}
+
+size_t large_lds(int model_id, int N) {
+  switch (model_id) {
+    case MI_MODEL_SYNTH36: return large_lds_bytes<Synth36::n, Synth36::m>(N);
     default: return 0;
   }
 }
@@ -114,6 +123,35 @@ int launch_mode(mi_ilqr* h, int mode, const KArgs& a) {
   return MI_ILQR_E_BAD_ARG;
 }
 
+template <class M, int JAC, int MODE>
+int launch_one_large(mi_ilqr* h, const KArgs& a) {
+  auto kern = ilqr_large_kernel<M, JAC, MODE>;
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
+  HIPCHK(hipEventRecord(h->ev0, h->stream));
+  hipLaunchKernelGGL(kern, dim3(h->B), dim3(kLargeThreads), h->lds, h->stream, a);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(h->ev1, h->stream));
+  return MI_ILQR_OK;
+}
+
+template <class M, int JAC>
+int launch_mode_large(mi_ilqr* h, int mode, const KArgs& a) {
+  switch (mode) {
+    case MODE_SOLVE: return launch_one_large<M, JAC, MODE_SOLVE>(h, a);
+    case MODE_ROLLOUT: return launch_one_large<M, JAC, MODE_ROLLOUT>(h, a);
+    case MODE_FORWARD: return launch_one_large<M, JAC, MODE_FORWARD>(h, a);
+    case MODE_LINEARIZE: return launch_one_large<M, JAC, MODE_LINEARIZE>(h, a);
+    case MODE_BACKWARD: return launch_one_large<M, JAC, MODE_BACKWARD>(h, a);
+  }
+  return MI_ILQR_E_BAD_ARG;
+}
+
+template <class M>
+int launch_jac_large(mi_ilqr* h, int mode, const KArgs& a) {
+  if (h->d.jacobian_mode == MI_JAC_AUTODIFF) return launch_mode_large<M, MI_JAC_AUTODIFF>(h, mode, a);
+  return launch_mode_large<M, MI_JAC_FD_CENTRAL>(h, mode, a);
+}
+
 template <class M>
 int launch_jac(mi_ilqr* h, int mode, const KArgs& a) {
   if (h->d.jacobian_mode == MI_JAC_AUTODIFF) return launch_mode<M, MI_JAC_AUTODIFF>(h, mode, a);
@@ -131,6 +169,7 @@ int launch(mi_ilqr* h, int mode) {
     case MI_MODEL_ACROBOT: rc = launch_jac<Acrobot>(h, mode, a); break;
     case MI_MODEL_CARTPOLE: rc = launch_jac<CartPole>(h, mode, a); break;
     case MI_MODEL_CARTPOLE_WALL: rc = launch_jac<CartPoleWall>(h, mode, a); break;
+    case MI_MODEL_SYNTH36: rc = launch_jac_large<Synth36>(h, mode, a); break;
     default: return MI_ILQR_E_UNSUPPORTED;
   }
   return rc;
@@ -169,6 +208,45 @@ __global__ void mpc_shift_kernel(const double* x_bar, const double* u_bar, doubl
     const int src = (t + r < M1) ? t + r : M1 - 1;
     u_guess[((size_t)b * m + k) * M1 + t] = u_bar[((size_t)b * m + k) * M1 + src];
   }
+}
+
+__global__ void mpc_shift_kernel_tm(const double* x_bar, const double* u_bar, double* x0, double* u_guess,
+                                    int B, int n, int m, int N, int r) {
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) x0[(size_t)b * n + i] = x_bar[((size_t)b * N + r) * n + i];
+  const int M1 = N - 1;
+  for (int idx = threadIdx.x; idx < m * M1; idx += blockDim.x) {
+    const int t = idx / m, k = idx - t * m;
+    const int src = (t + r < M1) ? t + r : M1 - 1;
+    u_guess[((size_t)b * M1 + t) * m + k] = u_bar[((size_t)b * M1 + src) * m + k];
+  }
+}
+
+// rows of the (rows,len) time-last view of a double field; 0 = not a trajectory array
+int traj_rows(const mi_ilqr* h, int which, int* len) {
+  const int n = h->n, m = h->m, N = h->N;
+  switch (which) {
+    case MI_F_X_BAR: case MI_F_X_TRIAL: *len = N; return n;
+    case MI_F_U_BAR: case MI_F_U_TRIAL: case MI_F_KAPPA: *len = N - 1; return m;
+    case MI_F_K: *len = N - 1; return m * n;
+    case MI_F_FX: *len = N - 1; return n * n;
+    case MI_F_FU: *len = N - 1; return n * m;
+  }
+  *len = 0;
+  return 0;
+}
+
+// host-side layout conversion for the time-major (large-state) path
+void to_time_last(const double* tm, double* tl, int B, int rows, int len) {
+  for (int b = 0; b < B; ++b)
+    for (int t = 0; t < len; ++t)
+      for (int r = 0; r < rows; ++r) tl[((size_t)b * rows + r) * len + t] = tm[((size_t)b * len + t) * rows + r];
+}
+void to_time_major(const double* tl, double* tm, int B, int rows, int len) {
+  for (int b = 0; b < B; ++b)
+    for (int t = 0; t < len; ++t)
+      for (int r = 0; r < rows; ++r) tm[((size_t)b * len + t) * rows + r] = tl[((size_t)b * rows + r) * len + t];
 }
 
 struct Field { void* ptr; size_t bytes; bool is_int; };
@@ -243,7 +321,8 @@ double mi_ilqr_bytes_per_iteration(int32_t n, int32_t m, int32_t N, int32_t ls) 
 
 size_t mi_ilqr_lds_bytes(const mi_ilqr_desc* d) {
   if (!d) return 0;
-  return small_lds_bytes(d->model_id, d->N);
+  const size_t s_ = small_lds_bytes(d->model_id, d->N);
+  return s_ ? s_ : large_lds(d->model_id, d->N);
 }
 
 int mi_ilqr_create(const mi_ilqr_desc* desc, mi_ilqr_t** out) {
@@ -263,7 +342,9 @@ int mi_ilqr_create(const mi_ilqr_desc* desc, mi_ilqr_t** out) {
   if (desc->device_id < 0 || desc->device_id >= ndev) return MI_ILQR_E_NO_DEVICE;
   HIPCHK(hipSetDevice(desc->device_id));
 
-  const size_t lds = small_lds_bytes(desc->model_id, desc->N);
+  size_t lds = small_lds_bytes(desc->model_id, desc->N);
+  bool large = false;
+  if (lds == 0) { lds = large_lds(desc->model_id, desc->N); large = true; }
   if (lds == 0 || lds > kMaxLds) return MI_ILQR_E_UNSUPPORTED;
 
   mi_ilqr* h = new (std::nothrow) mi_ilqr();
@@ -273,6 +354,7 @@ int mi_ilqr_create(const mi_ilqr_desc* desc, mi_ilqr_t** out) {
   if (h->d.hist_cap <= 0) h->d.hist_cap = 64;
   h->n = desc->n; h->m = desc->m; h->N = desc->N; h->B = desc->B;
   h->lds = lds;
+  h->large = large;
   const size_t n = h->n, m = h->m, N = h->N, B = h->B;
 
 #define ALLOC(p, count, T)                                             \
@@ -353,7 +435,14 @@ int mi_ilqr_set_initial(mi_ilqr_t* h, const double* x0, const double* u_guess) {
   HIPCHK(hipStreamSynchronize(h->stream));
   if (x0) HIPCHK(hipMemcpy(h->x0, x0, (size_t)h->B * h->n * 8, hipMemcpyHostToDevice));
   if (u_guess) {
-    HIPCHK(hipMemcpy(h->u_guess, u_guess, (size_t)h->B * h->m * (h->N - 1) * 8, hipMemcpyHostToDevice));
+    const size_t cnt = (size_t)h->B * h->m * (h->N - 1);
+    if (h->large) {
+      std::vector<double> tm(cnt);
+      to_time_major(u_guess, tm.data(), h->B, h->m, h->N - 1);
+      HIPCHK(hipMemcpy(h->u_guess, tm.data(), cnt * 8, hipMemcpyHostToDevice));
+    } else {
+      HIPCHK(hipMemcpy(h->u_guess, u_guess, cnt * 8, hipMemcpyHostToDevice));
+    }
     h->u_pending = true;
   }
   return MI_ILQR_OK;
@@ -482,8 +571,12 @@ int mi_ilqr_mpc_shift(mi_ilqr_t* h, int32_t replan_steps) {
   int rc;
   if ((rc = materialize_zero_state(h)) != MI_ILQR_OK) return rc;
   if ((rc = materialize_u(h)) != MI_ILQR_OK) return rc;
-  hipLaunchKernelGGL(mpc_shift_kernel, dim3(h->B), dim3(64), 0, h->stream, h->x_bar, h->u_bar, h->x0, h->u_guess,
-                     h->B, h->n, h->m, h->N, (int)replan_steps);
+  if (h->large)
+    hipLaunchKernelGGL(mpc_shift_kernel_tm, dim3(h->B), dim3(64), 0, h->stream, h->x_bar, h->u_bar, h->x0, h->u_guess,
+                       h->B, h->n, h->m, h->N, (int)replan_steps);
+  else
+    hipLaunchKernelGGL(mpc_shift_kernel, dim3(h->B), dim3(64), 0, h->stream, h->x_bar, h->u_bar, h->x0, h->u_guess,
+                       h->B, h->n, h->m, h->N, (int)replan_steps);
   HIPCHK(hipGetLastError());
   h->u_pending = true;
   return MI_ILQR_OK;
@@ -497,8 +590,16 @@ int mi_ilqr_get(mi_ilqr_t* h, int which, double* dst, size_t bytes) {
   HIPCHK(hipSetDevice(h->d.device_id));
   HIPCHK(hipStreamSynchronize(h->stream));
   if (h->cold && is_state_field(which)) { std::memset(dst, 0, bytes); return MI_ILQR_OK; }
-  if (h->u_pending && which == MI_F_U_BAR) { HIPCHK(hipMemcpy(dst, h->u_guess, bytes, hipMemcpyDeviceToHost)); return MI_ILQR_OK; }
-  HIPCHK(hipMemcpy(dst, f.ptr, bytes, hipMemcpyDeviceToHost));
+  const void* src = (h->u_pending && which == MI_F_U_BAR) ? (const void*)h->u_guess : f.ptr;
+  int len = 0;
+  const int rows = h->large ? traj_rows(h, which, &len) : 0;
+  if (rows > 1) {
+    std::vector<double> tm(bytes / 8);
+    HIPCHK(hipMemcpy(tm.data(), src, bytes, hipMemcpyDeviceToHost));
+    to_time_last(tm.data(), dst, h->B, rows, len);
+    return MI_ILQR_OK;
+  }
+  HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
   return MI_ILQR_OK;
 }
 
@@ -521,7 +622,15 @@ int mi_ilqr_set(mi_ilqr_t* h, int which, const double* src, size_t bytes) {
   HIPCHK(hipSetDevice(h->d.device_id));
   if (is_state_field(which)) { int rc = materialize_zero_state(h); if (rc != MI_ILQR_OK) return rc; }
   HIPCHK(hipStreamSynchronize(h->stream));
-  HIPCHK(hipMemcpy(f.ptr, src, bytes, hipMemcpyHostToDevice));
+  int len = 0;
+  const int rows = h->large ? traj_rows(h, which, &len) : 0;
+  if (rows > 1) {
+    std::vector<double> tm(bytes / 8);
+    to_time_major(src, tm.data(), h->B, rows, len);
+    HIPCHK(hipMemcpy(f.ptr, tm.data(), bytes, hipMemcpyHostToDevice));
+  } else {
+    HIPCHK(hipMemcpy(f.ptr, src, bytes, hipMemcpyHostToDevice));
+  }
   if (which == MI_F_U_BAR) h->u_pending = false;
   return MI_ILQR_OK;
 }

@@ -107,6 +107,7 @@ struct Synth36 {             // params [ks, c, kc, bu]; 18 coupled pendula, dofs
   }
   template <class T>
   __device__ static inline void step(const T* x, const T* u, T* xn, const double* p, double dt) {
+#pragma unroll
     for (int i = 0; i < nq; ++i) dof(i, x, u, xn[i], xn[nq + i], p, dt);
   }
 };
