@@ -234,8 +234,17 @@ __device__ __forceinline__ void tile_mm(double (&acc)[TR][TC], AFn A, BFn B) {
 }
 
 // Backward Riccati pass (ilqr.py:623-667), cost expansion (:161-206) fused.
+#ifdef MI_PROF_BACKWARD
+#define BP_TICK(k) do { const long long c_ = clock64(); bp_acc[k] += c_ - bp_last; bp_last = c_; } while (0)
+#else
+#define BP_TICK(k) do {} while (0)
+#endif
+
 template <class M>
-__device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds) {
+__device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, long long* bp_acc = nullptr) {
+#ifdef MI_PROF_BACKWARD
+  long long bp_last = clock64();
+#endif
   constexpr int n = M::n, m = M::m, nm = n + m;
   using Ly = LLay<n, m>;
   constexpr int TS = Ly::TS;
@@ -271,6 +280,7 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds) {
     if (tid < n) xb[tid] = v.X[(size_t)t * n + tid];
     else if (tid < nm) xb[tid] = v.U[(size_t)t * m + (tid - n)];
     __syncthreads();
+    BP_TICK(0);
     // T1 = Vxx F  (n x nm), 2x4 tiles;  T1[:, nm] = Vx
     {
       constexpr int TR = 2, TC = 4, tr = n / TR, tc = nm / TC;
@@ -288,6 +298,7 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds) {
       if (tid < n) T1[tid * TS + nm] = Vx[tid];
     }
     __syncthreads();
+    BP_TICK(1);
     // H = F^T T1  ((nm) x (nm+1)), 3x4 tiles; the unused fx^T Vxx fu block is skipped
     {
       constexpr int TR = 3, TC = 4, tr = nm / TR, tc = TS / TC;
@@ -317,6 +328,7 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds) {
       H[tid * TS + nm] += s;
     }
     __syncthreads();
+    BP_TICK(2);
     // Quu = 2R + H[n:,n:] ; solve Quu * Y = [Qux | Qu]: one right-hand side per thread (:655-660)
     if (tid <= n) {
       double A[m][m];
@@ -372,6 +384,7 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds) {
       }
     }
     __syncthreads();
+    BP_TICK(3);
     // Vxx = Qxx - Qux^T K ; Vx = Qx - Qux^T kappa  (:666-667), K/kappa staged in T1 rows 0..m-1
     for (int e = tid; e < n * (n + 1); e += kLargeThreads) {
       const int i = e / (n + 1), j = e - i * (n + 1);
@@ -383,6 +396,7 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds) {
       if (j < n) Vxx[i * n + j] = s; else Vx[i] = s;
     }
     __syncthreads();
+    BP_TICK(4);
   }
 }
 
@@ -485,7 +499,13 @@ __global__ void __launch_bounds__(kLargeThreads) ilqr_large_kernel(const KArgs a
     nk = do_linearize();                                                             // :370
     __syncthreads();
     const long long c2 = clock64();
+#ifdef MI_PROF_BACKWARD
+    long long bpa[5] = {0, 0, 0, 0, 0};
+    if (MODE == MODE_SOLVE) { large_backward<M>(v, lds, bpa); __syncthreads(); }
+    if (tid == 0 && iters == 0) { for (int q_ = 0; q_ < 4; ++q_) a.prof[4 * b + q_] = bpa[q_]; a.hist[(size_t)b * a.hist_cap * 4 + 4 * (a.hist_cap - 1)] = (double)bpa[4]; }
+#else
     if (MODE == MODE_SOLVE) { large_backward<M>(v, lds); __syncthreads(); }          // :697
+#endif
     const long long c3 = clock64();
     c_ls += c1 - c0; c_lin += c2 - c1; c_bp += c3 - c2;
     if (tid == 0 && iters < a.hist_cap) {
@@ -500,7 +520,9 @@ __global__ void __launch_bounds__(kLargeThreads) ilqr_large_kernel(const KArgs a
   for (int i = tid; i < nk; i += kLargeThreads) a.kp_list[(size_t)b * (N - 1) + i] = acc.kp[i];
   if (tid == 0) {
     a.cost[b] = L; a.iters[b] = iters; a.status[b] = status; a.ls_trials[b] = ls_total; a.kp_count[b] = nk;
+#ifndef MI_PROF_BACKWARD
     a.prof[4 * b + 0] = c_ls; a.prof[4 * b + 1] = c_lin; a.prof[4 * b + 2] = c_bp; a.prof[4 * b + 3] = clock64() - c_begin;
+#endif
   }
 }
 
