@@ -36,12 +36,18 @@ constexpr int kLargeThreads = 256;
 template <int n, int m>
 struct LLay {
   static constexpr int nm = n + m;
-  static constexpr int TS = ((nm + 1 + 3) / 4) * 4;      // padded row stride of T1 / H (multiple of 4)
+  static constexpr int TS = ((n + m + 15) / 16) * 16 + 4;  // row stride of T1 / H: whole tiles + the Vx/first-order column
   // doubles
+  static constexpr int QC = m * (m + 1) / 2;               // packed lower triangle of Quu
+  static constexpr int T16 = 16;                           // MFMA tile edge
+  static constexpr int NP = ((n + 15) / 16) * 16;          // n padded to whole tiles (rows of Vxx)
+  static constexpr int NMP = ((nm + 15) / 16) * 16;
+  static constexpr int VS = n + 1;                         // odd row stride of Vxx: conflict-free column-of-tile reads
   static constexpr int oQ = 0, oQf = oQ + n * n, oR = oQf + n * n, oXnom = oR + m * m, oQn = oXnom + n,
-                       oQfn = oQn + n, oVxx = oQfn + n, oVx = oVxx + n * n, oF = oVx + n,
-                       oT1 = oF + n * nm, oH = oT1 + n * TS, oXs = oH + nm * TS, oUs = oXs + n,
-                       oRed = oUs + m, oXb = oRed + kLargeThreads, oEnd = oXb + n + m;
+                       oQfn = oQn + n, oVxx = oQfn + n, oVx = oVxx + NP * VS, oF = oVx + n,
+                       oT1 = oF + n * NMP, oH = oT1 + n * TS, oXs = oH + NMP * TS, oUs = oXs + n,
+                       oRed = oUs + m, oXb = oRed + kLargeThreads, oQc = oXb + n + m + ((n + m) & 1),
+                       oEnd = oQc + m * m + m + (m & 1);
   static constexpr size_t doubles = oEnd + 8;
 };
 
@@ -81,50 +87,85 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
 }
 
 // One line-search trial (ilqr.py:306-327).  Returns L on every thread; trajectory -> Xn/Un.
+// Per step: (1) 16 lanes per control row form K_t(x-x_bar) partial dots — K_t, x_bar_t,
+// u_bar_t, kappa_t come from HBM/L2 and are prefetched one step ahead into registers;
+// (2) one lane per degree of freedom advances the dynamics while other waves add the
+// stage-cost rows (their Q/R rows live in registers); (3) the new state is published.
 template <class M>
 __device__ inline double large_rollout(const LView<M::n, M::m>& v, double* lds, const KArgs& a,
                                        const double* x0g, double eps, double& expd_out) {
   constexpr int n = M::n, m = M::m;
   using Ly = LLay<n, m>;
+  constexpr int JR = (n + 15) / 16;    // K-row elements per lane
   const int tid = threadIdx.x, N = v.N;
   double* xs = lds + Ly::oXs;
   double* us = lds + Ly::oUs;
-  double* xb = lds + Ly::oXb;          // x_bar_t | (u_bar_t - eps*kappa_t)
-  const double* Q = lds + Ly::oQ;
-  const double* R = lds + Ly::oR;
-  const double* Qf = lds + Ly::oQf;
   const double* xnom = lds + Ly::oXnom;
+  const bool urole = tid < m * 16;
+  const int uk = tid >> 4, ul = tid & 15;
+  const bool qrole = tid >= 64 && tid < 64 + n;      // cost row i = tid-64
+  const bool rrole = tid >= 128 && tid < 128 + m;    // control-cost row k = tid-128
+  // cost rows -> registers (one-off)
+  double qrow[n], rrow[m];
+  if (qrole) {
+#pragma unroll
+    for (int j = 0; j < n; ++j) qrow[j] = lds[Ly::oQ + (tid - 64) * n + j];
+  }
+  if (rrole) {
+#pragma unroll
+    for (int j = 0; j < m; ++j) rrow[j] = lds[Ly::oR + (tid - 128) * m + j];
+  }
   if (tid < n) { xs[tid] = x0g[tid]; v.Xn[tid] = x0g[tid]; }
   double acc = 0.0;                    // per-thread cost partial over all time steps
+  // prefetch registers for step t
+  double kr[JR], xbr[JR], ubk = 0.0, kpk = 0.0;
+  auto prefetch = [&](int t) __attribute__((always_inline)) {
+    if (urole) {
+      const double* Kr = v.K + ((size_t)t * m + uk) * n;
+      const double* xbt = v.X + (size_t)t * n;
+#pragma unroll
+      for (int q = 0; q < JR; ++q) {
+        const int j = ul + 16 * q;
+        kr[q] = (j < n) ? Kr[j] : 0.0;
+        xbr[q] = (j < n) ? xbt[j] : 0.0;
+      }
+      if (ul == 0) { ubk = v.U[(size_t)t * m + uk]; kpk = v.kap[(size_t)t * m + uk]; }
+    }
+  };
+  prefetch(0);
   __syncthreads();
   for (int t = 0; t < N - 1; ++t) {
-    // u_t = u_bar_t - eps*kappa_t - K_t (x_t - x_bar_t)   (ilqr.py:313): 16 lanes per control row
-    if (tid < m * 16) {
-      const int k = tid >> 4, l = tid & 15;
-      const double* Kr = v.K + ((size_t)t * m + k) * n;
-      const double* xbt = v.X + (size_t)t * n;
+    // u_t = u_bar_t - eps*kappa_t - K_t (x_t - x_bar_t)   (ilqr.py:313)
+    if (urole) {
       double p = 0.0;
-      for (int j = l; j < n; j += 16) p += Kr[j] * (xs[j] - xbt[j]);
+#pragma unroll
+      for (int q = 0; q < JR; ++q) {
+        const int j = ul + 16 * q;
+        if (j < n) p += kr[q] * (xs[j] - xbr[q]);
+      }
       p += __shfl_xor(p, 8, 16);
       p += __shfl_xor(p, 4, 16);
       p += __shfl_xor(p, 2, 16);
       p += __shfl_xor(p, 1, 16);
-      if (l == 0) us[k] = (v.U[(size_t)t * m + k] - eps * v.kap[(size_t)t * m + k]) - p;
+      if (ul == 0) us[uk] = (ubk - eps * kpk) - p;
     }
+    if (t + 1 < N - 1) prefetch(t + 1);          // lands while the dynamics run
     __syncthreads();
     // dynamics: one lane per degree of freedom (ilqr.py:316); cost rows on the other waves (:325)
     double qn_ = 0.0, vn_ = 0.0;
     if (tid < M::nq) {
       M::template dof<double>(tid, xs, us, qn_, vn_, a.params, a.dt);
-    } else if (tid >= 64 && tid < 64 + n) {
+    } else if (qrole) {
       const int i = tid - 64;
       double r = 0.0;
-      for (int j = 0; j < n; ++j) r += Q[i * n + j] * (xs[j] - xnom[j]);
+#pragma unroll
+      for (int j = 0; j < n; ++j) r += qrow[j] * (xs[j] - xnom[j]);
       acc += (xs[i] - xnom[i]) * r;
-    } else if (tid >= 128 && tid < 128 + m) {
+    } else if (rrole) {
       const int k = tid - 128;
       double r = 0.0;
-      for (int j = 0; j < m; ++j) r += R[k * m + j] * us[j];
+#pragma unroll
+      for (int j = 0; j < m; ++j) r += rrow[j] * us[j];
       acc += us[k] * r;
       v.Un[(size_t)t * m + k] = us[k];
     }
@@ -136,8 +177,9 @@ __device__ inline double large_rollout(const LView<M::n, M::m>& v, double* lds, 
     }
     __syncthreads();
   }
-  if (tid >= 64 && tid < 64 + n) {     // terminal cost (ilqr.py:327)
+  if (qrole) {                         // terminal cost (ilqr.py:327)
     const int i = tid - 64;
+    const double* Qf = lds + Ly::oQf;
     double r = 0.0;
     for (int j = 0; j < n; ++j) r += Qf[i * n + j] * (xs[j] - xnom[j]);
     acc += (xs[i] - xnom[i]) * r;
@@ -148,7 +190,6 @@ __device__ inline double large_rollout(const LView<M::n, M::m>& v, double* lds, 
   const double L = block_sum(acc, red);
   const double dvs = block_sum(dvp, red);
   expd_out = -eps * (1.0 - eps / 2.0) * dvs;             // ilqr.py:326
-  (void)xb;
   return L;
 }
 
@@ -216,53 +257,120 @@ __device__ __forceinline__ void large_jac_at(const LView<M::n, M::m>& v, const K
   }
 }
 
-// C[r][c] (+)= sum_k A(r,k) * B(k,c) for a TR x TC register tile; A/B/C in LDS.
-template <int TR, int TC, int KD, class AFn, class BFn>
-__device__ __forceinline__ void tile_mm(double (&acc)[TR][TC], AFn A, BFn B) {
-#pragma unroll 4
-  for (int k = 0; k < KD; ++k) {
-    double av[TR], bv[TC];
-#pragma unroll
-    for (int r = 0; r < TR; ++r) av[r] = A(r, k);
-#pragma unroll
-    for (int c = 0; c < TC; ++c) bv[c] = B(k, c);
-#pragma unroll
-    for (int r = 0; r < TR; ++r)
-#pragma unroll
-      for (int c = 0; c < TC; ++c) acc[r][c] += av[r] * bv[c];
-  }
-}
-
-// Backward Riccati pass (ilqr.py:623-667), cost expansion (:161-206) fused.
 #ifdef MI_PROF_BACKWARD
-#define BP_TICK(k) do { const long long c_ = clock64(); bp_acc[k] += c_ - bp_last; bp_last = c_; } while (0)
+#define BP_TICK(k) do { const long long c_ = clock64(); if (bp_acc) bp_acc[k] += c_ - bp_last; bp_last = c_; } while (0)
 #else
 #define BP_TICK(k) do {} while (0)
 #endif
 
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+// One 16x16 output tile on the matrix core: acc += sum over KSTEPS of A(16x4) B(4x16) with
+// v_mfma_f64_16x16x4_f64.  Lane l supplies A[r = l&15][k0 + (l>>4)] and B[k0 + (l>>4)][c = l&15];
+// it receives D[(l>>4) + 4*reg][l&15], reg = 0..3 (layout verified by tools/ubench/mfma64.hip).
+//   a_ptr: address of A[r][0]-equivalent for this lane, a_ks: stride between k-steps (4 k's)
+template <int KSTEPS>
+struct TileOps {
+  double av[KSTEPS], bv[KSTEPS];
+  __device__ __forceinline__ void load(const double* a_ptr, int a_kstride, const double* b_ptr, int b_kstride) {
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) { av[ks] = a_ptr[ks * a_kstride]; bv[ks] = b_ptr[ks * b_kstride]; }
+  }
+  __device__ __forceinline__ d4_t run(d4_t acc) const {
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], bv[ks], acc, 0, 0, 0);
+    return acc;
+  }
+};
+
+// value of lane LANE of this lane's 16-lane row (DPP row_share), for a double
+template <int LANE>
+__device__ __forceinline__ double row_share(double v) {
+  union { double d; int i[2]; } u, r;
+  u.d = v;
+  r.i[0] = __builtin_amdgcn_update_dpp(0, u.i[0], 0x150 + LANE, 0xF, 0xF, false);
+  r.i[1] = __builtin_amdgcn_update_dpp(0, u.i[1], 0x150 + LANE, 0xF, 0xF, false);
+  return r.d;
+}
+
+// Right-looking LDL^T of an m x m matrix held one ROW PER LANE (lane i of a 16-lane row holds
+// A[i][0..m-1]); pivots and column entries travel by DPP row_share, no LDS, no barriers.
+// On exit lane i holds L[i][k] in a[k] for k < i, and every lane holds 1/D[k] in dinv[k].
+template <int m, int K, int J>
+struct LdlInner {
+  static __device__ __forceinline__ void run(double (&a)[m], double lik) {
+    const double ajk = row_share<J>(a[K]);          // A[J][K] before scaling = D[K] * L[J][K]
+    a[J] = fma(-lik, ajk, a[J]);
+    LdlInner<m, K, J + 1>::run(a, lik);
+  }
+};
+template <int m, int K>
+struct LdlInner<m, K, m> {
+  static __device__ __forceinline__ void run(double (&)[m], double) {}
+};
+template <int m, int K>
+struct LdlOuter {
+  static __device__ __forceinline__ void run(double (&a)[m], double (&dinv)[m]) {
+    const double d = row_share<K>(a[K]);
+    const double inv = fast_rcp(d);
+    dinv[K] = inv;
+    const double lik = a[K] * inv;
+    LdlInner<m, K, K + 1>::run(a, lik);
+    a[K] = lik;
+    LdlOuter<m, K + 1>::run(a, dinv);
+  }
+};
+template <int m>
+struct LdlOuter<m, m> {
+  static __device__ __forceinline__ void run(double (&)[m], double (&)[m]) {}
+};
+
+// Backward Riccati pass (ilqr.py:623-667), cost expansion (:161-206) fused.
+//
+// Per time step, with F = [fx | fu] (n x (n+m)):
+//     T1 = Vxx F                      (n x (n+m))      9 tiles x 9 k-steps
+//     H  = F^T [T1 | Vx]              ((n+m) x (n+m+1)) = [[Qxx-lxx, . ],[Qux, Quu-luu]] and F^T Vx
+//     Vxx' = Qxx - Qux^T K            (n x n)          9 tiles x 3 k-steps
+// run as 16x16 tiles of v_mfma_f64_16x16x4_f64, 2-3 tiles per wave.  On gfx950 the fp64
+// matrix rate equals the fp64 VALU rate (65 cycles per 16x16x4 = 15.7 FMA/clk/SIMD), so
+// the point of the matrix core here is OPERAND DELIVERY: two 8-byte LDS reads per lane
+// feed 1024 FMAs, where a VALU formulation needs a (broadcast) LDS read per 1-2 FMAs and
+// is LDS-issue-bound at one wave per SIMD (tools/ubench/t1.hip: 4.5-10.7k cycles for T1
+// alone vs ~1.8k here).  Quu is factorized ONCE per step (LDL^T) by 16 lanes with DPP
+// row broadcasts; n+1 threads then substitute one right-hand side each (columns of Qux, Qu).
 template <class M>
 __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, long long* bp_acc = nullptr) {
-#ifdef MI_PROF_BACKWARD
-  long long bp_last = clock64();
-#endif
   constexpr int n = M::n, m = M::m, nm = n + m;
   using Ly = LLay<n, m>;
-  constexpr int TS = Ly::TS;
-  const int tid = threadIdx.x, N = v.N;
+  constexpr int TS = Ly::TS, VS = Ly::VS, FS = Ly::NMP, NP = Ly::NP;
+  constexpr int RT = NP / 16, CT = Ly::NMP / 16;       // row tiles of an n-row matrix, col tiles of an nm-col one
+  static_assert(n % 4 == 0 && m % 4 == 0, "k-steps of 4");
+  const int tid = threadIdx.x, N = v.N, wave = tid >> 6, lane = tid & 63;
+  const int lr = lane & 15, lk = lane >> 4;
   const double* Q = lds + Ly::oQ;
   const double* R = lds + Ly::oR;
   const double* Qf = lds + Ly::oQf;
   const double* qn = lds + Ly::oQn;
   const double* qfn = lds + Ly::oQfn;
-  double* Vxx = lds + Ly::oVxx;
+  double* Vxx = lds + Ly::oVxx;      // [NP][VS], rows >= n are zero
   double* Vx = lds + Ly::oVx;
-  double* F = lds + Ly::oF;          // [n][nm]  = [fx | fu]
-  double* T1 = lds + Ly::oT1;        // [n][TS]  = [Vxx F | Vx]
-  double* H = lds + Ly::oH;          // [nm][TS] = F^T T1
+  double* F = lds + Ly::oF;          // [n][FS]  = [fx | fu | 0-pad]
+  double* T1 = lds + Ly::oT1;        // [n][TS]  = [Vxx F | . | Vx at column FS]; later rows 0..m-1 hold [K | kappa]
+  double* H = lds + Ly::oH;          // [NMP][TS] = F^T T1, first-order terms in column FS
   double* xb = lds + Ly::oXb;        // x_bar_t (n) | u_bar_t (m)
+  double* Qc = lds + Ly::oQc;        // packed lower triangle: Quu, then its LDL^T factor
+  constexpr int CV = FS;             // column index of Vx / first-order terms
+#ifdef MI_PROF_BACKWARD
+  long long bp_last = clock64();
+#endif
 
-  // terminal: Vx = 2 Qf x_T - 2 x_nom^T Qf ; Vxx = 2 Qf   (ilqr.py:203-204, :638)
-  for (int e = tid; e < n * n; e += kLargeThreads) Vxx[e] = 2.0 * Qf[e];
+  // terminal: Vx = 2 Qf x_T - 2 x_nom^T Qf ; Vxx = 2 Qf   (ilqr.py:203-204, :638); pads = 0
+  for (int e = tid; e < NP * VS; e += kLargeThreads) {
+    const int i = e / VS, j = e - i * VS;
+    Vxx[e] = (i < n && j < n) ? 2.0 * Qf[i * n + j] : 0.0;
+  }
+  for (int e = tid; e < n * FS; e += kLargeThreads) F[e] = 0.0;
+  for (int e = tid; e < Ly::NMP * TS; e += kLargeThreads) H[e] = 0.0;
   if (tid < n) {
     const double* xT = v.X + (size_t)(N - 1) * n;
     double s = 0.0;
@@ -270,131 +378,203 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
     Vx[tid] = s - qfn[tid];
   }
   __syncthreads();
-
-  for (int t = N - 2; t >= 0; --t) {
-    // stage F = [fx_t | fu_t], x_bar_t, u_bar_t
+  // prefetch registers: elements tid + 256*r of the contiguous fx_t (n*n) and fu_t (n*m) blocks
+  constexpr int NFX = (n * n + kLargeThreads - 1) / kLargeThreads, NFU = (n * m + kLargeThreads - 1) / kLargeThreads;
+  double frx[NFX], fru[NFU], xbr = 0.0;
+  const int fx_i0 = tid / n, fx_j0 = tid - fx_i0 * n, fu_i0 = tid / m, fu_k0 = tid - fu_i0 * m;
+  auto fetch = [&](int t) __attribute__((always_inline)) {
     const double* fxg = v.Fx + (size_t)t * n * n;
     const double* fug = v.Fu + (size_t)t * n * m;
-    for (int e = tid; e < n * n; e += kLargeThreads) { const int i = e / n, j = e - i * n; F[i * nm + j] = fxg[e]; }
-    for (int e = tid; e < n * m; e += kLargeThreads) { const int i = e / m, k = e - i * m; F[i * nm + n + k] = fug[e]; }
-    if (tid < n) xb[tid] = v.X[(size_t)t * n + tid];
-    else if (tid < nm) xb[tid] = v.U[(size_t)t * m + (tid - n)];
-    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < NFX; ++r) { const int e = tid + kLargeThreads * r; frx[r] = fxg[e < n * n ? e : n * n - 1]; }
+#pragma unroll
+    for (int r = 0; r < NFU; ++r) { const int e = tid + kLargeThreads * r; fru[r] = fug[e < n * m ? e : n * m - 1]; }
+    const int xi = tid < nm ? tid : nm - 1;
+    const double* xsrc = (xi < n) ? (v.X + (size_t)t * n + xi) : (v.U + (size_t)t * m + (xi - n));
+    xbr = *xsrc;
+  };
+  auto publish = [&]() __attribute__((always_inline)) {
+    int i = fx_i0, j = fx_j0;
+#pragma unroll
+    for (int r = 0; r < NFX; ++r) {
+      if (tid + kLargeThreads * r < n * n) F[i * FS + j] = frx[r];
+      i += kLargeThreads / n; j += kLargeThreads % n;
+      if (j >= n) { j -= n; i += 1; }
+    }
+    i = fu_i0; j = fu_k0;
+#pragma unroll
+    for (int r = 0; r < NFU; ++r) {
+      if (tid + kLargeThreads * r < n * m) F[i * FS + n + j] = fru[r];
+      i += kLargeThreads / m; j += kLargeThreads % m;
+      if (j >= m) { j -= m; i += 1; }
+    }
+    if (tid < nm) xb[tid] = xbr;
+  };
+  fetch(N - 2);
+  publish();
+  __syncthreads();
+
+  for (int t = N - 2; t >= 0; --t) {
+    if (t > 0) fetch(t - 1);                     // next step's operands: in flight during this step
     BP_TICK(0);
-    // T1 = Vxx F  (n x nm), 2x4 tiles;  T1[:, nm] = Vx
-    {
-      constexpr int TR = 2, TC = 4, tr = n / TR, tc = nm / TC;
-      static_assert(n % TR == 0 && nm % TC == 0, "tile shape");
-      for (int tile = tid; tile < tr * tc; tile += kLargeThreads) {
-        const int i0 = (tile / tc) * TR, j0 = (tile % tc) * TC;
-        double acc[TR][TC] = {};
-        tile_mm<TR, TC, n>(acc, [&](int r, int k) { return Vxx[(i0 + r) * n + k]; },
-                           [&](int k, int c) { return F[k * nm + j0 + c]; });
+    // ---- T1 = Vxx F : RT x CT tiles, K = n.  Operands of ALL of this wave's tiles are loaded
+    //      before the first MFMA (sched_barrier) so LDS latency is paid once, not per k-step.
+    //      Wave w < CT owns column tile w and sweeps the RT row tiles, so every tile offset is a
+    //      compile-time immediate on top of one per-lane base address (no address registers kept
+    //      live across the time loop); the spare wave does the Vx column.
+    if (wave < CT) {
+      const double* a_base = Vxx + lr * VS + lk;
+      const double* b_base = F + lk * FS + 16 * wave + lr;
+      double* d_base = T1 + lk * TS + 16 * wave + lr;
+      TileOps<n / 4> ops[RT];
 #pragma unroll
-        for (int r = 0; r < TR; ++r)
+      for (int q = 0; q < RT; ++q) ops[q].load(a_base + 16 * q * VS, 4, b_base, 4 * FS);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int c = 0; c < TC; ++c) T1[(i0 + r) * TS + j0 + c] = acc[r][c];
+      for (int q = 0; q < RT; ++q) {
+        d4_t acc = {0.0, 0.0, 0.0, 0.0};
+        acc = ops[q].run(acc);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int ib = 16 * q + 4 * reg;                 // rows ib + lk, lk = 0..3
+          if (ib + 3 < n) d_base[ib * TS] = acc[reg];
+          else if (ib < n) { if (ib + lk < n) d_base[ib * TS] = acc[reg]; }
+        }
       }
-      if (tid < n) T1[tid * TS + nm] = Vx[tid];
+    } else if (lane < n) {
+      T1[lane * TS + CV] = Vx[lane];
     }
     __syncthreads();
     BP_TICK(1);
-    // H = F^T T1  ((nm) x (nm+1)), 3x4 tiles; the unused fx^T Vxx fu block is skipped
-    {
-      constexpr int TR = 3, TC = 4, tr = nm / TR, tc = TS / TC;
-      static_assert(nm % TR == 0, "tile shape");
-      for (int tile = tid; tile < tr * tc; tile += kLargeThreads) {
-        const int p0 = (tile / tc) * TR, q0 = (tile % tc) * TC;
-        if (p0 + TR <= n && q0 >= n && q0 + TC <= nm) continue;
-        double acc[TR][TC] = {};
-        tile_mm<TR, TC, n>(acc, [&](int r, int k) { return F[k * nm + p0 + r]; },
-                           [&](int k, int c) { return T1[k * TS + q0 + c]; });
+    // ---- H = F^T T1 : CT x CT tiles, K = n;  H[:, CV] = F^T Vx
+    if (wave < CT) {
+      const double* a_base = F + lk * FS + lr;                       // A = F^T: A[p][k] = F[k][p]
+      const double* b_base = T1 + lk * TS + 16 * wave + lr;
+      double* d_base = H + lk * TS + 16 * wave + lr;
+      TileOps<n / 4> ops[CT];
 #pragma unroll
-        for (int r = 0; r < TR; ++r)
+      for (int q = 0; q < CT; ++q) ops[q].load(a_base + 16 * q, 4 * FS, b_base, 4 * TS);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int c = 0; c < TC; ++c) H[(p0 + r) * TS + q0 + c] = acc[r][c];
+      for (int q = 0; q < CT; ++q) {
+        d4_t acc = {0.0, 0.0, 0.0, 0.0};
+        acc = ops[q].run(acc);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) d_base[(16 * q + 4 * reg) * TS] = acc[reg];
       }
+    } else if (lane < nm) {                                // spare wave: H[:, CV] = F^T Vx
+      double s = 0.0;
+#pragma unroll 6
+      for (int k = 0; k < n; ++k) s += F[k * FS + lane] * Vx[k];
+      H[lane * TS + CV] = s;
     }
     __syncthreads();
-    // first-order terms into column nm of H: Qx = lx + fx^T Vx, Qu = lu + fu^T Vx   (:651-652)
+    BP_TICK(2);
+    // ---- first-order terms (Qx = lx + fx^T Vx, Qu = lu + fu^T Vx, :651-652) on wave 0;
+    //      meanwhile wave 1 factorizes Quu = 2R + fu^T Vxx fu (:654) = L D L^T, one row per lane
     if (tid < n) {
       double s = 0.0;
       for (int j = 0; j < n; ++j) s += (2.0 * Q[tid * n + j]) * xb[j];
-      H[tid * TS + nm] += s - qn[tid];
+      H[tid * TS + CV] += s - qn[tid];
     } else if (tid < nm) {
       const int k = tid - n;
       double s = 0.0;
       for (int j = 0; j < m; ++j) s += (2.0 * R[k * m + j]) * xb[n + j];
-      H[tid * TS + nm] += s;
+      H[tid * TS + CV] += s;
+    } else if (wave == 1) {
+      static_assert(m <= 16, "one Quu row per lane of a 16-lane DPP row");
+      const int i = lane < m ? lane : m - 1;               // lanes >= m shadow the last row (harmless)
+      double arow[m], dinv[m];
+#pragma unroll
+      for (int j = 0; j < m; ++j) arow[j] = 2.0 * R[i * m + j] + H[(n + i) * TS + n + j];
+      LdlOuter<m, 0>::run(arow, dinv);
+      if (lane < m) {
+#pragma unroll
+        for (int k = 0; k < m; ++k) Qc[lane * m + k] = arow[k];      // L[lane][k] for k < lane
+      }
+      if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < m; ++k) Qc[m * m + k] = dinv[k];
+      }
     }
     __syncthreads();
-    BP_TICK(2);
-    // Quu = 2R + H[n:,n:] ; solve Quu * Y = [Qux | Qu]: one right-hand side per thread (:655-660)
+    // ---- Y = Quu^{-1} [Qux | Qu] (:655-660): one right-hand side per thread, forward/back substitution
     if (tid <= n) {
-      double A[m][m];
+      double y[m], dinv[m];
+      const int rhs = tid < n ? tid : CV;
+#pragma unroll
+      for (int i = 0; i < m; ++i) { y[i] = H[(n + i) * TS + rhs]; dinv[i] = Qc[m * m + i]; }
 #pragma unroll
       for (int i = 0; i < m; ++i)
 #pragma unroll
-        for (int j = 0; j < m; ++j) A[i][j] = 2.0 * R[i * m + j] + H[(n + i) * TS + n + j];
-      // LDL^T (unit lower L stored below the diagonal of A, D on it)
+        for (int k = 0; k < i; ++k) y[i] -= Qc[i * m + k] * y[k];
 #pragma unroll
-      for (int j = 0; j < m; ++j) {
-        double dj = A[j][j];
-#pragma unroll
-        for (int k = 0; k < j; ++k) dj -= A[j][k] * A[j][k] * A[k][k];
-        A[j][j] = dj;
-        const double idj = 1.0 / dj;
-#pragma unroll
-        for (int i = j + 1; i < m; ++i) {
-          double s = A[i][j];
-#pragma unroll
-          for (int k = 0; k < j; ++k) s -= A[i][k] * A[j][k] * A[k][k];
-          A[i][j] = s * idj;
-        }
-      }
-      double y[m];
-#pragma unroll
-      for (int i = 0; i < m; ++i) y[i] = H[(n + i) * TS + (tid < n ? tid : nm)];
-#pragma unroll
-      for (int i = 0; i < m; ++i)
-#pragma unroll
-        for (int k = 0; k < i; ++k) y[i] -= A[i][k] * y[k];
-#pragma unroll
-      for (int i = 0; i < m; ++i) y[i] /= A[i][i];
+      for (int i = 0; i < m; ++i) y[i] *= dinv[i];
 #pragma unroll
       for (int i = m - 1; i >= 0; --i)
 #pragma unroll
-        for (int k = i + 1; k < m; ++k) y[i] -= A[k][i] * y[k];
+        for (int k = i + 1; k < m; ++k) y[i] -= Qc[k * m + i] * y[k];
       if (tid < n) {
-        // K_t[:, tid]  (:660) -> HBM and into rows n.. of T1 (scratch) for the Vxx update
 #pragma unroll
         for (int i = 0; i < m; ++i) {
-          v.K[((size_t)t * m + i) * n + tid] = y[i];
+          v.K[((size_t)t * m + i) * n + tid] = y[i];              // K_t[:, tid]  (:660)
           T1[i * TS + tid] = y[i];
         }
       } else {
         double dv = 0.0;
 #pragma unroll
         for (int i = 0; i < m; ++i) {
-          v.kap[(size_t)t * m + i] = y[i];                       // kappa_t (:659)
-          T1[i * TS + nm] = y[i];
-          dv += H[(n + i) * TS + nm] * y[i];                      // Qu^T Quu^{-1} Qu (:663)
+          v.kap[(size_t)t * m + i] = y[i];                        // kappa_t (:659)
+          T1[i * TS + CV] = y[i];
+          dv += H[(n + i) * TS + CV] * y[i];                      // Qu^T Quu^{-1} Qu (:663)
         }
         v.dV[t] = dv;
       }
     }
     __syncthreads();
     BP_TICK(3);
-    // Vxx = Qxx - Qux^T K ; Vx = Qx - Qux^T kappa  (:666-667), K/kappa staged in T1 rows 0..m-1
-    for (int e = tid; e < n * (n + 1); e += kLargeThreads) {
-      const int i = e / (n + 1), j = e - i * (n + 1);
-      const int col = (j < n) ? j : nm;
-      double s = H[i * TS + col];
-      if (j < n) s += 2.0 * Q[i * n + j];
+    // ---- Vxx = Qxx - Qux^T K (RT x RT tiles, K = m; :667) ; Vx = Qx - Qux^T kappa (:666)
+    if (wave < RT) {
+      const double* a_base = H + (n + lk) * TS + lr;                 // A = Qux^T: A[i][a] = H[n+a][i]
+      const double* b_base = T1 + lk * TS + 16 * wave + lr;          // B = K
+      const double* c_base = H + lk * TS + 16 * wave + lr;           // C = Qxx - lxx
+      const double* q_base = Q + lk * n + 16 * wave + lr;
+      double* d_base = Vxx + lk * VS + 16 * wave + lr;
+      const bool col_ok = 16 * wave + lr < n;
+      TileOps<m / 4> ops[RT];
+      d4_t accs[RT];
 #pragma unroll
-      for (int a_ = 0; a_ < m; ++a_) s -= H[(n + a_) * TS + i] * T1[a_ * TS + col];
-      if (j < n) Vxx[i * n + j] = s; else Vx[i] = s;
+      for (int q = 0; q < RT; ++q) {
+        ops[q].load(a_base + 16 * q, 4 * TS, b_base, 4 * TS);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int ib = 16 * q + 4 * reg;
+          const bool ok = col_ok && (ib + 3 < n || (ib < n && ib + lk < n));
+          accs[q][reg] = ok ? c_base[ib * TS] + 2.0 * q_base[ib * n] : 0.0;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < RT; ++q) {
+#pragma unroll
+        for (int ks = 0; ks < m / 4; ++ks) ops[q].av[ks] = -ops[q].av[ks];
+        const d4_t acc = ops[q].run(accs[q]);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int ib = 16 * q + 4 * reg;
+          const bool ok = col_ok && (ib + 3 < n || (ib < n && ib + lk < n));
+          if (ok) d_base[ib * VS] = acc[reg];
+        }
+      }
     }
+    if (wave == 3 && lane < n) {
+      static_assert(RT <= 3 && CT <= 3, "wave 3 is the spare wave");
+      double s = H[lane * TS + CV];
+#pragma unroll
+      for (int a_ = 0; a_ < m; ++a_) s -= H[(n + a_) * TS + lane] * T1[a_ * TS + CV];
+      Vx[lane] = s;
+    }
+    if (t > 0) publish();                        // F/xb are free after the H phase
     __syncthreads();
     BP_TICK(4);
   }
