@@ -47,13 +47,14 @@ struct LLay {
                        oQfn = oQn + n, oVxx = oQfn + n, oVx = oVxx + NP * VS, oF = oVx + n,
                        oT1 = oF + n * NMP, oH = oT1 + n * TS, oXs = oH + NMP * TS, oUs = oXs + n,
                        oRed = oUs + m, oXb = oRed + kLargeThreads, oQc = oXb + n + m + ((n + m) & 1),
-                       oEnd = oQc + m * m + m + (m & 1);
+                       oQT = oQc + m * m + m + (m & 1), oEnd = oQT + n * n;
   static constexpr size_t doubles = oEnd + 8;
 };
 
 template <int n, int m>
 __host__ __device__ constexpr size_t large_lds_bytes(int N) {
-  return LLay<n, m>::doubles * 8 + (size_t)7 * N * 4 + 16;
+  // fixed block + per-step cost gradients [N][n+m] + integer scratch of the key-point code
+  return (LLay<n, m>::doubles + (size_t)N * (n + m)) * 8 + (size_t)7 * N * 4 + 16;
 }
 
 // Per-problem views of the time-major HBM arrays.
@@ -357,8 +358,8 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
   double* F = lds + Ly::oF;          // [n][FS]  = [fx | fu | 0-pad]
   double* T1 = lds + Ly::oT1;        // [n][TS]  = [Vxx F | . | Vx at column FS]; later rows 0..m-1 hold [K | kappa]
   double* H = lds + Ly::oH;          // [NMP][TS] = F^T T1, first-order terms in column FS
-  double* xb = lds + Ly::oXb;        // x_bar_t (n) | u_bar_t (m)
-  double* Qc = lds + Ly::oQc;        // packed lower triangle: Quu, then its LDL^T factor
+  double* Qc = lds + Ly::oQc;        // L (m x m, row-major, strictly-lower part valid) then 1/D (m)
+  double* QT = lds + Ly::oQT;        // Q^T
   constexpr int CV = FS;             // column index of Vx / first-order terms
 #ifdef MI_PROF_BACKWARD
   long long bp_last = clock64();
@@ -370,6 +371,7 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
     Vxx[e] = (i < n && j < n) ? 2.0 * Qf[i * n + j] : 0.0;
   }
   for (int e = tid; e < n * FS; e += kLargeThreads) F[e] = 0.0;
+  for (int e = tid; e < n * n; e += kLargeThreads) { const int i = e / n, j = e - i * n; QT[j * n + i] = Q[e]; }
   for (int e = tid; e < Ly::NMP * TS; e += kLargeThreads) H[e] = 0.0;
   if (tid < n) {
     const double* xT = v.X + (size_t)(N - 1) * n;
@@ -378,9 +380,27 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
     Vx[tid] = s - qfn[tid];
   }
   __syncthreads();
+  // cost gradients for ALL steps, off the recursion (ilqr.py:180-181): lx_t = 2Q x_bar_t - 2 x_nom^T Q,
+  // lu_t = 2R u_bar_t.  Q^T is read so consecutive lanes hit consecutive banks.
+  double* Lxu = lds + Ly::doubles;
+  for (int idx = tid; idx < (N - 1) * nm; idx += kLargeThreads) {
+    const int tt = idx / nm, pp = idx - tt * nm;
+    double s_;
+    if (pp < n) {
+      const double* xg = v.X + (size_t)tt * n;
+      s_ = -qn[pp];
+      for (int j = 0; j < n; ++j) s_ += (2.0 * QT[j * n + pp]) * xg[j];
+    } else {
+      const double* ug = v.U + (size_t)tt * m;
+      s_ = 0.0;
+      for (int j = 0; j < m; ++j) s_ += (2.0 * R[(pp - n) * m + j]) * ug[j];
+    }
+    Lxu[idx] = s_;
+  }
+  __syncthreads();
   // prefetch registers: elements tid + 256*r of the contiguous fx_t (n*n) and fu_t (n*m) blocks
   constexpr int NFX = (n * n + kLargeThreads - 1) / kLargeThreads, NFU = (n * m + kLargeThreads - 1) / kLargeThreads;
-  double frx[NFX], fru[NFU], xbr = 0.0;
+  double frx[NFX], fru[NFU];
   const int fx_i0 = tid / n, fx_j0 = tid - fx_i0 * n, fu_i0 = tid / m, fu_k0 = tid - fu_i0 * m;
   auto fetch = [&](int t) __attribute__((always_inline)) {
     const double* fxg = v.Fx + (size_t)t * n * n;
@@ -389,9 +409,6 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
     for (int r = 0; r < NFX; ++r) { const int e = tid + kLargeThreads * r; frx[r] = fxg[e < n * n ? e : n * n - 1]; }
 #pragma unroll
     for (int r = 0; r < NFU; ++r) { const int e = tid + kLargeThreads * r; fru[r] = fug[e < n * m ? e : n * m - 1]; }
-    const int xi = tid < nm ? tid : nm - 1;
-    const double* xsrc = (xi < n) ? (v.X + (size_t)t * n + xi) : (v.U + (size_t)t * m + (xi - n));
-    xbr = *xsrc;
   };
   auto publish = [&]() __attribute__((always_inline)) {
     int i = fx_i0, j = fx_j0;
@@ -408,7 +425,6 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
       i += kLargeThreads / m; j += kLargeThreads % m;
       if (j >= m) { j -= m; i += 1; }
     }
-    if (tid < nm) xb[tid] = xbr;
   };
   fetch(N - 2);
   publish();
@@ -462,25 +478,16 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) d_base[(16 * q + 4 * reg) * TS] = acc[reg];
       }
-    } else if (lane < nm) {                                // spare wave: H[:, CV] = F^T Vx
-      double s = 0.0;
+    } else if (lane < nm) {                                // spare wave: H[:, CV] = l_{x,u} + F^T Vx  (:651-652)
+      double s = Lxu[t * nm + lane];                       // lx_t / lu_t (precomputed for all t)
 #pragma unroll 6
       for (int k = 0; k < n; ++k) s += F[k * FS + lane] * Vx[k];
       H[lane * TS + CV] = s;
     }
     __syncthreads();
     BP_TICK(2);
-    // ---- first-order terms (Qx = lx + fx^T Vx, Qu = lu + fu^T Vx, :651-652) on wave 0;
-    //      meanwhile wave 1 factorizes Quu = 2R + fu^T Vxx fu (:654) = L D L^T, one row per lane
-    if (tid < n) {
-      double s = 0.0;
-      for (int j = 0; j < n; ++j) s += (2.0 * Q[tid * n + j]) * xb[j];
-      H[tid * TS + CV] += s - qn[tid];
-    } else if (tid < nm) {
-      const int k = tid - n;
-      double s = 0.0;
-      for (int j = 0; j < m; ++j) s += (2.0 * R[k * m + j]) * xb[n + j];
-      H[tid * TS + CV] += s;
+    // ---- wave 1 factorizes Quu = 2R + fu^T Vxx fu (:654) = L D L^T, one row per lane
+    if (false) {
     } else if (wave == 1) {
       static_assert(m <= 16, "one Quu row per lane of a 16-lane DPP row");
       const int i = lane < m ? lane : m - 1;               // lanes >= m shadow the last row (harmless)
@@ -500,26 +507,28 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
     __syncthreads();
     // ---- Y = Quu^{-1} [Qux | Qu] (:655-660): one right-hand side per thread, forward/back substitution
     if (tid <= n) {
-      double y[m], dinv[m];
+      double y[m], dinv[m], Lr[m][m];
       const int rhs = tid < n ? tid : CV;
 #pragma unroll
       for (int i = 0; i < m; ++i) { y[i] = H[(n + i) * TS + rhs]; dinv[i] = Qc[m * m + i]; }
 #pragma unroll
+      for (int i = 1; i < m; ++i)
+#pragma unroll
+        for (int k = 0; k < i; ++k) Lr[i][k] = Qc[i * m + k];
+      __builtin_amdgcn_sched_barrier(0);                   // all (broadcast) LDS reads in flight before the FMA chains
+#pragma unroll
       for (int i = 0; i < m; ++i)
 #pragma unroll
-        for (int k = 0; k < i; ++k) y[i] -= Qc[i * m + k] * y[k];
+        for (int k = 0; k < i; ++k) y[i] -= Lr[i][k] * y[k];
 #pragma unroll
       for (int i = 0; i < m; ++i) y[i] *= dinv[i];
 #pragma unroll
       for (int i = m - 1; i >= 0; --i)
 #pragma unroll
-        for (int k = i + 1; k < m; ++k) y[i] -= Qc[k * m + i] * y[k];
+        for (int k = i + 1; k < m; ++k) y[i] -= Lr[k][i] * y[k];
       if (tid < n) {
 #pragma unroll
-        for (int i = 0; i < m; ++i) {
-          v.K[((size_t)t * m + i) * n + tid] = y[i];              // K_t[:, tid]  (:660)
-          T1[i * TS + tid] = y[i];
-        }
+        for (int i = 0; i < m; ++i) T1[i * TS + tid] = y[i];       // K_t[:, tid] (:660), stored to HBM below
       } else {
         double dv = 0.0;
 #pragma unroll
@@ -567,6 +576,10 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
         }
       }
     }
+    if (wave == 3) {                              // K_t (m x n, contiguous in HBM): coalesced store from its LDS copy
+      double* Kg = v.K + (size_t)t * m * n;
+      for (int e = lane; e < m * n; e += 64) { const int i = e / n, j = e - i * n; Kg[e] = T1[i * TS + j]; }
+    }
     if (wave == 3 && lane < n) {
       static_assert(RT <= 3 && CT <= 3, "wave 3 is the spare wave");
       double s = H[lane * TS + CV];
@@ -586,7 +599,7 @@ __global__ void __launch_bounds__(kLargeThreads) ilqr_large_kernel(const KArgs a
   using Ly = LLay<n, m>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* lds = reinterpret_cast<double*>(smem);
-  int* ilds = reinterpret_cast<int*>(lds + Ly::doubles);
+  int* ilds = reinterpret_cast<int*>(lds + Ly::doubles + (size_t)a.N * (n + m));
   const int b = blockIdx.x, tid = threadIdx.x, N = a.N;
   LView<n, m> v;
   v.N = N;
