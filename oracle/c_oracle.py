@@ -1,0 +1,48 @@
+"""ctypes loader for oracle/lib/libilqr_oracle.so (test infrastructure / CPU baseline)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "lib", "libilqr_oracle.so")
+
+
+class Cfg(C.Structure):
+    _fields_ = [("n", C.c_int), ("m", C.c_int), ("N", C.c_int), ("model_id", C.c_int),
+                ("params", C.c_double * 16), ("dt", C.c_double), ("delta", C.c_double), ("beta", C.c_double),
+                ("gamma", C.c_double), ("minN", C.c_int), ("fd_h", C.c_double), ("max_iters", C.c_int)]
+
+
+def load():
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(os.path.join(HERE, "ilqr_oracle.c")):
+        subprocess.check_call(["make", "-C", HERE, "-s"])
+    lib = C.CDLL(LIB)
+    lib.oracle_solve_batch.restype = C.c_int
+    return lib
+
+
+def solve_batch(model, prob, x0, u_guess=None, minN=1, fd_h=1e-5, nthreads=0, want_arrays=True):
+    """Cold-start batched solve on the host.  model: oracle.models_np.Model."""
+    lib = load()
+    n, m, N = model.n, model.m, prob["N"]
+    x0 = np.ascontiguousarray(x0, dtype=np.float64).reshape(-1, n)
+    B = x0.shape[0]
+    cfg = Cfg(n=n, m=m, N=N, model_id=model.model_id, dt=model.dt, delta=prob["delta"], beta=prob["beta"],
+              gamma=prob["gamma"], minN=minN, fd_h=fd_h, max_iters=100000)
+    for i, v in enumerate(model.params):
+        cfg.params[i] = float(v)
+    f = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    Q, R, Qf, xn = f(prob["Q"]), f(prob["R"]), f(prob["Qf"]), f(prob["x_nom"])
+    ug = None if u_guess is None else f(np.broadcast_to(u_guess, (B, m, N - 1)))
+    out = dict(cost=np.empty(B), iters=np.empty(B, np.int32), ls=np.empty(B, np.int32), status=np.empty(B, np.int32))
+    if want_arrays:
+        out.update(x_bar=np.empty((B, n, N)), u_bar=np.empty((B, m, N - 1)), K=np.empty((B, m, n, N - 1)),
+                   kappa=np.empty((B, m, N - 1)))
+    p = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
+    used = lib.oracle_solve_batch(C.byref(cfg), B, p(Q), p(R), p(Qf), p(xn), p(x0), p(ug),
+                                  p(out.get("x_bar")), p(out.get("u_bar")), p(out.get("K")), p(out.get("kappa")),
+                                  p(out["cost"]), p(out["iters"]), p(out["ls"]), p(out["status"]), int(nthreads))
+    out["threads"] = used
+    return out
