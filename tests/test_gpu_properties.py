@@ -1,0 +1,169 @@
+"""GPU tests at BASELINE.json's full sizes through size-independent properties, plus the edge
+cases of the reference's control flow (line-search exhaustion, iteration cap, warm starts,
+SaveSolution), all through the C ABI."""
+import os
+
+import numpy as np
+import pytest
+
+from test_gpu_parity import make_solver
+
+pytestmark = pytest.mark.gpu
+
+
+def c2_setup(B, **kw):
+    from drake_ddp_amd import workloads as W
+    prob = W.pendulum_problem()
+    x0 = W.pendulum_batch_x0(1024)[:B]
+    s = make_solver(prob, B=B, jac="fd", **kw)
+    s.SetInitialState(x0)
+    s.SetInitialGuess(np.zeros((1, prob["N"] - 1)))
+    return prob, x0, s
+
+
+def test_c2_full_batch_properties():
+    """B=1024 (config C2): every problem converges, costs decrease monotonically, the solution is a
+    fixed point of the dynamics, batch element i == the same problem solved alone or in a different
+    batch position (bitwise: problems never interact), and two 512-problem shards == the full batch."""
+    from drake_ddp_amd import workloads as W
+    from oracle import models_np as M
+    prob, x0, s = c2_setup(1024)
+    x, u, _, L = s.Solve()
+    it, st = s.iterations, s.status
+    assert (st == 0).all() and it.min() >= 2 and it.max() < 64
+    h = s.history
+    for b in range(0, 1024, 37):
+        costs = h[b, :it[b], 0]
+        assert np.all(np.diff(costs) < 0)                               # accepted steps only ever decrease L
+        assert abs(costs[-1] - L[b]) == 0
+        assert costs[-2] - costs[-1] <= prob["delta"]                   # termination rule (ilqr.py:692)
+    # returned trajectory satisfies x_{t+1} = f(x_t,u_t) under the oracle's model to round-off
+    model = M.Model(prob["model_id"], prob["dt"])
+    for b in (0, 511, 1023):
+        xr = x[b][:, 0].copy()
+        assert np.array_equal(xr, x0[b])
+        for t in range(prob["N"] - 1):
+            xr = model.step(xr, u[b][:, t])
+            assert np.max(np.abs(xr - x[b][:, t + 1])) < 1e-9
+    # permutation / position invariance, bitwise
+    perm = np.random.default_rng(0).permutation(1024)
+    _, _, s2 = c2_setup(1024)
+    s2.SetInitialState(x0[perm])
+    x2, u2, _, L2 = s2.Solve()
+    assert np.array_equal(L2, L[perm]) and np.array_equal(x2, x[perm]) and np.array_equal(s2.K, s.K[perm])
+    # shard invariance (what the multi-GPU path relies on): two handles of 512 == one of 1024
+    from drake_ddp_amd.dist import shard_range
+    for r in range(2):
+        lo, hi = shard_range(1024, r, 2)
+        _, _, sh = c2_setup(hi - lo)
+        sh.SetInitialState(x0[lo:hi])
+        xs, us, _, Ls = sh.Solve()
+        assert np.array_equal(Ls, L[lo:hi]) and np.array_equal(xs, x[lo:hi]) and np.array_equal(us, u[lo:hi])
+    # single-problem class == batch element
+    from drake_ddp_amd.ilqr import IterativeLinearQuadraticRegulator
+    from drake_ddp_amd.models import ModelSystem
+    one = IterativeLinearQuadraticRegulator(ModelSystem(prob["model_id"], prob["dt"]), prob["N"], delta=prob["delta"],
+                                            beta=prob["beta"], gamma=prob["gamma"], jacobian_mode="fd", verbose=False)
+    one.SetTargetState(prob["x_nom"]); one.SetRunningCost(prob["Q"], prob["R"]); one.SetTerminalCost(prob["Qf"])
+    one.SetInitialState(x0[77]); one.SetInitialGuess(np.zeros((1, prob["N"] - 1)))
+    x1, u1, _, L1 = one.Solve()
+    assert L1 == L[77] and np.array_equal(x1, x[77]) and np.array_equal(u1, u[77])
+    assert x1.shape == (2, 200) and u1.shape == (1, 199) and one.K.shape == (1, 2, 199)
+
+
+@pytest.mark.parametrize("B,N", [(1, 4), (3, 5), (65, 17)])
+def test_ragged_sizes_vs_oracle(B, N):
+    from drake_ddp_amd import workloads as W
+    from common import make_oracle, rel_err
+    prob = dict(W.pendulum_problem(), N=N)
+    x0 = W.pendulum_batch_x0(128, seed=3)[:B]
+    s = make_solver(prob, B=B, jac="ad")
+    s.SetInitialState(x0)
+    s.SetInitialGuess(np.zeros((1, N - 1)))
+    x, u, _, L = s.Solve()
+    for b in range(0, B, max(1, B // 4)):
+        o = make_oracle(prob)
+        o.set_problem(x0[b], prob["x_nom"], prob["Q"], prob["R"], prob["Qf"], np.zeros((1, N - 1)))
+        xo, uo, Lo, hist = o.solve()
+        assert len(hist) == s.iterations[b] and abs(L[b] - Lo) < 1e-9 * abs(Lo)
+        assert rel_err(x[b], xo) < 1e-9 and rel_err(s.K[b], o.K) < 1e-7
+
+
+def test_linesearch_exhaustion_and_iteration_cap():
+    """ilqr.py:337: RuntimeError after eps < 1e-8; the batch reports it per problem instead."""
+    from drake_ddp_amd import workloads as W
+    from drake_ddp_amd.ilqr import IterativeLinearQuadraticRegulator
+    from drake_ddp_amd.models import ModelSystem
+    prob = dict(W.acrobot_problem())                         # beta = 0.5 -> 27 valid eps values
+    x0 = W.acrobot_batch_x0(4)
+    x0[2, 0] = np.nan                                        # NaN state -> cost NaN -> never accepted
+    s = make_solver(prob, B=4, jac="fd")
+    s.SetInitialState(x0)
+    s.SetInitialGuess(np.zeros((1, prob["N"] - 1)))
+    s.Solve()
+    st = s.status
+    assert st[2] == 2 and (np.delete(st, 2) == 0).all()     # one failed lane does not abort the batch
+    assert s.ls_trials[2] == 27 and s.iterations[2] == 0
+    assert s.stats.n_ls_failed == 1 and s.stats.n_converged == 3
+    one = IterativeLinearQuadraticRegulator(ModelSystem(prob["model_id"], prob["dt"]), prob["N"], beta=0.5, verbose=False)
+    one.SetTargetState(prob["x_nom"]); one.SetRunningCost(prob["Q"], prob["R"]); one.SetTerminalCost(prob["Qf"])
+    one.SetInitialState(x0[2]); one.SetInitialGuess(np.zeros((1, prob["N"] - 1)))
+    with pytest.raises(RuntimeError, match="linesearch failed after 27 iterations"):
+        one.Solve()
+    # iteration cap (the reference has none; the device needs one)
+    capped = make_solver(prob, B=2, jac="fd", max_iters=2)
+    capped.SetInitialState(W.acrobot_batch_x0(2))
+    capped.SetInitialGuess(np.zeros((1, prob["N"] - 1)))
+    capped.Solve()
+    assert (capped.status == 1).all() and (capped.iterations == 2).all()
+
+
+def test_history_cap_and_resolve_semantics(tmp_path):
+    """More iterations than hist_cap rows must not corrupt anything; a second Solve() without
+    SetInitialGuess continues from the stored u_bar and gains (ilqr.py:375);
+    SaveSolution writes the reference's npz keys/shapes (ilqr.py:712-733)."""
+    from drake_ddp_amd import workloads as W
+    from drake_ddp_amd.ilqr import IterativeLinearQuadraticRegulator
+    from drake_ddp_amd.models import ModelSystem
+    prob = W.cartpole_wall_problem(N=100)
+    s = IterativeLinearQuadraticRegulator(ModelSystem(prob["model_id"], prob["dt"]), prob["N"], beta=prob["beta"],
+                                          jacobian_mode="ad", hist_cap=4, verbose=False)
+    s.SetTargetState(prob["x_nom"]); s.SetRunningCost(prob["Q"], prob["R"]); s.SetTerminalCost(prob["Qf"])
+    s.SetInitialState(np.array([0, np.pi + 0.5, 0, 0.0])); s.SetInitialGuess(np.zeros((1, 99)))
+    x, u, _, L = s.Solve()
+    assert s.iterations[0] > 4 and np.isfinite(L) and np.all(np.isfinite(s.history[0]))
+    x2, u2, _, L2 = s.Solve()                                # warm re-solve from the converged point
+    assert s.iterations[0] >= 1 and L2 <= L + 1e-9          # keeps descending from where it stopped
+    f = os.path.join(tmp_path, "sol.npz")
+    s.SaveSolution(f)
+    z = np.load(f)
+    assert sorted(z.files) == ["K", "t", "u_bar", "x_bar"]
+    assert z["x_bar"].shape == (4, 99) and z["u_bar"].shape == (1, 99) and z["K"].shape == (1, 4, 99)
+    assert z["t"].shape == (99,) and abs(z["t"][1] - prob["dt"]) < 1e-15
+
+
+def test_c3_c4_c5_configs_converge_at_full_size():
+    from drake_ddp_amd import workloads as W
+    # C3: acrobot MPC, B=512, 1 + 5 receding-horizon re-solves on the device
+    a = W.acrobot_problem()
+    s = make_solver(a, B=512, jac="fd")
+    s.SetInitialState(W.acrobot_batch_x0(512)); s.SetInitialGuess(np.zeros((1, a["N"] - 1)))
+    s.Solve()
+    first = s.cost.copy()
+    for _ in range(5):
+        s.MPCShift(2)
+        st = s.solve_resident()
+        assert st.n_converged == 512
+    assert np.all(np.isfinite(s.cost)) and np.all(np.abs(s.cost - first) < 0.2 * np.abs(first))
+    # C4: cart-pole with wall, B=256, FD Jacobians
+    c = W.cartpole_wall_problem()
+    s = make_solver(c, B=256, jac="fd", hist_cap=8)
+    s.SetInitialState(W.cartpole_wall_batch_x0(256)); s.SetInitialGuess(np.zeros((1, c["N"] - 1)))
+    _, _, _, L = s.Solve()
+    assert (s.status == 0).all() and np.all(L < 200.0) and s.ls_trials.sum() > s.iterations.sum()
+    # C5: cheetah-shaped, B=64
+    q = W.synth36_problem()
+    s = make_solver(q, B=64, jac="fd")
+    s.SetInitialState(W.synth36_batch_x0(64)); s.SetInitialGuess(W.synth36_u_guess(q["N"]))
+    _, _, _, L = s.Solve()
+    assert (s.status == 0).all() and np.all(np.isfinite(L))
