@@ -176,40 +176,8 @@ struct Consts {
 // to a per-lane dump slot so the loop carries no exec-mask branches.
 // ---------------------------------------------------------------------------
 template <class M>
-struct GRegs {
-  double xb[M::n], K[M::m][M::n], ub[M::m], kap[M::m], dv;
-  __device__ __forceinline__ void load(const double* g) {
-    using L = Lay<M::n, M::m>;
-#pragma unroll
-    for (int i = 0; i < M::n; ++i) xb[i] = g[L::XB + i];
-#pragma unroll
-    for (int k = 0; k < M::m; ++k) {
-#pragma unroll
-      for (int j = 0; j < M::n; ++j) K[k][j] = g[L::KK + k * M::n + j];
-      ub[k] = g[L::UB + k];
-      kap[k] = g[L::KAP + k];
-    }
-    dv = g[L::DV];
-  }
-};
-
-template <class M>
-__device__ __forceinline__ void rollout_step(const GRegs<M>& r, const Consts<M>& c, const KArgs& a, double eps,
-                                             double ce, double (&x)[M::n], double& L, double& expd, double* tw) {
+__device__ __forceinline__ double stage_cost(const Consts<M>& c, const double (&x)[M::n], const double (&u)[M::m]) {
   constexpr int n = M::n, m = M::m;
-  using Ly = Lay<n, m>;
-  // u_t = u_bar_t - eps*kappa_t - K_t (x_t - x_bar_t)          (ilqr.py:313)
-  double u[m];
-#pragma unroll
-  for (int k = 0; k < m; ++k) {
-    double acc = 0.0;
-#pragma unroll
-    for (int j = 0; j < n; ++j) acc += r.K[k][j] * (x[j] - r.xb[j]);
-    u[k] = (r.ub[k] - eps * r.kap[k]) - acc;
-  }
-  double xnext[n];
-  M::template step<double>(x, u, xnext, a.params, a.dt);        // ilqr.py:316
-  // stage cost (no 1/2 factor, ilqr.py:325) and expected improvement (:326)
   double dx[n];
 #pragma unroll
   for (int i = 0; i < n; ++i) dx[i] = x[i] - c.xnom[i];
@@ -229,8 +197,65 @@ __device__ __forceinline__ void rollout_step(const GRegs<M>& r, const Consts<M>&
     for (int j = 0; j < m; ++j) s += c.R[i][j] * u[j];
     ru += u[i] * s;
   }
-  L += q + ru;
-  expd += ce * r.dv;
+  return q + ru;
+}
+
+template <class M>
+__device__ __forceinline__ double terminal_cost(const Consts<M>& c, const double (&x)[M::n]) {
+  constexpr int n = M::n;
+  double dx[n];
+#pragma unroll
+  for (int i = 0; i < n; ++i) dx[i] = x[i] - c.xnom[i];
+  double q = 0.0;
+#pragma unroll
+  for (int i = 0; i < n; ++i) {
+    double s = 0.0;
+#pragma unroll
+    for (int j = 0; j < n; ++j) s += c.Qf[i][j] * dx[j];
+    q += dx[i] * s;
+  }
+  return q;
+}
+
+template <class M>
+struct GRegs {
+  double xb[M::n], K[M::m][M::n], ub[M::m], kap[M::m], dv;
+  __device__ __forceinline__ void load(const double* g) {
+    using L = Lay<M::n, M::m>;
+#pragma unroll
+    for (int i = 0; i < M::n; ++i) xb[i] = g[L::XB + i];
+#pragma unroll
+    for (int k = 0; k < M::m; ++k) {
+#pragma unroll
+      for (int j = 0; j < M::n; ++j) K[k][j] = g[L::KK + k * M::n + j];
+      ub[k] = g[L::UB + k];
+      kap[k] = g[L::KAP + k];
+    }
+    dv = g[L::DV];
+  }
+};
+
+template <class M, bool COST>
+__device__ __forceinline__ void rollout_step(const GRegs<M>& r, const Consts<M>& c, const KArgs& a, double eps,
+                                             double ce, double (&x)[M::n], double& L, double& expd, double* tw) {
+  constexpr int n = M::n, m = M::m;
+  using Ly = Lay<n, m>;
+  // u_t = u_bar_t - eps*kappa_t - K_t (x_t - x_bar_t)          (ilqr.py:313)
+  double u[m];
+#pragma unroll
+  for (int k = 0; k < m; ++k) {
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < n; ++j) acc += r.K[k][j] * (x[j] - r.xb[j]);
+    u[k] = (r.ub[k] - eps * r.kap[k]) - acc;
+  }
+  double xnext[n];
+  M::template step<double>(x, u, xnext, a.params, a.dt);        // ilqr.py:316
+  if (COST) {
+    // stage cost (no 1/2 factor, ilqr.py:325) and expected improvement (:326)
+    L += stage_cost<M>(c, x, u);
+    expd += ce * r.dv;
+  }
   // T_t.u = u_t ; T_{t+1}.x = x_{t+1}
 #pragma unroll
   for (int k = 0; k < m; ++k) tw[Ly::UN + k] = u[k];
@@ -240,7 +265,7 @@ __device__ __forceinline__ void rollout_step(const GRegs<M>& r, const Consts<M>&
   for (int i = 0; i < n; ++i) x[i] = xnext[i];
 }
 
-template <class M>
+template <class M, bool COST = true>
 __device__ inline void rollout(const WS& w, const Consts<M>& c, const KArgs& a, const double* x0r,
                                double eps, bool store, double& L_out, double& exp_out) {
   constexpr int n = M::n, m = M::m;
@@ -264,32 +289,51 @@ __device__ inline void rollout(const WS& w, const Consts<M>& c, const KArgs& a, 
   for (; t + 1 < N - 1; t += 2) {
     B.load(g + Ly::GS);
     __builtin_amdgcn_sched_barrier(0);      // keep the prefetch a full step ahead of its first use
-    rollout_step<M>(A, c, a, eps, ce, x, L, expd, tw);
+    rollout_step<M, COST>(A, c, a, eps, ce, x, L, expd, tw);
     tw += tstep;
     A.load(g + 2 * Ly::GS);                 // t+2 <= N-1: a real record (or the pad at N)
     __builtin_amdgcn_sched_barrier(0);
-    rollout_step<M>(B, c, a, eps, ce, x, L, expd, tw);
+    rollout_step<M, COST>(B, c, a, eps, ce, x, L, expd, tw);
     tw += tstep;
     g += 2 * Ly::GS;
   }
-  if (t < N - 1) rollout_step<M>(A, c, a, eps, ce, x, L, expd, tw);
-  // terminal cost (ilqr.py:327)
-  {
-    double dx[n];
-#pragma unroll
-    for (int i = 0; i < n; ++i) dx[i] = x[i] - c.xnom[i];
-    double q = 0.0;
-#pragma unroll
-    for (int i = 0; i < n; ++i) {
-      double s = 0.0;
-#pragma unroll
-      for (int j = 0; j < n; ++j) s += c.Qf[i][j] * dx[j];
-      q += dx[i] * s;
-    }
-    L += q;
-  }
+  if (t < N - 1) rollout_step<M, COST>(A, c, a, eps, ce, x, L, expd, tw);
+  if (COST) L += terminal_cost<M>(c, x);            // ilqr.py:327
   L_out = L;
   exp_out = expd;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// Total cost (ilqr.py:325,327) and expected improvement (:326) of the trajectory stored in
+// the T records, evaluated time-parallel (one time step per lane, fixed-order wave reduction).
+template <class M>
+__device__ inline void traj_cost(const WS& w, const Consts<M>& c, double eps, double& L_out, double& exp_out) {
+  constexpr int n = M::n, m = M::m;
+  using Ly = Lay<n, m>;
+  const int N = w.N;
+  double acc = 0.0, dvs = 0.0;
+  for (int t = threadIdx.x; t < N; t += 64) {
+    const double* tr = w.T + t * Ly::TS;
+    double x[n];
+#pragma unroll
+    for (int i = 0; i < n; ++i) x[i] = tr[Ly::XN + i];
+    if (t < N - 1) {
+      double u[m];
+#pragma unroll
+      for (int k = 0; k < m; ++k) u[k] = tr[Ly::UN + k];
+      acc += stage_cost<M>(c, x, u);
+      dvs += w.G[t * Ly::GS + Ly::DV];
+    } else {
+      acc += terminal_cost<M>(c, x);
+    }
+  }
+  L_out = wave_sum(acc);
+  exp_out = -eps * (1.0 - eps / 2.0) * wave_sum(dvs);
 }
 
 // ---------------------------------------------------------------------------
@@ -297,12 +341,30 @@ __device__ inline void rollout(const WS& w, const Consts<M>& c, const KArgs& a, 
 // the T records then hold the accepted trajectory.  `trials` is the
 // reference-equivalent sequential trial count (accepted candidate index + 1).
 // ---------------------------------------------------------------------------
+// `optimistic`: the caller expects eps = 1 to be accepted (it was at the previous iteration, or
+// this is the first one).  Then the first trial is rolled out WITHOUT the per-step cost
+// arithmetic (a fifth of the sequential instruction stream) and its cost is evaluated
+// time-parallel afterwards; only if that trial is rejected does the speculative 64-candidate
+// pass run.  The accepted candidate is the same either way.
 template <class M>
 __device__ inline bool linesearch(const WS& w, const Consts<M>& c, const KArgs& a, const double* x0r,
-                                  double L_last, double& L_out, double& eps_out, int& trials) {
+                                  double L_last, bool optimistic, double& L_out, double& eps_out, int& trials) {
   const int lane = threadIdx.x;
   int base = 0;
   double eps_base = 1.0;
+  if (optimistic) {
+    double L, ex;
+    rollout<M, false>(w, c, a, x0r, 1.0, lane == 0, L, ex);
+    wave_sync();
+    traj_cost<M>(w, c, 1.0, L, ex);
+    if ((L_last - L) > a.gamma * ex) {                         // ilqr.py:330-331
+      L_out = L;
+      eps_out = 1.0;
+      trials = 1;
+      return true;
+    }
+    wave_sync();
+  }
   for (;;) {
     double eps = eps_base;
     for (int i = 0; i < lane; ++i) eps *= a.beta;   // eps *= beta, repeated (ilqr.py:335): bit-identical sequence
@@ -701,6 +763,7 @@ __global__ void __launch_bounds__(64) ilqr_small_kernel(const KArgs a) {
   double improvement = __builtin_inf();
   int iters = 0, ls_total = 0, nk = 0;
   int status = MI_STATUS_CONVERGED;
+  bool optimistic = true;
   double* hist = a.hist + (size_t)b * a.hist_cap * 4;
   // the reference's stopwatches (time_fp / time_getDerivs / time_backwardsPass, ilqr.py:364-372,696-699)
   long long c_ls = 0, c_lin = 0, c_bp = 0;
@@ -709,7 +772,8 @@ __global__ void __launch_bounds__(64) ilqr_small_kernel(const KArgs a) {
     if (iters >= a.max_iters) { status = MI_STATUS_MAX_ITERS; break; }
     double L_new, eps; int trials;
     const long long c0 = clock64();
-    const bool ok = linesearch<M>(w, c, a, x0r, L, L_new, eps, trials);
+    const bool ok = linesearch<M>(w, c, a, x0r, L, optimistic, L_new, eps, trials);
+    optimistic = ok && trials == 1;
     ls_total += trials;
     if (!ok) { status = MI_STATUS_LINESEARCH_FAILED; break; }
     wave_sync();

@@ -19,6 +19,13 @@
 
 using namespace mi;
 
+// Per-solve aggregate written by stats_kernel into pinned, device-mapped host memory.
+struct DevStats {
+  long long total_iters, total_ls;
+  int n_conv, n_max, n_fail, max_iters_seen, best_index, pad;
+  double best_cost;
+};
+
 struct mi_ilqr {
   mi_ilqr_desc d;
   int n, m, N, B;
@@ -30,6 +37,8 @@ struct mi_ilqr {
   double *x_trial = nullptr, *u_trial = nullptr, *trial_cost = nullptr, *stage_in = nullptr, *costmat = nullptr;
   int32_t *iters = nullptr, *status = nullptr, *ls_trials = nullptr, *kp_count = nullptr, *kp_list = nullptr;
   long long* prof = nullptr;
+  DevStats* h_stats = nullptr;   // pinned host memory, device-mapped
+  DevStats* d_stats = nullptr;   // its device alias
   bool cold = true;        // persistent state is known to be all zero (fresh object / after reset)
   bool u_pending = false;  // SetInitialGuess input waiting in u_guess
   size_t lds = 0;
@@ -249,6 +258,40 @@ void to_time_major(const double* tl, double* tm, int B, int rows, int len) {
       for (int r = 0; r < rows; ++r) tm[((size_t)b * len + t) * rows + r] = tl[((size_t)b * rows + r) * len + t];
 }
 
+// Aggregate per-problem results on the device so a blocking solve costs ONE small host read
+// (pinned, device-mapped) instead of four D2H copies.
+
+__global__ void __launch_bounds__(256) stats_kernel(const int32_t* iters, const int32_t* status, const int32_t* ls,
+                                                    const double* cost, int B, DevStats* out) {
+  __shared__ long long s_it[256], s_ls[256];
+  __shared__ int s_c[256], s_m[256], s_f[256], s_mx[256], s_bi[256];
+  __shared__ double s_bc[256];
+  const int tid = threadIdx.x;
+  long long it = 0, l = 0; int c = 0, m = 0, f = 0, mx = 0, bi = -1; double bc = INFINITY;
+  for (int b = tid; b < B; b += 256) {
+    it += iters[b]; l += ls[b];
+    if (iters[b] > mx) mx = iters[b];
+    if (status[b] == MI_STATUS_CONVERGED) { c++; if (cost[b] < bc) { bc = cost[b]; bi = b; } }
+    else if (status[b] == MI_STATUS_MAX_ITERS) m++;
+    else f++;
+  }
+  s_it[tid] = it; s_ls[tid] = l; s_c[tid] = c; s_m[tid] = m; s_f[tid] = f; s_mx[tid] = mx; s_bi[tid] = bi; s_bc[tid] = bc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) {
+      s_it[tid] += s_it[tid + o]; s_ls[tid] += s_ls[tid + o]; s_c[tid] += s_c[tid + o]; s_m[tid] += s_m[tid + o]; s_f[tid] += s_f[tid + o];
+      if (s_mx[tid + o] > s_mx[tid]) s_mx[tid] = s_mx[tid + o];
+      // ties resolve to the lower problem index, like a sequential scan
+      if (s_bc[tid + o] < s_bc[tid] || (s_bc[tid + o] == s_bc[tid] && s_bi[tid + o] >= 0 && (s_bi[tid] < 0 || s_bi[tid + o] < s_bi[tid]))) { s_bc[tid] = s_bc[tid + o]; s_bi[tid] = s_bi[tid + o]; }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    out->total_iters = s_it[0]; out->total_ls = s_ls[0]; out->n_conv = s_c[0]; out->n_max = s_m[0]; out->n_fail = s_f[0];
+    out->max_iters_seen = s_mx[0]; out->best_index = s_bi[0]; out->best_cost = s_bc[0];
+  }
+}
+
 struct Field { void* ptr; size_t bytes; bool is_int; };
 
 Field field_of(mi_ilqr* h, int which) {
@@ -397,6 +440,11 @@ int mi_ilqr_create(const mi_ilqr_desc* desc, mi_ilqr_t** out) {
     mi_ilqr_destroy(h);
     return MI_ILQR_E_HIP;
   }
+  if (hipHostMalloc(reinterpret_cast<void**>(&h->h_stats), sizeof(DevStats), hipHostMallocMapped) != hipSuccess ||
+      hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_stats), h->h_stats, 0) != hipSuccess) {
+    mi_ilqr_destroy(h);
+    return MI_ILQR_E_HIP;
+  }
   h->cold = true;
   h->u_pending = false;
   *out = h;
@@ -411,6 +459,7 @@ void mi_ilqr_destroy(mi_ilqr_t* h) {
                   h->x_trial, h->u_trial, h->trial_cost, h->stage_in, h->costmat, h->iters, h->status, h->ls_trials,
                   h->kp_count, h->kp_list, h->prof};
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  if (h->h_stats) (void)hipHostFree(h->h_stats);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -471,6 +520,8 @@ int mi_ilqr_solve_async(mi_ilqr_t* h) {
   if (!h) return MI_ILQR_E_BAD_ARG;
   int rc = launch(h, MODE_SOLVE);
   if (rc != MI_ILQR_OK) return rc;
+  hipLaunchKernelGGL(stats_kernel, dim3(1), dim3(256), 0, h->stream, h->iters, h->status, h->ls_trials, h->cost, h->B, h->d_stats);
+  HIPCHK(hipGetLastError());
   h->cold = false;
   h->u_pending = false;
   return MI_ILQR_OK;
@@ -480,26 +531,11 @@ int mi_ilqr_collect_stats(mi_ilqr_t* h, mi_ilqr_stats* st) {
   if (!h || !st) return MI_ILQR_E_BAD_ARG;
   HIPCHK(hipSetDevice(h->d.device_id));
   HIPCHK(hipStreamSynchronize(h->stream));
-  const int B = h->B;
-  std::vector<int32_t> iters(B), status(B), ls(B);
-  std::vector<double> cost(B);
-  HIPCHK(hipMemcpy(iters.data(), h->iters, B * 4, hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(status.data(), h->status, B * 4, hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(ls.data(), h->ls_trials, B * 4, hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(cost.data(), h->cost, B * 8, hipMemcpyDeviceToHost));
   std::memset(st, 0, sizeof(*st));
-  st->best_cost = INFINITY;
-  st->best_index = -1;
-  for (int b = 0; b < B; ++b) {
-    st->total_iters += iters[b];
-    st->total_ls_trials += ls[b];
-    if (iters[b] > st->max_iters_seen) st->max_iters_seen = iters[b];
-    if (status[b] == MI_STATUS_CONVERGED) {
-      st->n_converged++;
-      if (cost[b] < st->best_cost) { st->best_cost = cost[b]; st->best_index = b; }
-    } else if (status[b] == MI_STATUS_MAX_ITERS) st->n_max_iters++;
-    else st->n_ls_failed++;
-  }
+  const DevStats ds = *h->h_stats;     // written by stats_kernel, visible after the stream sync above
+  st->total_iters = ds.total_iters; st->total_ls_trials = ds.total_ls;
+  st->n_converged = ds.n_conv; st->n_max_iters = ds.n_max; st->n_ls_failed = ds.n_fail;
+  st->max_iters_seen = ds.max_iters_seen; st->best_cost = ds.best_cost; st->best_index = ds.best_index;
   float ms = 0.f;
   if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) st->kernel_ms = ms;
   // bytes_iter is affine in ls: sum over iterations = ls_total*roll + iters*(deriv+back)
