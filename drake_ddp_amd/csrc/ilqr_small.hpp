@@ -654,7 +654,7 @@ __device__ __forceinline__ void backward_step(const BRegs<M>& r, const Consts<M>
 }
 
 template <class M>
-__device__ inline void backward(const WS& w, const Consts<M>& c) {
+__device__ inline void backward_scalar(const WS& w, const Consts<M>& c) {
   constexpr int n = M::n, m = M::m;
   using Ly = Lay<n, m>;
   const int N = w.N;
@@ -699,6 +699,144 @@ __device__ inline void backward(const WS& w, const Consts<M>& c) {
     j -= 2 * Ly::JS;
   }
   if (t == 0) backward_step<M>(A, c, Q2, R2, Vx, Vxx, gw);
+}
+
+typedef double d4s_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double readlane_f64(double v, int srclane) {
+  union { double d; int i[2]; } u;
+  u.d = v;
+  u.i[0] = __builtin_amdgcn_readlane(u.i[0], srclane);
+  u.i[1] = __builtin_amdgcn_readlane(u.i[1], srclane);
+  return u.d;
+}
+
+// ---------------------------------------------------------------------------
+// Backward Riccati pass on the fp64 matrix core, for 3 <= n <= 4, m = 1.
+//
+// The scalar formulation costs ~70 n^2 wave-uniform instructions per step at one
+// instruction per ~5 cycles (n = 4: ~1100+ cycles).  Here the whole second-order
+// expansion of a step is TWO v_mfma_f64_16x16x4_f64 with the matrices spread one
+// element per lane (lane = 16*lk + lr):
+//     F = [fx | fu]           held at lane (lk = k, lr = c)        (B layout == A^T layout)
+//     S = [Vxx | Vx at col CV]  at lane (lk = i, lr = j)           (the D layout of a result)
+//     T  = S^T F              : A = S (read through its D-layout registers), B = F
+//     H  = F^T [T | Vx]       : A = F (as F^T), B = T with column CV replaced by Vx
+// H holds Qxx-lxx (rows < n), Qux, Quu-luu, and F^T Vx in column CV, so the gains are a
+// few lane-local operations plus two cross-lane shuffles.  S is consumed through its
+// transpose (the D layout of one product is the A^T layout of the next); Vxx is
+// symmetric up to round-off — the reference never symmetrizes it either — so results
+// differ from the scalar path at the 1e-16 level only.
+// ---------------------------------------------------------------------------
+template <class M>
+__device__ inline void backward_mfma(const WS& w, const Consts<M>& c) {
+  constexpr int n = M::n, m = M::m, nm = n + m, CV = nm;
+  static_assert(m == 1 && n <= 4 && nm + 1 <= 16, "shape covered by one 16x16x4 tile");
+  using Ly = Lay<n, m>;
+  const int N = w.N, lane = threadIdx.x, lr = lane & 15, lk = lane >> 4;
+  constexpr int RQ = n / 4, LQ = n % 4;                 // H row n lives in register RQ of lanes with lk == LQ
+  const bool in_blk = lk < n && lr < n;
+  const bool is_cv = lk < n && lr == CV;
+  // lane constants
+  double q2e = 0.0, q2row[n], qn_l = 0.0;
+#pragma unroll
+  for (int i = 0; i < n; ++i) q2row[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < n; ++i)
+#pragma unroll
+    for (int j = 0; j < n; ++j) {
+      if (lk == i && lr == j) q2e = 2.0 * c.Q[i][j];
+      if (lk == i) q2row[j] = 2.0 * c.Q[i][j];
+    }
+#pragma unroll
+  for (int i = 0; i < n; ++i) if (lk == i) qn_l = c.qn[i];
+  const double R2 = 2.0 * c.R[0][0];
+  // F element of this lane inside a J record (clamped to a valid slot, masked by fvalid)
+  const bool fvalid = lk < n && lr < nm;
+  int foff = Ly::FX;
+  if (fvalid) foff = (lr < n) ? (Ly::FX + lk * n + lr) : (Ly::FU + lk * m + (lr - n));
+  const int src_col = LQ * 16 + lr, src_row = LQ * 16 + (lk < n ? lk : 0);
+
+  // terminal: S = [2 Qf | 2 Qf x_T - 2 x_nom^T Qf]   (ilqr.py:203-204, :638)
+  double S = 0.0;
+  {
+    const double* gT = w.G + (N - 1) * Ly::GS;
+    double vx = 0.0, qfe = 0.0;
+#pragma unroll
+    for (int i = 0; i < n; ++i) {
+      if (lk == i) {
+        double s_ = -c.qfn[i];
+#pragma unroll
+        for (int j = 0; j < n; ++j) { s_ += (2.0 * c.Qf[i][j]) * gT[Ly::XB + j]; if (lr == j) qfe = 2.0 * c.Qf[i][j]; }
+        vx = s_;
+      }
+    }
+    S = in_blk ? qfe : (is_cv ? vx : 0.0);
+  }
+  // write targets: K[j] from lanes (lk == 0, lr < n); kappa, dV from lane 0; everything else to the dump slot
+  const bool kwriter = lk == 0 && lr < n;
+  double* kw = kwriter ? (w.G + (N - 2) * Ly::GS + Ly::KK + lr) : (w.dump + 2 * lane);
+  double* sw = lane == 0 ? (w.G + (N - 2) * Ly::GS) : (w.dump + 2 * lane);
+  const int kstep = kwriter ? Ly::GS : 0, sstep = lane == 0 ? Ly::GS : 0;
+
+  const double* g = w.G + (N - 2) * Ly::GS;
+  const double* jrec = w.J + (N - 2) * Ly::JS;
+  struct Regs { double f, xb[n], ub; };
+  auto load = [&](Regs& r, const double* gp, const double* jp) __attribute__((always_inline)) {
+    r.f = jp[foff];
+#pragma unroll
+    for (int i = 0; i < n; ++i) r.xb[i] = gp[Ly::XB + i];
+    r.ub = gp[Ly::UB];
+  };
+  auto step = [&](const Regs& r) __attribute__((always_inline)) {
+    const double f = fvalid ? r.f : 0.0;
+    const double a1 = (lr < n) ? S : 0.0;                          // Vxx part of S (as S^T through the layout)
+    d4s_t z = {0.0, 0.0, 0.0, 0.0};
+    const d4s_t T = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, f, z, 0, 0, 0);
+    const double b2 = (lr == CV) ? S : T[0];                       // [T | Vx]
+    const d4s_t H = __builtin_amdgcn_mfma_f64_16x16x4f64(f, b2, z, 0, 0, 0);
+    const double hq = H[RQ];
+    const double qux_col = __shfl(hq, src_col);                    // H[n][lr]: Qux[lr] for lr < n
+    const double qux_row = __shfl(hq, src_row);                    // H[n][lk]: Qux[lk]
+    const double Quu = readlane_f64(hq, LQ * 16 + n) + R2;         // :654
+    const double Qu = readlane_f64(hq, LQ * 16 + CV) + R2 * r.ub;  // :652 (lu = 2 R u)
+    const double inv = fast_rcp(Quu);                              // :655
+    const double kap = inv * Qu;                                   // :659
+    const double dv = Qu * kap;                                    // :663
+    const double Kq = inv * qux_col;                               // :660
+    // lx of this lane's row (ilqr.py:180)
+    double lx = -qn_l;
+#pragma unroll
+    for (int i = 0; i < n; ++i) lx += q2row[i] * r.xb[i];
+    const double sxx = fma(-qux_row, Kq, H[0] + q2e);              // Qxx - Qux^T K   (:653,:667)
+    const double svx = fma(-qux_row, kap, H[0] + lx);              // Qx - Qux^T kappa (:651,:666)
+    S = in_blk ? sxx : (is_cv ? svx : 0.0);
+    kw[0] = Kq;
+    sw[Ly::KAP] = kap;
+    sw[Ly::DV] = dv;
+    kw -= kstep;
+    sw -= sstep;
+  };
+  Regs A, B;
+  load(A, g, jrec);
+  int t = N - 2;
+  for (; t >= 1; t -= 2) {
+    load(B, g - Ly::GS, jrec - Ly::JS);
+    __builtin_amdgcn_sched_barrier(0);
+    step(A);
+    load(A, g - 2 * Ly::GS, jrec - 2 * Ly::JS);          // t-2 >= -1: the leading pad record
+    __builtin_amdgcn_sched_barrier(0);
+    step(B);
+    g -= 2 * Ly::GS;
+    jrec -= 2 * Ly::JS;
+  }
+  if (t == 0) step(A);
+}
+
+template <class M>
+__device__ inline void backward(const WS& w, const Consts<M>& c) {
+  if constexpr (M::n >= 3 && M::n <= 4 && M::m == 1) backward_mfma<M>(w, c);
+  else backward_scalar<M>(w, c);
 }
 
 // ---------------------------------------------------------------------------
