@@ -27,6 +27,7 @@ EXPORTS = [
     "mi_ilqr_set_cost", "mi_ilqr_set_initial", "mi_ilqr_reset", "mi_ilqr_rearm_initial_guess",
     "mi_ilqr_solve", "mi_ilqr_solve_async", "mi_ilqr_collect_stats",
     "mi_ilqr_rollout", "mi_ilqr_forward", "mi_ilqr_linearize", "mi_ilqr_backward", "mi_ilqr_mpc_shift",
+    "mi_ilqr_mpc_run", "mi_ilqr_get_mpc_log",
     "mi_ilqr_get", "mi_ilqr_get_int", "mi_ilqr_set", "mi_ilqr_device_ptr", "mi_ilqr_get_stream",
     "mi_ilqr_synchronize", "mi_ilqr_last_kernel_ms", "mi_ilqr_get_cycles", "mi_ilqr_bytes_per_iteration", "mi_ilqr_lds_bytes",
 ]
@@ -87,6 +88,8 @@ def load():
     lib.mi_ilqr_rollout.argtypes = [H, C.c_void_p]
     lib.mi_ilqr_forward.argtypes = [H, C.c_void_p]
     lib.mi_ilqr_mpc_shift.argtypes = [H, C.c_int32]
+    lib.mi_ilqr_mpc_run.argtypes = [H, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(Stats)]
+    lib.mi_ilqr_get_mpc_log.argtypes = [H, C.c_void_p, C.c_size_t]
     lib.mi_ilqr_get.argtypes = [H, C.c_int, C.c_void_p, C.c_size_t]
     lib.mi_ilqr_get_int.argtypes = [H, C.c_int, C.c_void_p, C.c_size_t]
     lib.mi_ilqr_set.argtypes = [H, C.c_int, C.c_void_p, C.c_size_t]

@@ -30,7 +30,7 @@
 
 namespace mi {
 
-enum KernelMode { MODE_SOLVE = 0, MODE_ROLLOUT = 1, MODE_FORWARD = 2, MODE_LINEARIZE = 3, MODE_BACKWARD = 4 };
+enum KernelMode { MODE_SOLVE = 0, MODE_ROLLOUT = 1, MODE_FORWARD = 2, MODE_LINEARIZE = 3, MODE_BACKWARD = 4, MODE_MPC = 5 };
 
 struct KArgs {
   // persistent per-problem solver state, reference layout with a leading batch axis
@@ -49,6 +49,10 @@ struct KArgs {
   int32_t N, B, kp_method, minN, maxN, max_iters, hist_cap;
   int32_t cold;       // 1: persistent state is all-zero, do not read it
   int32_t u_pending;  // 1: take u_bar from u_guess
+  // MODE_MPC: receding-horizon loop kept on the device (acrobot.py:145-155, mini_cheetah.py:190-201)
+  int32_t mpc_resolves, mpc_replan;
+  double mpc_target_step[8];   // added to x_nom before every re-solve (mini_cheetah.py:151-156); zeros = fixed target
+  double* mpc_log;             // (B, mpc_resolves, n+2): x0 of the re-solve | cost | iterations
 };
 
 __device__ __forceinline__ double bcast_lane0(double v) {
@@ -896,48 +900,104 @@ __global__ void __launch_bounds__(64) ilqr_small_kernel(const KArgs a) {
     return;
   }
 
-  // MODE_SOLVE / MODE_FORWARD: the Solve loop (ilqr.py:680-708)
+  // MODE_SOLVE / MODE_FORWARD / MODE_MPC: the Solve loop (ilqr.py:680-708); MODE_MPC wraps it in
+  // the receding-horizon loop with the solver state staying in LDS between re-solves.
   double L = (MODE == MODE_FORWARD) ? a.stage_in[b] : __builtin_inf();
-  double improvement = __builtin_inf();
   int iters = 0, ls_total = 0, nk = 0;
   int status = MI_STATUS_CONVERGED;
-  bool optimistic = true;
   double* hist = a.hist + (size_t)b * a.hist_cap * 4;
   // the reference's stopwatches (time_fp / time_getDerivs / time_backwardsPass, ilqr.py:364-372,696-699)
   long long c_ls = 0, c_lin = 0, c_bp = 0;
   const long long c_begin = clock64();
-  while (improvement > a.delta) {
-    if (iters >= a.max_iters) { status = MI_STATUS_MAX_ITERS; break; }
-    double L_new, eps; int trials;
-    const long long c0 = clock64();
-    const bool ok = linesearch<M>(w, c, a, x0r, L, optimistic, L_new, eps, trials);
-    optimistic = ok && trials == 1;
-    ls_total += trials;
-    if (!ok) { status = MI_STATUS_LINESEARCH_FAILED; break; }
-    wave_sync();
-    const long long c1 = clock64();
-    commit_trial<n, m>(w);                                      // u_bar <- u, x_bar <- x (:375-376)
-    wave_sync();
-    nk = linearize<M, JAC>(w, a);                               // at the ACCEPTED trajectory (:370)
-    const long long c2 = clock64();
-    if (MODE == MODE_SOLVE) { backward<M>(w, c); wave_sync(); } // :697
-    const long long c3 = clock64();
-    c_ls += c1 - c0; c_lin += c2 - c1; c_bp += c3 - c2;
-    if (lane == 0 && iters < a.hist_cap) {
-      hist[4 * iters + 0] = L_new; hist[4 * iters + 1] = eps;
-      hist[4 * iters + 2] = (double)trials; hist[4 * iters + 3] = (double)nk / (double)(N - 1) * 100.0;   // :406
+  const int n_solves = (MODE == MODE_MPC) ? a.mpc_resolves : 1;
+  for (int rs = 0; rs < n_solves; ++rs) {
+    if (MODE == MODE_MPC) {
+      // warm start (acrobot.py:147-152): x0 <- x_bar[:, replan]; u_bar <- [u_bar[:, replan:], repeat(last)]
+      const int r = a.mpc_replan;
+      constexpr int TPL = 8;                       // time steps per lane held in registers (N <= 512)
+      double ush[TPL][m];
+#pragma unroll
+      for (int q = 0; q < TPL; ++q) {
+        const int t = lane + 64 * q;
+        const int src = (t + r < N - 1) ? t + r : N - 2;
+#pragma unroll
+        for (int k = 0; k < m; ++k) ush[q][k] = (t < N - 1) ? w.G[src * Ly::GS + Ly::UB + k] : 0.0;
+      }
+#pragma unroll
+      for (int i = 0; i < n; ++i) x0r[i] = w.G[r * Ly::GS + Ly::XB + i];
+      wave_sync();
+#pragma unroll
+      for (int q = 0; q < TPL; ++q) {
+        const int t = lane + 64 * q;
+        if (t < N - 1) {
+#pragma unroll
+          for (int k = 0; k < m; ++k) w.G[t * Ly::GS + Ly::UB + k] = ush[q][k];
+        }
+      }
+      // moving target (mini_cheetah.py:151-156) and the constants derived from it (ilqr.py:180,203)
+#pragma unroll
+      for (int i = 0; i < n; ++i) c.xnom[i] += a.mpc_target_step[i];
+#pragma unroll
+      for (int j = 0; j < n; ++j) {
+        double s_ = 0.0, sf_ = 0.0;
+#pragma unroll
+        for (int i = 0; i < n; ++i) { s_ += (2.0 * c.xnom[i]) * c.Q[i][j]; sf_ += (2.0 * c.xnom[i]) * c.Qf[i][j]; }
+        c.qn[j] = s_; c.qfn[j] = sf_;
+      }
+      wave_sync();
+      L = __builtin_inf();
     }
-    improvement = L - L_new;                                    // :706
-    L = L_new;
-    iters += 1;
-    if (MODE == MODE_FORWARD) break;
+    double improvement = __builtin_inf();
+    bool optimistic = true;
+    int it_this = 0;
+    while (improvement > a.delta) {
+      if (it_this >= a.max_iters) { status = MI_STATUS_MAX_ITERS; break; }
+      double L_new, eps; int trials;
+      const long long c0 = clock64();
+      const bool ok = linesearch<M>(w, c, a, x0r, L, optimistic, L_new, eps, trials);
+      optimistic = ok && trials == 1;
+      ls_total += trials;
+      if (!ok) { status = MI_STATUS_LINESEARCH_FAILED; break; }
+      wave_sync();
+      const long long c1 = clock64();
+      commit_trial<n, m>(w);                                      // u_bar <- u, x_bar <- x (:375-376)
+      wave_sync();
+      nk = linearize<M, JAC>(w, a);                               // at the ACCEPTED trajectory (:370)
+      const long long c2 = clock64();
+      if (MODE != MODE_FORWARD) { backward<M>(w, c); wave_sync(); } // :697
+      const long long c3 = clock64();
+      c_ls += c1 - c0; c_lin += c2 - c1; c_bp += c3 - c2;
+      if (lane == 0 && it_this < a.hist_cap) {                    // history of the LAST solve
+        hist[4 * it_this + 0] = L_new; hist[4 * it_this + 1] = eps;
+        hist[4 * it_this + 2] = (double)trials; hist[4 * it_this + 3] = (double)nk / (double)(N - 1) * 100.0;   // :406
+      }
+      improvement = L - L_new;                                    // :706
+      L = L_new;
+      it_this += 1;
+      if (MODE == MODE_FORWARD) break;
+    }
+    iters += it_this;
+    if (MODE == MODE_MPC) {
+      double* lg = a.mpc_log + ((size_t)b * a.mpc_resolves + rs) * (n + 2);
+      if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < n; ++i) lg[i] = x0r[i];
+        lg[n] = L; lg[n + 1] = (double)it_this;
+      }
+      if (status == MI_STATUS_LINESEARCH_FAILED) break;
+    }
+  }
+  if (MODE == MODE_MPC && lane < n) {               // the re-solves moved x0: keep the HBM copy consistent
+    double* x0g = const_cast<double*>(a.x0) + (size_t)b * n;
+#pragma unroll
+    for (int i = 0; i < n; ++i) if (lane == i) x0g[i] = x0r[i];
   }
   wave_sync();
   stage_out(a.x_bar + oX, w.G, Ly::GS, Ly::XB, n, N);
   stage_out(a.u_bar + oU, w.G, Ly::GS, Ly::UB, m, N - 1);
   stage_out(a.fx + oFx, w.J, Ly::JS, Ly::FX, n * n, N - 1);
   stage_out(a.fu + oFu, w.J, Ly::JS, Ly::FU, n * m, N - 1);
-  if (MODE == MODE_SOLVE) {
+  if (MODE == MODE_SOLVE || MODE == MODE_MPC) {
     stage_out(a.K + oK, w.G, Ly::GS, Ly::KK, m * n, N - 1);
     stage_out(a.kappa + oU, w.G, Ly::GS, Ly::KAP, m, N - 1);
     stage_out(a.dV + oT, w.G, Ly::GS, Ly::DV, 1, N - 1);

@@ -39,6 +39,10 @@ struct mi_ilqr {
   long long* prof = nullptr;
   DevStats* h_stats = nullptr;   // pinned host memory, device-mapped
   DevStats* d_stats = nullptr;   // its device alias
+  double* mpc_log = nullptr;     // (B, mpc_log_resolves, n+2)
+  int mpc_log_resolves = 0;
+  int mpc_resolves = 0, mpc_replan = 0;
+  double mpc_target_step[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   bool cold = true;        // persistent state is known to be all zero (fresh object / after reset)
   bool u_pending = false;  // SetInitialGuess input waiting in u_guess
   size_t lds = 0;
@@ -106,6 +110,8 @@ KArgs make_args(const mi_ilqr* h) {
   a.max_iters = h->d.max_iters; a.hist_cap = h->d.hist_cap;
   a.cold = h->cold ? 1 : 0;
   a.u_pending = h->u_pending ? 1 : 0;
+  a.mpc_resolves = h->mpc_resolves; a.mpc_replan = h->mpc_replan; a.mpc_log = h->mpc_log;
+  for (int i = 0; i < 8; ++i) a.mpc_target_step[i] = h->mpc_target_step[i];
   return a;
 }
 
@@ -128,6 +134,7 @@ int launch_mode(mi_ilqr* h, int mode, const KArgs& a) {
     case MODE_FORWARD: return launch_one<M, JAC, MODE_FORWARD>(h, a);
     case MODE_LINEARIZE: return launch_one<M, JAC, MODE_LINEARIZE>(h, a);
     case MODE_BACKWARD: return launch_one<M, JAC, MODE_BACKWARD>(h, a);
+    case MODE_MPC: return launch_one<M, JAC, MODE_MPC>(h, a);
   }
   return MI_ILQR_E_BAD_ARG;
 }
@@ -460,6 +467,7 @@ void mi_ilqr_destroy(mi_ilqr_t* h) {
                   h->kp_count, h->kp_list, h->prof};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->h_stats) (void)hipHostFree(h->h_stats);
+  if (h->mpc_log) (void)hipFree(h->mpc_log);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -615,6 +623,68 @@ int mi_ilqr_mpc_shift(mi_ilqr_t* h, int32_t replan_steps) {
                        h->B, h->n, h->m, h->N, (int)replan_steps);
   HIPCHK(hipGetLastError());
   h->u_pending = true;
+  return MI_ILQR_OK;
+}
+
+int mi_ilqr_mpc_run(mi_ilqr_t* h, int32_t num_resolves, int32_t replan_steps, const double* target_step, mi_ilqr_stats* stats) {
+  if (!h) return MI_ILQR_E_BAD_ARG;
+  if (num_resolves < 1 || replan_steps < 1 || replan_steps >= h->N - 1) return MI_ILQR_E_BAD_ARG;
+  HIPCHK(hipSetDevice(h->d.device_id));
+  int rc;
+  if (h->large || h->N > 512 || h->n > 8) {
+    // workgroup-per-problem path: the state lives in HBM anyway; loop shift + solve on the host
+    std::vector<double> xn(h->n);
+    if (target_step) HIPCHK(hipMemcpy(xn.data(), h->costmat + 2 * (size_t)h->n * h->n + (size_t)h->m * h->m, h->n * 8, hipMemcpyDeviceToHost));
+    mi_ilqr_stats acc; std::memset(&acc, 0, sizeof(acc)); acc.best_cost = INFINITY; acc.best_index = -1;
+    for (int r = 0; r < num_resolves; ++r) {
+      if ((rc = mi_ilqr_mpc_shift(h, replan_steps)) != MI_ILQR_OK) return rc;
+      if (target_step) {
+        for (int i = 0; i < h->n; ++i) xn[i] += target_step[i];
+        if ((rc = mi_ilqr_set_cost(h, nullptr, nullptr, nullptr, xn.data())) != MI_ILQR_OK) return rc;
+      }
+      mi_ilqr_stats st;
+      if ((rc = mi_ilqr_solve(h, &st)) != MI_ILQR_OK) return rc;
+      acc.total_iters += st.total_iters; acc.total_ls_trials += st.total_ls_trials; acc.kernel_ms += st.kernel_ms;
+      acc.algorithmic_bytes += st.algorithmic_bytes;
+      acc.n_converged = st.n_converged; acc.n_max_iters = st.n_max_iters; acc.n_ls_failed = st.n_ls_failed;
+      if (st.max_iters_seen > acc.max_iters_seen) acc.max_iters_seen = st.max_iters_seen;
+      acc.best_cost = st.best_cost; acc.best_index = st.best_index;
+    }
+    if (stats) *stats = acc;
+    return MI_ILQR_OK;
+  }
+  if ((rc = materialize_zero_state(h)) != MI_ILQR_OK) return rc;
+  if ((rc = materialize_u(h)) != MI_ILQR_OK) return rc;
+  if (h->mpc_log_resolves < num_resolves) {
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->mpc_log) HIPCHK(hipFree(h->mpc_log));
+    h->mpc_log = nullptr;
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&h->mpc_log), (size_t)h->B * num_resolves * (h->n + 2) * 8));
+    h->mpc_log_resolves = num_resolves;
+  }
+  h->mpc_resolves = num_resolves; h->mpc_replan = replan_steps;
+  for (int i = 0; i < 8; ++i) h->mpc_target_step[i] = (target_step && i < h->n) ? target_step[i] : 0.0;
+  rc = launch(h, MODE_MPC);
+  if (rc != MI_ILQR_OK) return rc;
+  hipLaunchKernelGGL(stats_kernel, dim3(1), dim3(256), 0, h->stream, h->iters, h->status, h->ls_trials, h->cost, h->B, h->d_stats);
+  HIPCHK(hipGetLastError());
+  if (target_step) {          // keep the handle's x_nom in step with what the kernel accumulated
+    std::vector<double> xn(h->n);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(xn.data(), h->costmat + 2 * (size_t)h->n * h->n + (size_t)h->m * h->m, h->n * 8, hipMemcpyDeviceToHost));
+    for (int i = 0; i < h->n; ++i) xn[i] += num_resolves * target_step[i];
+    HIPCHK(hipMemcpy(h->costmat + 2 * (size_t)h->n * h->n + (size_t)h->m * h->m, xn.data(), h->n * 8, hipMemcpyHostToDevice));
+  }
+  if (stats) return mi_ilqr_collect_stats(h, stats);
+  return mi_ilqr_synchronize(h);
+}
+
+int mi_ilqr_get_mpc_log(mi_ilqr_t* h, double* dst, size_t bytes) {
+  if (!h || !dst || !h->mpc_log) return MI_ILQR_E_BAD_ARG;
+  if (bytes != (size_t)h->B * h->mpc_resolves * (h->n + 2) * 8) return MI_ILQR_E_BAD_SHAPE;
+  HIPCHK(hipSetDevice(h->d.device_id));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipMemcpy(dst, h->mpc_log, bytes, hipMemcpyDeviceToHost));
   return MI_ILQR_OK;
 }
 

@@ -212,6 +212,28 @@ class BatchedIterativeLQR:
         """On-device warm start of the receding-horizon loop (acrobot.py:147-152)."""
         _capi.check(self._lib.mi_ilqr_mpc_shift(self._h, int(replan_steps)), "mi_ilqr_mpc_shift")
 
+    def MPCRun(self, num_resolves, replan_steps, target_step=None):
+        """The receding-horizon loop (acrobot.py:145-155, mini_cheetah.py:190-201) kept on the device:
+        num_resolves x { shift warm start; x_nom += target_step; Solve }.  One launch for the
+        wave-per-problem models.  Returns the aggregate stats; `mpc_log` has the per-re-solve record."""
+        ts = None
+        if target_step is not None:
+            ts = _capi.as_f64(target_step, (self.n,))
+            self.x_nom = np.asarray(self.x_nom, dtype=np.float64) + num_resolves * ts
+        stats = _capi.Stats()
+        _capi.check(self._lib.mi_ilqr_mpc_run(self._h, int(num_resolves), int(replan_steps), _capi.ptr(ts), C.byref(stats)),
+                    "mi_ilqr_mpc_run")
+        self.stats = stats
+        self._mpc_resolves = int(num_resolves)
+        return stats
+
+    @property
+    def mpc_log(self):
+        """(B, num_resolves, n+2): x0 of each re-solve | cost | iterations (wave-per-problem models)."""
+        out = np.empty((self.B, self._mpc_resolves, self.n + 2), dtype=np.float64)
+        _capi.check(self._lib.mi_ilqr_get_mpc_log(self._h, _capi.ptr(out), out.nbytes), "mi_ilqr_get_mpc_log")
+        return out
+
     def SetTargetStateResident(self, x_nom):
         """Moving target between resident re-solves (mini_cheetah.py:151-156)."""
         self.SetTargetState(x_nom)

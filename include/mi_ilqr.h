@@ -169,6 +169,14 @@ int mi_ilqr_backward(mi_ilqr_t* h);
  * x0 <- x_bar[:, replan_steps]; u_bar <- [u_bar[:, replan_steps:], repeat(u_bar[:, -1])]. */
 int mi_ilqr_mpc_shift(mi_ilqr_t* h, int32_t replan_steps);
 
+/* The whole receding-horizon loop of acrobot.py:145-155 / mini_cheetah.py:190-201 on the device:
+ * `num_resolves` times { mpc_shift(replan_steps); x_nom += target_step (may be NULL); Solve }.
+ * For the wave-per-problem kernels this is ONE launch and the solver state stays in LDS between
+ * re-solves; per re-solve the log keeps (x0 (n), cost, iterations) for every problem:
+ * mi_ilqr_get_mpc_log -> (B, num_resolves, n+2).  stats aggregate the whole loop. */
+int mi_ilqr_mpc_run(mi_ilqr_t* h, int32_t num_resolves, int32_t replan_steps, const double* target_step, mi_ilqr_stats* stats);
+int mi_ilqr_get_mpc_log(mi_ilqr_t* h, double* dst, size_t bytes);
+
 /* Copy a field out / in (host memory; `bytes` must equal the field size). */
 int mi_ilqr_get(mi_ilqr_t* h, int which, double* dst, size_t bytes);
 int mi_ilqr_get_int(mi_ilqr_t* h, int which, int32_t* dst, size_t bytes);

@@ -39,11 +39,11 @@ def mpc(name, prob, x0, u_guess, resolves, replan, move=None, **kw):
         s.SetInitialState(x0); s.SetInitialGuess(u_guess); s._push_problem()
         it = 0; kms = 0; ab = 0
         st = s.solve_resident(); it += st.total_iters; kms += st.kernel_ms; ab += st.algorithmic_bytes
-        for r in range(resolves):
-            s.MPCShift(replan)
-            if move is not None:
-                x_nom[move[0]] += move[1]; s.SetTargetStateResident(x_nom)
-            st = s.solve_resident(); it += st.total_iters; kms += st.kernel_ms; ab += st.algorithmic_bytes
+        step = None
+        if move is not None:
+            step = np.zeros(s.n); step[move[0]] = move[1]
+        st = s.MPCRun(resolves, replan, target_step=step)       # the whole receding-horizon loop on the device
+        it += st.total_iters; kms += st.kernel_ms; ab += st.algorithmic_bytes
         return it, kms, ab
     run()
     t0 = time.perf_counter(); it, kms, ab = run(); dt = time.perf_counter() - t0
