@@ -39,6 +39,29 @@ def allreduce_min(value, device_id=0):
     return float(t.item())
 
 
+class PendingMin:
+    """Handle of an in-flight all-reduce(min): lets the collective overlap the next solve."""
+
+    def __init__(self, tensor, work):
+        self.tensor, self.work = tensor, work
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        return float(self.tensor.item())
+
+
+def allreduce_min_async(value, device_id=0):
+    """Non-blocking variant of allreduce_min (RCCL runs it on its own stream)."""
+    import torch
+    dist = _dist()
+    if dist is None:
+        return PendingMin(torch.tensor([float(value)], dtype=torch.float64), None)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=_device(device_id))
+    return PendingMin(t, dist.all_reduce(t, op=dist.ReduceOp.MIN, async_op=True))
+
+
 def best_of_all_ranks(local_best_cost, local_best_index, shard_lo, device_id=0):
     """(cost, global problem index, owning rank) of the best converged problem of the
     whole batch: all-gather of one {cost, global index} pair per rank + local argmin."""

@@ -23,7 +23,7 @@ _JAC_IDS = {"fd": _capi.JAC_FD_CENTRAL, "fd_central": _capi.JAC_FD_CENTRAL,
             "autodiff": _capi.JAC_AUTODIFF, "ad": _capi.JAC_AUTODIFF}
 
 
-from .dist import shard_range, allreduce_min  # noqa: E402,F401
+from .dist import shard_range, allreduce_min, allreduce_min_async  # noqa: E402,F401
 
 
 class BatchedIterativeLQR:
@@ -271,6 +271,12 @@ class BatchedIterativeLQR:
         the per-iteration path.  No-op without an initialized process group."""
         best = float(self.stats.best_cost) if self.stats is not None else float(np.min(self.cost))
         return allreduce_min(best, self._desc.device_id)
+
+    def best_cost_allreduce_async(self):
+        """Same collective, non-blocking: returns a handle whose .wait() yields the global best
+        cost, so the 8-byte RCCL reduction overlaps the next batched solve."""
+        best = float(self.stats.best_cost) if self.stats is not None else float(np.min(self.cost))
+        return allreduce_min_async(best, self._desc.device_id)
 
 
 class IterativeLinearQuadraticRegulator(BatchedIterativeLQR):

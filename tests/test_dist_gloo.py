@@ -64,3 +64,31 @@ def test_world2_shard_and_best_cost_reduction():
         assert r[7] == (0 if r[6] < 3 else 1)
         assert r[8][1] == 5                                           # summed shard sizes = global batch
     assert res[0][8] == res[1][8]
+
+
+def _worker_async(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from drake_ddp_amd.dist import allreduce_min_async
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    hs = [allreduce_min_async(10.0 * (rank + 1) + k) for k in range(3)]     # several in flight
+    out.put((rank, [h.wait() for h in hs]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_world2_async_min_overlaps():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker_async, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(out.get(timeout=100) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == [10.0, 11.0, 12.0] and res[1][1] == [10.0, 11.0, 12.0]
