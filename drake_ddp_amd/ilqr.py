@@ -318,17 +318,23 @@ class IterativeLinearQuadraticRegulator(BatchedIterativeLQR):
         iters = int(self.iterations[0])
         hist = self.history[0]
         status = int(self.status[0])
+        # the reference's stopwatches (ilqr.py:364-372,696-699) from the in-kernel cycle counters:
+        # per-iteration AVERAGES of the last solve (the fused kernel does not log per-iteration clocks)
+        cyc = self.stage_cycles[0].astype(np.float64)
+        sec_per_cycle = stats.kernel_ms * 1e-3 / max(cyc[3], 1.0)
+        self.time_fp = cyc[0] * sec_per_cycle / max(iters, 1)
+        self.time_getDerivs = cyc[1] * sec_per_cycle / max(iters, 1)
+        self.time_backwardsPass = cyc[2] * sec_per_cycle / max(iters, 1)
         if self.verbose:
-            # same table as ilqr.py:685-704; the fused kernel has no per-stage clocks, so the
-            # per-iteration time columns carry the kernel time divided by the iteration count
+            # same table as ilqr.py:685-704
             print("----------------------------------------------------------------------------------------------------------------------------------")
             print("|    iter    |    cost    |    eps    |    ls    | derivs time | derivs '%'  | bp time  | fp time  |   iter time    |    time    |")
             print("----------------------------------------------------------------------------------------------------------------------------------")
             per_iter = stats.kernel_ms * 1e-3 / max(iters, 1)
             for i in range(min(iters, self.hist_cap)):
                 L_new, eps, ls, pct = hist[i]
-                print(f"{i + 1:^14}{L_new:11.4f}  {eps:^12.4f}{int(ls):^11}   {0.0:1.5f}         {pct:.1f}       "
-                      f"{0.0:1.5f}    {0.0:1.5f}      {per_iter:1.5f}          {per_iter * (i + 1):4.2f}")
+                print(f"{i + 1:^14}{L_new:11.4f}  {eps:^12.4f}{int(ls):^11}   {self.time_getDerivs:1.5f}         {pct:.1f}       "
+                      f"{self.time_backwardsPass:1.5f}    {self.time_fp:1.5f}      {per_iter:1.5f}          {per_iter * (i + 1):4.2f}")
         if status == _capi.STATUS_LINESEARCH_FAILED:
             raise RuntimeError("linesearch failed after %s iterations" % int(self.ls_trials[0]))   # ilqr.py:337
         return self.x_bar, self.u_bar, total_time, float(self.cost[0])

@@ -167,3 +167,13 @@ def test_c3_c4_c5_configs_converge_at_full_size():
     s.SetInitialState(W.synth36_batch_x0(64)); s.SetInitialGuess(W.synth36_u_guess(q["N"]))
     _, _, _, L = s.Solve()
     assert (s.status == 0).all() and np.all(np.isfinite(L))
+
+
+@pytest.mark.parametrize("script", ["swingup_pendulum.py", "mpc_acrobot.py"])
+def test_example_scripts_run(script):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "examples", script)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert ("Optimal cost: 0.23997" in out.stdout) or ("device loop" in out.stdout)
