@@ -47,6 +47,7 @@ struct KArgs {
   double params[MI_ILQR_MAX_PARAMS];
   double dt, delta, beta, gamma, jerk_thr, err_thr, fd_h;
   int32_t N, B, kp_method, minN, maxN, max_iters, hist_cap;
+  int32_t n_store;    // line-search candidates whose trajectories are kept in LDS (>= 1)
   int32_t cold;       // 1: persistent state is all-zero, do not read it
   int32_t u_pending;  // 1: take u_bar from u_guess
   // MODE_MPC: receding-horizon loop kept on the device (acrobot.py:145-155, mini_cheetah.py:190-201)
@@ -96,23 +97,25 @@ struct WS {
   double* dump;            // per-lane sink for predicated-off stores (lane*16 B)
   int *kp, *aux, *need, *binA, *binB;
   int N;
+  int n_store, t_stride;   // T holds n_store trajectories, t_stride doubles apart
 };
 
 template <int n, int m>
-__host__ __device__ constexpr size_t ws_bytes(int N) {
+__host__ __device__ constexpr size_t ws_bytes(int N, int n_store = 1) {
   using L = Lay<n, m>;
-  return ((size_t)(N + 2) * L::GS + (size_t)(N + 2) * L::TS + (size_t)(N + 2) * L::JS + L::DUMP_DOUBLES) * 8 +
+  return ((size_t)(N + 2) * L::GS + (size_t)n_store * (N + 2) * L::TS + (size_t)(N + 2) * L::JS + L::DUMP_DOUBLES) * 8 +
          (size_t)7 * N * 4 + 16;
 }
 
 template <int n, int m>
-__device__ inline WS carve(char* base, int N) {
+__device__ inline WS carve(char* base, int N, int n_store) {
   using L = Lay<n, m>;
   WS w;
   w.N = N;
   double* p = reinterpret_cast<double*>(base);
   w.G = p + L::GS; p += (size_t)(N + 2) * L::GS;
-  w.T = p + L::TS; p += (size_t)(N + 2) * L::TS;
+  w.T = p + L::TS; p += (size_t)n_store * (N + 2) * L::TS;
+  w.n_store = n_store; w.t_stride = (N + 2) * L::TS;
   w.J = p + L::JS; p += (size_t)(N + 2) * L::JS;
   w.dump = p; p += L::DUMP_DOUBLES;
   int* q = reinterpret_cast<int*>(p);
@@ -269,9 +272,10 @@ __device__ __forceinline__ void rollout_step(const GRegs<M>& r, const Consts<M>&
   for (int i = 0; i < n; ++i) x[i] = xnext[i];
 }
 
+// `slot` >= 0: this lane stores its trajectory into T buffer `slot`; < 0: stores are parked.
 template <class M, bool COST = true>
 __device__ inline void rollout(const WS& w, const Consts<M>& c, const KArgs& a, const double* x0r,
-                               double eps, bool store, double& L_out, double& exp_out) {
+                               double eps, int slot, double& L_out, double& exp_out) {
   constexpr int n = M::n, m = M::m;
   using Ly = Lay<n, m>;
   const int N = w.N;
@@ -279,7 +283,8 @@ __device__ inline void rollout(const WS& w, const Consts<M>& c, const KArgs& a, 
 #pragma unroll
   for (int i = 0; i < n; ++i) x[i] = x0r[i];
   // store==true (lane 0): walk the T records; otherwise park on this lane's dump slot
-  double* tw = store ? w.T : (w.dump + 2 * threadIdx.x);
+  const bool store = slot >= 0;
+  double* tw = store ? (w.T + slot * w.t_stride) : (w.dump + 2 * threadIdx.x);
   const int tstep = store ? Ly::TS : 0;
 #pragma unroll
   for (int i = 0; i < n; ++i) tw[Ly::XN + i] = x[i];
@@ -316,7 +321,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 // Total cost (ilqr.py:325,327) and expected improvement (:326) of the trajectory stored in
 // the T records, evaluated time-parallel (one time step per lane, fixed-order wave reduction).
 template <class M>
-__device__ inline void traj_cost(const WS& w, const Consts<M>& c, double eps, double& L_out, double& exp_out) {
+__device__ inline void traj_cost(const WS& w, const Consts<M>& c, double eps, double& L_out, double& exp_out) {   // T buffer 0
   constexpr int n = M::n, m = M::m;
   using Ly = Lay<n, m>;
   const int N = w.N;
@@ -352,19 +357,20 @@ __device__ inline void traj_cost(const WS& w, const Consts<M>& c, double eps, do
 // pass run.  The accepted candidate is the same either way.
 template <class M>
 __device__ inline bool linesearch(const WS& w, const Consts<M>& c, const KArgs& a, const double* x0r,
-                                  double L_last, bool optimistic, double& L_out, double& eps_out, int& trials) {
+                                  double L_last, bool optimistic, double& L_out, double& eps_out, int& trials, int& slot_out) {
   const int lane = threadIdx.x;
   int base = 0;
   double eps_base = 1.0;
   if (optimistic) {
     double L, ex;
-    rollout<M, false>(w, c, a, x0r, 1.0, lane == 0, L, ex);
+    rollout<M, false>(w, c, a, x0r, 1.0, lane == 0 ? 0 : -1, L, ex);
     wave_sync();
     traj_cost<M>(w, c, 1.0, L, ex);
     if ((L_last - L) > a.gamma * ex) {                         // ilqr.py:330-331
       L_out = L;
       eps_out = 1.0;
       trials = 1;
+      slot_out = 0;
       return true;
     }
     wave_sync();
@@ -374,15 +380,18 @@ __device__ inline bool linesearch(const WS& w, const Consts<M>& c, const KArgs& 
     for (int i = 0; i < lane; ++i) eps *= a.beta;   // eps *= beta, repeated (ilqr.py:335): bit-identical sequence
     const bool valid = eps >= 1e-8;                 // while eps >= 1e-8 (ilqr.py:302)
     double L, ex;
-    rollout<M>(w, c, a, x0r, eps, lane == 0, L, ex);
+    // the first n_store candidates keep their trajectories (coarse line searches, beta <= 0.75,
+    // usually accept one of them: no second rollout needed)
+    rollout<M>(w, c, a, x0r, eps, lane < w.n_store ? lane : -1, L, ex);
     const bool acc = valid && ((L_last - L) > a.gamma * ex);   // ilqr.py:330-331
     const unsigned long long mask = __ballot(acc);
     if (mask != 0ull) {
       const int k = __ffsll((long long)mask) - 1;
-      if (k == 0) {
-        L_out = bcast_lane0(L);
-        eps_out = eps_base;
-        trials = base + 1;
+      if (k < w.n_store) {
+        L_out = __shfl(L, k);
+        eps_out = __shfl(eps, k);
+        trials = base + k + 1;
+        slot_out = k;
         return true;
       }
       // candidate base+k wins: re-run with it in lane 0 so its trajectory is stored
@@ -404,10 +413,11 @@ __device__ inline bool linesearch(const WS& w, const Consts<M>& c, const KArgs& 
 
 // Commit the accepted trial: x_bar <- x, u_bar <- u (ilqr.py:375-376).
 template <int n, int m>
-__device__ inline void commit_trial(const WS& w) {
+__device__ inline void commit_trial(const WS& w, int slot) {
   using Ly = Lay<n, m>;
+  const double* Ts = w.T + slot * w.t_stride;
   for (int t = threadIdx.x; t < w.N; t += 64) {
-    const double* s = w.T + t * Ly::TS;
+    const double* s = Ts + t * Ly::TS;
     double* d = w.G + t * Ly::GS;
 #pragma unroll
     for (int i = 0; i < n; ++i) d[Ly::XB + i] = s[Ly::XN + i];
@@ -854,7 +864,7 @@ __global__ void __launch_bounds__(64) ilqr_small_kernel(const KArgs a) {
   const int b = blockIdx.x;
   const int lane = threadIdx.x;
   const int N = a.N;
-  WS w = carve<n, m>(smem, N);
+  WS w = carve<n, m>(smem, N, a.n_store);
   const size_t oX = (size_t)b * n * N, oU = (size_t)b * m * (N - 1), oK = (size_t)b * m * n * (N - 1);
   const size_t oFx = (size_t)b * n * n * (N - 1), oFu = (size_t)b * n * m * (N - 1), oT = (size_t)b * (N - 1);
 
@@ -876,7 +886,7 @@ __global__ void __launch_bounds__(64) ilqr_small_kernel(const KArgs a) {
 
   if (MODE == MODE_ROLLOUT) {
     double L, ex;
-    rollout<M>(w, c, a, x0r, a.stage_in[b], lane == 0, L, ex);
+    rollout<M>(w, c, a, x0r, a.stage_in[b], lane == 0 ? 0 : -1, L, ex);
     wave_sync();
     stage_out(a.x_trial + oX, w.T, Ly::TS, Ly::XN, n, N);
     stage_out(a.u_trial + oU, w.T, Ly::TS, Ly::UN, m, N - 1);
@@ -952,15 +962,15 @@ __global__ void __launch_bounds__(64) ilqr_small_kernel(const KArgs a) {
     int it_this = 0;
     while (improvement > a.delta) {
       if (it_this >= a.max_iters) { status = MI_STATUS_MAX_ITERS; break; }
-      double L_new, eps; int trials;
+      double L_new, eps; int trials, slot = 0;
       const long long c0 = clock64();
-      const bool ok = linesearch<M>(w, c, a, x0r, L, optimistic, L_new, eps, trials);
+      const bool ok = linesearch<M>(w, c, a, x0r, L, optimistic, L_new, eps, trials, slot);
       optimistic = ok && trials == 1;
       ls_total += trials;
       if (!ok) { status = MI_STATUS_LINESEARCH_FAILED; break; }
       wave_sync();
       const long long c1 = clock64();
-      commit_trial<n, m>(w);                                      // u_bar <- u, x_bar <- x (:375-376)
+      commit_trial<n, m>(w, slot);                                // u_bar <- u, x_bar <- x (:375-376)
       wave_sync();
       nk = linearize<M, JAC>(w, a);                               // at the ACCEPTED trajectory (:370)
       const long long c2 = clock64();

@@ -47,6 +47,7 @@ struct mi_ilqr {
   bool u_pending = false;  // SetInitialGuess input waiting in u_guess
   size_t lds = 0;
   bool large = false;      // workgroup-per-problem path: state arrays are TIME-MAJOR in HBM
+  int n_store = 1;         // line-search candidate trajectories kept in LDS
   float last_ms = 0.f;
 };
 
@@ -75,12 +76,12 @@ const ModelInfo* model_info(int id) {
   return &table[id];
 }
 
-size_t small_lds_bytes(int model_id, int N) {
+size_t small_lds_bytes(int model_id, int N, int n_store = 1) {
   switch (model_id) {
-    case MI_MODEL_PENDULUM: return ws_bytes<2, 1>(N);
+    case MI_MODEL_PENDULUM: return ws_bytes<2, 1>(N, n_store);
     case MI_MODEL_ACROBOT:
     case MI_MODEL_CARTPOLE:
-    case MI_MODEL_CARTPOLE_WALL: return ws_bytes<4, 1>(N);
+    case MI_MODEL_CARTPOLE_WALL: return ws_bytes<4, 1>(N, n_store);
     default: return 0;
   }
 }
@@ -108,6 +109,7 @@ KArgs make_args(const mi_ilqr* h) {
   a.jerk_thr = h->d.jerk_threshold; a.err_thr = h->d.iterative_error_threshold; a.fd_h = h->d.fd_step;
   a.N = h->N; a.B = h->B; a.kp_method = h->d.keypoint_method; a.minN = h->d.minN; a.maxN = h->d.maxN;
   a.max_iters = h->d.max_iters; a.hist_cap = h->d.hist_cap;
+  a.n_store = h->n_store;
   a.cold = h->cold ? 1 : 0;
   a.u_pending = h->u_pending ? 1 : 0;
   a.mpc_resolves = h->mpc_resolves; a.mpc_replan = h->mpc_replan; a.mpc_log = h->mpc_log;
@@ -394,8 +396,19 @@ int mi_ilqr_create(const mi_ilqr_desc* desc, mi_ilqr_t** out) {
 
   size_t lds = small_lds_bytes(desc->model_id, desc->N);
   bool large = false;
+  int n_store = 1;
   if (lds == 0) { lds = large_lds(desc->model_id, desc->N); large = true; }
   if (lds == 0 || lds > kMaxLds) return MI_ILQR_E_UNSUPPORTED;
+  if (!large && desc->beta <= 0.75) {
+    // Coarse backtracking (beta <= 0.75) accepts one of the first few eps values: keep up to 6
+    // candidate trajectories in LDS as long as that does not lower the problems-per-CU this
+    // batch needs (256 CUs) — it removes the second rollout of a backtracking iteration.
+    const size_t per_cu_needed = ((size_t)desc->B + 255) / 256;
+    for (int ns = 6; ns > 1; --ns) {
+      const size_t l = small_lds_bytes(desc->model_id, desc->N, ns);
+      if (l <= kMaxLds && kMaxLds / l >= per_cu_needed) { n_store = ns; lds = l; break; }
+    }
+  }
 
   mi_ilqr* h = new (std::nothrow) mi_ilqr();
   if (!h) return MI_ILQR_E_BAD_ARG;
@@ -405,6 +418,7 @@ int mi_ilqr_create(const mi_ilqr_desc* desc, mi_ilqr_t** out) {
   h->n = desc->n; h->m = desc->m; h->N = desc->N; h->B = desc->B;
   h->lds = lds;
   h->large = large;
+  h->n_store = n_store;
   const size_t n = h->n, m = h->m, N = h->N, B = h->B;
 
 #define ALLOC(p, count, T)                                             \
