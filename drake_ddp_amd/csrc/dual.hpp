@@ -50,11 +50,17 @@ __device__ inline Dual1 mi_cos(Dual1 a) { return {fast_cos(a.v), -fast_sin(a.v) 
 __device__ inline Dual1 mi_exp(Dual1 a) { const double e = exp(a.v); return {e, e * a.d}; }
 __device__ inline Dual1 mi_log1p(Dual1 a) { return {log1p(a.v), a.d / (1.0 + a.v)}; }
 
-// log(1+exp(z)), overflow-safe; branch on the VALUE like oracle/dual.py:softplus.
-template <class T>
-__device__ inline T mi_softplus(T z) {
-  if (value_of(z) > 0.0) return z + mi_log1p(mi_exp(-z));
-  return mi_log1p(mi_exp(z));
+// log(1+exp(z)) = max(z,0) + log1p(exp(-|z|)), overflow-safe and branch-free; same value as the
+// two-branch form of oracle/dual.py:softplus.  d/dz = logistic(z).
+__device__ inline double mi_softplus(double z) {
+  const double t = fast_exp_nonpos(-fabs(z));
+  return fmax(z, 0.0) + fast_log1p01(t);
+}
+__device__ inline Dual1 mi_softplus(Dual1 z) {
+  const double t = fast_exp_nonpos(-fabs(z.v));
+  const double r = fast_rcp(1.0 + t);
+  const double sig = z.v > 0.0 ? r : t * r;
+  return {fmax(z.v, 0.0) + fast_log1p01(t), sig * z.d};
 }
 
 }  // namespace mi

@@ -25,6 +25,15 @@ constexpr double kPi1 = 0x1.921fb54400000p+1;
 constexpr double kPi2 = 0x1.0b4611a600000p-33;
 constexpr double kPi3 = 0x1.3198a2e037073p-68;
 constexpr double kInvPi = 0x1.45f306dc9c883p-2;
+// exp(r) = 1 + r + r^2 P(r), |r| <= ln2/2 (1 ulp) ; log1p(f) = 2s + s w R(w), s = f/(2+f), w = s^2 <= 0.03 (2 ulp)
+// (tools/gen_explog_poly.py)
+constexpr double kE[11] = {0x1.0000000000000p-1, 0x1.5555555555557p-3, 0x1.5555555555556p-5, 0x1.111111110ff87p-7,
+                           0x1.6c16c16c16212p-10, 0x1.a01a01aca0134p-13, 0x1.a01a01a741b3cp-16, 0x1.71ddffef9e7b1p-19,
+                           0x1.27e4da1a3bf04p-22, 0x1.af52906239de4p-26, 0x1.1f75aba0b1e2ep-29};
+constexpr double kL[8] = {0x1.5555555555555p-1, 0x1.9999999999a4ep-2, 0x1.24924924736ddp-2, 0x1.c71c720742c1ep-3,
+                          0x1.745cf692c6200p-3, 0x1.3b1cb90bb738fp-3, 0x1.0fb0f07f1be07p-3, 0x1.0c90f788b03b1p-3};
+constexpr double kLn2Hi = 0x1.62e42fee00000p-1, kLn2Lo = 0x1.a39ef35793c76p-33, kLog2e = 0x1.71547652b82fep+0,
+                 kLn2 = 0x1.62e42fefa39efp-1, kSqrt2m1 = 0x1.a827999fcef32p-2;
 }  // namespace fm
 
 // sin of a reduced argument |r| <= pi/2 (+ small margin)
@@ -75,6 +84,33 @@ __device__ __forceinline__ double fast_rcp(double x) {
   e = fma(-x, r, 1.0);
   r = fma(r, e, r);
   return r;
+}
+
+// exp(x) for x <= 0 (the only range the contact model needs): Cody-Waite reduction by ln2,
+// degree-10 polynomial, scale by 2^n (underflows cleanly to 0 for very negative x).
+__device__ __forceinline__ double fast_exp_nonpos(double x) {
+  x = fmax(x, -745.0);
+  const double nd = rint(x * fm::kLog2e);
+  double r = fma(-nd, fm::kLn2Hi, x);
+  r = fma(-nd, fm::kLn2Lo, r);
+  double p = fm::kE[10];
+#pragma unroll
+  for (int k = 9; k >= 0; --k) p = fma(p, r, fm::kE[k]);
+  const double e = 1.0 + fma(r * r, p, r);
+  return ldexp(e, (int)nd);
+}
+
+// log1p(y) for 0 <= y <= 1: fold 1+y into [sqrt(1/2), sqrt 2] exactly, then 2 atanh(s).
+__device__ __forceinline__ double fast_log1p01(double y) {
+  const bool hi = y > fm::kSqrt2m1;
+  const double f = hi ? 0.5 * (y - 1.0) : y;           // 1+y = 2(1+f) resp. 1+f, both exact
+  const double s = f * fast_rcp(2.0 + f);
+  const double w = s * s;
+  double R = fm::kL[7];
+#pragma unroll
+  for (int k = 6; k >= 0; --k) R = fma(R, w, fm::kL[k]);
+  const double l = fma(s * w, R, 2.0 * s);
+  return hi ? l + fm::kLn2 : l;
 }
 
 }  // namespace mi
