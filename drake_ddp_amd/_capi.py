@@ -12,12 +12,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmi_ilqr.so")
 
 MAX_PARAMS = 16
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # enums (include/mi_ilqr.h)
 OK, E_BAD_SHAPE, E_BAD_METHOD, E_LINESEARCH, E_HIP, E_NO_DEVICE, E_BAD_ARG, E_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6, -7
 KP_SET_INTERVAL, KP_ADAPTIVE_JERK, KP_ITERATIVE_ERROR = 0, 1, 2
 JAC_FD_CENTRAL, JAC_AUTODIFF = 0, 1
+KERNEL_AUTO, KERNEL_LATENCY, KERNEL_THROUGHPUT = 0, 1, 2
 STATUS_CONVERGED, STATUS_MAX_ITERS, STATUS_LINESEARCH_FAILED = 0, 1, 2
 F_X_BAR, F_U_BAR, F_K, F_KAPPA, F_DV, F_FX, F_FU, F_COST, F_X0, F_HIST, F_X_TRIAL, F_U_TRIAL, F_TRIAL_COST = range(13)
 I_ITERS, I_STATUS, I_LS_TRIALS, I_KP_COUNT, I_KP_LIST = 100, 101, 102, 103, 104
@@ -42,7 +43,7 @@ class Desc(C.Structure):
         ("keypoint_method", C.c_int32), ("minN", C.c_int32), ("maxN", C.c_int32),
         ("jerk_threshold", C.c_double), ("iterative_error_threshold", C.c_double),
         ("jacobian_mode", C.c_int32), ("fd_step", C.c_double),
-        ("max_iters", C.c_int32), ("hist_cap", C.c_int32), ("device_id", C.c_int32),
+        ("max_iters", C.c_int32), ("hist_cap", C.c_int32), ("device_id", C.c_int32), ("kernel_mode", C.c_int32),
     ]
 
 

@@ -1,0 +1,392 @@
+// Lane-per-problem iLQR kernel ("throughput mode") for small state dimension, gfx950.
+//
+// The wave-per-problem kernels (ilqr_small.hpp) minimize the latency of ONE problem and keep
+// its state in LDS: the right shape up to ~2048 problems per GPU (LDS admits 4-6 per CU).
+// For tens of thousands of problems the batch axis itself fills the machine: here every LANE
+// owns one problem and the solver state streams through HBM in a BATCH-MINOR layout
+//     x_bar[t][i][b], u_bar[t][k][b], K[t][k][j][b], kappa[t][k][b], dV[t][b],
+//     fx[t][i][j][b], fu[t][i][k][b]            (b fastest)
+// so a wavefront's 64 lanes touch 64 consecutive doubles: every access of the rollout
+// (ilqr.py:306-327) and of the backward pass (:623-667) is one fully coalesced 512-byte
+// transaction, prefetched 1-2 time steps ahead (addresses never depend on the state).  The
+// kernel moves ~the algorithmic bytes of SURVEY.md §8d per iteration (no re-reads), i.e. at
+// large B it is HBM-bound by construction, which is what the roofline accounting assumes.
+//
+// Control flow is per lane: line-search trials are sequential like the reference's
+// (:300-337), lanes that have accepted / converged are masked while the wave finishes the
+// slowest of its 64 problems.  x_bar/u_bar are double-buffered with a per-lane parity, so
+// accepting a trial is a flip, not a copy.  Linearization (central FD, :233-272 replaced)
+// is fused into the backward sweep.  Key-point method: 'setInterval' with minN = 1.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mi_ilqr.h"
+#include "fastmath.hpp"
+#include "ilqr_small.hpp"   // KArgs, Consts, stage_cost, terminal_cost, invert_small
+#include "models.hpp"
+
+namespace mi {
+
+// batch-minor addressing helpers: element (t, r) of an array with `rows` rows per time step
+__device__ __forceinline__ size_t bm(int t, int r, int rows, int B) { return ((size_t)t * rows + r) * B; }
+
+template <class M, int JAC>
+__global__ void __launch_bounds__(64) ilqr_batch_kernel(const KArgs a) {
+  constexpr int n = M::n, m = M::m, nc = n + m;
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  const int B = a.B, N = a.N;
+  const bool live = b < B;
+  const int bb = live ? b : B - 1;             // out-of-range lanes shadow the last problem, stores parked
+  // x_bar / u_bar live in two buffers: a.x_bar|a.x_trial and a.u_bar|a.u_trial; `cur` selects
+  double* const X0 = a.x_bar + bb;
+  double* const X1 = a.x_trial + bb;
+  double* const U0 = a.u_bar + bb;
+  double* const U1 = a.u_trial + bb;
+  double* Kp = a.K + bb;
+  double* kapp = a.kappa + bb;
+  double* dVp = a.dV + bb;
+  double* Fxp = a.fx + bb;
+  double* Fup = a.fu + bb;
+  // per-lane sink for masked stores: the last column of a scratch row (a.trial_cost, (B,2))
+  double* sink = a.trial_cost + 2 * (size_t)bb;
+
+  Consts<M> c;
+  c.load(a.costmat);
+  double x0r[n];
+#pragma unroll
+  for (int i = 0; i < n; ++i) x0r[i] = a.x0[(size_t)bb * n + i];
+  double Q2[n][n], R2[m][m];
+#pragma unroll
+  for (int i = 0; i < n; ++i)
+#pragma unroll
+    for (int j = 0; j < n; ++j) Q2[i][j] = 2.0 * c.Q[i][j];
+#pragma unroll
+  for (int i = 0; i < m; ++i)
+#pragma unroll
+    for (int j = 0; j < m; ++j) R2[i][j] = 2.0 * c.R[i][j];
+
+  // cold start / pending initial guess
+  if (a.cold) {
+    for (int t = 0; t < N; ++t) {
+#pragma unroll
+      for (int i = 0; i < n; ++i) X0[bm(t, i, n, B)] = 0.0;
+    }
+    for (int t = 0; t < N - 1; ++t) {
+#pragma unroll
+      for (int k = 0; k < m; ++k) {
+        kapp[bm(t, k, m, B)] = 0.0;
+#pragma unroll
+        for (int j = 0; j < n; ++j) Kp[bm(t, k * n + j, m * n, B)] = 0.0;
+      }
+      dVp[(size_t)t * B] = 0.0;
+    }
+  }
+  if (a.u_pending) {
+    const double* ug = a.u_guess + bb;
+    for (int t = 0; t < N - 1; ++t) {
+#pragma unroll
+      for (int k = 0; k < m; ++k) U0[bm(t, k, m, B)] = ug[bm(t, k, m, B)];
+    }
+  }
+
+  int cur = 0;                                  // which buffer holds x_bar/u_bar for this lane
+  double L = __builtin_inf(), improvement = __builtin_inf();
+  int iters = 0, ls_total = 0, status = MI_STATUS_CONVERGED;
+  bool active = live;
+  double* hist = a.hist + (size_t)bb * a.hist_cap * 4;
+
+  while (__any(active && improvement > a.delta)) {
+    const bool it_active = active && improvement > a.delta;
+    if (it_active && iters >= a.max_iters) { status = MI_STATUS_MAX_ITERS; active = false; }
+    const bool go = it_active && active;
+    // ---------------- line search: sequential trials per lane (ilqr.py:300-337)
+    double eps = 1.0, L_new = 0.0, eps_acc = 1.0;
+    int trials = 0;
+    bool accepted = !go;
+    while (__any(!accepted && eps >= 1e-8)) {
+      const bool run = !accepted && eps >= 1e-8;
+      const double* xb = cur ? X1 : X0;
+      const double* ub = cur ? U1 : U0;
+      double* xw = run ? (cur ? X0 : X1) : sink; // masked lanes park their stores
+      double* uw = run ? (cur ? U0 : U1) : sink;
+      const size_t wstep_x = run ? (size_t)B : 0, wstep_u = run ? (size_t)B : 0;
+      double x[n];
+#pragma unroll
+      for (int i = 0; i < n; ++i) { x[i] = x0r[i]; xw[(size_t)i * wstep_x] = x[i]; }
+      double Lc = 0.0, ex = 0.0;
+      const double ce = -eps * (1.0 - eps / 2.0);
+      struct Regs { double xbv[n], ubv[m], kv[m], Kv[m][n], dv; };
+      auto load = [&](Regs& r, int t) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < n; ++i) r.xbv[i] = xb[bm(t, i, n, B)];
+#pragma unroll
+        for (int k = 0; k < m; ++k) {
+          r.ubv[k] = ub[bm(t, k, m, B)];
+          r.kv[k] = kapp[bm(t, k, m, B)];
+#pragma unroll
+          for (int j = 0; j < n; ++j) r.Kv[k][j] = Kp[bm(t, k * n + j, m * n, B)];
+        }
+        r.dv = dVp[(size_t)t * B];
+      };
+      auto step = [&](const Regs& r, int t) __attribute__((always_inline)) {
+        double u[m];
+#pragma unroll
+        for (int k = 0; k < m; ++k) {
+          double acc = 0.0;
+#pragma unroll
+          for (int j = 0; j < n; ++j) acc += r.Kv[k][j] * (x[j] - r.xbv[j]);
+          u[k] = (r.ubv[k] - eps * r.kv[k]) - acc;                     // :313
+        }
+        double xn[n];
+        M::template step<double>(x, u, xn, a.params, a.dt);             // :316
+        Lc += stage_cost<M>(c, x, u);                                   // :325
+        ex += ce * r.dv;                                                // :326
+#pragma unroll
+        for (int k = 0; k < m; ++k) uw[((size_t)t * m + k) * wstep_u] = u[k];
+#pragma unroll
+        for (int i = 0; i < n; ++i) { xw[((size_t)(t + 1) * n + i) * wstep_x] = xn[i]; x[i] = xn[i]; }
+      };
+      Regs A, Bq;
+      load(A, 0);
+      int t = 0;
+      const int tlast = N - 2;                   // last valid control index
+      for (; t + 1 < N - 1; t += 2) {
+        load(Bq, t + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        step(A, t);
+        load(A, (t + 2 <= tlast) ? t + 2 : tlast);
+        __builtin_amdgcn_sched_barrier(0);
+        step(Bq, t + 1);
+      }
+      if (t < N - 1) step(A, t);
+      Lc += terminal_cost<M>(c, x);                                     // :327
+      if (run) {
+        trials += 1;
+        if ((L - Lc) > a.gamma * ex) { accepted = true; L_new = Lc; eps_acc = eps; }   // :330-331
+        else eps *= a.beta;                                             // :335
+      }
+    }
+    bool ok = go && accepted;
+    if (go) {
+      ls_total += trials;
+      if (!ok) { status = MI_STATUS_LINESEARCH_FAILED; active = false; }
+    }
+    if (ok) cur ^= 1;                            // u_bar <- u, x_bar <- x (:375-376): a flip
+    // ---------------- linearization fused into the backward sweep (:380-415 with setInterval/1, :623-667)
+    if (__any(ok)) {
+      const double* xb = cur ? X1 : X0;
+      const double* ub = cur ? U1 : U0;
+      double* Kw = ok ? Kp : sink;
+      double* kw = ok ? kapp : sink;
+      double* dw = ok ? dVp : sink;
+      double* fxw = ok ? Fxp : sink;
+      double* fuw = ok ? Fup : sink;
+      const size_t ws = ok ? (size_t)B : 0;
+      double Vx[n], Vxx[n][n];
+      {
+        double xT[n];
+#pragma unroll
+        for (int i = 0; i < n; ++i) xT[i] = xb[bm(N - 1, i, n, B)];
+#pragma unroll
+        for (int i = 0; i < n; ++i) {
+          double s = -c.qfn[i];
+#pragma unroll
+          for (int j = 0; j < n; ++j) { s += (2.0 * c.Qf[i][j]) * xT[j]; Vxx[i][j] = 2.0 * c.Qf[i][j]; }
+          Vx[i] = s;                                                   // :203-204
+        }
+      }
+      const double h = a.fd_h, inv2h = 1.0 / (2.0 * h);
+      struct XU { double x[n], u[m]; };
+      auto loadxu = [&](XU& r, int t) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < n; ++i) r.x[i] = xb[bm(t, i, n, B)];
+#pragma unroll
+        for (int k = 0; k < m; ++k) r.u[k] = ub[bm(t, k, m, B)];
+      };
+      XU cu, nx;
+      loadxu(cu, N - 2);
+      for (int t = N - 2; t >= 0; --t) {
+        loadxu(nx, t > 0 ? t - 1 : 0);
+        // dynamics partials at (x_bar_t, u_bar_t)
+        double fx[n][n], fu[n][m];
+#pragma unroll
+        for (int col = 0; col < nc; ++col) {
+          double d[n];
+          if (JAC == MI_JAC_FD_CENTRAL) {
+            double xp[n], up[m], fp[n], fmv[n];
+#pragma unroll
+            for (int i = 0; i < n; ++i) xp[i] = (col == i) ? cu.x[i] + h : cu.x[i];
+#pragma unroll
+            for (int k = 0; k < m; ++k) up[k] = (col == n + k) ? cu.u[k] + h : cu.u[k];
+            M::template step<double>(xp, up, fp, a.params, a.dt);
+#pragma unroll
+            for (int i = 0; i < n; ++i) xp[i] = (col == i) ? cu.x[i] - h : cu.x[i];
+#pragma unroll
+            for (int k = 0; k < m; ++k) up[k] = (col == n + k) ? cu.u[k] - h : cu.u[k];
+            M::template step<double>(xp, up, fmv, a.params, a.dt);
+#pragma unroll
+            for (int i = 0; i < n; ++i) d[i] = (fp[i] - fmv[i]) * inv2h;
+          } else {
+            Dual1 xd[n], ud[m], fd[n];
+#pragma unroll
+            for (int i = 0; i < n; ++i) xd[i] = Dual1(cu.x[i], (col == i) ? 1.0 : 0.0);
+#pragma unroll
+            for (int k = 0; k < m; ++k) ud[k] = Dual1(cu.u[k], (col == n + k) ? 1.0 : 0.0);
+            M::template step<Dual1>(xd, ud, fd, a.params, a.dt);
+#pragma unroll
+            for (int i = 0; i < n; ++i) d[i] = fd[i].d;
+          }
+#pragma unroll
+          for (int i = 0; i < n; ++i) {
+            if (col < n) { fx[i][col] = d[i]; fxw[((size_t)t * n * n + i * n + col) * ws] = d[i]; }
+            else { fu[i][col - n] = d[i]; fuw[((size_t)t * n * m + i * m + (col - n)) * ws] = d[i]; }
+          }
+        }
+        // cost expansion + Riccati step (same arithmetic as backward_scalar)
+        double Qx[n], Qu[m], Qxx[n][n], Quu[m][m], Qux[m][n], Am[n][n], Bm[m][n];
+#pragma unroll
+        for (int i = 0; i < n; ++i) {
+          double s = -c.qn[i];
+#pragma unroll
+          for (int j = 0; j < n; ++j) s += Q2[i][j] * cu.x[j];
+#pragma unroll
+          for (int k = 0; k < n; ++k) s += fx[k][i] * Vx[k];
+          Qx[i] = s;
+        }
+#pragma unroll
+        for (int a_ = 0; a_ < m; ++a_) {
+          double s = 0.0;
+#pragma unroll
+          for (int j = 0; j < m; ++j) s += R2[a_][j] * cu.u[j];
+#pragma unroll
+          for (int k = 0; k < n; ++k) s += fu[k][a_] * Vx[k];
+          Qu[a_] = s;
+        }
+#pragma unroll
+        for (int i = 0; i < n; ++i)
+#pragma unroll
+          for (int j = 0; j < n; ++j) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < n; ++k) s += fx[k][i] * Vxx[k][j];
+            Am[i][j] = s;
+          }
+#pragma unroll
+        for (int a_ = 0; a_ < m; ++a_)
+#pragma unroll
+          for (int j = 0; j < n; ++j) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < n; ++k) s += fu[k][a_] * Vxx[k][j];
+            Bm[a_][j] = s;
+          }
+#pragma unroll
+        for (int i = 0; i < n; ++i)
+#pragma unroll
+          for (int j = 0; j < n; ++j) {
+            double s = Q2[i][j];
+#pragma unroll
+            for (int k = 0; k < n; ++k) s += Am[i][k] * fx[k][j];
+            Qxx[i][j] = s;
+          }
+#pragma unroll
+        for (int a_ = 0; a_ < m; ++a_) {
+#pragma unroll
+          for (int b_ = 0; b_ < m; ++b_) {
+            double s = R2[a_][b_];
+#pragma unroll
+            for (int k = 0; k < n; ++k) s += Bm[a_][k] * fu[k][b_];
+            Quu[a_][b_] = s;
+          }
+#pragma unroll
+          for (int j = 0; j < n; ++j) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < n; ++k) s += Bm[a_][k] * fx[k][j];
+            Qux[a_][j] = s;
+          }
+        }
+        double Qi[m][m];
+        invert_small<m>(Quu, Qi);
+        double kap[m], Kg[m][n], QuQi[m];
+#pragma unroll
+        for (int a_ = 0; a_ < m; ++a_) {
+          double s = 0.0, q = 0.0;
+#pragma unroll
+          for (int b_ = 0; b_ < m; ++b_) { s += Qi[a_][b_] * Qu[b_]; q += Qu[b_] * Qi[b_][a_]; }
+          kap[a_] = s; QuQi[a_] = q;
+#pragma unroll
+          for (int j = 0; j < n; ++j) {
+            double g = 0.0;
+#pragma unroll
+            for (int b_ = 0; b_ < m; ++b_) g += Qi[a_][b_] * Qux[b_][j];
+            Kg[a_][j] = g;
+          }
+        }
+        double dv = 0.0;
+#pragma unroll
+        for (int a_ = 0; a_ < m; ++a_) dv += QuQi[a_] * Qu[a_];
+#pragma unroll
+        for (int a_ = 0; a_ < m; ++a_) {
+          kw[((size_t)t * m + a_) * ws] = kap[a_];
+#pragma unroll
+          for (int j = 0; j < n; ++j) Kw[((size_t)t * m * n + a_ * n + j) * ws] = Kg[a_][j];
+        }
+        dw[(size_t)t * ws] = dv;
+#pragma unroll
+        for (int j = 0; j < n; ++j) {
+          double s = Qx[j];
+#pragma unroll
+          for (int a_ = 0; a_ < m; ++a_) s -= QuQi[a_] * Qux[a_][j];
+          Vx[j] = s;
+        }
+        double QuxTQi[n][m];
+#pragma unroll
+        for (int i = 0; i < n; ++i)
+#pragma unroll
+          for (int b_ = 0; b_ < m; ++b_) {
+            double s = 0.0;
+#pragma unroll
+            for (int a_ = 0; a_ < m; ++a_) s += Qux[a_][i] * Qi[a_][b_];
+            QuxTQi[i][b_] = s;
+          }
+#pragma unroll
+        for (int i = 0; i < n; ++i)
+#pragma unroll
+          for (int j = 0; j < n; ++j) {
+            double s = Qxx[i][j];
+#pragma unroll
+            for (int b_ = 0; b_ < m; ++b_) s -= QuxTQi[i][b_] * Qux[b_][j];
+            Vxx[i][j] = s;
+          }
+        cu = nx;
+      }
+    }
+    if (ok) {
+      if (iters < a.hist_cap) {
+        hist[4 * iters + 0] = L_new; hist[4 * iters + 1] = eps_acc;
+        hist[4 * iters + 2] = (double)trials; hist[4 * iters + 3] = 100.0;
+      }
+      improvement = L - L_new;                                          // :706
+      L = L_new;
+      iters += 1;
+    }
+  }
+  // make buffer 0 the canonical x_bar/u_bar
+  if (live && cur == 1) {
+    for (int t = 0; t < N; ++t) {
+#pragma unroll
+      for (int i = 0; i < n; ++i) X0[bm(t, i, n, B)] = X1[bm(t, i, n, B)];
+    }
+    for (int t = 0; t < N - 1; ++t) {
+#pragma unroll
+      for (int k = 0; k < m; ++k) U0[bm(t, k, m, B)] = U1[bm(t, k, m, B)];
+    }
+  }
+  if (live) {
+    a.cost[b] = L; a.iters[b] = iters; a.status[b] = status; a.ls_trials[b] = ls_total; a.kp_count[b] = N - 1;
+  }
+}
+
+}  // namespace mi

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/mi_ilqr.h"
+#include "ilqr_batch.hpp"
 #include "ilqr_large.hpp"
 #include "ilqr_small.hpp"
 
@@ -48,6 +49,7 @@ struct mi_ilqr {
   size_t lds = 0;
   bool large = false;      // workgroup-per-problem path: state arrays are TIME-MAJOR in HBM
   int n_store = 1;         // line-search candidate trajectories kept in LDS
+  bool batch_minor = false; // lane-per-problem path: state arrays are [t][row][b] in HBM
   float last_ms = 0.f;
 };
 
@@ -170,6 +172,23 @@ int launch_jac_large(mi_ilqr* h, int mode, const KArgs& a) {
   return launch_mode_large<M, MI_JAC_FD_CENTRAL>(h, mode, a);
 }
 
+template <class M, int JAC>
+int launch_batch_one(mi_ilqr* h, const KArgs& a) {
+  auto kern = ilqr_batch_kernel<M, JAC>;
+  HIPCHK(hipEventRecord(h->ev0, h->stream));
+  hipLaunchKernelGGL(kern, dim3((h->B + 63) / 64), dim3(64), 0, h->stream, a);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(h->ev1, h->stream));
+  return MI_ILQR_OK;
+}
+
+template <class M>
+int launch_batch(mi_ilqr* h, int mode, const KArgs& a) {
+  if (mode != MODE_SOLVE) return MI_ILQR_E_UNSUPPORTED;    // stage-level entries: latency kernels only
+  if (h->d.jacobian_mode == MI_JAC_AUTODIFF) return launch_batch_one<M, MI_JAC_AUTODIFF>(h, a);
+  return launch_batch_one<M, MI_JAC_FD_CENTRAL>(h, a);
+}
+
 template <class M>
 int launch_jac(mi_ilqr* h, int mode, const KArgs& a) {
   if (h->d.jacobian_mode == MI_JAC_AUTODIFF) return launch_mode<M, MI_JAC_AUTODIFF>(h, mode, a);
@@ -182,6 +201,15 @@ int launch(mi_ilqr* h, int mode) {
   HIPCHK(hipSetDevice(h->d.device_id));
   const KArgs a = make_args(h);
   int rc;
+  if (h->batch_minor) {
+    switch (h->d.model_id) {
+      case MI_MODEL_PENDULUM: return launch_batch<Pendulum>(h, mode, a);
+      case MI_MODEL_ACROBOT: return launch_batch<Acrobot>(h, mode, a);
+      case MI_MODEL_CARTPOLE: return launch_batch<CartPole>(h, mode, a);
+      case MI_MODEL_CARTPOLE_WALL: return launch_batch<CartPoleWall>(h, mode, a);
+      default: return MI_ILQR_E_UNSUPPORTED;
+    }
+  }
   switch (h->d.model_id) {
     case MI_MODEL_PENDULUM: rc = launch_jac<Pendulum>(h, mode, a); break;
     case MI_MODEL_ACROBOT: rc = launch_jac<Acrobot>(h, mode, a); break;
@@ -241,6 +269,30 @@ __global__ void mpc_shift_kernel_tm(const double* x_bar, const double* u_bar, do
   }
 }
 
+__global__ void mpc_shift_kernel_bm(const double* x_bar, const double* u_bar, double* x0, double* u_guess,
+                                    int B, int n, int m, int N, int r) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  for (int i = 0; i < n; ++i) x0[(size_t)b * n + i] = x_bar[((size_t)r * n + i) * B + b];
+  const int M1 = N - 1;
+  for (int t = 0; t < M1; ++t) {
+    const int src = (t + r < M1) ? t + r : M1 - 1;
+    for (int k = 0; k < m; ++k) u_guess[((size_t)t * m + k) * B + b] = u_bar[((size_t)src * m + k) * B + b];
+  }
+}
+
+// batch-minor [t][row][b]  <->  reference time-last (b, row, t)
+void bm_to_time_last(const double* bmv, double* tl, int B, int rows, int len) {
+  for (int t = 0; t < len; ++t)
+    for (int r = 0; r < rows; ++r)
+      for (int b = 0; b < B; ++b) tl[((size_t)b * rows + r) * len + t] = bmv[((size_t)t * rows + r) * B + b];
+}
+void time_last_to_bm(const double* tl, double* bmv, int B, int rows, int len) {
+  for (int t = 0; t < len; ++t)
+    for (int r = 0; r < rows; ++r)
+      for (int b = 0; b < B; ++b) bmv[((size_t)t * rows + r) * B + b] = tl[((size_t)b * rows + r) * len + t];
+}
+
 // rows of the (rows,len) time-last view of a double field; 0 = not a trajectory array
 int traj_rows(const mi_ilqr* h, int which, int* len) {
   const int n = h->n, m = h->m, N = h->N;
@@ -250,6 +302,7 @@ int traj_rows(const mi_ilqr* h, int which, int* len) {
     case MI_F_K: *len = N - 1; return m * n;
     case MI_F_FX: *len = N - 1; return n * n;
     case MI_F_FU: *len = N - 1; return n * m;
+    case MI_F_DV: *len = N - 1; return 1;
   }
   *len = 0;
   return 0;
@@ -399,7 +452,14 @@ int mi_ilqr_create(const mi_ilqr_desc* desc, mi_ilqr_t** out) {
   int n_store = 1;
   if (lds == 0) { lds = large_lds(desc->model_id, desc->N); large = true; }
   if (lds == 0 || lds > kMaxLds) return MI_ILQR_E_UNSUPPORTED;
-  if (!large && desc->beta <= 0.75) {
+  bool batch_minor = false;
+  if (desc->kernel_mode < MI_KERNEL_AUTO || desc->kernel_mode > MI_KERNEL_THROUGHPUT) return MI_ILQR_E_BAD_ARG;
+  {
+    const bool can = !large && desc->keypoint_method == MI_KP_SET_INTERVAL && desc->minN == 1;
+    if (desc->kernel_mode == MI_KERNEL_THROUGHPUT && !can) return MI_ILQR_E_UNSUPPORTED;
+    batch_minor = can && (desc->kernel_mode == MI_KERNEL_THROUGHPUT || (desc->kernel_mode == MI_KERNEL_AUTO && desc->B >= 8192));
+  }
+  if (!large && !batch_minor && desc->beta <= 0.75) {
     // Coarse backtracking (beta <= 0.75) accepts one of the first few eps values: keep up to 6
     // candidate trajectories in LDS as long as that does not lower the problems-per-CU this
     // batch needs (256 CUs) — it removes the second rollout of a backtracking iteration.
@@ -419,6 +479,7 @@ int mi_ilqr_create(const mi_ilqr_desc* desc, mi_ilqr_t** out) {
   h->lds = lds;
   h->large = large;
   h->n_store = n_store;
+  h->batch_minor = batch_minor;
   const size_t n = h->n, m = h->m, N = h->N, B = h->B;
 
 #define ALLOC(p, count, T)                                             \
@@ -507,9 +568,10 @@ int mi_ilqr_set_initial(mi_ilqr_t* h, const double* x0, const double* u_guess) {
   if (x0) HIPCHK(hipMemcpy(h->x0, x0, (size_t)h->B * h->n * 8, hipMemcpyHostToDevice));
   if (u_guess) {
     const size_t cnt = (size_t)h->B * h->m * (h->N - 1);
-    if (h->large) {
+    if (h->large || h->batch_minor) {
       std::vector<double> tm(cnt);
-      to_time_major(u_guess, tm.data(), h->B, h->m, h->N - 1);
+      if (h->large) to_time_major(u_guess, tm.data(), h->B, h->m, h->N - 1);
+      else time_last_to_bm(u_guess, tm.data(), h->B, h->m, h->N - 1);
       HIPCHK(hipMemcpy(h->u_guess, tm.data(), cnt * 8, hipMemcpyHostToDevice));
     } else {
       HIPCHK(hipMemcpy(h->u_guess, u_guess, cnt * 8, hipMemcpyHostToDevice));
@@ -629,7 +691,10 @@ int mi_ilqr_mpc_shift(mi_ilqr_t* h, int32_t replan_steps) {
   int rc;
   if ((rc = materialize_zero_state(h)) != MI_ILQR_OK) return rc;
   if ((rc = materialize_u(h)) != MI_ILQR_OK) return rc;
-  if (h->large)
+  if (h->batch_minor)
+    hipLaunchKernelGGL(mpc_shift_kernel_bm, dim3((h->B + 255) / 256), dim3(256), 0, h->stream, h->x_bar, h->u_bar, h->x0,
+                       h->u_guess, h->B, h->n, h->m, h->N, (int)replan_steps);
+  else if (h->large)
     hipLaunchKernelGGL(mpc_shift_kernel_tm, dim3(h->B), dim3(64), 0, h->stream, h->x_bar, h->u_bar, h->x0, h->u_guess,
                        h->B, h->n, h->m, h->N, (int)replan_steps);
   else
@@ -645,8 +710,8 @@ int mi_ilqr_mpc_run(mi_ilqr_t* h, int32_t num_resolves, int32_t replan_steps, co
   if (num_resolves < 1 || replan_steps < 1 || replan_steps >= h->N - 1) return MI_ILQR_E_BAD_ARG;
   HIPCHK(hipSetDevice(h->d.device_id));
   int rc;
-  if (h->large || h->N > 512 || h->n > 8) {
-    // workgroup-per-problem path: the state lives in HBM anyway; loop shift + solve on the host
+  if (h->large || h->batch_minor || h->N > 512 || h->n > 8) {
+    // workgroup-per-problem / lane-per-problem paths: the state lives in HBM anyway; loop shift + solve on the host
     std::vector<double> xn(h->n);
     if (target_step) HIPCHK(hipMemcpy(xn.data(), h->costmat + 2 * (size_t)h->n * h->n + (size_t)h->m * h->m, h->n * 8, hipMemcpyDeviceToHost));
     mi_ilqr_stats acc; std::memset(&acc, 0, sizeof(acc)); acc.best_cost = INFINITY; acc.best_index = -1;
@@ -712,11 +777,12 @@ int mi_ilqr_get(mi_ilqr_t* h, int which, double* dst, size_t bytes) {
   if (h->cold && is_state_field(which)) { std::memset(dst, 0, bytes); return MI_ILQR_OK; }
   const void* src = (h->u_pending && which == MI_F_U_BAR) ? (const void*)h->u_guess : f.ptr;
   int len = 0;
-  const int rows = h->large ? traj_rows(h, which, &len) : 0;
-  if (rows > 1) {
+  const int rows = (h->large || h->batch_minor) ? traj_rows(h, which, &len) : 0;
+  if (rows > 1 || (h->batch_minor && rows == 1)) {
     std::vector<double> tm(bytes / 8);
     HIPCHK(hipMemcpy(tm.data(), src, bytes, hipMemcpyDeviceToHost));
-    to_time_last(tm.data(), dst, h->B, rows, len);
+    if (h->batch_minor) bm_to_time_last(tm.data(), dst, h->B, rows, len);
+    else to_time_last(tm.data(), dst, h->B, rows, len);
     return MI_ILQR_OK;
   }
   HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
@@ -743,10 +809,11 @@ int mi_ilqr_set(mi_ilqr_t* h, int which, const double* src, size_t bytes) {
   if (is_state_field(which)) { int rc = materialize_zero_state(h); if (rc != MI_ILQR_OK) return rc; }
   HIPCHK(hipStreamSynchronize(h->stream));
   int len = 0;
-  const int rows = h->large ? traj_rows(h, which, &len) : 0;
-  if (rows > 1) {
+  const int rows = (h->large || h->batch_minor) ? traj_rows(h, which, &len) : 0;
+  if (rows > 1 || (h->batch_minor && rows == 1)) {
     std::vector<double> tm(bytes / 8);
-    to_time_major(src, tm.data(), h->B, rows, len);
+    if (h->batch_minor) time_last_to_bm(src, tm.data(), h->B, rows, len);
+    else to_time_major(src, tm.data(), h->B, rows, len);
     HIPCHK(hipMemcpy(f.ptr, tm.data(), bytes, hipMemcpyHostToDevice));
   } else {
     HIPCHK(hipMemcpy(f.ptr, src, bytes, hipMemcpyHostToDevice));

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MI_ILQR_ABI_VERSION 1
+#define MI_ILQR_ABI_VERSION 2
 #define MI_ILQR_MAX_PARAMS 16
 
 /* Error codes (0 = OK).  The Python wrapper maps them onto the exception types
@@ -65,6 +65,13 @@ enum { MI_KP_SET_INTERVAL = 0, MI_KP_ADAPTIVE_JERK = 1, MI_KP_ITERATIVE_ERROR = 
 
 /* How fx/fu are obtained (replaces _calc_dynamics_partials, ilqr.py:233-272). */
 enum { MI_JAC_FD_CENTRAL = 0, MI_JAC_AUTODIFF = 1 };
+
+/* Which kernel family serves a small-state model (mi_ilqr_desc.kernel_mode):
+ *   LATENCY    wave-per-problem, state in LDS: minimal time-to-solution, up to ~2k problems/GPU in flight;
+ *   THROUGHPUT lane-per-problem, batch-minor state streamed through HBM: for tens of thousands of
+ *              problems (setInterval/1 key-points; stage-level entries are not available);
+ *   AUTO       THROUGHPUT when B >= 8192 and the configuration allows it, else LATENCY. */
+enum { MI_KERNEL_AUTO = 0, MI_KERNEL_LATENCY = 1, MI_KERNEL_THROUGHPUT = 2 };
 
 /* Per-problem status written by solve/forward. */
 enum { MI_STATUS_CONVERGED = 0, MI_STATUS_MAX_ITERS = 1, MI_STATUS_LINESEARCH_FAILED = 2 };
@@ -106,6 +113,7 @@ typedef struct {
   int32_t max_iters;                         /* safety cap (reference has none); <=0 -> 1000 */
   int32_t hist_cap;                          /* per-problem iteration rows kept; <=0 -> 64 */
   int32_t device_id;                         /* HIP device ordinal */
+  int32_t kernel_mode;                       /* MI_KERNEL_AUTO / _LATENCY / _THROUGHPUT */
 } mi_ilqr_desc;
 
 typedef struct {
