@@ -50,7 +50,6 @@ struct mi_ilqr {
   bool large = false;      // workgroup-per-problem path: state arrays are TIME-MAJOR in HBM
   int n_store = 1;         // line-search candidate trajectories kept in LDS
   bool batch_minor = false; // lane-per-problem path: state arrays are [t][row][b] in HBM
-  float last_ms = 0.f;
 };
 
 namespace {
@@ -451,14 +450,19 @@ int mi_ilqr_create(const mi_ilqr_desc* desc, mi_ilqr_t** out) {
   bool large = false;
   int n_store = 1;
   if (lds == 0) { lds = large_lds(desc->model_id, desc->N); large = true; }
-  if (lds == 0 || lds > kMaxLds) return MI_ILQR_E_UNSUPPORTED;
+  if (lds == 0) return MI_ILQR_E_UNSUPPORTED;
   bool batch_minor = false;
   if (desc->kernel_mode < MI_KERNEL_AUTO || desc->kernel_mode > MI_KERNEL_THROUGHPUT) return MI_ILQR_E_BAD_ARG;
   {
     const bool can = !large && desc->keypoint_method == MI_KP_SET_INTERVAL && desc->minN == 1;
     if (desc->kernel_mode == MI_KERNEL_THROUGHPUT && !can) return MI_ILQR_E_UNSUPPORTED;
     batch_minor = can && (desc->kernel_mode == MI_KERNEL_THROUGHPUT || (desc->kernel_mode == MI_KERNEL_AUTO && desc->B >= 8192));
+    // horizons whose per-problem state exceeds the 160 KB of LDS (e.g. acrobot.py's literal N = 750) are
+    // served by the HBM-streaming kernel, which has no such limit
+    if (!batch_minor && lds > kMaxLds && can && desc->kernel_mode == MI_KERNEL_AUTO) batch_minor = true;
   }
+  if (!batch_minor && lds > kMaxLds) return MI_ILQR_E_UNSUPPORTED;
+  if (batch_minor) lds = 0;
   if (!large && !batch_minor && desc->beta <= 0.75) {
     // Coarse backtracking (beta <= 0.75) accepts one of the first few eps values: keep up to 6
     // candidate trajectories in LDS as long as that does not lower the problems-per-CU this

@@ -179,3 +179,22 @@ def test_example_scripts_run(script):
     out = subprocess.run([sys.executable, os.path.join(root, "examples", script)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert ("Optimal cost: 0.23997" in out.stdout) or ("device loop" in out.stdout)
+
+
+def test_long_horizon_falls_back_to_streaming_kernel():
+    """acrobot.py's literal horizon (T=3, dt=0.004 -> N=750, acrobot.py:19-20) does not fit LDS;
+    AUTO serves it with the HBM-streaming kernel.  Checked against the oracle."""
+    from drake_ddp_amd import workloads as W
+    from common import make_oracle, rel_err
+    prob = W.acrobot_problem(N=750)
+    s = make_solver(prob, B=2, jac="ad", hist_cap=128)
+    x0 = np.zeros((2, 4)); x0[1] = [0.05, -0.03, 0.0, 0.0]
+    s.SetInitialState(x0)
+    s.SetInitialGuess(np.zeros((1, 749)))
+    x, u, _, L = s.Solve()
+    assert (s.status == 0).all()
+    o = make_oracle(prob)
+    o.set_problem(x0[1], prob["x_nom"], prob["Q"], prob["R"], prob["Qf"], np.zeros((1, 749)))
+    xo, uo, Lo, hist = o.solve()
+    assert len(hist) == s.iterations[1]
+    assert abs(L[1] - Lo) < 1e-8 * abs(Lo) and rel_err(x[1], xo) < 1e-6
