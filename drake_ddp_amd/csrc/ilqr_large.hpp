@@ -77,6 +77,16 @@ struct LargeAcc {
   __device__ __forceinline__ void set_fu(int t, int r, double v) const { Fu[(size_t)t * n * m + r] = v; }
 };
 
+// Workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does NOT drain the
+// vector-memory counter, so global prefetches issued before it stay in flight across it (and
+// global stores are not waited for).  Use only where no thread reads global data another thread
+// of the workgroup wrote since the last full __syncthreads().
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 __device__ __forceinline__ double block_sum(double v, double* red) {
   // deterministic fixed-order tree: 64-lane butterfly, then 4 wave partials
 #pragma unroll
@@ -151,7 +161,7 @@ __device__ inline double large_rollout(const LView<M::n, M::m>& v, double* lds, 
       if (ul == 0) us[uk] = (ubk - eps * kpk) - p;
     }
     if (t + 1 < N - 1) prefetch(t + 1);          // lands while the dynamics run
-    __syncthreads();
+    lds_barrier();
     // dynamics: one lane per degree of freedom (ilqr.py:316); cost rows on the other waves (:325)
     double qn_ = 0.0, vn_ = 0.0;
     if (tid < M::nq) {
@@ -170,13 +180,13 @@ __device__ inline double large_rollout(const LView<M::n, M::m>& v, double* lds, 
       acc += us[k] * r;
       v.Un[(size_t)t * m + k] = us[k];
     }
-    __syncthreads();
+    lds_barrier();
     if (tid < M::nq) {
       xs[tid] = qn_; xs[M::nq + tid] = vn_;
       v.Xn[(size_t)(t + 1) * n + tid] = qn_;
       v.Xn[(size_t)(t + 1) * n + M::nq + tid] = vn_;
     }
-    __syncthreads();
+    lds_barrier();
   }
   if (qrole) {                         // terminal cost (ilqr.py:327)
     const int i = tid - 64;
@@ -460,7 +470,7 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
     } else if (lane < n) {
       T1[lane * TS + CV] = Vx[lane];
     }
-    __syncthreads();
+    lds_barrier();
     BP_TICK(1);
     // ---- H = F^T T1 : CT x CT tiles, K = n;  H[:, CV] = F^T Vx
     if (wave < CT) {
@@ -484,7 +494,7 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
       for (int k = 0; k < n; ++k) s += F[k * FS + lane] * Vx[k];
       H[lane * TS + CV] = s;
     }
-    __syncthreads();
+    lds_barrier();
     BP_TICK(2);
     // ---- wave 1 factorizes Quu = 2R + fu^T Vxx fu (:654) = L D L^T, one row per lane
     if (false) {
@@ -504,7 +514,8 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
         for (int k = 0; k < m; ++k) Qc[m * m + k] = dinv[k];
       }
     }
-    __syncthreads();
+    lds_barrier();
+    BP_TICK(5);
     // ---- Y = Quu^{-1} [Qux | Qu] (:655-660): one right-hand side per thread, forward/back substitution
     if (tid <= n) {
       double y[m], dinv[m], Lr[m][m];
@@ -540,7 +551,7 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
         v.dV[t] = dv;
       }
     }
-    __syncthreads();
+    lds_barrier();
     BP_TICK(3);
     // ---- Vxx = Qxx - Qux^T K (RT x RT tiles, K = m; :667) ; Vx = Qx - Qux^T kappa (:666)
     if (wave < RT) {
@@ -588,7 +599,7 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
       Vx[lane] = s;
     }
     if (t > 0) publish();                        // F/xb are free after the H phase
-    __syncthreads();
+    lds_barrier();
     BP_TICK(4);
   }
 }
@@ -693,9 +704,9 @@ __global__ void __launch_bounds__(kLargeThreads) ilqr_large_kernel(const KArgs a
     __syncthreads();
     const long long c2 = clock64();
 #ifdef MI_PROF_BACKWARD
-    long long bpa[5] = {0, 0, 0, 0, 0};
+    long long bpa[6] = {0, 0, 0, 0, 0, 0};
     if (MODE == MODE_SOLVE) { large_backward<M>(v, lds, bpa); __syncthreads(); }
-    if (tid == 0 && iters == 0) { for (int q_ = 0; q_ < 4; ++q_) a.prof[4 * b + q_] = bpa[q_]; a.hist[(size_t)b * a.hist_cap * 4 + 4 * (a.hist_cap - 1)] = (double)bpa[4]; }
+    if (tid == 0 && iters == 0) { for (int q_ = 0; q_ < 4; ++q_) a.prof[4 * b + q_] = bpa[q_]; a.hist[(size_t)b * a.hist_cap * 4 + 4 * (a.hist_cap - 1)] = (double)bpa[4]; a.hist[(size_t)b * a.hist_cap * 4 + 4 * (a.hist_cap - 1) + 1] = (double)bpa[5]; }
 #else
     if (MODE == MODE_SOLVE) { large_backward<M>(v, lds); __syncthreads(); }          // :697
 #endif

@@ -8,5 +8,5 @@ s = BatchedIterativeLQR(ModelSystem(q["model_id"], q["dt"]), N, 1, delta=q["delt
 s.SetTargetState(q["x_nom"]); s.SetRunningCost(q["Q"], q["R"]); s.SetTerminalCost(q["Qf"])
 s.SetInitialState(W.synth36_batch_x0(64)[:1]); s.SetInitialGuess(W.synth36_u_guess(N))
 s.Solve()
-c = s.stage_cycles[0]; h = s.history[0, -1, 0]
-print("per-step cycles: stage", c[0]/39, "T1", c[1]/39, "H+first", c[2]/39, "solve", c[3]/39, "Vxx", h/39)
+c = s.stage_cycles[0]; h = s.history[0, -1, 0]; f = s.history[0, -1, 1]
+print("per-step cycles: fetch %.0f  T1 %.0f  H %.0f  factor %.0f  subst %.0f  Vxx+publish %.0f" % (c[0]/39, c[1]/39, c[2]/39, f/39, c[3]/39, h/39))
