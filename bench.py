@@ -24,11 +24,9 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def pmc_traffic(batch):
-    """HBM bytes per launch of the solve kernel from the committed rocprofv3 PMC passes
-    (profiles/rNN_pmc_c2.json: FETCH_SIZE and WRITE_SIZE collected in separate runs of THIS
-    command, gfx950 read correction applied).  bench.py cannot run the profiler on itself,
-    so the latest committed measurement for the same workload is reported; null otherwise."""
+def pmc_traffic_committed(batch):
+    """Fallback: HBM bytes per launch from the committed rocprofv3 PMC passes of THIS command
+    (profiles/rNN_pmc_c2.json)."""
     import glob
     if batch != 1024:
         return None, None
@@ -37,7 +35,54 @@ def pmc_traffic(batch):
         return None, None
     with open(files[-1]) as fh:
         d = json.load(fh)
-    return d.get("hbm_bytes_per_launch_corrected"), os.path.basename(files[-1])
+    return d.get("hbm_bytes_per_launch_corrected"), "committed " + os.path.basename(files[-1])
+
+
+def pmc_traffic_live(batch):
+    """HBM bytes per launch of the solve kernel, measured now: two separate rocprofv3 --pmc passes
+    (FETCH_SIZE, WRITE_SIZE; they do not fit one pass) over a short nested run of this script.
+    Units are KB; FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 tallies wide coalesced
+    reads at half their bytes — an upper bound for our 8 B/lane loads).  None on any failure."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    vals = {}
+    env = dict(os.environ, TMPDIR="/tmp", MI_BENCH_NESTED="1")
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="mi_pmc_", dir="/tmp")
+        try:
+            cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", out, "--",
+                   sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1",
+                   "--batch", str(batch), "--no-cpu-baseline"]
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                           timeout=180, check=True)
+            rows = []
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    rows += [float(r["Counter_Value"]) for r in csv.DictReader(fh)
+                             if "ilqr_small_kernel" in r["Kernel_Name"] and r["Counter_Name"] == ctr]
+            if len(rows) < 2:
+                return None
+            vals[ctr] = sum(rows[1:]) / len(rows[1:])          # skip the first (cold) launch
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+
+
+def pmc_traffic(batch):
+    if os.environ.get("MI_BENCH_NESTED"):
+        return None, None
+    live = pmc_traffic_live(batch)
+    if live is not None:
+        return live, "live rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH x2 gfx950 correction"
+    return pmc_traffic_committed(batch)
 
 
 def cpu_baseline(prob, x0, sample, budget_s=8.0):
@@ -196,7 +241,7 @@ def main():
         k_ms = kernel_ms / args.steps                       # avg launch duration of the dominant kernel (HIP events)
         bytes_per_launch = alg_bytes / args.steps
         achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic(B)
+        traffic, traffic_src = pmc_traffic(B) if world == 1 else pmc_traffic_committed(B)
         out = {
             "metric": "iLQR iterations/sec (batch, whole node)",
             "value": iters_all / elapsed,
