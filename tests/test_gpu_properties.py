@@ -45,6 +45,13 @@ def test_c2_full_batch_properties():
         for t in range(prob["N"] - 1):
             xr = model.step(xr, u[b][:, t])
             assert np.max(np.abs(xr - x[b][:, t + 1])) < 1e-9
+    # every one of the 1024 problems against the C oracle (pinned to the reference's goldens)
+    from oracle import c_oracle
+    r = c_oracle.solve_batch(model, prob, x0, np.zeros((1, prob["N"] - 1)))
+    assert np.array_equal(r["iters"], it) and np.array_equal(r["ls"], s.ls_trials) and (r["status"] == 0).all()
+    assert np.max(np.abs(L - r["cost"]) / np.abs(r["cost"])) < 5e-8       # both sides central FD: 1e-16/h round-off amplification
+    assert np.max(np.abs(x - r["x_bar"])) < 1e-6 and np.max(np.abs(u - r["u_bar"])) < 1e-6
+    assert np.max(np.abs(s.K - r["K"])) / np.max(np.abs(r["K"])) < 1e-6
     # permutation / position invariance, bitwise
     perm = np.random.default_rng(0).permutation(1024)
     _, _, s2 = c2_setup(1024)
