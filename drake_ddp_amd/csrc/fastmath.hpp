@@ -45,12 +45,27 @@ __device__ __forceinline__ double sin_reduced(double r) {
   return fma(r * s, p, r);
 }
 
-__device__ __forceinline__ double flip_sign_if_odd(double v, double n) {
-  // n is integer-valued; (-1)^n via the parity bit of (int)n xor-ed into the sign
-  const int ni = (int)n;
+// Round-to-nearest-even integer by the 1.5*2^52 trick: t = y + magic has ulp(t) = 1, so the
+// addition's rounding IS the rint; one subtraction recovers the integer as a double, and the low
+// mantissa word of t is the integer in two's complement.  v_rndne_f64 + v_cvt_i32_f64 are
+// quarter-rate (16-cycle) instructions; these are full rate.  Valid for |y| < 2^51 (beyond that
+// the callers' results are garbage-but-rejected, see fast_sin).
+constexpr double kRoundMagic = 0x1.8p52;
+struct Rounded { double n; int lo; };
+__device__ __forceinline__ Rounded round_magic(double t) {   // t = y + kRoundMagic, already rounded
+  Rounded r;
+  r.n = t - kRoundMagic;
+  r.lo = __double2loint(t);
+  return r;
+}
+// rint(a*b): the product is rounded ONCE, inside the fma
+__device__ __forceinline__ Rounded round_mul(double a, double b) { return round_magic(fma(a, b, kRoundMagic)); }
+
+__device__ __forceinline__ double flip_sign_if_odd(double v, int n_lo) {
+  // (-1)^n: the parity bit of n xor-ed into the sign
   union { double d; unsigned long long u; } w;
   w.d = v;
-  w.u ^= ((unsigned long long)(unsigned)(ni & 1)) << 63;
+  w.u ^= ((unsigned long long)(unsigned)n_lo) << 63;
   return w.d;
 }
 
@@ -58,22 +73,24 @@ __device__ __forceinline__ double flip_sign_if_odd(double v, double n) {
 // bounded: such states only occur in diverging line-search trials, whose cost is
 // rejected anyway — /root/reference/ilqr.py:315-335).  NaN/inf propagate to NaN.
 __device__ __forceinline__ double fast_sin(double x) {
-  const double n = rint(x * fm::kInvPi);
+  const Rounded k = round_mul(x, fm::kInvPi);
+  const double n = k.n;
   double r = fma(-n, fm::kPi1, x);
   r = fma(-n, fm::kPi2, r);
   r = fma(-n, fm::kPi3, r);
-  return flip_sign_if_odd(sin_reduced(r), n);
+  return flip_sign_if_odd(sin_reduced(r), k.lo);
 }
 
 // cos(x) = sin(x + pi/2): reduce by odd multiples of pi/2 so the sin kernel keeps
 // full RELATIVE accuracy near the zeros of cos.
 __device__ __forceinline__ double fast_cos(double x) {
-  const double n = rint(fma(x, fm::kInvPi, 0.5));        // x + pi/2 = r + n*pi
+  const Rounded kn = round_magic(fma(x, fm::kInvPi, 0.5) + kRoundMagic);      // x + pi/2 = r + n*pi
+  const double n = kn.n;
   const double k = fma(2.0, n, -1.0);                    // r = x - (2n-1)*pi/2
   double r = fma(-k, 0.5 * fm::kPi1, x);
   r = fma(-k, 0.5 * fm::kPi2, r);
   r = fma(-k, 0.5 * fm::kPi3, r);
-  return flip_sign_if_odd(sin_reduced(r), n);
+  return flip_sign_if_odd(sin_reduced(r), kn.lo);
 }
 
 // 1/x: hardware seed + two Newton steps (~1 ulp); no denormal/overflow rescaling.
@@ -90,14 +107,15 @@ __device__ __forceinline__ double fast_rcp(double x) {
 // degree-10 polynomial, scale by 2^n (underflows cleanly to 0 for very negative x).
 __device__ __forceinline__ double fast_exp_nonpos(double x) {
   x = fmax(x, -745.0);
-  const double nd = rint(x * fm::kLog2e);
+  const Rounded kn = round_mul(x, fm::kLog2e);
+  const double nd = kn.n;
   double r = fma(-nd, fm::kLn2Hi, x);
   r = fma(-nd, fm::kLn2Lo, r);
   double p = fm::kE[10];
 #pragma unroll
   for (int k = 9; k >= 0; --k) p = fma(p, r, fm::kE[k]);
   const double e = 1.0 + fma(r * r, p, r);
-  return ldexp(e, (int)nd);
+  return ldexp(e, kn.lo);
 }
 
 // log1p(y) for 0 <= y <= 1: fold 1+y into [sqrt(1/2), sqrt 2] exactly, then 2 atanh(s).

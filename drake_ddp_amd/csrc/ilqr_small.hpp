@@ -283,8 +283,11 @@ __device__ inline void rollout(const WS& w, const Consts<M>& c, const KArgs& a, 
 #pragma unroll
   for (int i = 0; i < n; ++i) x[i] = x0r[i];
   // store==true (lane 0): walk the T records; otherwise park on this lane's dump slot
-  const bool store = slot >= 0;
-  double* tw = store ? (w.T + slot * w.t_stride) : (w.dump + 2 * threadIdx.x);
+  // COST == false is the optimistic trial: every lane carries the SAME eps = 1 trajectory, so all
+  // lanes store to lane 0's address (one LDS word per bank pass instead of 64 parked slots:
+  // tools/ubench/rollstep.hip, 385 -> 289 cycles/step with four waves per CU)
+  const bool store = slot >= 0 || !COST;
+  double* tw = store ? (w.T + (slot >= 0 ? slot : 0) * w.t_stride) : (w.dump + 2 * threadIdx.x);
   const int tstep = store ? Ly::TS : 0;
 #pragma unroll
   for (int i = 0; i < n; ++i) tw[Ly::XN + i] = x[i];
