@@ -47,7 +47,8 @@ struct LLay {
                        oQfn = oQn + n, oVxx = oQfn + n, oVx = oVxx + NP * VS, oF = oVx + n,
                        oT1 = oF + n * NMP, oH = oT1 + n * TS, oXs = oH + NMP * TS, oUs = oXs + n,
                        oRed = oUs + m, oXb = oRed + kLargeThreads, oQc = oXb + n + m + ((n + m) & 1),
-                       oQT = oQc + m * m + m + (m & 1), oEnd = oQT + n * n;
+                       oQT = oQc + m * m + m + (m & 1), oS = oQT + n * n + ((n * n) & 1),
+                       oEnd = oS + 16 * 17 + 1;                // 16x16 tile, odd row stride
   static constexpr size_t doubles = oEnd + 8;
 };
 
@@ -294,46 +295,116 @@ struct TileOps {
   }
 };
 
-// value of lane LANE of this lane's 16-lane row (DPP row_share), for a double
+// value of lane LANE of this lane's 16-lane row (DPP row_share), for a double.  bound_ctrl with full
+// row/bank masks: every lane is written, so no "old" value has to be materialized first.
 template <int LANE>
 __device__ __forceinline__ double row_share(double v) {
-  union { double d; int i[2]; } u, r;
-  u.d = v;
-  r.i[0] = __builtin_amdgcn_update_dpp(0, u.i[0], 0x150 + LANE, 0xF, 0xF, false);
-  r.i[1] = __builtin_amdgcn_update_dpp(0, u.i[1], 0x150 + LANE, 0xF, 0xF, false);
-  return r.d;
+  return __builtin_amdgcn_update_dpp(v, v, 0x150 + LANE, 0xF, 0xF, true);   // one v_mov_b64_dpp (gfx90a+ DPP64 row_newbcast)
 }
 
 // Right-looking LDL^T of an m x m matrix held one ROW PER LANE (lane i of a 16-lane row holds
 // A[i][0..m-1]); pivots and column entries travel by DPP row_share, no LDS, no barriers.
 // On exit lane i holds L[i][k] in a[k] for k < i, and every lane holds 1/D[k] in dinv[k].
+// The serial part is pivot -> reciprocal (16-cycle v_rcp_f64 + four dependent FMAs) -> column
+// scale -> next pivot, and the wave issues in order: each step updates column K+1 first, starts
+// the next pivot's reciprocal, and places one independent column update between every two
+// dependent instructions of that reciprocal (sched_barrier pins the order).
 template <int m, int K, int J>
-struct LdlInner {
-  static __device__ __forceinline__ void run(double (&a)[m], double lik) {
+__device__ __forceinline__ void ldl_update(double (&a)[m], double lik) {
+  if constexpr (J < m) {
     const double ajk = row_share<J>(a[K]);          // A[J][K] before scaling = D[K] * L[J][K]
     a[J] = fma(-lik, ajk, a[J]);
-    LdlInner<m, K, J + 1>::run(a, lik);
+  }
+}
+template <int m, int K, int J>
+struct LdlRest {
+  static __device__ __forceinline__ void run(double (&a)[m], double lik) {
+    ldl_update<m, K, J>(a, lik);
+    LdlRest<m, K, J + 1>::run(a, lik);
   }
 };
 template <int m, int K>
-struct LdlInner<m, K, m> {
+struct LdlRest<m, K, m> {
   static __device__ __forceinline__ void run(double (&)[m], double) {}
 };
 template <int m, int K>
 struct LdlOuter {
-  static __device__ __forceinline__ void run(double (&a)[m], double (&dinv)[m]) {
-    const double d = row_share<K>(a[K]);
-    const double inv = fast_rcp(d);
+  // `inv` = 1 / D[K], already computed
+  static __device__ __forceinline__ void run(double (&a)[m], double (&dinv)[m], double inv) {
     dinv[K] = inv;
     const double lik = a[K] * inv;
-    LdlInner<m, K, K + 1>::run(a, lik);
+    double r = 0.0;
+    if constexpr (K + 1 < m) {
+      ldl_update<m, K, K + 1>(a, lik);
+      ldl_update<m, K, K + 2>(a, lik);              // also covers the DPP-after-VALU wait states of the pivot read
+      __builtin_amdgcn_sched_barrier(0);
+      const double d = row_share<K + 1>(a[K + 1]);
+      r = __builtin_amdgcn_rcp(d);
+      ldl_update<m, K, K + 3>(a, lik);
+      ldl_update<m, K, K + 4>(a, lik);
+      __builtin_amdgcn_sched_barrier(0);
+      double e = fma(-d, r, 1.0);
+      ldl_update<m, K, K + 5>(a, lik);
+      __builtin_amdgcn_sched_barrier(0);
+      r = fma(r, e, r);
+      ldl_update<m, K, K + 6>(a, lik);
+      __builtin_amdgcn_sched_barrier(0);
+      e = fma(-d, r, 1.0);
+      ldl_update<m, K, K + 7>(a, lik);
+      __builtin_amdgcn_sched_barrier(0);
+      r = fma(r, e, r);                             // == fast_rcp(d)
+      LdlRest<m, K, (K + 8 < m ? K + 8 : m)>::run(a, lik);
+    }
     a[K] = lik;
-    LdlOuter<m, K + 1>::run(a, dinv);
+    LdlOuter<m, K + 1>::run(a, dinv, r);
+  }
+  static __device__ __forceinline__ void run(double (&a)[m], double (&dinv)[m]) {
+    static_assert(K == 0, "entry point");
+    run(a, dinv, fast_rcp(row_share<0>(a[0])));
   }
 };
 template <int m>
 struct LdlOuter<m, m> {
-  static __device__ __forceinline__ void run(double (&)[m], double (&)[m]) {}
+  static __device__ __forceinline__ void run(double (&)[m], double (&)[m], double) {}
+};
+
+// Triangular solves with L held one row per lane (lane i: a[k] = L[i][k], k < i) and one
+// right-hand side per lane: y <- L^{-1} y and z <- L^{-T} z.  L[I][K] = row_share<I>(a[K]).
+template <int m, int I, int K>
+struct FwdRow {
+  static __device__ __forceinline__ void run(const double (&a)[m], double (&y)[m]) {
+    if constexpr (K < I) {
+      y[I] = fma(-row_share<I>(a[K]), y[K], y[I]);
+      FwdRow<m, I, K + 1>::run(a, y);
+    }
+  }
+};
+template <int m, int I>
+struct FwdSubst {
+  static __device__ __forceinline__ void run(const double (&a)[m], double (&y)[m]) {
+    if constexpr (I < m) {
+      FwdRow<m, I, 0>::run(a, y);
+      FwdSubst<m, I + 1>::run(a, y);
+    }
+  }
+};
+template <int m, int I, int K>
+struct BackRow {
+  static __device__ __forceinline__ void run(const double (&a)[m], double (&z)[m]) {
+    if constexpr (K < m) {
+      z[I] = fma(-row_share<K>(a[I]), z[K], z[I]);          // L[K][I]
+      BackRow<m, I, K + 1>::run(a, z);
+    }
+  }
+};
+template <int m, int I>
+struct BackSubst {
+  static __device__ __forceinline__ void run(const double (&a)[m], double (&z)[m]) {
+    if constexpr (I >= 0) {
+      BackRow<m, I, I + 1>::run(a, z);
+      BackSubst<m, I - 1>::run(a, z);
+    }
+  }
 };
 
 // Backward Riccati pass (ilqr.py:623-667), cost expansion (:161-206) fused.
@@ -368,7 +439,6 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
   double* F = lds + Ly::oF;          // [n][FS]  = [fx | fu | 0-pad]
   double* T1 = lds + Ly::oT1;        // [n][TS]  = [Vxx F | . | Vx at column FS]; later rows 0..m-1 hold [K | kappa]
   double* H = lds + Ly::oH;          // [NMP][TS] = F^T T1, first-order terms in column FS
-  double* Qc = lds + Ly::oQc;        // L (m x m, row-major, strictly-lower part valid) then 1/D (m)
   double* QT = lds + Ly::oQT;        // Q^T
   constexpr int CV = FS;             // column index of Vx / first-order terms
 #ifdef MI_PROF_BACKWARD
@@ -380,84 +450,155 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
     const int i = e / VS, j = e - i * VS;
     Vxx[e] = (i < n && j < n) ? 2.0 * Qf[i * n + j] : 0.0;
   }
-  for (int e = tid; e < n * FS; e += kLargeThreads) F[e] = 0.0;
   for (int e = tid; e < n * n; e += kLargeThreads) { const int i = e / n, j = e - i * n; QT[j * n + i] = Q[e]; }
-  for (int e = tid; e < Ly::NMP * TS; e += kLargeThreads) H[e] = 0.0;
   if (tid < n) {
     const double* xT = v.X + (size_t)(N - 1) * n;
+    double xr[n];
+#pragma unroll
+    for (int j = 0; j < n; ++j) xr[j] = xT[j];               // all loads in flight at once (L2 latency paid once)
     double s = 0.0;
-    for (int j = 0; j < n; ++j) s += (2.0 * Qf[tid * n + j]) * xT[j];
+#pragma unroll
+    for (int j = 0; j < n; ++j) s += (2.0 * Qf[tid * n + j]) * xr[j];
     Vx[tid] = s - qfn[tid];
   }
   __syncthreads();
+  BP_TICK(13);
   // cost gradients for ALL steps, off the recursion (ilqr.py:180-181): lx_t = 2Q x_bar_t - 2 x_nom^T Q,
-  // lu_t = 2R u_bar_t.  Q^T is read so consecutive lanes hit consecutive banks.
+  // lu_t = 2R u_bar_t.  x_bar/u_bar are first copied to LDS with coalesced loads (the T1|H and F
+  // areas are not live yet): reading them from L2 inside the dot products costs one vector-memory
+  // instruction per FMA, 31 k cycles per pass; from LDS it is 5 k.  Q^T is read so consecutive
+  // lanes hit consecutive banks.
   double* Lxu = lds + Ly::doubles;
-  for (int idx = tid; idx < (N - 1) * nm; idx += kLargeThreads) {
-    const int tt = idx / nm, pp = idx - tt * nm;
-    double s_;
-    if (pp < n) {
-      const double* xg = v.X + (size_t)tt * n;
-      s_ = -qn[pp];
-      for (int j = 0; j < n; ++j) s_ += (2.0 * QT[j * n + pp]) * xg[j];
-    } else {
-      const double* ug = v.U + (size_t)tt * m;
-      s_ = 0.0;
-      for (int j = 0; j < m; ++j) s_ += (2.0 * R[(pp - n) * m + j]) * ug[j];
+  {
+    double* Xs_ = T1;                                        // T1 and H are contiguous
+    double* Us_ = F;
+    const bool staged = (size_t)n * N <= (size_t)(n + Ly::NMP) * TS && (size_t)m * (N - 1) <= (size_t)n * FS;
+    if (staged) {
+      for (int e = tid; e < n * (N - 1); e += kLargeThreads) Xs_[e] = v.X[e];
+      for (int e = tid; e < m * (N - 1); e += kLargeThreads) Us_[e] = v.U[e];
+      __syncthreads();
     }
-    Lxu[idx] = s_;
+    if (wave == 0) BP_TICK(5);
+    const double* Xsrc = staged ? Xs_ : v.X;
+    const double* Usrc = staged ? Us_ : v.U;
+    for (int idx = tid; idx < (N - 1) * nm; idx += kLargeThreads) {
+      const int tt = idx / nm, pp = idx - tt * nm;
+      double s_;
+      if (pp < n) {
+        const double* xg = Xsrc + (size_t)tt * n;
+        s_ = -qn[pp];
+        constexpr int CH = (n % 12 == 0) ? 12 : (n % 4 == 0 ? 4 : 1);   // loads of a chunk in flight together
+#pragma unroll
+        for (int j0 = 0; j0 < n; j0 += CH) {
+          double qv[CH], xv[CH];
+#pragma unroll
+          for (int j = 0; j < CH; ++j) { qv[j] = QT[(j0 + j) * n + pp]; xv[j] = xg[j0 + j]; }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < CH; ++j) s_ += (2.0 * qv[j]) * xv[j];
+        }
+      } else {
+        const double* ug = Usrc + (size_t)tt * m;
+        s_ = 0.0;
+#pragma unroll
+        for (int j = 0; j < m; ++j) s_ += (2.0 * R[(pp - n) * m + j]) * ug[j];
+      }
+      Lxu[idx] = s_;
+    }
+    if (wave == 0) BP_TICK(6);
+    __syncthreads();
+    if (wave == 0) BP_TICK(7);
+    // the zero padding the tiles rely on (F's pad columns; H for tidiness)
+    for (int e = tid; e < n * FS; e += kLargeThreads) F[e] = 0.0;
+    for (int e = tid; e < Ly::NMP * TS; e += kLargeThreads) H[e] = 0.0;
   }
   __syncthreads();
-  // prefetch registers: elements tid + 256*r of the contiguous fx_t (n*n) and fu_t (n*m) blocks
-  constexpr int NFX = (n * n + kLargeThreads - 1) / kLargeThreads, NFU = (n * m + kLargeThreads - 1) / kLargeThreads;
-  double frx[NFX], fru[NFU];
-  const int fx_i0 = tid / n, fx_j0 = tid - fx_i0 * n, fu_i0 = tid / m, fu_k0 = tid - fu_i0 * m;
+  BP_TICK(14);
+  // The spare wave (wave 3) prefetches the WHOLE next F = [fx_t | fu_t] (contiguous n*n and n*m
+  // blocks in HBM) as 16-byte pairs into registers during the T1 phase and publishes it to LDS
+  // during the last phase: the three matrix-core waves never touch global memory in the loop.
+  static_assert(n % 2 == 0 && m % 2 == 0 && FS % 2 == 0 && Ly::oF % 2 == 0, "16-byte pairs of F stay inside a row");
+  constexpr int PFX = n * n / 2, PFU = n * m / 2;                       // pairs
+  constexpr int NFX = (PFX + 63) / 64, NFU = (PFU + 63) / 64;
+  typedef double d2_t __attribute__((ext_vector_type(2)));
+  d2_t frx[NFX], fru[NFU];
+  int fx_off[NFX], fu_off[NFU];                                          // LDS offsets (doubles) of this lane's pairs
+#pragma unroll
+  for (int r = 0; r < NFX; ++r) { int e = 2 * (lane + 64 * r); e = e < n * n ? e : n * n - 2; fx_off[r] = (e / n) * FS + (e % n); }
+#pragma unroll
+  for (int r = 0; r < NFU; ++r) { int e = 2 * (lane + 64 * r); e = e < n * m ? e : n * m - 2; fu_off[r] = (e / m) * FS + n + (e % m); }
   auto fetch = [&](int t) __attribute__((always_inline)) {
-    const double* fxg = v.Fx + (size_t)t * n * n;
-    const double* fug = v.Fu + (size_t)t * n * m;
+    const d2_t* fxg = reinterpret_cast<const d2_t*>(v.Fx + (size_t)t * n * n);
+    const d2_t* fug = reinterpret_cast<const d2_t*>(v.Fu + (size_t)t * n * m);
 #pragma unroll
-    for (int r = 0; r < NFX; ++r) { const int e = tid + kLargeThreads * r; frx[r] = fxg[e < n * n ? e : n * n - 1]; }
+    for (int r = 0; r < NFX; ++r) { const int pi = lane + 64 * r; frx[r] = fxg[pi < PFX ? pi : PFX - 1]; }
 #pragma unroll
-    for (int r = 0; r < NFU; ++r) { const int e = tid + kLargeThreads * r; fru[r] = fug[e < n * m ? e : n * m - 1]; }
+    for (int r = 0; r < NFU; ++r) { const int pi = lane + 64 * r; fru[r] = fug[pi < PFU ? pi : PFU - 1]; }
   };
-  auto publish = [&]() __attribute__((always_inline)) {
-    int i = fx_i0, j = fx_j0;
+  auto publish = [&]() __attribute__((always_inline)) {       // clamped duplicates rewrite the last pair with itself
 #pragma unroll
-    for (int r = 0; r < NFX; ++r) {
-      if (tid + kLargeThreads * r < n * n) F[i * FS + j] = frx[r];
-      i += kLargeThreads / n; j += kLargeThreads % n;
-      if (j >= n) { j -= n; i += 1; }
-    }
-    i = fu_i0; j = fu_k0;
+    for (int r = 0; r < NFX; ++r) *reinterpret_cast<d2_t*>(F + fx_off[r]) = frx[r];
 #pragma unroll
-    for (int r = 0; r < NFU; ++r) {
-      if (tid + kLargeThreads * r < n * m) F[i * FS + n + j] = fru[r];
-      i += kLargeThreads / m; j += kLargeThreads % m;
-      if (j >= m) { j -= m; i += 1; }
-    }
+    for (int r = 0; r < NFU; ++r) *reinterpret_cast<d2_t*>(F + fu_off[r]) = fru[r];
   };
-  fetch(N - 2);
-  publish();
+  if (wave == 3) { fetch(N - 2); publish(); }
   __syncthreads();
+  BP_TICK(15);
+  double* Sq = lds + Ly::oS;         // wave 3's private copy of the H tile that holds Quu - luu
+  constexpr int SS = 17;
+  static_assert(RT == 3 && CT == 3 && 2 * m <= n && m <= 16, "wave roles below: three matrix-core waves + one spare");
+  static_assert(16 * (CT - 1) <= n && n + m <= 16 * CT, "Quu lies inside the last diagonal tile of H");
+  constexpr int QO = n - 16 * (CT - 1);                       // Quu's offset inside that tile
+  // Solver-wave state, alive across phases and steps: row i of L (lane i), 1/D, and this lane's
+  // column of D^{-1} Y whose back-substitution is deferred into the next step's phase A.
+  double arow[m], dinv[m], zcol[m];
+#pragma unroll
+  for (int i = 0; i < m; ++i) { arow[i] = 0.0; dinv[i] = 0.0; zcol[i] = 0.0; }
+  // gains of step tk: K = L^{-T} (D^{-1} Y) (:659-660).  L[k][i] sits in lane k's registers and
+  // reaches every lane with one DPP64 row broadcast - no LDS traffic.
+  // All 64 lanes take part (every 16-lane DPP row holds a copy of L's rows and DPP reads from
+  // exec-masked lanes return 0); lanes beyond the n+1 right-hand sides compute on garbage and
+  // store nothing.
+  auto back_substitute = [&](int tk) __attribute__((always_inline)) {
+    BackSubst<m, m - 1>::run(arow, zcol);
+    if (lane < n) {
+      double* Kg = v.K + (size_t)tk * m * n + lane;                  // K_t[:, lane]
+#pragma unroll
+      for (int i = 0; i < m; ++i) Kg[i * n] = zcol[i];
+    } else if (lane == n) {
+#pragma unroll
+      for (int i = 0; i < m; ++i) v.kap[(size_t)tk * m + i] = zcol[i];     // kappa_t
+    }
+  };
+  // 2 lxx = 2Q entries this lane adds to its Vxx tiles (phase D): constant over the sweep
+  double q2[RT][4];
+#pragma unroll
+  for (int q = 0; q < RT; ++q)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int row = 16 * q + 4 * reg + lk, col = 16 * (wave < RT ? wave : 0) + lr;
+      q2[q][reg] = (row < n && col < n) ? 2.0 * Q[row * n + col] : 0.0;
+    }
 
   for (int t = N - 2; t >= 0; --t) {
-    if (t > 0) fetch(t - 1);                     // next step's operands: in flight during this step
     BP_TICK(0);
-    // ---- T1 = Vxx F : RT x CT tiles, K = n.  Operands of ALL of this wave's tiles are loaded
-    //      before the first MFMA (sched_barrier) so LDS latency is paid once, not per k-step.
-    //      Wave w < CT owns column tile w and sweeps the RT row tiles, so every tile offset is a
-    //      compile-time immediate on top of one per-lane base address (no address registers kept
-    //      live across the time loop); the spare wave does the Vx column.
+    // ---- phase A.  T1 = Vxx F : RT x CT tiles, K = n.  Operands of ALL of a wave's tiles are
+    //      loaded before the first MFMA (sched_barrier) so LDS latency is paid once, not per
+    //      k-step.  Wave w < CT owns column tile w and sweeps the RT row tiles, so every tile
+    //      offset is a compile-time immediate on top of one per-lane base address.
+    //      Spare wave: next step's F into registers; first-order column H[:, CV] = l_{x,u} + F^T Vx.
     if (wave < CT) {
       const double* a_base = Vxx + lr * VS + lk;
       const double* b_base = F + lk * FS + 16 * wave + lr;
       double* d_base = T1 + lk * TS + 16 * wave + lr;
       TileOps<n / 4> ops[RT];
-#pragma unroll
-      for (int q = 0; q < RT; ++q) ops[q].load(a_base + 16 * q * VS, 4, b_base, 4 * FS);
-      __builtin_amdgcn_sched_barrier(0);
+      ops[0].load(a_base, 4, b_base, 4 * FS);
 #pragma unroll
       for (int q = 0; q < RT; ++q) {
+        // tile q+1's operands are requested before tile q's MFMAs are issued and land while
+        // the matrix core works (sched_barrier: the compiler may not sink them to their use)
+        if (q + 1 < RT) ops[q + 1].load(a_base + 16 * (q + 1) * VS, 4, b_base, 4 * FS);
+        __builtin_amdgcn_sched_barrier(0);
         d4_t acc = {0.0, 0.0, 0.0, 0.0};
         acc = ops[q].run(acc);
 #pragma unroll
@@ -467,98 +608,96 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
           else if (ib < n) { if (ib + lk < n) d_base[ib * TS] = acc[reg]; }
         }
       }
-    } else if (lane < n) {
-      T1[lane * TS + CV] = Vx[lane];
+    } else {
+      if (t > 0) fetch(t - 1);
+      BP_TICK(5);
+      if (lane < nm) {                                     // (:651-652) lx_t / lu_t precomputed for all t
+        double s = Lxu[t * nm + lane];
+        constexpr int CH = (n % 12 == 0) ? 12 : (n % 4 == 0 ? 4 : 1);   // a chunk's LDS reads are in flight together
+#pragma unroll
+        for (int k0 = 0; k0 < n; k0 += CH) {
+          double fv[CH], vv[CH];
+#pragma unroll
+          for (int k = 0; k < CH; ++k) { fv[k] = F[(k0 + k) * FS + lane]; vv[k] = Vx[k0 + k]; }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int k = 0; k < CH; ++k) s += fv[k] * vv[k];
+        }
+        H[lane * TS + CV] = s;
+      }
+      BP_TICK(6);
+      if (t < N - 2) back_substitute(t + 1);               // previous step's gains, off the recursion
+      BP_TICK(9);
     }
     lds_barrier();
     BP_TICK(1);
-    // ---- H = F^T T1 : CT x CT tiles, K = n;  H[:, CV] = F^T Vx
+    // ---- phase B.  H = F^T T1 : CT x CT tiles, K = n.  Meanwhile the spare wave recomputes the
+    //      one tile that contains Quu - luu (bitwise the tile wave CT-1 stores), turns it into one
+    //      row per lane through a private LDS scratch and factorizes Quu = 2R + fu^T Vxx fu (:654)
+    //      = L D L^T (DPP row broadcasts, no barriers): the factorization is off the critical path.
     if (wave < CT) {
       const double* a_base = F + lk * FS + lr;                       // A = F^T: A[p][k] = F[k][p]
       const double* b_base = T1 + lk * TS + 16 * wave + lr;
       double* d_base = H + lk * TS + 16 * wave + lr;
       TileOps<n / 4> ops[CT];
-#pragma unroll
-      for (int q = 0; q < CT; ++q) ops[q].load(a_base + 16 * q, 4 * FS, b_base, 4 * TS);
-      __builtin_amdgcn_sched_barrier(0);
+      ops[0].load(a_base, 4 * FS, b_base, 4 * TS);
 #pragma unroll
       for (int q = 0; q < CT; ++q) {
+        if (q + 1 < CT) ops[q + 1].load(a_base + 16 * (q + 1), 4 * FS, b_base, 4 * TS);
+        __builtin_amdgcn_sched_barrier(0);
         d4_t acc = {0.0, 0.0, 0.0, 0.0};
         acc = ops[q].run(acc);
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) d_base[(16 * q + 4 * reg) * TS] = acc[reg];
       }
-    } else if (lane < nm) {                                // spare wave: H[:, CV] = l_{x,u} + F^T Vx  (:651-652)
-      double s = Lxu[t * nm + lane];                       // lx_t / lu_t (precomputed for all t)
-#pragma unroll 6
-      for (int k = 0; k < n; ++k) s += F[k * FS + lane] * Vx[k];
-      H[lane * TS + CV] = s;
+    } else {
+      TileOps<n / 4> op;
+      op.load(F + lk * FS + 16 * (CT - 1) + lr, 4 * FS, T1 + lk * TS + 16 * (CT - 1) + lr, 4 * TS);
+      d4_t acc = {0.0, 0.0, 0.0, 0.0};
+      acc = op.run(acc);
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) Sq[(lk + 4 * reg) * SS + lr] = acc[reg];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+      BP_TICK(7);
+      const int i = lr < m ? lr : m - 1;                   // lanes >= m of each 16-lane row shadow the last row
+#pragma unroll
+      for (int j = 0; j < m; ++j) arow[j] = 2.0 * R[i * m + j] + Sq[(QO + i) * SS + QO + j];
+      LdlOuter<m, 0>::run(arow, dinv);                     // lane i < m: arow[k] = L[i][k], k < i
+      BP_TICK(8);
     }
     lds_barrier();
     BP_TICK(2);
-    // ---- wave 1 factorizes Quu = 2R + fu^T Vxx fu (:654) = L D L^T, one row per lane
-    if (false) {
-    } else if (wave == 1) {
-      static_assert(m <= 16, "one Quu row per lane of a 16-lane DPP row");
-      const int i = lane < m ? lane : m - 1;               // lanes >= m shadow the last row (harmless)
-      double arow[m], dinv[m];
+    // ---- phase C (solver wave only).  Forward substitution Y = L^{-1} [Qux | Qu], one right-hand
+    //      side per lane, L through v_readlane.  The recursion needs just Y:
+    //      Qux^T Quu^{-1} Qux = Y^T D^{-1} Y  (:666-667).  T1 rows [0,m) <- D^{-1}Y, rows [m,2m) <- Y.
+    if (wave == 3) {
+      double y[m];
+      const int rhs = lane < n ? lane : CV;                 // lanes > n shadow the Qu column, store nothing
 #pragma unroll
-      for (int j = 0; j < m; ++j) arow[j] = 2.0 * R[i * m + j] + H[(n + i) * TS + n + j];
-      LdlOuter<m, 0>::run(arow, dinv);
-      if (lane < m) {
+      for (int i = 0; i < m; ++i) y[i] = H[(n + i) * TS + rhs];
+      FwdSubst<m, 1>::run(arow, y);
+      double dv = 0.0;
 #pragma unroll
-        for (int k = 0; k < m; ++k) Qc[lane * m + k] = arow[k];      // L[lane][k] for k < lane
+      for (int i = 0; i < m; ++i) {
+        zcol[i] = y[i] * dinv[i];
+        dv = fma(y[i], zcol[i], dv);                        // Qu^T Quu^{-1} Qu = y_u^T D^{-1} y_u (:663)
       }
-      if (lane == 0) {
+      if (lane <= n) {
 #pragma unroll
-        for (int k = 0; k < m; ++k) Qc[m * m + k] = dinv[k];
+        for (int i = 0; i < m; ++i) { T1[(m + i) * TS + rhs] = y[i]; T1[i * TS + rhs] = zcol[i]; }
       }
-    }
-    lds_barrier();
-    BP_TICK(5);
-    // ---- Y = Quu^{-1} [Qux | Qu] (:655-660): one right-hand side per thread, forward/back substitution
-    if (tid <= n) {
-      double y[m], dinv[m], Lr[m][m];
-      const int rhs = tid < n ? tid : CV;
-#pragma unroll
-      for (int i = 0; i < m; ++i) { y[i] = H[(n + i) * TS + rhs]; dinv[i] = Qc[m * m + i]; }
-#pragma unroll
-      for (int i = 1; i < m; ++i)
-#pragma unroll
-        for (int k = 0; k < i; ++k) Lr[i][k] = Qc[i * m + k];
-      __builtin_amdgcn_sched_barrier(0);                   // all (broadcast) LDS reads in flight before the FMA chains
-#pragma unroll
-      for (int i = 0; i < m; ++i)
-#pragma unroll
-        for (int k = 0; k < i; ++k) y[i] -= Lr[i][k] * y[k];
-#pragma unroll
-      for (int i = 0; i < m; ++i) y[i] *= dinv[i];
-#pragma unroll
-      for (int i = m - 1; i >= 0; --i)
-#pragma unroll
-        for (int k = i + 1; k < m; ++k) y[i] -= Lr[k][i] * y[k];
-      if (tid < n) {
-#pragma unroll
-        for (int i = 0; i < m; ++i) T1[i * TS + tid] = y[i];       // K_t[:, tid] (:660), stored to HBM below
-      } else {
-        double dv = 0.0;
-#pragma unroll
-        for (int i = 0; i < m; ++i) {
-          v.kap[(size_t)t * m + i] = y[i];                        // kappa_t (:659)
-          T1[i * TS + CV] = y[i];
-          dv += H[(n + i) * TS + CV] * y[i];                      // Qu^T Quu^{-1} Qu (:663)
-        }
-        v.dV[t] = dv;
-      }
+      if (lane == n) v.dV[t] = dv;
     }
     lds_barrier();
     BP_TICK(3);
-    // ---- Vxx = Qxx - Qux^T K (RT x RT tiles, K = m; :667) ; Vx = Qx - Qux^T kappa (:666)
+    // ---- phase D.  Vxx = Qxx - Y^T (D^{-1} Y) : RT x RT tiles, K = m (:667).
+    //      Solver wave: Vx = Qx - Y^T D^{-1} y_u (:666); next step's F into LDS (F is free after B).
     if (wave < RT) {
-      const double* a_base = H + (n + lk) * TS + lr;                 // A = Qux^T: A[i][a] = H[n+a][i]
-      const double* b_base = T1 + lk * TS + 16 * wave + lr;          // B = K
+      const double* a_base = T1 + (m + lk) * TS + lr;                // A = Y^T: A[i][a] = Y[a][i]
+      const double* b_base = T1 + lk * TS + 16 * wave + lr;          // B = D^{-1} Y
       const double* c_base = H + lk * TS + 16 * wave + lr;           // C = Qxx - lxx
-      const double* q_base = Q + lk * n + 16 * wave + lr;
       double* d_base = Vxx + lk * VS + 16 * wave + lr;
       const bool col_ok = 16 * wave + lr < n;
       TileOps<m / 4> ops[RT];
@@ -570,12 +709,14 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
         for (int reg = 0; reg < 4; ++reg) {
           const int ib = 16 * q + 4 * reg;
           const bool ok = col_ok && (ib + 3 < n || (ib < n && ib + lk < n));
-          accs[q][reg] = ok ? c_base[ib * TS] + 2.0 * q_base[ib * n] : 0.0;
+          accs[q][reg] = ok ? c_base[ib * TS] : 0.0;
         }
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int q = 0; q < RT; ++q) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) accs[q][reg] += q2[q][reg];
 #pragma unroll
         for (int ks = 0; ks < m / 4; ++ks) ops[q].av[ks] = -ops[q].av[ks];
         const d4_t acc = ops[q].run(accs[q]);
@@ -586,22 +727,26 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
           if (ok) d_base[ib * VS] = acc[reg];
         }
       }
-    }
-    if (wave == 3) {                              // K_t (m x n, contiguous in HBM): coalesced store from its LDS copy
-      double* Kg = v.K + (size_t)t * m * n;
-      for (int e = lane; e < m * n; e += 64) { const int i = e / n, j = e - i * n; Kg[e] = T1[i * TS + j]; }
-    }
-    if (wave == 3 && lane < n) {
-      static_assert(RT <= 3 && CT <= 3, "wave 3 is the spare wave");
-      double s = H[lane * TS + CV];
+      BP_TICK(12);
+    } else {
+      if (lane < n) {
+        double ya[m], za[m];
 #pragma unroll
-      for (int a_ = 0; a_ < m; ++a_) s -= H[(n + a_) * TS + lane] * T1[a_ * TS + CV];
-      Vx[lane] = s;
+        for (int a_ = 0; a_ < m; ++a_) { ya[a_] = T1[(m + a_) * TS + lane]; za[a_] = T1[a_ * TS + CV]; }
+        double s = H[lane * TS + CV];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int a_ = 0; a_ < m; ++a_) s -= ya[a_] * za[a_];
+        Vx[lane] = s;
+      }
+      BP_TICK(10);
+      if (t > 0) publish();
+      BP_TICK(11);
     }
-    if (t > 0) publish();                        // F/xb are free after the H phase
     lds_barrier();
     BP_TICK(4);
   }
+  if (wave == 3) back_substitute(0);
 }
 
 template <class M, int JAC, int MODE>
@@ -704,9 +849,14 @@ __global__ void __launch_bounds__(kLargeThreads) ilqr_large_kernel(const KArgs a
     __syncthreads();
     const long long c2 = clock64();
 #ifdef MI_PROF_BACKWARD
-    long long bpa[6] = {0, 0, 0, 0, 0, 0};
+    // profiling build only: 16 phase accumulators of thread 0 (a matrix-core wave) and of thread
+    // 192 (the spare wave) land in the last 8 rows of the history buffer (tools/bp_prof.py)
+    long long bpa[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (MODE == MODE_SOLVE) { large_backward<M>(v, lds, bpa); __syncthreads(); }
-    if (tid == 0 && iters == 0) { for (int q_ = 0; q_ < 4; ++q_) a.prof[4 * b + q_] = bpa[q_]; a.hist[(size_t)b * a.hist_cap * 4 + 4 * (a.hist_cap - 1)] = (double)bpa[4]; a.hist[(size_t)b * a.hist_cap * 4 + 4 * (a.hist_cap - 1) + 1] = (double)bpa[5]; }
+    if ((tid == 0 || tid == 192) && iters == 0) {
+      double* hp = a.hist + (size_t)b * a.hist_cap * 4 + 4 * (a.hist_cap - (tid == 0 ? 4 : 8));
+      for (int q_ = 0; q_ < 16; ++q_) hp[q_] = (double)bpa[q_];
+    }
 #else
     if (MODE == MODE_SOLVE) { large_backward<M>(v, lds); __syncthreads(); }          // :697
 #endif
