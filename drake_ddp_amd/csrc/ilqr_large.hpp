@@ -464,46 +464,61 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
   __syncthreads();
   BP_TICK(13);
   // cost gradients for ALL steps, off the recursion (ilqr.py:180-181): lx_t = 2Q x_bar_t - 2 x_nom^T Q,
-  // lu_t = 2R u_bar_t.  x_bar/u_bar are first copied to LDS with coalesced loads (the T1|H and F
-  // areas are not live yet): reading them from L2 inside the dot products costs one vector-memory
-  // instruction per FMA, 31 k cycles per pass; from LDS it is 5 k.  Q^T is read so consecutive
-  // lanes hit consecutive banks.
+  // lu_t = 2R u_bar_t.  lx for the whole horizon is one (N-1) x n x n product: x_bar is copied to
+  // LDS (the T1|H area is not live yet) and the product runs as 16x16 tiles on the matrix core,
+  // tiles dealt round-robin to the four waves (dot products out of L2: 31 k cycles per pass; out
+  // of LDS on the VALU: 17 k, LDS-bandwidth-bound; this: ~3 k).  lu is small and stays scalar.
   double* Lxu = lds + Ly::doubles;
   {
     double* Xs_ = T1;                                        // T1 and H are contiguous
     double* Us_ = F;
-    const bool staged = (size_t)n * N <= (size_t)(n + Ly::NMP) * TS && (size_t)m * (N - 1) <= (size_t)n * FS;
+    // the last row tile reads up to 15 rows past step N-2: they must stay inside the staging area
+    const bool staged = (size_t)n * (N + 15) <= (size_t)(n + Ly::NMP) * TS && (size_t)m * (N - 1) <= (size_t)n * FS;
     if (staged) {
       for (int e = tid; e < n * (N - 1); e += kLargeThreads) Xs_[e] = v.X[e];
       for (int e = tid; e < m * (N - 1); e += kLargeThreads) Us_[e] = v.U[e];
       __syncthreads();
-    }
-    if (wave == 0) BP_TICK(5);
-    const double* Xsrc = staged ? Xs_ : v.X;
-    const double* Usrc = staged ? Us_ : v.U;
-    for (int idx = tid; idx < (N - 1) * nm; idx += kLargeThreads) {
-      const int tt = idx / nm, pp = idx - tt * nm;
-      double s_;
-      if (pp < n) {
-        const double* xg = Xsrc + (size_t)tt * n;
-        s_ = -qn[pp];
-        constexpr int CH = (n % 12 == 0) ? 12 : (n % 4 == 0 ? 4 : 1);   // loads of a chunk in flight together
+      if (wave == 0) BP_TICK(5);
+      constexpr int CTn = (n + 15) / 16;
+      const int ntiles = ((N - 1 + 15) / 16) * CTn;
+      for (int tile = wave; tile < ntiles; tile += 4) {
+        const int q = tile / CTn, c = tile - q * CTn;
+        TileOps<n / 4> op;                                   // A = x_bar rows, B[j][pp] = 2 Q[pp][j] = 2 Q^T[j][pp]
+        op.load(Xs_ + (16 * q + lr) * n + lk, 4, QT + lk * n + 16 * c + lr, 4 * n);
 #pragma unroll
-        for (int j0 = 0; j0 < n; j0 += CH) {
-          double qv[CH], xv[CH];
+        for (int ks = 0; ks < n / 4; ++ks) op.bv[ks] *= 2.0;
+        const int pp = 16 * c + lr;
+        const double c0 = pp < n ? -qn[pp] : 0.0;
+        d4_t acc = {c0, c0, c0, c0};
+        acc = op.run(acc);
 #pragma unroll
-          for (int j = 0; j < CH; ++j) { qv[j] = QT[(j0 + j) * n + pp]; xv[j] = xg[j0 + j]; }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int j = 0; j < CH; ++j) s_ += (2.0 * qv[j]) * xv[j];
+        for (int reg = 0; reg < 4; ++reg) {
+          const int tt = 16 * q + lk + 4 * reg;
+          if (tt < N - 1 && pp < n) Lxu[tt * nm + pp] = acc[reg];
         }
-      } else {
-        const double* ug = Usrc + (size_t)tt * m;
-        s_ = 0.0;
-#pragma unroll
-        for (int j = 0; j < m; ++j) s_ += (2.0 * R[(pp - n) * m + j]) * ug[j];
       }
-      Lxu[idx] = s_;
+      for (int idx = tid; idx < (N - 1) * m; idx += kLargeThreads) {
+        const int tt = idx / m, a_ = idx - tt * m;
+        double s_ = 0.0;
+#pragma unroll
+        for (int j = 0; j < m; ++j) s_ += (2.0 * R[a_ * m + j]) * Us_[tt * m + j];
+        Lxu[tt * nm + n + a_] = s_;
+      }
+    } else {
+      for (int idx = tid; idx < (N - 1) * nm; idx += kLargeThreads) {   // long horizons: straight from L2
+        const int tt = idx / nm, pp = idx - tt * nm;
+        double s_;
+        if (pp < n) {
+          const double* xg = v.X + (size_t)tt * n;
+          s_ = -qn[pp];
+          for (int j = 0; j < n; ++j) s_ += (2.0 * QT[j * n + pp]) * xg[j];
+        } else {
+          const double* ug = v.U + (size_t)tt * m;
+          s_ = 0.0;
+          for (int j = 0; j < m; ++j) s_ += (2.0 * R[(pp - n) * m + j]) * ug[j];
+        }
+        Lxu[idx] = s_;
+      }
     }
     if (wave == 0) BP_TICK(6);
     __syncthreads();
@@ -592,20 +607,27 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
       const double* b_base = F + lk * FS + 16 * wave + lr;
       double* d_base = T1 + lk * TS + 16 * wave + lr;
       TileOps<n / 4> ops[RT];
+      d4_t accs[RT];
       ops[0].load(a_base, 4, b_base, 4 * FS);
 #pragma unroll
       for (int q = 0; q < RT; ++q) {
-        // tile q+1's operands are requested before tile q's MFMAs are issued and land while
-        // the matrix core works (sched_barrier: the compiler may not sink them to their use)
+        // tile q+1's operands are requested before tile q's MFMAs are issued and land while the
+        // matrix core works; each tile has its own accumulator and all results are stored after
+        // the last MFMA, so the matrix pipe runs the wave's 27 instructions back to back
+        // (sched_barrier: the compiler may not sink loads to their use or hoist the stores)
         if (q + 1 < RT) ops[q + 1].load(a_base + 16 * (q + 1) * VS, 4, b_base, 4 * FS);
         __builtin_amdgcn_sched_barrier(0);
-        d4_t acc = {0.0, 0.0, 0.0, 0.0};
-        acc = ops[q].run(acc);
+        const d4_t zero = {0.0, 0.0, 0.0, 0.0};
+        accs[q] = ops[q].run(zero);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < RT; ++q) {
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
           const int ib = 16 * q + 4 * reg;                 // rows ib + lk, lk = 0..3
-          if (ib + 3 < n) d_base[ib * TS] = acc[reg];
-          else if (ib < n) { if (ib + lk < n) d_base[ib * TS] = acc[reg]; }
+          if (ib + 3 < n) d_base[ib * TS] = accs[q][reg];
+          else if (ib < n) { if (ib + lk < n) d_base[ib * TS] = accs[q][reg]; }
         }
       }
     } else {
@@ -640,16 +662,20 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
       const double* b_base = T1 + lk * TS + 16 * wave + lr;
       double* d_base = H + lk * TS + 16 * wave + lr;
       TileOps<n / 4> ops[CT];
+      d4_t accs[CT];
       ops[0].load(a_base, 4 * FS, b_base, 4 * TS);
 #pragma unroll
       for (int q = 0; q < CT; ++q) {
         if (q + 1 < CT) ops[q + 1].load(a_base + 16 * (q + 1), 4 * FS, b_base, 4 * TS);
         __builtin_amdgcn_sched_barrier(0);
-        d4_t acc = {0.0, 0.0, 0.0, 0.0};
-        acc = ops[q].run(acc);
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) d_base[(16 * q + 4 * reg) * TS] = acc[reg];
+        const d4_t zero = {0.0, 0.0, 0.0, 0.0};
+        accs[q] = ops[q].run(zero);
       }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < CT; ++q)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) d_base[(16 * q + 4 * reg) * TS] = accs[q][reg];
     } else {
       TileOps<n / 4> op;
       op.load(F + lk * FS + 16 * (CT - 1) + lr, 4 * FS, T1 + lk * TS + 16 * (CT - 1) + lr, 4 * TS);
@@ -706,11 +732,7 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
       for (int q = 0; q < RT; ++q) {
         ops[q].load(a_base + 16 * q, 4 * TS, b_base, 4 * TS);
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const int ib = 16 * q + 4 * reg;
-          const bool ok = col_ok && (ib + 3 < n || (ib < n && ib + lk < n));
-          accs[q][reg] = ok ? c_base[ib * TS] : 0.0;
-        }
+        for (int reg = 0; reg < 4; ++reg) accs[q][reg] = c_base[(16 * q + 4 * reg) * TS];   // pad rows/cols: in-bounds, never stored
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -719,12 +741,16 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
         for (int reg = 0; reg < 4; ++reg) accs[q][reg] += q2[q][reg];
 #pragma unroll
         for (int ks = 0; ks < m / 4; ++ks) ops[q].av[ks] = -ops[q].av[ks];
-        const d4_t acc = ops[q].run(accs[q]);
+        accs[q] = ops[q].run(accs[q]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < RT; ++q) {
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
           const int ib = 16 * q + 4 * reg;
           const bool ok = col_ok && (ib + 3 < n || (ib < n && ib + lk < n));
-          if (ok) d_base[ib * VS] = acc[reg];
+          if (ok) d_base[ib * VS] = accs[q][reg];
         }
       }
       BP_TICK(12);
