@@ -98,6 +98,24 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
   return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// Sum over each 16-lane row, result in every lane of the row: four DPP row rotations (8, 4, 2, 1)
+// instead of four ds_bpermute round trips through the LDS crossbar.
+template <int ROT>
+__device__ __forceinline__ double row_ror_f64(double v) {
+  union { double d; int i[2]; } u, r;
+  u.d = v;
+  r.i[0] = __builtin_amdgcn_mov_dpp(u.i[0], 0x120 + ROT, 0xF, 0xF, true);
+  r.i[1] = __builtin_amdgcn_mov_dpp(u.i[1], 0x120 + ROT, 0xF, 0xF, true);
+  return r.d;
+}
+__device__ __forceinline__ double row16_sum(double p) {
+  p += row_ror_f64<8>(p);
+  p += row_ror_f64<4>(p);
+  p += row_ror_f64<2>(p);
+  p += row_ror_f64<1>(p);
+  return p;
+}
+
 // One line-search trial (ilqr.py:306-327).  Returns L on every thread; trajectory -> Xn/Un.
 // Per step: (1) 16 lanes per control row form K_t(x-x_bar) partial dots — K_t, x_bar_t,
 // u_bar_t, kappa_t come from HBM/L2 and are prefetched one step ahead into registers;
@@ -127,52 +145,60 @@ __device__ inline double large_rollout(const LView<M::n, M::m>& v, double* lds, 
 #pragma unroll
     for (int j = 0; j < m; ++j) rrow[j] = lds[Ly::oR + (tid - 128) * m + j];
   }
+  // the state ping-pongs between two LDS buffers so the new state is written while the old one
+  // is still being read: two workgroup barriers per step instead of three
+  double* xs2 = lds + Ly::oXb;
+  static_assert(Ly::oQc - Ly::oXb >= n, "second state buffer");
   if (tid < n) { xs[tid] = x0g[tid]; v.Xn[tid] = x0g[tid]; }
   double acc = 0.0;                    // per-thread cost partial over all time steps
-  // prefetch registers for step t
-  double kr[JR], xbr[JR], ubk = 0.0, kpk = 0.0;
-  auto prefetch = [&](int t) __attribute__((always_inline)) {
+  // Operands of the control law (K_t row slice, x_bar_t slice, u_bar_t, kappa_t) come from
+  // L2/MALL: they are requested TWO steps ahead into two alternating register sets (a step is
+  // ~1.5 k cycles of work; an Infinity-Cache hit costs about that much on its own).
+  struct Pf { double kr[JR], xbr[JR], ubk, kpk; };
+  Pf pfA, pfB;
+  auto prefetch = [&](Pf& f, int t) __attribute__((always_inline)) {
     if (urole) {
       const double* Kr = v.K + ((size_t)t * m + uk) * n;
       const double* xbt = v.X + (size_t)t * n;
 #pragma unroll
       for (int q = 0; q < JR; ++q) {
         const int j = ul + 16 * q;
-        kr[q] = (j < n) ? Kr[j] : 0.0;
-        xbr[q] = (j < n) ? xbt[j] : 0.0;
+        f.kr[q] = (j < n) ? Kr[j] : 0.0;
+        f.xbr[q] = (j < n) ? xbt[j] : 0.0;
       }
-      if (ul == 0) { ubk = v.U[(size_t)t * m + uk]; kpk = v.kap[(size_t)t * m + uk]; }
+      f.ubk = 0.0; f.kpk = 0.0;
+      if (ul == 0) { f.ubk = v.U[(size_t)t * m + uk]; f.kpk = v.kap[(size_t)t * m + uk]; }
     }
   };
-  prefetch(0);
-  __syncthreads();
-  for (int t = 0; t < N - 1; ++t) {
+  double* xc = xs;                     // current state
+  double* xn_ = xs2;                   // next state
+  auto one_step = [&](Pf& f, int t) __attribute__((always_inline)) {
     // u_t = u_bar_t - eps*kappa_t - K_t (x_t - x_bar_t)   (ilqr.py:313)
     if (urole) {
       double p = 0.0;
 #pragma unroll
       for (int q = 0; q < JR; ++q) {
         const int j = ul + 16 * q;
-        if (j < n) p += kr[q] * (xs[j] - xbr[q]);
+        if (j < n) p += f.kr[q] * (xc[j] - f.xbr[q]);
       }
-      p += __shfl_xor(p, 8, 16);
-      p += __shfl_xor(p, 4, 16);
-      p += __shfl_xor(p, 2, 16);
-      p += __shfl_xor(p, 1, 16);
-      if (ul == 0) us[uk] = (ubk - eps * kpk) - p;
+      p = row16_sum(p);
+      if (ul == 0) us[uk] = (f.ubk - eps * f.kpk) - p;
     }
-    if (t + 1 < N - 1) prefetch(t + 1);          // lands while the dynamics run
+    if (t + 2 < N - 1) prefetch(f, t + 2);       // this set is free again
     lds_barrier();
     // dynamics: one lane per degree of freedom (ilqr.py:316); cost rows on the other waves (:325)
-    double qn_ = 0.0, vn_ = 0.0;
     if (tid < M::nq) {
-      M::template dof<double>(tid, xs, us, qn_, vn_, a.params, a.dt);
+      double qn_ = 0.0, vn_ = 0.0;
+      M::template dof<double>(tid, xc, us, qn_, vn_, a.params, a.dt);
+      xn_[tid] = qn_; xn_[M::nq + tid] = vn_;
+      v.Xn[(size_t)(t + 1) * n + tid] = qn_;
+      v.Xn[(size_t)(t + 1) * n + M::nq + tid] = vn_;
     } else if (qrole) {
       const int i = tid - 64;
       double r = 0.0;
 #pragma unroll
-      for (int j = 0; j < n; ++j) r += qrow[j] * (xs[j] - xnom[j]);
-      acc += (xs[i] - xnom[i]) * r;
+      for (int j = 0; j < n; ++j) r += qrow[j] * (xc[j] - xnom[j]);
+      acc += (xc[i] - xnom[i]) * r;
     } else if (rrole) {
       const int k = tid - 128;
       double r = 0.0;
@@ -182,13 +208,16 @@ __device__ inline double large_rollout(const LView<M::n, M::m>& v, double* lds, 
       v.Un[(size_t)t * m + k] = us[k];
     }
     lds_barrier();
-    if (tid < M::nq) {
-      xs[tid] = qn_; xs[M::nq + tid] = vn_;
-      v.Xn[(size_t)(t + 1) * n + tid] = qn_;
-      v.Xn[(size_t)(t + 1) * n + M::nq + tid] = vn_;
-    }
-    lds_barrier();
+    double* tmp_ = xc; xc = xn_; xn_ = tmp_;
+  };
+  prefetch(pfA, 0);
+  if (1 < N - 1) prefetch(pfB, 1);
+  __syncthreads();
+  for (int t = 0; t < N - 1; t += 2) {
+    one_step(pfA, t);
+    if (t + 1 < N - 1) one_step(pfB, t + 1);
   }
+  xs = xc;                             // final state x_{N-1}
   if (qrole) {                         // terminal cost (ilqr.py:327)
     const int i = tid - 64;
     const double* Qf = lds + Ly::oQf;
