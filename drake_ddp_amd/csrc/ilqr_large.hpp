@@ -324,13 +324,6 @@ struct TileOps {
   }
 };
 
-// value of lane LANE of this lane's 16-lane row (DPP row_share), for a double.  bound_ctrl with full
-// row/bank masks: every lane is written, so no "old" value has to be materialized first.
-template <int LANE>
-__device__ __forceinline__ double row_share(double v) {
-  return __builtin_amdgcn_update_dpp(v, v, 0x150 + LANE, 0xF, 0xF, true);   // one v_mov_b64_dpp (gfx90a+ DPP64 row_newbcast)
-}
-
 // Right-looking LDL^T of an m x m matrix held one ROW PER LANE (lane i of a 16-lane row holds
 // A[i][0..m-1]); pivots and column entries travel by DPP row_share, no LDS, no barriers.
 // On exit lane i holds L[i][k] in a[k] for k < i, and every lane holds 1/D[k] in dinv[k].

@@ -754,6 +754,13 @@ __device__ inline void backward_scalar(const WS& w, const Consts<M>& c) {
 
 typedef double d4s_t __attribute__((ext_vector_type(4)));
 
+// value of lane LANE of this lane's 16-lane row, for a double: one v_mov_b64_dpp row_newbcast
+// (gfx90a+ DPP64).  bound_ctrl with full row/bank masks: every lane is written.
+template <int LANE>
+__device__ __forceinline__ double row_share(double v) {
+  return __builtin_amdgcn_update_dpp(v, v, 0x150 + LANE, 0xF, 0xF, true);
+}
+
 __device__ __forceinline__ double readlane_f64(double v, int srclane) {
   union { double d; int i[2]; } u;
   u.d = v;
@@ -773,19 +780,20 @@ __device__ __forceinline__ double readlane_f64(double v, int srclane) {
 //     S = [Vxx | Vx at col CV]  at lane (lk = i, lr = j)           (the D layout of a result)
 //     T  = S^T F              : A = S (read through its D-layout registers), B = F
 //     H  = F^T [T | Vx]       : A = F (as F^T), B = T with column CV replaced by Vx
-// H holds Qxx-lxx (rows < n), Qux, Quu-luu, and F^T Vx in column CV, so the gains are a
-// few lane-local operations plus two cross-lane shuffles.  S is consumed through its
-// transpose (the D layout of one product is the A^T layout of the next); Vxx is
-// symmetric up to round-off — the reference never symmetrizes it either — so results
-// differ from the scalar path at the 1e-16 level only.
+// H holds Qxx-lxx (rows < n), Qux, Quu-luu, and F^T Vx in column CV.  The A operand of the second
+// product carries fu a second time in rows 8..11, so output register 2 of EVERY lane holds
+// H[n][lr] (the Qux row, Quu and Qu) and the gains need no cross-row shuffle: Quu, Qu and the
+// column form of Qux arrive by one DPP64 row broadcast each.  S is consumed through its
+// transpose and Qux^T is taken from column n of H (the D layout of one product is the A^T layout
+// of the next); Vxx is symmetric up to round-off — the reference never symmetrizes it either —
+// so results differ from the scalar path at the 1e-16 level only.
 // ---------------------------------------------------------------------------
 template <class M>
 __device__ inline void backward_mfma(const WS& w, const Consts<M>& c) {
   constexpr int n = M::n, m = M::m, nm = n + m, CV = nm;
-  static_assert(m == 1 && n <= 4 && nm + 1 <= 16, "shape covered by one 16x16x4 tile");
+  static_assert(m == 1 && n <= 4 && nm + 1 <= 8, "shape covered by one 16x16x4 tile with rows 8..11 spare");
   using Ly = Lay<n, m>;
   const int N = w.N, lane = threadIdx.x, lr = lane & 15, lk = lane >> 4;
-  constexpr int RQ = n / 4, LQ = n % 4;                 // H row n lives in register RQ of lanes with lk == LQ
   const bool in_blk = lk < n && lr < n;
   const bool is_cv = lk < n && lr == CV;
   // lane constants
@@ -802,11 +810,12 @@ __device__ inline void backward_mfma(const WS& w, const Consts<M>& c) {
 #pragma unroll
   for (int i = 0; i < n; ++i) if (lk == i) qn_l = c.qn[i];
   const double R2 = 2.0 * c.R[0][0];
-  // F element of this lane inside a J record (clamped to a valid slot, masked by fvalid)
-  const bool fvalid = lk < n && lr < nm;
+  // F element of this lane inside a J record (clamped to a valid slot, masked by fvalid);
+  // lanes lr = 8..11 carry fu[lk] again: rows 8..11 of F^T, see above
+  const bool frep = lk < n && lr >= 8 && lr < 12;
+  const bool fvalid = lk < n && (lr < nm || frep);
   int foff = Ly::FX;
-  if (fvalid) foff = (lr < n) ? (Ly::FX + lk * n + lr) : (Ly::FU + lk * m + (lr - n));
-  const int src_col = LQ * 16 + lr, src_row = LQ * 16 + (lk < n ? lk : 0);
+  if (fvalid) foff = (lr < n) ? (Ly::FX + lk * n + lr) : (Ly::FU + lk * m);
 
   // terminal: S = [2 Qf | 2 Qf x_T - 2 x_nom^T Qf]   (ilqr.py:203-204, :638)
   double S = 0.0;
@@ -846,11 +855,11 @@ __device__ inline void backward_mfma(const WS& w, const Consts<M>& c) {
     const d4s_t T = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, f, z, 0, 0, 0);
     const double b2 = (lr == CV) ? S : T[0];                       // [T | Vx]
     const d4s_t H = __builtin_amdgcn_mfma_f64_16x16x4f64(f, b2, z, 0, 0, 0);
-    const double hq = H[RQ];
-    const double qux_col = __shfl(hq, src_col);                    // H[n][lr]: Qux[lr] for lr < n
-    const double qux_row = __shfl(hq, src_row);                    // H[n][lk]: Qux[lk]
-    const double Quu = readlane_f64(hq, LQ * 16 + n) + R2;         // :654
-    const double Qu = readlane_f64(hq, LQ * 16 + CV) + R2 * r.ub;  // :652 (lu = 2 R u)
+    const double hq = H[2];                                        // H[n][lr] in every lane (rows 8..11 = row n)
+    const double qux_col = hq;                                     // Qux[lr] for lr < n
+    const double qux_row = row_share<n>(H[0]);                     // H[lk][n] = Qxu[lk] = Qux[lk] to round-off
+    const double Quu = row_share<n>(hq) + R2;                      // :654
+    const double Qu = row_share<CV>(hq) + R2 * r.ub;               // :652 (lu = 2 R u)
     const double inv = fast_rcp(Quu);                              // :655
     const double kap = inv * Qu;                                   // :659
     const double dv = Qu * kap;                                    // :663
