@@ -252,6 +252,68 @@ __device__ inline bool large_linesearch(const LView<M::n, M::m>& v, double* lds,
 }
 
 // Dynamics partials at the listed time steps of the nominal trajectory (X,U).
+// Accessors that present [x | u] with one entry perturbed (finite differences) or seeded
+// (forward-mode dual), reading the nominal values where they lie (L2).
+struct PertAcc {
+  const double* p; int col; double dh;
+  __device__ __forceinline__ double operator[](int i) const { const double v_ = p[i]; return i == col ? v_ + dh : v_; }
+};
+struct SeedAcc {
+  const double* p; int col;
+  __device__ __forceinline__ Dual1 operator[](int i) const { return Dual1(p[i], i == col ? 1.0 : 0.0); }
+};
+template <class M, class = void>
+struct HasSparsity { static constexpr bool value = false; };
+template <class M>
+struct HasSparsity<M, decltype((void)M::kMaxAffected)> { static constexpr bool value = true; };
+
+// Sparse variant: only the dofs that read input column `col` are evaluated (M::affected); the
+// rest of the column is written as the exact zeros the dense evaluation produces.
+template <class M, int JAC>
+__device__ __forceinline__ void large_jac_at_sparse(const LView<M::n, M::m>& v, const KArgs& a, const int* list, int count,
+                                                    const double* Xsrc, const double* Usrc) {
+  constexpr int n = M::n, m = M::m, nc = n + m, nq = M::nq;
+  const double h = a.fd_h, inv2h = 1.0 / (2.0 * h);
+  for (int it = threadIdx.x; it < count * nc; it += kLargeThreads) {
+    const int ki = it / nc, col = it - ki * nc;
+    const int t = list[ki];
+    const double* xg = Xsrc + (size_t)t * n;
+    const double* ug = Usrc + (size_t)t * m;
+    double* o;
+    int stride;
+    if (col < n) { o = v.Fx + (size_t)t * n * n + col; stride = n; }
+    else { o = v.Fu + (size_t)t * n * m + (col - n); stride = m; }
+    // the whole column is (re)written: zeros first, overlapped with the evaluations below (a
+    // separate coalesced zero-fill pass was measured slower: the CU's 64 B/clk store path is the
+    // floor for the 540 KB of Jacobians either way, and here it hides under the arithmetic)
+#pragma unroll
+    for (int i = 0; i < n; ++i) o[i * stride] = 0.0;
+    int dofs[M::kMaxAffected];
+    const int na = M::affected(col, dofs);
+#pragma unroll
+    for (int a_ = 0; a_ < M::kMaxAffected; ++a_) {
+      if (a_ < na) {
+        const int i = dofs[a_];
+        double dq, dv;
+        if (JAC == MI_JAC_FD_CENTRAL) {
+          double qp, vp, qm, vm;
+          M::template dof<double>(i, PertAcc{xg, col, h}, PertAcc{ug, col - n, h}, qp, vp, a.params, a.dt);
+          M::template dof<double>(i, PertAcc{xg, col, -h}, PertAcc{ug, col - n, -h}, qm, vm, a.params, a.dt);
+          dq = (qp - qm) * inv2h;
+          dv = (vp - vm) * inv2h;
+        } else {
+          Dual1 qd, vd;
+          M::template dof<Dual1>(i, SeedAcc{xg, col}, SeedAcc{ug, col - n}, qd, vd, a.params, a.dt);
+          dq = qd.d;
+          dv = vd.d;
+        }
+        o[i * stride] = dq;                       // same thread, same address as the zero above: program order holds
+        o[(nq + i) * stride] = dv;
+      }
+    }
+  }
+}
+
 template <class M, int JAC>
 __device__ __forceinline__ void large_jac_at(const LView<M::n, M::m>& v, const KArgs& a, const int* list, int count) {
   constexpr int n = M::n, m = M::m, nc = n + m;
@@ -852,8 +914,25 @@ __global__ void __launch_bounds__(kLargeThreads) ilqr_large_kernel(const KArgs a
   }
   __syncthreads();
 
-  auto jac = [&](const int* list, int count) __attribute__((always_inline)) { large_jac_at<M, JAC>(v, a, list, count); };
-  auto do_linearize = [&]() __attribute__((always_inline)) {
+  // The sparse Jacobian code reads a handful of x/u entries per evaluation: it takes them from an
+  // LDS copy of the nominal trajectory (the backward pass's T1|H and F areas are idle during the
+  // linearization) instead of paying an L2 round trip per dependent access.
+  const bool lin_staged = HasSparsity<M>::value && (size_t)n * N <= (size_t)(n + Ly::NMP) * Ly::TS &&
+                          (size_t)m * (N - 1) <= (size_t)n * Ly::NMP;
+  const double* lin_X = lin_staged ? lds + Ly::oT1 : v.X;
+  const double* lin_U = lin_staged ? lds + Ly::oF : v.U;
+  auto jac = [&](const int* list, int count) __attribute__((always_inline)) {
+    if constexpr (HasSparsity<M>::value) large_jac_at_sparse<M, JAC>(v, a, list, count, lin_X, lin_U);
+    else large_jac_at<M, JAC>(v, a, list, count);
+  };
+  auto do_linearize = [&](bool have_copy) __attribute__((always_inline)) {
+    if (lin_staged && !have_copy) {
+      double* xs_ = lds + Ly::oT1;
+      double* us_ = lds + Ly::oF;
+      for (int e = tid; e < n * N; e += kLargeThreads) xs_[e] = v.X[e];
+      for (int e = tid; e < m * (N - 1); e += kLargeThreads) us_[e] = v.U[e];
+      __syncthreads();
+    }
     return linearize_generic(acc, a.kp_method, a.minN, a.maxN, a.jerk_thr, a.err_thr, jac);
   };
 
@@ -864,7 +943,7 @@ __global__ void __launch_bounds__(kLargeThreads) ilqr_large_kernel(const KArgs a
     return;
   }
   if (MODE == MODE_LINEARIZE) {
-    const int nk = do_linearize();
+    const int nk = do_linearize(false);
     for (int i = tid; i < nk; i += kLargeThreads) a.kp_list[(size_t)b * (N - 1) + i] = acc.kp[i];
     if (tid == 0) a.kp_count[b] = nk;
     return;
@@ -890,10 +969,14 @@ __global__ void __launch_bounds__(kLargeThreads) ilqr_large_kernel(const KArgs a
     if (!ok) { status = MI_STATUS_LINESEARCH_FAILED; break; }
     __syncthreads();
     const long long c1 = clock64();
-    for (int e = tid; e < n * N; e += kLargeThreads) v.X[e] = v.Xn[e];              // :375-376
-    for (int e = tid; e < m * (N - 1); e += kLargeThreads) v.U[e] = v.Un[e];
+    {                                                                                // :375-376 (+ the LDS copy the
+      double* xs_ = lds + Ly::oT1;                                                   //  linearization reads)
+      double* us_ = lds + Ly::oF;
+      for (int e = tid; e < n * N; e += kLargeThreads) { const double x_ = v.Xn[e]; v.X[e] = x_; if (lin_staged) xs_[e] = x_; }
+      for (int e = tid; e < m * (N - 1); e += kLargeThreads) { const double u_ = v.Un[e]; v.U[e] = u_; if (lin_staged) us_[e] = u_; }
+    }
     __syncthreads();
-    nk = do_linearize();                                                             // :370
+    nk = do_linearize(true);                                                         // :370
     __syncthreads();
     const long long c2 = clock64();
 #ifdef MI_PROF_BACKWARD

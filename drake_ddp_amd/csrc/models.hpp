@@ -91,19 +91,36 @@ using CartPoleWall = CartPoleT<true>;
 
 struct Synth36 {             // params [ks, c, kc, bu]; 18 coupled pendula, dofs 6..17 actuated
   static constexpr int n = 36, m = 12, n_params = 4, nq = 18;
-  // One dof of the chain: usable dof-parallel (one lane per dof) by the large-n kernels.
-  template <class T>
-  __device__ static inline void dof(int i, const T* x, const T* u, T& qn, T& vn, const double* p, double dt) {
+  // One dof of the chain: usable dof-parallel (one lane per dof) by the large-n kernels.  x and u
+  // are anything indexable (pointers, or accessors that perturb / seed one entry on the fly).
+  template <class T, class XA, class UA>
+  __device__ static inline void dof(int i, const XA& x, const UA& u, T& qn, T& vn, const double* p, double dt) {
     const double ks = p[0], c = p[1], kc = p[2], bu = p[3];
-    const T* q = x;
-    const T* v = x + nq;
-    T a = -ks * mi_sin(q[i]) - c * v[i];
-    if (i < nq - 1) a = a + kc * mi_sin(q[i + 1] - q[i]);
-    if (i > 0) a = a - kc * mi_sin(q[i] - q[i - 1]);
+    const T qi = x[i], vi = x[nq + i];
+    T a = -ks * mi_sin(qi) - c * vi;
+    if (i < nq - 1) a = a + kc * mi_sin(x[i + 1] - qi);
+    if (i > 0) a = a - kc * mi_sin(qi - x[i - 1]);
     if (i >= 6) a = a + u[i - 6];
     else a = a + bu * (u[2 * i] - u[2 * i + 1]);
-    vn = v[i] + dt * a;
-    qn = q[i] + dt * vn;
+    vn = vi + dt * a;
+    qn = qi + dt * vn;
+  }
+  // Dynamics sparsity for the Jacobian code: the dofs whose update reads input column `col` of
+  // [x | u] (q_j: j-1, j, j+1;  v_j: j;  u_k: 6+k and k/2).  Every other entry of that Jacobian
+  // column is an exact zero (f(x+h e) and f(x-h e) coincide bitwise there).
+  static constexpr int kMaxAffected = 3;
+  __device__ static inline int affected(int col, int (&idx)[kMaxAffected]) {
+    if (col < nq) {
+      int c_ = 0;
+      if (col > 0) idx[c_++] = col - 1;
+      idx[c_++] = col;
+      if (col < nq - 1) idx[c_++] = col + 1;
+      return c_;
+    }
+    if (col < n) { idx[0] = col - nq; return 1; }
+    const int k = col - n;
+    idx[0] = k / 2; idx[1] = 6 + k;
+    return 2;
   }
   template <class T>
   __device__ static inline void step(const T* x, const T* u, T* xn, const double* p, double dt) {
