@@ -98,24 +98,6 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
   return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// Sum over each 16-lane row, result in every lane of the row: four DPP row rotations (8, 4, 2, 1)
-// instead of four ds_bpermute round trips through the LDS crossbar.
-template <int ROT>
-__device__ __forceinline__ double row_ror_f64(double v) {
-  union { double d; int i[2]; } u, r;
-  u.d = v;
-  r.i[0] = __builtin_amdgcn_mov_dpp(u.i[0], 0x120 + ROT, 0xF, 0xF, true);
-  r.i[1] = __builtin_amdgcn_mov_dpp(u.i[1], 0x120 + ROT, 0xF, 0xF, true);
-  return r.d;
-}
-__device__ __forceinline__ double row16_sum(double p) {
-  p += row_ror_f64<8>(p);
-  p += row_ror_f64<4>(p);
-  p += row_ror_f64<2>(p);
-  p += row_ror_f64<1>(p);
-  return p;
-}
-
 // One line-search trial (ilqr.py:306-327).  Returns L on every thread; trajectory -> Xn/Un.
 // Per step: (1) 16 lanes per control row form K_t(x-x_bar) partial dots — K_t, x_bar_t,
 // u_bar_t, kappa_t come from HBM/L2 and are prefetched one step ahead into registers;

@@ -315,10 +315,30 @@ __device__ inline void rollout(const WS& w, const Consts<M>& c, const KArgs& a, 
   exp_out = expd;
 }
 
+// Sum over each 16-lane row, result in every lane of the row: four DPP row rotations (8, 4, 2, 1)
+// instead of four ds_bpermute round trips through the LDS crossbar.
+template <int ROT>
+__device__ __forceinline__ double row_ror_f64(double v) {
+  union { double d; int i[2]; } u, r;
+  u.d = v;
+  r.i[0] = __builtin_amdgcn_mov_dpp(u.i[0], 0x120 + ROT, 0xF, 0xF, true);
+  r.i[1] = __builtin_amdgcn_mov_dpp(u.i[1], 0x120 + ROT, 0xF, 0xF, true);
+  return r.d;
+}
+__device__ __forceinline__ double row16_sum(double p) {
+  p += row_ror_f64<8>(p);
+  p += row_ror_f64<4>(p);
+  p += row_ror_f64<2>(p);
+  p += row_ror_f64<1>(p);
+  return p;
+}
+
+// Sum over the wave, result in every lane, fixed order: DPP row sums, then the four row totals
+// through v_readlane (SGPRs) - no ds_bpermute round trips.
+__device__ __forceinline__ double readlane_f64(double v, int srclane);
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+  v = row16_sum(v);
+  return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
 }
 
 // Total cost (ilqr.py:325,327) and expected improvement (:326) of the trajectory stored in
