@@ -70,9 +70,10 @@ struct CartPoleT {           // params [mc, mp, l, g, wall_face_x, ball_radius, 
     T r2 = -mp * g * l * s;
     if (WALL) {
       const double face = p[4], rad = p[5], k = p[6], sig = p[7];
+      const double inv_sig = 1.0 / sig;      // loop-invariant: hoisted (a full fp64 division is ~12 instructions)
       const T tip = px + l * s;
       const T phi = tip - rad - face;
-      const T F = k * sig * mi_softplus(-phi / sig);
+      const T F = k * sig * mi_softplus(-phi * inv_sig);
       r1 = r1 + F;
       r2 = r2 + F * l * c;
     }
