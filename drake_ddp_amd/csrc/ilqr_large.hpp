@@ -935,54 +935,104 @@ __global__ void __launch_bounds__(kLargeThreads) ilqr_large_kernel(const KArgs a
     return;
   }
 
+  // MODE_SOLVE / MODE_FORWARD / MODE_MPC: the Solve loop (ilqr.py:680-708); MODE_MPC wraps it in the
+  // receding-horizon loop of the callers (mini_cheetah.py:190-201) so 100 re-solves are one launch.
   double L = (MODE == MODE_FORWARD) ? a.stage_in[b] : __builtin_inf();
-  double improvement = __builtin_inf();
   int iters = 0, ls_total = 0, nk = 0;
   int status = MI_STATUS_CONVERGED;
   double* hist = a.hist + (size_t)b * a.hist_cap * 4;
   long long c_ls = 0, c_lin = 0, c_bp = 0;
   const long long c_begin = clock64();
-  while (improvement > a.delta) {
-    if (iters >= a.max_iters) { status = MI_STATUS_MAX_ITERS; break; }
-    double L_new, eps; int trials;
-    const long long c0 = clock64();
-    const bool ok = large_linesearch<M>(v, lds, a, x0g, L, L_new, eps, trials);
-    ls_total += trials;
-    if (!ok) { status = MI_STATUS_LINESEARCH_FAILED; break; }
-    __syncthreads();
-    const long long c1 = clock64();
-    {                                                                                // :375-376 (+ the LDS copy the
-      double* xs_ = lds + Ly::oT1;                                                   //  linearization reads)
-      double* us_ = lds + Ly::oF;
-      for (int e = tid; e < n * N; e += kLargeThreads) { const double x_ = v.Xn[e]; v.X[e] = x_; if (lin_staged) xs_[e] = x_; }
-      for (int e = tid; e < m * (N - 1); e += kLargeThreads) { const double u_ = v.Un[e]; v.U[e] = u_; if (lin_staged) us_[e] = u_; }
+  const int n_solves = (MODE == MODE_MPC) ? a.mpc_resolves : 1;
+  for (int rs = 0; rs < n_solves; ++rs) {
+    if (MODE == MODE_MPC) {
+      // warm start (mini_cheetah.py:193-198): x0 <- x_bar[:, replan]; u_bar <- [u_bar[:, replan:], repeat(last)]
+      const int r = a.mpc_replan;
+      double* x0w = const_cast<double*>(x0g);
+      constexpr int UPT = 8;                               // (m*(N-1) + 255) / 256 <= 8 for every admissible N
+      double ush[UPT];
+#pragma unroll
+      for (int q = 0; q < UPT; ++q) {
+        const int e = tid + kLargeThreads * q;             // element (t, k) of the time-major u_bar
+        const int t = e / m, k = e - t * m;
+        const int src = (t + r < N - 1) ? t + r : N - 2;
+        ush[q] = (e < m * (N - 1)) ? v.U[(size_t)src * m + k] : 0.0;
+      }
+      double x0n = (tid < n) ? v.X[(size_t)r * n + tid] : 0.0;
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < UPT; ++q) {
+        const int e = tid + kLargeThreads * q;
+        if (e < m * (N - 1)) v.U[e] = ush[q];
+      }
+      if (tid < n) {
+        x0w[tid] = x0n;
+        // moving target (mini_cheetah.py:151-156) and the constants derived from it (ilqr.py:180,203)
+        lds[Ly::oXnom + tid] += a.mpc_target_step[tid];
+      }
+      __syncthreads();
+      if (tid < n) {
+        double s_ = 0.0, sf_ = 0.0;
+        for (int i = 0; i < n; ++i) {
+          s_ += (2.0 * lds[Ly::oXnom + i]) * lds[Ly::oQ + i * n + tid];
+          sf_ += (2.0 * lds[Ly::oXnom + i]) * lds[Ly::oQf + i * n + tid];
+        }
+        lds[Ly::oQn + tid] = s_; lds[Ly::oQfn + tid] = sf_;
+      }
+      __syncthreads();
+      L = __builtin_inf();
     }
-    __syncthreads();
-    nk = do_linearize(true);                                                         // :370
-    __syncthreads();
-    const long long c2 = clock64();
+    double improvement = __builtin_inf();
+    int it_this = 0;
+    while (improvement > a.delta) {
+      if (it_this >= a.max_iters) { status = MI_STATUS_MAX_ITERS; break; }
+      double L_new, eps; int trials;
+      const long long c0 = clock64();
+      const bool ok = large_linesearch<M>(v, lds, a, x0g, L, L_new, eps, trials);
+      ls_total += trials;
+      if (!ok) { status = MI_STATUS_LINESEARCH_FAILED; break; }
+      __syncthreads();
+      const long long c1 = clock64();
+      {                                                                              // :375-376 (+ the LDS copy the
+        double* xs_ = lds + Ly::oT1;                                                 //  linearization reads)
+        double* us_ = lds + Ly::oF;
+        for (int e = tid; e < n * N; e += kLargeThreads) { const double x_ = v.Xn[e]; v.X[e] = x_; if (lin_staged) xs_[e] = x_; }
+        for (int e = tid; e < m * (N - 1); e += kLargeThreads) { const double u_ = v.Un[e]; v.U[e] = u_; if (lin_staged) us_[e] = u_; }
+      }
+      __syncthreads();
+      nk = do_linearize(true);                                                       // :370
+      __syncthreads();
+      const long long c2 = clock64();
 #ifdef MI_PROF_BACKWARD
-    // profiling build only: 16 phase accumulators of thread 0 (a matrix-core wave) and of thread
-    // 192 (the spare wave) land in the last 8 rows of the history buffer (tools/bp_prof.py)
-    long long bpa[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (MODE == MODE_SOLVE) { large_backward<M>(v, lds, bpa); __syncthreads(); }
-    if ((tid == 0 || tid == 192) && iters == 0) {
-      double* hp = a.hist + (size_t)b * a.hist_cap * 4 + 4 * (a.hist_cap - (tid == 0 ? 4 : 8));
-      for (int q_ = 0; q_ < 16; ++q_) hp[q_] = (double)bpa[q_];
-    }
+      // profiling build only: 16 phase accumulators of thread 0 (a matrix-core wave) and of thread
+      // 192 (the spare wave) land in the last 8 rows of the history buffer (tools/bp_prof.py)
+      long long bpa[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      if (MODE != MODE_FORWARD) { large_backward<M>(v, lds, bpa); __syncthreads(); }
+      if ((tid == 0 || tid == 192) && iters == 0 && it_this == 0) {
+        double* hp = a.hist + (size_t)b * a.hist_cap * 4 + 4 * (a.hist_cap - (tid == 0 ? 4 : 8));
+        for (int q_ = 0; q_ < 16; ++q_) hp[q_] = (double)bpa[q_];
+      }
 #else
-    if (MODE == MODE_SOLVE) { large_backward<M>(v, lds); __syncthreads(); }          // :697
+      if (MODE != MODE_FORWARD) { large_backward<M>(v, lds); __syncthreads(); }      // :697
 #endif
-    const long long c3 = clock64();
-    c_ls += c1 - c0; c_lin += c2 - c1; c_bp += c3 - c2;
-    if (tid == 0 && iters < a.hist_cap) {
-      hist[4 * iters + 0] = L_new; hist[4 * iters + 1] = eps;
-      hist[4 * iters + 2] = (double)trials; hist[4 * iters + 3] = (double)nk / (double)(N - 1) * 100.0;
+      const long long c3 = clock64();
+      c_ls += c1 - c0; c_lin += c2 - c1; c_bp += c3 - c2;
+      if (tid == 0 && it_this < a.hist_cap) {                                        // history of the LAST solve
+        hist[4 * it_this + 0] = L_new; hist[4 * it_this + 1] = eps;
+        hist[4 * it_this + 2] = (double)trials; hist[4 * it_this + 3] = (double)nk / (double)(N - 1) * 100.0;
+      }
+      improvement = L - L_new;
+      L = L_new;
+      it_this += 1;
+      if (MODE == MODE_FORWARD) break;
     }
-    improvement = L - L_new;
-    L = L_new;
-    iters += 1;
-    if (MODE == MODE_FORWARD) break;
+    iters += it_this;
+    if (MODE == MODE_MPC) {
+      double* lg = a.mpc_log + ((size_t)b * a.mpc_resolves + rs) * (n + 2);
+      if (tid < n) lg[tid] = x0g[tid];
+      if (tid == 0) { lg[n] = L; lg[n + 1] = (double)it_this; }
+      if (status == MI_STATUS_LINESEARCH_FAILED) break;
+    }
   }
   for (int i = tid; i < nk; i += kLargeThreads) a.kp_list[(size_t)b * (N - 1) + i] = acc.kp[i];
   if (tid == 0) {

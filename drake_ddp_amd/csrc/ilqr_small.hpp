@@ -32,6 +32,8 @@ namespace mi {
 
 enum KernelMode { MODE_SOLVE = 0, MODE_ROLLOUT = 1, MODE_FORWARD = 2, MODE_LINEARIZE = 3, MODE_BACKWARD = 4, MODE_MPC = 5 };
 
+constexpr int kMaxStateDim = 40;   // largest model state (Synth36: 36), for by-value kernel arguments
+
 struct KArgs {
   // persistent per-problem solver state, reference layout with a leading batch axis
   double *x_bar, *u_bar, *K, *kappa, *dV, *fx, *fu;
@@ -52,7 +54,7 @@ struct KArgs {
   int32_t u_pending;  // 1: take u_bar from u_guess
   // MODE_MPC: receding-horizon loop kept on the device (acrobot.py:145-155, mini_cheetah.py:190-201)
   int32_t mpc_resolves, mpc_replan;
-  double mpc_target_step[8];   // added to x_nom before every re-solve (mini_cheetah.py:151-156); zeros = fixed target
+  double mpc_target_step[kMaxStateDim];   // added to x_nom before every re-solve (mini_cheetah.py:151-156); zeros = fixed target
   double* mpc_log;             // (B, mpc_resolves, n+2): x0 of the re-solve | cost | iterations
 };
 

@@ -43,7 +43,7 @@ struct mi_ilqr {
   double* mpc_log = nullptr;     // (B, mpc_log_resolves, n+2)
   int mpc_log_resolves = 0;
   int mpc_resolves = 0, mpc_replan = 0;
-  double mpc_target_step[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double mpc_target_step[mi::kMaxStateDim] = {};
   bool cold = true;        // persistent state is known to be all zero (fresh object / after reset)
   bool u_pending = false;  // SetInitialGuess input waiting in u_guess
   size_t lds = 0;
@@ -114,7 +114,7 @@ KArgs make_args(const mi_ilqr* h) {
   a.cold = h->cold ? 1 : 0;
   a.u_pending = h->u_pending ? 1 : 0;
   a.mpc_resolves = h->mpc_resolves; a.mpc_replan = h->mpc_replan; a.mpc_log = h->mpc_log;
-  for (int i = 0; i < 8; ++i) a.mpc_target_step[i] = h->mpc_target_step[i];
+  for (int i = 0; i < kMaxStateDim; ++i) a.mpc_target_step[i] = h->mpc_target_step[i];
   return a;
 }
 
@@ -161,6 +161,7 @@ int launch_mode_large(mi_ilqr* h, int mode, const KArgs& a) {
     case MODE_FORWARD: return launch_one_large<M, JAC, MODE_FORWARD>(h, a);
     case MODE_LINEARIZE: return launch_one_large<M, JAC, MODE_LINEARIZE>(h, a);
     case MODE_BACKWARD: return launch_one_large<M, JAC, MODE_BACKWARD>(h, a);
+    case MODE_MPC: return launch_one_large<M, JAC, MODE_MPC>(h, a);
   }
   return MI_ILQR_E_BAD_ARG;
 }
@@ -714,8 +715,9 @@ int mi_ilqr_mpc_run(mi_ilqr_t* h, int32_t num_resolves, int32_t replan_steps, co
   if (num_resolves < 1 || replan_steps < 1 || replan_steps >= h->N - 1) return MI_ILQR_E_BAD_ARG;
   HIPCHK(hipSetDevice(h->d.device_id));
   int rc;
-  if (h->large || h->batch_minor || h->N > 512 || h->n > 8) {
-    // workgroup-per-problem / lane-per-problem paths: the state lives in HBM anyway; loop shift + solve on the host
+  const bool large_on_device = h->large && (size_t)h->m * (h->N - 1) <= 8 * (size_t)kLargeThreads;
+  if ((h->large && !large_on_device) || h->batch_minor || (!h->large && (h->N > 512 || h->n > 8))) {
+    // lane-per-problem path (and horizons the in-kernel shift does not cover): loop shift + solve on the host
     std::vector<double> xn(h->n);
     if (target_step) HIPCHK(hipMemcpy(xn.data(), h->costmat + 2 * (size_t)h->n * h->n + (size_t)h->m * h->m, h->n * 8, hipMemcpyDeviceToHost));
     mi_ilqr_stats acc; std::memset(&acc, 0, sizeof(acc)); acc.best_cost = INFINITY; acc.best_index = -1;
@@ -746,7 +748,7 @@ int mi_ilqr_mpc_run(mi_ilqr_t* h, int32_t num_resolves, int32_t replan_steps, co
     h->mpc_log_resolves = num_resolves;
   }
   h->mpc_resolves = num_resolves; h->mpc_replan = replan_steps;
-  for (int i = 0; i < 8; ++i) h->mpc_target_step[i] = (target_step && i < h->n) ? target_step[i] : 0.0;
+  for (int i = 0; i < kMaxStateDim; ++i) h->mpc_target_step[i] = (target_step && i < h->n) ? target_step[i] : 0.0;
   rc = launch(h, MODE_MPC);
   if (rc != MI_ILQR_OK) return rc;
   hipLaunchKernelGGL(stats_kernel, dim3(1), dim3(256), 0, h->stream, h->iters, h->status, h->ls_trials, h->cost, h->B, h->d_stats);

@@ -217,7 +217,8 @@ class BatchedIterativeLQR:
     def MPCRun(self, num_resolves, replan_steps, target_step=None):
         """The receding-horizon loop (acrobot.py:145-155, mini_cheetah.py:190-201) kept on the device:
         num_resolves x { shift warm start; x_nom += target_step; Solve }.  One launch for the
-        wave-per-problem models.  Returns the aggregate stats; `mpc_log` has the per-re-solve record."""
+        wave-per-problem and workgroup-per-problem models (the lane-per-problem "throughput" kernels loop on
+        the host).  Returns the aggregate stats; `mpc_log` has the per-re-solve record."""
         ts = None
         if target_step is not None:
             ts = _capi.as_f64(target_step, (self.n,))
@@ -231,7 +232,7 @@ class BatchedIterativeLQR:
 
     @property
     def mpc_log(self):
-        """(B, num_resolves, n+2): x0 of each re-solve | cost | iterations (wave-per-problem models)."""
+        """(B, num_resolves, n+2): x0 of each re-solve | cost | iterations (single-launch paths)."""
         out = np.empty((self.B, self._mpc_resolves, self.n + 2), dtype=np.float64)
         _capi.check(self._lib.mi_ilqr_get_mpc_log(self._h, _capi.ptr(out), out.nbytes), "mi_ilqr_get_mpc_log")
         return out
