@@ -6,17 +6,18 @@
 // it stays in HBM/L2 in a TIME-MAJOR layout ([t][row][col]: one time step's matrices
 // are contiguous, loads are coalesced) and each sequential step stages what it needs
 // through LDS:
-//   rollout  (ilqr.py:306-327): K_t(x-x_bar) as 16-lane partial dot products, one
-//            lane per degree of freedom for the dynamics, per-thread cost partials
-//            reduced once per trial;
+//   rollout  (ilqr.py:306-327): K_t(x-x_bar) as 16-lane partial dot products (DPP row
+//            reductions), one lane per degree of freedom for the dynamics, per-thread cost
+//            partials reduced once per trial; operands prefetched two steps ahead;
 //   linearize(ilqr.py:380-415): (key-point, column) items over the 256 threads,
-//            central differences or forward-mode duals; shared key-point code;
-//   backward (ilqr.py:623-667): per step  T1 = [Vxx F | Vx],  H = F^T T1  with
-//            F = [fx | fu]  (one (n+m)x(n+m+1) product yields Qxx,Qux,Quu,Qx,Qu at
-//            once), register-tiled out of LDS; Quu is factorized (LDL^T, in
-//            registers, no pivot search — Quu = 2R + fu^T Vxx fu) redundantly by the
-//            n+1 threads that each solve one right-hand side (columns of Qux, and Qu),
-//            so the solve needs no intra-step synchronization; Vxx <- Qxx - Qux^T K.
+//            central differences or forward-mode duals, only the dofs that read the
+//            perturbed input when the model declares its sparsity; shared key-point code;
+//   backward (ilqr.py:623-667): per step  T1 = Vxx F,  H = F^T T1  with  F = [fx | fu]
+//            (one (n+m)x(n+m) product yields Qxx,Qux,Quu at once) as 16x16x4 fp64 MFMA
+//            tiles on three matrix-core waves, while a fourth "solver" wave factorizes
+//            Quu = 2R + fu^T Vxx fu (LDL^T, one row per lane, DPP broadcasts), substitutes
+//            forward for Y = L^{-1}[Qux|Qu] and finishes the gains off the critical path;
+//            Vxx <- Qxx - Y^T D^{-1} Y.  See large_backward().
 // The (B,...) arrays of this path are time-major in HBM; mi_ilqr_get/_set transpose
 // to/from the reference's time-last layout at the boundary.
 #pragma once
@@ -476,16 +477,18 @@ struct BackSubst {
 // Backward Riccati pass (ilqr.py:623-667), cost expansion (:161-206) fused.
 //
 // Per time step, with F = [fx | fu] (n x (n+m)):
-//     T1 = Vxx F                      (n x (n+m))      9 tiles x 9 k-steps
-//     H  = F^T [T1 | Vx]              ((n+m) x (n+m+1)) = [[Qxx-lxx, . ],[Qux, Quu-luu]] and F^T Vx
-//     Vxx' = Qxx - Qux^T K            (n x n)          9 tiles x 3 k-steps
-// run as 16x16 tiles of v_mfma_f64_16x16x4_f64, 2-3 tiles per wave.  On gfx950 the fp64
-// matrix rate equals the fp64 VALU rate (65 cycles per 16x16x4 = 15.7 FMA/clk/SIMD), so
-// the point of the matrix core here is OPERAND DELIVERY: two 8-byte LDS reads per lane
-// feed 1024 FMAs, where a VALU formulation needs a (broadcast) LDS read per 1-2 FMAs and
-// is LDS-issue-bound at one wave per SIMD (tools/ubench/t1.hip: 4.5-10.7k cycles for T1
-// alone vs ~1.8k here).  Quu is factorized ONCE per step (LDL^T) by 16 lanes with DPP
-// row broadcasts; n+1 threads then substitute one right-hand side each (columns of Qux, Qu).
+//     T1 = Vxx F                      (n x (n+m))       9 tiles x 9 k-steps   (phase A)
+//     H  = F^T T1                     ((n+m) x (n+m)) = [[Qxx-lxx, . ],[Qux, Quu-luu]]  (phase B)
+//     Quu = L D L^T,  Y = L^{-1} [Qux | Qu]             solver wave            (phases B, C)
+//     Vxx' = Qxx - Y^T D^{-1} Y       (n x n)           9 tiles x 3 k-steps   (phase D)
+//     K = L^{-T} D^{-1} Y             gains, off the recursion's critical path (next phase A)
+// The products run as 16x16 tiles of v_mfma_f64_16x16x4_f64, three tiles per matrix-core
+// wave.  On gfx950 the fp64 matrix rate equals the fp64 VALU rate (64 cycles per 16x16x4 =
+// 16 FMA/clk/SIMD, tools/ubench/mfma_cu.hip; 76-79 cycles when every operand comes from LDS,
+// tools/ubench/mfma_lds.hip), so the point of the matrix core here is OPERAND DELIVERY: two
+// 8-byte LDS reads per lane feed 1024 FMAs, where a VALU formulation needs a (broadcast) LDS
+// read per 1-2 FMAs and is LDS-issue-bound at one wave per SIMD (tools/ubench/t1.hip: 4.5-10.7k
+// cycles for T1 alone vs ~2.1k here).
 template <class M>
 __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, long long* bp_acc = nullptr) {
   constexpr int n = M::n, m = M::m, nm = n + m;
