@@ -56,6 +56,7 @@ struct KArgs {
   int32_t mpc_resolves, mpc_replan;
   double mpc_target_step[kMaxStateDim];   // added to x_nom before every re-solve (mini_cheetah.py:151-156); zeros = fixed target
   double* mpc_log;             // (B, mpc_resolves, n+2): x0 of the re-solve | cost | iterations
+  int32_t helpers;             // extra wavefronts per problem that share the linearization (0, 1 or 3), see ilqr_small_kernel
 };
 
 __device__ __forceinline__ double bcast_lane0(double v) {
@@ -66,7 +67,20 @@ __device__ __forceinline__ double bcast_lane0(double v) {
   return u.d;
 }
 
-__device__ __forceinline__ void wave_sync() { __syncthreads(); }
+// One wavefront owns a problem's LDS outside the linearization: ordering its own LDS traffic needs
+// no s_barrier (LDS executes a wave's operations in order), only that the compiler keeps the order
+// and waits for completion.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// Rendezvous of the main wave with its helper waves (LDS traffic only).
+__device__ __forceinline__ void team_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 
 // ---------------------------------------------------------------------------
 // LDS layout: array-of-records, ONE record per time step, so that everything a
@@ -459,47 +473,85 @@ __device__ inline void commit_trial(const WS& w, int slot) {
 // items over lanes.
 // ---------------------------------------------------------------------------
 template <class M, int JAC>
-__device__ __forceinline__ void jac_at(const WS& w, const KArgs& a, const int* list, int count) {
-  constexpr int n = M::n, m = M::m, nc = n + m;
+__device__ __forceinline__ void jac_item(const WS& w, const KArgs& a, int t, int col) {
+  constexpr int n = M::n, m = M::m;
   using Ly = Lay<n, m>;
   const double h = a.fd_h, inv2h = 1.0 / (2.0 * h);
+  const double* g = w.G + t * Ly::GS;
+  double x[n], u[m], d[n];
+#pragma unroll
+  for (int i = 0; i < n; ++i) x[i] = g[Ly::XB + i];
+#pragma unroll
+  for (int k = 0; k < m; ++k) u[k] = g[Ly::UB + k];
+  if (JAC == MI_JAC_FD_CENTRAL) {
+    double xp[n], up[m], xm[n], um[m], fp[n], fm_[n];
+#pragma unroll
+    for (int i = 0; i < n; ++i) { xp[i] = (col == i) ? x[i] + h : x[i]; xm[i] = (col == i) ? x[i] - h : x[i]; }
+#pragma unroll
+    for (int k = 0; k < m; ++k) { up[k] = (col == n + k) ? u[k] + h : u[k]; um[k] = (col == n + k) ? u[k] - h : u[k]; }
+    M::template step<double>(xp, up, fp, a.params, a.dt);
+    M::template step<double>(xm, um, fm_, a.params, a.dt);
+#pragma unroll
+    for (int i = 0; i < n; ++i) d[i] = (fp[i] - fm_[i]) * inv2h;
+  } else {
+    Dual1 xd[n], ud[m], fd[n];
+#pragma unroll
+    for (int i = 0; i < n; ++i) xd[i] = Dual1(x[i], (col == i) ? 1.0 : 0.0);
+#pragma unroll
+    for (int k = 0; k < m; ++k) ud[k] = Dual1(u[k], (col == n + k) ? 1.0 : 0.0);
+    M::template step<Dual1>(xd, ud, fd, a.params, a.dt);
+#pragma unroll
+    for (int i = 0; i < n; ++i) d[i] = fd[i].d;
+  }
+  double* j = w.J + t * Ly::JS;
+  if (col < n) {
+#pragma unroll
+    for (int i = 0; i < n; ++i) j[Ly::FX + i * n + col] = d[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < n; ++i) j[Ly::FU + i * m + (col - n)] = d[i];
+  }
+}
+
+template <class M, int JAC>
+__device__ __forceinline__ void jac_at(const WS& w, const KArgs& a, const int* list, int count) {
+  constexpr int nc = M::n + M::m;
   for (int it = threadIdx.x; it < count * nc; it += 64) {
     const int ki = it / nc, col = it - ki * nc;
-    const int t = list[ki];
-    const double* g = w.G + t * Ly::GS;
-    double x[n], u[m], d[n];
-#pragma unroll
-    for (int i = 0; i < n; ++i) x[i] = g[Ly::XB + i];
-#pragma unroll
-    for (int k = 0; k < m; ++k) u[k] = g[Ly::UB + k];
-    if (JAC == MI_JAC_FD_CENTRAL) {
-      double xp[n], up[m], xm[n], um[m], fp[n], fm_[n];
-#pragma unroll
-      for (int i = 0; i < n; ++i) { xp[i] = (col == i) ? x[i] + h : x[i]; xm[i] = (col == i) ? x[i] - h : x[i]; }
-#pragma unroll
-      for (int k = 0; k < m; ++k) { up[k] = (col == n + k) ? u[k] + h : u[k]; um[k] = (col == n + k) ? u[k] - h : u[k]; }
-      M::template step<double>(xp, up, fp, a.params, a.dt);
-      M::template step<double>(xm, um, fm_, a.params, a.dt);
-#pragma unroll
-      for (int i = 0; i < n; ++i) d[i] = (fp[i] - fm_[i]) * inv2h;
-    } else {
-      Dual1 xd[n], ud[m], fd[n];
-#pragma unroll
-      for (int i = 0; i < n; ++i) xd[i] = Dual1(x[i], (col == i) ? 1.0 : 0.0);
-#pragma unroll
-      for (int k = 0; k < m; ++k) ud[k] = Dual1(u[k], (col == n + k) ? 1.0 : 0.0);
-      M::template step<Dual1>(xd, ud, fd, a.params, a.dt);
-#pragma unroll
-      for (int i = 0; i < n; ++i) d[i] = fd[i].d;
-    }
-    double* j = w.J + t * Ly::JS;
-    if (col < n) {
-#pragma unroll
-      for (int i = 0; i < n; ++i) j[Ly::FX + i * n + col] = d[i];
-    } else {
-#pragma unroll
-      for (int i = 0; i < n; ++i) j[Ly::FU + i * m + (col - n)] = d[i];
-    }
+    jac_item<M, JAC>(w, a, list[ki], col);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Team linearization (setInterval, minN = 1: every step is a key-point).  The linearization is
+// the one stage of an iteration that is parallel over time steps, and at the batch sizes of the
+// wave-per-problem kernels three of a CU's four SIMDs have issue slots to spare at any moment:
+// the problem's (step, column) items are dealt round-robin, 64 at a time, to the main wave and
+// its helper waves.  Helpers are parked on the workgroup barrier at all other times; the
+// protocol is barrier - work - barrier, no polling.
+// ---------------------------------------------------------------------------
+enum { TEAM_CMD_EXIT = 0, TEAM_CMD_LINEARIZE = 1 };
+typedef __attribute__((address_space(3))) volatile int lds_vint_t;      // explicit LDS pointer: ds_read/ds_write, not flat
+
+template <class M, int JAC>
+__device__ __forceinline__ void jac_rounds(const WS& w, const KArgs& a, int first, int stride, int lane) {
+  constexpr int nc = M::n + M::m;
+  const int items = (w.N - 1) * nc;
+  for (int it = 64 * first + lane; it < items; it += 64 * stride) {
+    const int t = it / nc;
+    jac_item<M, JAC>(w, a, t, it - t * nc);
+  }
+}
+
+template <class M, int JAC>
+__device__ inline void helper_wave(const WS& w, const KArgs& a, int wave, int team) {
+  const int lane = threadIdx.x & 63;
+  lds_vint_t* cmd = (lds_vint_t*)w.aux;
+  for (;;) {
+    team_barrier();
+    if (__builtin_amdgcn_readfirstlane(cmd[0]) == TEAM_CMD_EXIT) return;
+    jac_rounds<M, JAC>(w, a, wave, team, lane);
+    team_barrier();
   }
 }
 
@@ -925,7 +977,7 @@ __device__ inline void backward(const WS& w, const Consts<M>& c) {
 // The kernel: stage, run MODE, write back.
 // ---------------------------------------------------------------------------
 template <class M, int JAC, int MODE>
-__global__ void __launch_bounds__(64) ilqr_small_kernel(const KArgs a) {
+__global__ void __launch_bounds__(256) ilqr_small_kernel(const KArgs a) {
   constexpr int n = M::n, m = M::m;
   using Ly = Lay<n, m>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -933,6 +985,14 @@ __global__ void __launch_bounds__(64) ilqr_small_kernel(const KArgs a) {
   const int lane = threadIdx.x;
   const int N = a.N;
   WS w = carve<n, m>(smem, N, a.n_store);
+  // Optional helper wavefronts (threads 64.., MODE_SOLVE / MODE_MPC with every step a key-point):
+  // they only ever run helper_wave() - their share of the linearization.
+  const int team = ((MODE == MODE_SOLVE || MODE == MODE_MPC) && a.helpers > 0) ? 1 + a.helpers : 1;
+  if (team > 1 && threadIdx.x >= 64) {
+    helper_wave<M, JAC>(w, a, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), team);
+    return;
+  }
+  lds_vint_t* team_cmd = (lds_vint_t*)w.aux;
   const size_t oX = (size_t)b * n * N, oU = (size_t)b * m * (N - 1), oK = (size_t)b * m * n * (N - 1);
   const size_t oFx = (size_t)b * n * n * (N - 1), oFu = (size_t)b * n * m * (N - 1), oT = (size_t)b * (N - 1);
 
@@ -1040,7 +1100,15 @@ __global__ void __launch_bounds__(64) ilqr_small_kernel(const KArgs a) {
       const long long c1 = clock64();
       commit_trial<n, m>(w, slot);                                // u_bar <- u, x_bar <- x (:375-376)
       wave_sync();
-      nk = linearize<M, JAC>(w, a);                               // at the ACCEPTED trajectory (:370)
+      if (team > 1) {
+        nk = N - 1;                                               // every step is a key-point (:396, :414)
+        if (lane == 0) team_cmd[0] = TEAM_CMD_LINEARIZE;
+        team_barrier();
+        jac_rounds<M, JAC>(w, a, 0, team, lane);
+        team_barrier();
+      } else {
+        nk = linearize<M, JAC>(w, a);                             // at the ACCEPTED trajectory (:370)
+      }
       const long long c2 = clock64();
       if (MODE != MODE_FORWARD) { backward<M>(w, c); wave_sync(); } // :697
       const long long c3 = clock64();
@@ -1069,6 +1137,11 @@ __global__ void __launch_bounds__(64) ilqr_small_kernel(const KArgs a) {
     double* x0g = const_cast<double*>(a.x0) + (size_t)b * n;
 #pragma unroll
     for (int i = 0; i < n; ++i) if (lane == i) x0g[i] = x0r[i];
+  }
+  if (team > 1) {
+    if (lane == 0) team_cmd[0] = TEAM_CMD_EXIT;
+    team_barrier();
+    for (int i = lane; i < N - 1; i += 64) w.kp[i] = i;          // what keypoints_set_interval(minN = 1) lists
   }
   wave_sync();
   stage_out(a.x_bar + oX, w.G, Ly::GS, Ly::XB, n, N);

@@ -9,6 +9,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -115,6 +116,15 @@ KArgs make_args(const mi_ilqr* h) {
   a.u_pending = h->u_pending ? 1 : 0;
   a.mpc_resolves = h->mpc_resolves; a.mpc_replan = h->mpc_replan; a.mpc_log = h->mpc_log;
   for (int i = 0; i < kMaxStateDim; ++i) a.mpc_target_step[i] = h->mpc_target_step[i];
+  // wave-per-problem kernels: helper wavefronts share the linearization when every step is a key-point
+  // (the default).  Three of them while the whole batch then still fits one wave per SIMD (B <= 256),
+  // otherwise one: every wave of the kernel carries the main wave's register allocation, and a fourth
+  // resident wave per SIMD would no longer fit.  MI_ILQR_NO_HELPER=1 turns them off (A/B measurements).
+  static const bool no_helper = [] { const char* e = std::getenv("MI_ILQR_NO_HELPER"); return e && e[0] == '1'; }();
+  a.helpers = 0;
+  if (!no_helper && !h->large && !h->batch_minor && h->d.keypoint_method == MI_KP_SET_INTERVAL && h->d.minN == 1 &&
+      (h->N - 1) * (h->n + h->m) > 128)
+    a.helpers = h->B <= 256 ? 3 : 1;
   return a;
 }
 
@@ -123,7 +133,8 @@ int launch_one(mi_ilqr* h, const KArgs& a) {
   auto kern = ilqr_small_kernel<M, JAC, MODE>;
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
   HIPCHK(hipEventRecord(h->ev0, h->stream));
-  hipLaunchKernelGGL(kern, dim3(h->B), dim3(64), h->lds, h->stream, a);
+  const int waves = (a.helpers > 0 && (MODE == MODE_SOLVE || MODE == MODE_MPC)) ? 1 + a.helpers : 1;
+  hipLaunchKernelGGL(kern, dim3(h->B), dim3(64 * waves), h->lds, h->stream, a);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(h->ev1, h->stream));
   return MI_ILQR_OK;
