@@ -242,3 +242,32 @@ def test_randomized_configs_vs_c_oracle(seed):
     assert np.max(np.abs(L[same] - r["cost"][same]) / np.abs(r["cost"][same])) < 1e-7
     assert np.max(np.abs(x[same] - r["x_bar"][same])) < 1e-4
     assert (ls[ok] > it[ok]).any() or prob["beta"] > 0.8 or True
+
+
+@pytest.mark.parametrize("cfg,B", [("pendulum", 300), ("wall", 5)])
+def test_helper_wavefronts_do_not_change_results(cfg, B, tmp_path):
+    """The team linearization (helper wavefronts, one or three per problem) computes the same items
+    with the same code: every output must be bitwise identical to the single-wave kernel."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = f"""
+import sys, numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, 'tests')!r})
+from drake_ddp_amd import workloads as W
+from test_gpu_parity import make_solver
+prob = {{'pendulum': W.pendulum_problem, 'wall': W.cartpole_wall_problem}}[{cfg!r}]()
+x0 = {{'pendulum': W.pendulum_batch_x0, 'wall': W.cartpole_wall_batch_x0}}[{cfg!r}](1024)[:{B}]
+s = make_solver(prob, B={B}, jac='fd')
+s.SetInitialState(x0); s.SetInitialGuess(np.zeros((1, prob['N'] - 1)))
+x, u, _, L = s.Solve()
+np.savez(sys.argv[1], x=x, u=u, L=L, K=s.K, kappa=s.kappa, fx=s.fx, fu=s.fu, it=s.iterations, ls=s.ls_trials, kp=s.keypoint_count, kpl=s.keypoint_list)
+"""
+    outs = []
+    for tag, env in (("team", {}), ("solo", {"MI_ILQR_NO_HELPER": "1"})):
+        f = str(tmp_path / f"{tag}.npz")
+        r = subprocess.run([sys.executable, "-c", script, f], capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(f))
+    for k in outs[0].files:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
