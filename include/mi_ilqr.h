@@ -180,8 +180,10 @@ int mi_ilqr_mpc_shift(mi_ilqr_t* h, int32_t replan_steps);
 /* The whole receding-horizon loop of acrobot.py:145-155 / mini_cheetah.py:190-201 on the device:
  * `num_resolves` times { mpc_shift(replan_steps); x_nom += target_step (may be NULL); Solve }.
  * For the wave-per-problem kernels this is ONE launch and the solver state stays in LDS between
- * re-solves; per re-solve the log keeps (x0 (n), cost, iterations) for every problem:
- * mi_ilqr_get_mpc_log -> (B, num_resolves, n+2).  stats aggregate the whole loop. */
+ * re-solves; the workgroup-per-problem kernel (n = 36) runs the loop in one launch as well.  Per
+ * re-solve the log keeps (x0 (n), cost, iterations) for every problem:
+ * mi_ilqr_get_mpc_log -> (B, num_resolves, n+2).  stats aggregate the whole loop.  (The
+ * lane-per-problem "throughput" kernels loop shift + solve on the host and keep no log.) */
 int mi_ilqr_mpc_run(mi_ilqr_t* h, int32_t num_resolves, int32_t replan_steps, const double* target_step, mi_ilqr_stats* stats);
 int mi_ilqr_get_mpc_log(mi_ilqr_t* h, double* dst, size_t bytes);
 
