@@ -125,6 +125,8 @@ KArgs make_args(const mi_ilqr* h) {
   if (!no_helper && !h->large && !h->batch_minor && h->d.keypoint_method == MI_KP_SET_INTERVAL && h->d.minN == 1 &&
       (h->N - 1) * (h->n + h->m) > 128)
     a.helpers = h->B <= 256 ? 3 : 1;
+  static const bool seq_bp = [] { const char* e = std::getenv("MI_ILQR_SEQ_BACKWARD"); return e && e[0] == '1'; }();
+  a.seq_backward = seq_bp ? 1 : 0;
   return a;
 }
 
