@@ -1068,21 +1068,26 @@ __device__ __forceinline__ void ric_combine(RicElem<2>& o, const RicElem<2>& ei,
   }
 }
 
+// value of `v` in lane `src` (any lane; out-of-range callers mask the result)
+__device__ __forceinline__ double lane_read_f64(double v, int src) {
+  union { double d; int i[2]; } u, r;
+  u.d = v;
+  r.i[0] = __builtin_amdgcn_ds_bpermute(src << 2, u.i[0]);
+  r.i[1] = __builtin_amdgcn_ds_bpermute(src << 2, u.i[1]);
+  return r.d;
+}
+
 template <int n>
-__device__ __forceinline__ void ric_fetch(RicElem<n>& dst, const RicElem<n>& src, int from_lane, bool valid) {
-  RicElem<n> id;
-  ric_identity<n>(id);
+__device__ __forceinline__ void ric_fetch(RicElem<n>& dst, const RicElem<n>& src, int from_lane) {
 #pragma unroll
   for (int i = 0; i < n; ++i) {
-    const double b_ = __shfl(src.b[i], from_lane), e_ = __shfl(src.e[i], from_lane);
-    dst.b[i] = valid ? b_ : id.b[i];
-    dst.e[i] = valid ? e_ : id.e[i];
+    dst.b[i] = lane_read_f64(src.b[i], from_lane);
+    dst.e[i] = lane_read_f64(src.e[i], from_lane);
 #pragma unroll
     for (int j = 0; j < n; ++j) {
-      const double a_ = __shfl(src.A[i][j], from_lane), c_ = __shfl(src.C[i][j], from_lane), j_ = __shfl(src.J[i][j], from_lane);
-      dst.A[i][j] = valid ? a_ : id.A[i][j];
-      dst.C[i][j] = valid ? c_ : id.C[i][j];
-      dst.J[i][j] = valid ? j_ : id.J[i][j];
+      dst.A[i][j] = lane_read_f64(src.A[i][j], from_lane);
+      dst.C[i][j] = lane_read_f64(src.C[i][j], from_lane);
+      dst.J[i][j] = lane_read_f64(src.J[i][j], from_lane);
     }
   }
 }
@@ -1103,35 +1108,31 @@ __device__ inline void backward_scan(const WS& w, const Consts<M>& c) {
   R2[0][0] = 2.0 * c.R[0][0];
   const double R2i = fast_rcp(R2[0][0]);
   // ---- (1) this lane's chunk aggregate
+  // branch-free: a step element, the terminal element (0, 0, 0, -lf_x, lf_xx; ilqr.py:203-204) or,
+  // past the horizon, the identity - selected field by field
   auto element = [&](RicElem<n>& r, int t) __attribute__((always_inline)) {
-    if (t >= N) { ric_identity<n>(r); return; }
-    const double* g = w.G + t * Ly::GS;
-    double x[n];
+    const bool is_step = t < N - 1, is_term = t == N - 1;
+    const int tg = t < N ? t : N - 1, tj = t < N - 1 ? t : N - 2;
+    const double* g = w.G + tg * Ly::GS;
+    const double* jr = w.J + tj * Ly::JS;
+    double x[n], fu[n];
 #pragma unroll
-    for (int i = 0; i < n; ++i) x[i] = g[Ly::XB + i];
-    if (t == N - 1) {                                       // terminal: (0, 0, 0, -lf_x, lf_xx)   ilqr.py:203-204
-#pragma unroll
-      for (int i = 0; i < n; ++i) {
-        double s = 0.0;
-#pragma unroll
-        for (int j = 0; j < n; ++j) { s += (2.0 * c.Qf[i][j]) * x[j]; r.A[i][j] = 0.0; r.C[i][j] = 0.0; r.J[i][j] = 2.0 * c.Qf[i][j]; }
-        r.b[i] = 0.0;
-        r.e[i] = -(s - c.qfn[i]);
-      }
-      return;
-    }
-    const double* jr = w.J + t * Ly::JS;
+    for (int i = 0; i < n; ++i) { x[i] = g[Ly::XB + i]; fu[i] = jr[Ly::FU + i * m]; }
     const double u = g[Ly::UB];
-    double fu[n];
-#pragma unroll
-    for (int i = 0; i < n; ++i) fu[i] = jr[Ly::FU + i * m];
 #pragma unroll
     for (int i = 0; i < n; ++i) {
-      double s = -c.qn[i];
+      double s = -c.qn[i], sf = -c.qfn[i];
 #pragma unroll
-      for (int j = 0; j < n; ++j) { s += Q2[i][j] * x[j]; r.A[i][j] = jr[Ly::FX + i * n + j]; r.J[i][j] = Q2[i][j]; r.C[i][j] = (fu[i] * R2i) * fu[j]; }
-      r.e[i] = -s;                                          // -lx_t
-      r.b[i] = -fu[i] * u;                                  // -fu luu^{-1} lu = -fu u_bar
+      for (int j = 0; j < n; ++j) {
+        s += Q2[i][j] * x[j];
+        sf += (2.0 * c.Qf[i][j]) * x[j];
+        const double idm = (i == j) ? 1.0 : 0.0;
+        r.A[i][j] = is_step ? jr[Ly::FX + i * n + j] : (is_term ? 0.0 : idm);
+        r.J[i][j] = is_step ? Q2[i][j] : (is_term ? 2.0 * c.Qf[i][j] : 0.0);
+        r.C[i][j] = is_step ? (fu[i] * R2i) * fu[j] : 0.0;
+      }
+      r.e[i] = is_step ? -s : (is_term ? -sf : 0.0);         // -lx_t | -lf_x
+      r.b[i] = is_step ? -fu[i] * u : 0.0;                   // -fu luu^{-1} lu = -fu u_bar
     }
   };
   RicElem<n> S, T, U;
@@ -1144,17 +1145,19 @@ __device__ inline void backward_scan(const WS& w, const Consts<M>& c) {
   // ---- (2) inclusive suffix scan over the lanes:  S_l <- g_l (x) g_{l+1} (x) ... (x) g_63
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
-    ric_fetch<n>(T, S, lane + off, lane + off < 64);
-    ric_combine(U, S, T);
-    S = U;
+    ric_fetch<n>(T, S, lane + off);                         // all lanes take part in the exchange ...
+    if (lane + off < 64) {                                  // ... lanes without a partner keep their suffix
+      ric_combine(U, S, T);
+      S = U;
+    }
   }
   // value function at the right edge of this chunk = (J, -eta) of the NEXT lane's suffix
   double Vx[n], Vxx[n][n];
 #pragma unroll
   for (int i = 0; i < n; ++i) {
-    Vx[i] = -__shfl(S.e[i], lane + 1);
+    Vx[i] = -lane_read_f64(S.e[i], lane + 1);
 #pragma unroll
-    for (int j = 0; j < n; ++j) Vxx[i][j] = __shfl(S.J[i][j], lane + 1);
+    for (int j = 0; j < n; ++j) Vxx[i][j] = lane_read_f64(S.J[i][j], lane + 1);
   }
   // ---- (3) the reference recursion over this lane's own steps
   int t_hi = e0 + chunk - 1;                                // last element of the chunk
