@@ -50,6 +50,29 @@ __device__ inline Dual1 mi_cos(Dual1 a) { return {fast_cos(a.v), -fast_sin(a.v) 
 __device__ inline Dual1 mi_exp(Dual1 a) { const double e = exp(a.v); return {e, e * a.d}; }
 __device__ inline Dual1 mi_log1p(Dual1 a) { return {log1p(a.v), a.d / (1.0 + a.v)}; }
 
+// Two-directional forward-mode dual (value + derivatives along two seeds): the state Jacobian of a
+// two-state closed-loop step in one evaluation (time-parallel Newton rollout, ilqr_small.hpp).
+struct Dual2 {
+  double v, d0, d1;
+  __host__ __device__ Dual2() {}
+  __host__ __device__ Dual2(double v_) : v(v_), d0(0.0), d1(0.0) {}
+  __host__ __device__ Dual2(double v_, double a_, double b_) : v(v_), d0(a_), d1(b_) {}
+};
+__host__ __device__ inline Dual2 operator+(Dual2 a, Dual2 b) { return {a.v + b.v, a.d0 + b.d0, a.d1 + b.d1}; }
+__host__ __device__ inline Dual2 operator-(Dual2 a, Dual2 b) { return {a.v - b.v, a.d0 - b.d0, a.d1 - b.d1}; }
+__host__ __device__ inline Dual2 operator-(Dual2 a) { return {-a.v, -a.d0, -a.d1}; }
+__host__ __device__ inline Dual2 operator*(Dual2 a, Dual2 b) { return {a.v * b.v, a.d0 * b.v + b.d0 * a.v, a.d1 * b.v + b.d1 * a.v}; }
+__host__ __device__ inline Dual2 operator+(Dual2 a, double b) { return {a.v + b, a.d0, a.d1}; }
+__host__ __device__ inline Dual2 operator+(double a, Dual2 b) { return {a + b.v, b.d0, b.d1}; }
+__host__ __device__ inline Dual2 operator-(Dual2 a, double b) { return {a.v - b, a.d0, a.d1}; }
+__host__ __device__ inline Dual2 operator-(double a, Dual2 b) { return {a - b.v, -b.d0, -b.d1}; }
+__host__ __device__ inline Dual2 operator*(Dual2 a, double b) { return {a.v * b, a.d0 * b, a.d1 * b}; }
+__host__ __device__ inline Dual2 operator*(double a, Dual2 b) { return {a * b.v, a * b.d0, a * b.d1}; }
+__host__ __device__ inline double value_of(Dual2 a) { return a.v; }
+__device__ inline Dual2 mi_sin(Dual2 a) { const double c_ = fast_cos(a.v); return {fast_sin(a.v), c_ * a.d0, c_ * a.d1}; }
+__device__ inline Dual2 mi_cos(Dual2 a) { const double s_ = -fast_sin(a.v); return {fast_cos(a.v), s_ * a.d0, s_ * a.d1}; }
+__device__ inline Dual2 mi_rcp(Dual2 a) { const double r = fast_rcp(a.v), q = -(r * r); return {r, q * a.d0, q * a.d1}; }
+
 // log(1+exp(z)) = max(z,0) + log1p(exp(-|z|)), overflow-safe and branch-free; same value as the
 // two-branch form of oracle/dual.py:softplus.  d/dz = logistic(z).
 __device__ inline double mi_softplus(double z) {

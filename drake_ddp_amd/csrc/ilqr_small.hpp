@@ -58,6 +58,7 @@ struct KArgs {
   double* mpc_log;             // (B, mpc_resolves, n+2): x0 of the re-solve | cost | iterations
   int32_t helpers;             // extra wavefronts per problem that share the linearization (0, 1 or 3), see ilqr_small_kernel
   int32_t seq_backward;        // 1: sequential Riccati sweep instead of the parallel-in-time scan (A/B measurements)
+  int32_t newton_rollout;      // 1: the eps = 1 trial is rolled out parallel in time (Newton on the trajectory) when it converges
 };
 
 __device__ __forceinline__ double bcast_lane0(double v) {
@@ -386,6 +387,161 @@ __device__ inline void traj_cost(const WS& w, const Consts<M>& c, double eps, do
 }
 
 // ---------------------------------------------------------------------------
+// The eps = 1 trial rolled out PARALLEL IN TIME (n = 2): Newton's method on the whole trajectory.
+//
+// The rollout x_{t+1} = g_t(x_t) = f(x_t, u_bar_t - kappa_t - K_t (x_t - x_bar_t)) (ilqr.py:313-316)
+// is a nonlinear recurrence, 255 cycles per step when one wavefront walks it.  Given a guess X of the
+// whole trajectory, every lane evaluates g_t and its state Jacobian G_t (one forward-mode Dual2
+// evaluation) at its own few steps; the linearized recurrence x_{t+1} = g_t(X_t) + G_t (x_t - X_t)
+// is an affine map composition, i.e. a prefix scan over the lanes (Kogge-Stone, ds_bpermute); the
+// result is the next guess.  Started from the previous nominal trajectory, the iteration converges
+// quadratically: 4 sweeps (5 early in a solve) bring the update below 1e-9, after which the error
+// is at round-off (prototype against the sequential rollout: 1e-14 absolute, tools/... DESIGN.md).
+// Finally every lane re-runs its own chunk with the plain fp64 step from its converged start and
+// stores x_{t+1}, u_t: inside a chunk the stored trajectory satisfies the dynamics exactly, across
+// the 49 chunk edges to ~1e-14.  Not converged within the cap (cold starts, the first iteration of
+// hard problems) -> the caller falls back to the sequential rollout.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double lane_read_f64(double v, int src);
+
+struct Aff2 {                     // x -> G x + c
+  double G[2][2], c[2];
+};
+// later (o) earlier: apply `e` first, then `l`
+__device__ __forceinline__ void aff2_compose(Aff2& o, const Aff2& l, const Aff2& e) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    o.c[i] = fma(l.G[i][0], e.c[0], fma(l.G[i][1], e.c[1], l.c[i]));
+#pragma unroll
+    for (int j = 0; j < 2; ++j) o.G[i][j] = fma(l.G[i][0], e.G[0][j], l.G[i][1] * e.G[1][j]);
+  }
+}
+
+template <class M, int CH>
+__device__ inline bool rollout_newton_impl(const WS& w, const KArgs& a, const double* x0r) {
+  constexpr int n = 2, m = 1;
+  static_assert(M::n == 2 && M::m == 1, "2-state closed loop");
+  using Ly = Lay<n, m>;
+  const int N = w.N, lane = threadIdx.x & 63, steps = N - 1;
+  const int t0 = lane * CH;
+  // nominal data and the initial guess (= the nominal trajectory) of this lane's steps
+  double xb[CH][n], Kk[CH][n], dd[CH], X[CH][n];
+  bool valid[CH];
+#pragma unroll
+  for (int k = 0; k < CH; ++k) {
+    const int t = t0 + k;
+    valid[k] = t < steps;
+    const double* g = w.G + (valid[k] ? t : 0) * Ly::GS;
+#pragma unroll
+    for (int i = 0; i < n; ++i) { xb[k][i] = g[Ly::XB + i]; Kk[k][i] = g[Ly::KK + i]; X[k][i] = (t == 0) ? x0r[i] : xb[k][i]; }
+    dd[k] = g[Ly::UB] - 1.0 * g[Ly::KAP];                   // u_bar - eps kappa, eps = 1 (ilqr.py:313)
+  }
+  constexpr int kMaxSweeps = 7;
+  constexpr double kTol = 1e-9;
+  bool converged = false;
+  for (int sweep = 0; sweep < kMaxSweeps && !converged; ++sweep) {
+    Aff2 loc[CH], agg;
+    agg.G[0][0] = 1.0; agg.G[0][1] = 0.0; agg.G[1][0] = 0.0; agg.G[1][1] = 1.0; agg.c[0] = 0.0; agg.c[1] = 0.0;
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      // g_t and G_t at the current guess: one Dual2 evaluation of the closed-loop step
+      Dual2 xd[n] = {Dual2(X[k][0], 1.0, 0.0), Dual2(X[k][1], 0.0, 1.0)};
+      Dual2 ud[m] = {dd[k] - (Kk[k][0] * (xd[0] - xb[k][0]) + Kk[k][1] * (xd[1] - xb[k][1]))};
+      Dual2 xn[n];
+      M::template step<Dual2>(xd, ud, xn, a.params, a.dt);
+#pragma unroll
+      for (int i = 0; i < n; ++i) {
+        const double g0 = valid[k] ? xn[i].d0 : (i == 0 ? 1.0 : 0.0), g1 = valid[k] ? xn[i].d1 : (i == 1 ? 1.0 : 0.0);
+        loc[k].G[i][0] = g0; loc[k].G[i][1] = g1;
+        loc[k].c[i] = valid[k] ? (xn[i].v - (g0 * X[k][0] + g1 * X[k][1])) : 0.0;
+      }
+      Aff2 t_;
+      aff2_compose(t_, loc[k], agg);
+      agg = t_;
+    }
+    // inclusive prefix over the lanes: P_l = agg_l o agg_{l-1} o ... o agg_0
+    Aff2 P = agg;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      Aff2 f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        f.c[i] = lane_read_f64(P.c[i], lane - off);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) f.G[i][j] = lane_read_f64(P.G[i][j], lane - off);
+      }
+      if (lane >= off) {
+        Aff2 t_;
+        aff2_compose(t_, P, f);
+        P = t_;
+      }
+    }
+    // exclusive prefix applied to x0 = this lane's first state
+    double xs[n];
+    {
+      Aff2 E;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        E.c[i] = lane_read_f64(P.c[i], lane - 1);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) E.G[i][j] = lane_read_f64(P.G[i][j], lane - 1);
+      }
+#pragma unroll
+      for (int i = 0; i < n; ++i) xs[i] = (lane == 0) ? x0r[i] : fma(E.G[i][0], x0r[0], fma(E.G[i][1], x0r[1], E.c[i]));
+    }
+    double upd = 0.0;
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      if (valid[k]) {
+        upd = fmax(upd, fmax(fabs(xs[0] - X[k][0]), fabs(xs[1] - X[k][1])));
+        upd = (xs[0] == xs[0] && xs[1] == xs[1]) ? upd : __builtin_inf();      // NaN -> not converged
+      }
+      X[k][0] = xs[0]; X[k][1] = xs[1];
+      const double n0 = fma(loc[k].G[0][0], xs[0], fma(loc[k].G[0][1], xs[1], loc[k].c[0]));
+      const double n1 = fma(loc[k].G[1][0], xs[0], fma(loc[k].G[1][1], xs[1], loc[k].c[1]));
+      xs[0] = n0; xs[1] = n1;
+    }
+    // wave-wide max of the update
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) upd = fmax(upd, lane_read_f64(upd, lane ^ o));
+    converged = upd < kTol;
+  }
+  if (!converged) return false;
+  // final pass: the plain fp64 step over this lane's chunk from its converged start (ilqr.py:313-316)
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < n; ++i) w.T[Ly::XN + i] = x0r[i];
+  }
+  double x[n] = {X[0][0], X[0][1]};
+#pragma unroll
+  for (int k = 0; k < CH; ++k) {
+    if (valid[k]) {
+      const int t = t0 + k;
+      double u[m], xn[n];
+      u[0] = dd[k] - (Kk[k][0] * (x[0] - xb[k][0]) + Kk[k][1] * (x[1] - xb[k][1]));
+      M::template step<double>(x, u, xn, a.params, a.dt);
+      double* tr = w.T + t * Ly::TS;
+      tr[Ly::UN] = u[0];
+      tr[Ly::TS + Ly::XN + 0] = xn[0];
+      tr[Ly::TS + Ly::XN + 1] = xn[1];
+      x[0] = xn[0]; x[1] = xn[1];
+    }
+  }
+  return true;
+}
+
+template <class M>
+__device__ inline bool rollout_newton(const WS& w, const KArgs& a, const double* x0r) {
+  if constexpr (M::n == 2 && M::m == 1) {
+    const int steps = w.N - 1;
+    // four steps per lane: horizons up to N = 257 (a second instantiation with eight would raise the
+    // whole kernel's register allocation past two resident waves per SIMD)
+    if (steps <= 64 * 4) return rollout_newton_impl<M, 4>(w, a, x0r);
+  }
+  return false;
+}
+
+// ---------------------------------------------------------------------------
 // Speculative parallel line search (ilqr.py:300-337).  Returns true on accept;
 // the T records then hold the accepted trajectory.  `trials` is the
 // reference-equivalent sequential trial count (accepted candidate index + 1).
@@ -403,7 +559,12 @@ __device__ inline bool linesearch(const WS& w, const Consts<M>& c, const KArgs& 
   double eps_base = 1.0;
   if (optimistic) {
     double L, ex;
-    rollout<M, false>(w, c, a, x0r, 1.0, lane == 0 ? 0 : -1, L, ex);
+    bool done = false;
+    if constexpr (M::n == 2 && M::m == 1) {
+      // not at the first iteration of a solve (L_last = inf: no useful guess of the trajectory yet)
+      if (a.newton_rollout && L_last < __builtin_inf()) done = rollout_newton<M>(w, a, x0r);
+    }
+    if (!done) rollout<M, false>(w, c, a, x0r, 1.0, lane == 0 ? 0 : -1, L, ex);
     wave_sync();
     traj_cost<M>(w, c, 1.0, L, ex);
     if ((L_last - L) > a.gamma * ex) {                         // ilqr.py:330-331

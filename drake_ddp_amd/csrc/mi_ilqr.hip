@@ -117,16 +117,19 @@ KArgs make_args(const mi_ilqr* h) {
   a.mpc_resolves = h->mpc_resolves; a.mpc_replan = h->mpc_replan; a.mpc_log = h->mpc_log;
   for (int i = 0; i < kMaxStateDim; ++i) a.mpc_target_step[i] = h->mpc_target_step[i];
   // wave-per-problem kernels: helper wavefronts share the linearization when every step is a key-point
-  // (the default).  Three of them while the whole batch then still fits one wave per SIMD (B <= 256),
-  // otherwise one: every wave of the kernel carries the main wave's register allocation, and a fourth
-  // resident wave per SIMD would no longer fit.  MI_ILQR_NO_HELPER=1 turns them off (A/B measurements).
+  // (the default) - as many as keep the whole batch resident at ONE wave per SIMD (1024 slots): every
+  // wave of the kernel carries the main wave's register allocation (> 256 VGPRs with the time-parallel
+  // rollout and sweep), so a second resident wave per SIMD does not fit and extra waves would queue.
+  // MI_ILQR_NO_HELPER=1 turns them off (A/B measurements).
   static const bool no_helper = [] { const char* e = std::getenv("MI_ILQR_NO_HELPER"); return e && e[0] == '1'; }();
   a.helpers = 0;
   if (!no_helper && !h->large && !h->batch_minor && h->d.keypoint_method == MI_KP_SET_INTERVAL && h->d.minN == 1 &&
       (h->N - 1) * (h->n + h->m) > 128)
-    a.helpers = h->B <= 256 ? 3 : 1;
+    a.helpers = h->B <= 256 ? 3 : (h->B <= 512 ? 1 : 0);
   static const bool seq_bp = [] { const char* e = std::getenv("MI_ILQR_SEQ_BACKWARD"); return e && e[0] == '1'; }();
   a.seq_backward = seq_bp ? 1 : 0;
+  static const bool seq_ro = [] { const char* e = std::getenv("MI_ILQR_SEQ_ROLLOUT"); return e && e[0] == '1'; }();
+  a.newton_rollout = seq_ro ? 0 : 1;
   return a;
 }
 

@@ -12,6 +12,7 @@ namespace mi {
 
 struct Pendulum {            // params [ml2, b, mgl]
   static constexpr int n = 2, m = 1, n_params = 3;
+  static constexpr bool kNewtonRollout = true;   // step<Dual2> is available: time-parallel Newton rollout (ilqr_small.hpp)
   template <class T>
   __device__ static inline void step(const T* x, const T* u, T* xn, const double* p, double dt) {
     const double ml2 = p[0], b = p[1], mgl = p[2];
