@@ -1269,39 +1269,67 @@ __device__ inline void backward_scan(const WS& w, const Consts<M>& c) {
   R2[0][0] = 2.0 * c.R[0][0];
   const double R2i = fast_rcp(R2[0][0]);
   // ---- (1) this lane's chunk aggregate
-  // branch-free: a step element, the terminal element (0, 0, 0, -lf_x, lf_xx; ilqr.py:203-204) or,
-  // past the horizon, the identity - selected field by field
-  auto element = [&](RicElem<n>& r, int t) __attribute__((always_inline)) {
-    const bool is_step = t < N - 1, is_term = t == N - 1;
+  // Each lane reads the records of its OWN consecutive steps: the lanes' addresses are 4 records =
+  // 256 bytes apart, i.e. all in the same LDS banks (a 64-way conflict: ~64 cycles per 8-byte read).
+  // So every step's operands are read exactly once, here, and kept in registers for phase (3) -
+  // the wave runs alone on its SIMD at these batch sizes, registers are free.
+  constexpr int CHMAX = 4;
+  struct Raw { double x[n], u, fx[n][n], fu[n]; };
+  Raw raw[CHMAX];
+  const bool held = chunk <= CHMAX;                         // longer horizons: phase (3) re-reads
+  auto read_raw = [&](Raw& r, int t) __attribute__((always_inline)) {
     const int tg = t < N ? t : N - 1, tj = t < N - 1 ? t : N - 2;
     const double* g = w.G + tg * Ly::GS;
     const double* jr = w.J + tj * Ly::JS;
-    double x[n], fu[n];
 #pragma unroll
-    for (int i = 0; i < n; ++i) { x[i] = g[Ly::XB + i]; fu[i] = jr[Ly::FU + i * m]; }
-    const double u = g[Ly::UB];
+    for (int i = 0; i < n; ++i) {
+      r.x[i] = g[Ly::XB + i];
+      r.fu[i] = jr[Ly::FU + i * m];
+#pragma unroll
+      for (int j = 0; j < n; ++j) r.fx[i][j] = jr[Ly::FX + i * n + j];
+    }
+    r.u = g[Ly::UB];
+  };
+  // branch-free: a step element, the terminal element (0, 0, 0, -lf_x, lf_xx; ilqr.py:203-204) or,
+  // past the horizon, the identity - selected field by field
+  auto element = [&](RicElem<n>& r, const Raw& q, int t) __attribute__((always_inline)) {
+    const bool is_step = t < N - 1, is_term = t == N - 1;
 #pragma unroll
     for (int i = 0; i < n; ++i) {
       double s = -c.qn[i], sf = -c.qfn[i];
 #pragma unroll
       for (int j = 0; j < n; ++j) {
-        s += Q2[i][j] * x[j];
-        sf += (2.0 * c.Qf[i][j]) * x[j];
+        s += Q2[i][j] * q.x[j];
+        sf += (2.0 * c.Qf[i][j]) * q.x[j];
         const double idm = (i == j) ? 1.0 : 0.0;
-        r.A[i][j] = is_step ? jr[Ly::FX + i * n + j] : (is_term ? 0.0 : idm);
+        r.A[i][j] = is_step ? q.fx[i][j] : (is_term ? 0.0 : idm);
         r.J[i][j] = is_step ? Q2[i][j] : (is_term ? 2.0 * c.Qf[i][j] : 0.0);
-        r.C[i][j] = is_step ? (fu[i] * R2i) * fu[j] : 0.0;
+        r.C[i][j] = is_step ? (q.fu[i] * R2i) * q.fu[j] : 0.0;
       }
       r.e[i] = is_step ? -s : (is_term ? -sf : 0.0);         // -lx_t | -lf_x
-      r.b[i] = is_step ? -fu[i] * u : 0.0;                   // -fu luu^{-1} lu = -fu u_bar
+      r.b[i] = is_step ? -q.fu[i] * q.u : 0.0;               // -fu luu^{-1} lu = -fu u_bar
     }
   };
   RicElem<n> S, T, U;
-  element(S, e0);
-  for (int k = 1; k < chunk; ++k) {
-    element(T, e0 + k);
-    ric_combine(U, S, T);
-    S = U;
+  if (held) {
+#pragma unroll
+    for (int k = 0; k < CHMAX; ++k) {
+      if (k < chunk) {
+        read_raw(raw[k], e0 + k);
+        if (k == 0) element(S, raw[0], e0);
+        else { element(T, raw[k], e0 + k); ric_combine(U, S, T); S = U; }
+      }
+    }
+  } else {
+    Raw q;
+    read_raw(q, e0);
+    element(S, q, e0);
+    for (int k = 1; k < chunk; ++k) {
+      read_raw(q, e0 + k);
+      element(T, q, e0 + k);
+      ric_combine(U, S, T);
+      S = U;
+    }
   }
   // ---- (2) inclusive suffix scan over the lanes:  S_l <- g_l (x) g_{l+1} (x) ... (x) g_63
 #pragma unroll
@@ -1333,20 +1361,30 @@ __device__ inline void backward_scan(const WS& w, const Consts<M>& c) {
       Vx[i] = s - c.qfn[i];
     }
   }
-  for (int t = t_hi; t >= e0; --t) {
-    double* g = w.G + t * Ly::GS;
-    const double* jr = w.J + t * Ly::JS;
+  auto riccati_step = [&](const Raw& q, int t) __attribute__((always_inline)) {
     BRegs<M> r;
 #pragma unroll
     for (int i = 0; i < n; ++i) {
       double s = -c.qn[i];
 #pragma unroll
-      for (int j = 0; j < n; ++j) { s += Q2[i][j] * g[Ly::XB + j]; r.fx[i][j] = jr[Ly::FX + i * n + j]; }
+      for (int j = 0; j < n; ++j) { s += Q2[i][j] * q.x[j]; r.fx[i][j] = q.fx[i][j]; }
       r.lx[i] = s;
-      r.fu[i][0] = jr[Ly::FU + i * m];
+      r.fu[i][0] = q.fu[i];
     }
-    r.lu[0] = R2[0][0] * g[Ly::UB];
-    backward_step<M>(r, c, Q2, R2, Vx, Vxx, g);
+    r.lu[0] = R2[0][0] * q.u;
+    backward_step<M>(r, c, Q2, R2, Vx, Vxx, w.G + t * Ly::GS);
+  };
+  if (held) {
+#pragma unroll
+    for (int k = CHMAX - 1; k >= 0; --k) {
+      if (k < chunk && e0 + k <= t_hi) riccati_step(raw[k], e0 + k);
+    }
+  } else {
+    for (int t = t_hi; t >= e0; --t) {
+      Raw q;
+      read_raw(q, t);
+      riccati_step(q, t);
+    }
   }
 }
 
