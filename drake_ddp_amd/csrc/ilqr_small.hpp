@@ -104,9 +104,14 @@ struct Lay {
   static constexpr int UB = KK + even(m * n);
   static constexpr int KAP = UB + even(m);
   static constexpr int DV = KAP + m;
-  static constexpr int GS = even(DV + 1);
-  static constexpr int XN = 0, UN = even(n), TS = even(UN + m);
-  static constexpr int FX = 0, FU = even(n * n), JS = even(FU + n * m);
+  // n = 2 (the passes over time are lane-chunked there: Riccati scan, Newton rollout): record strides
+  // are ODD numbers of doubles, so lanes reading consecutive records hit 32 different bank pairs and
+  // lanes owning chunks of 2..4 consecutive records conflict at most 4-way instead of 32-way.  Larger
+  // n keeps 16-byte aligned records (b128 loads in the wave-uniform sweeps matter more there).
+  static constexpr int pad(int v) { return n <= 2 ? (v | 1) : even(v); }
+  static constexpr int GS = pad(DV + 1);
+  static constexpr int XN = 0, UN = even(n), TS = pad(UN + m);
+  static constexpr int FX = 0, FU = even(n * n), JS = pad(FU + n * m);
   static constexpr int DUMP_DOUBLES = 64 * 2 + (GS > JS ? GS : JS);   // 16 B per lane + one record of slack
 };
 
@@ -479,18 +484,14 @@ __device__ inline bool rollout_newton_impl(const WS& w, const KArgs& a, const do
         P = t_;
       }
     }
-    // exclusive prefix applied to x0 = this lane's first state
+    // this lane's first state = the END state of the previous lane's prefix: P_{l-1}(x0)
     double xs[n];
     {
-      Aff2 E;
+      double ye[n];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        E.c[i] = lane_read_f64(P.c[i], lane - 1);
+      for (int i = 0; i < n; ++i) ye[i] = fma(P.G[i][0], x0r[0], fma(P.G[i][1], x0r[1], P.c[i]));
 #pragma unroll
-        for (int j = 0; j < 2; ++j) E.G[i][j] = lane_read_f64(P.G[i][j], lane - 1);
-      }
-#pragma unroll
-      for (int i = 0; i < n; ++i) xs[i] = (lane == 0) ? x0r[i] : fma(E.G[i][0], x0r[0], fma(E.G[i][1], x0r[1], E.c[i]));
+      for (int i = 0; i < n; ++i) { const double yp = lane_read_f64(ye[i], lane - 1); xs[i] = (lane == 0) ? x0r[i] : yp; }
     }
     double upd = 0.0;
 #pragma unroll
@@ -504,9 +505,12 @@ __device__ inline bool rollout_newton_impl(const WS& w, const KArgs& a, const do
       const double n1 = fma(loc[k].G[1][0], xs[0], fma(loc[k].G[1][1], xs[1], loc[k].c[1]));
       xs[0] = n0; xs[1] = n1;
     }
-    // wave-wide max of the update
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) upd = fmax(upd, lane_read_f64(upd, lane ^ o));
+    // wave-wide max of the update: DPP row rotations, then the four row maxima through v_readlane
+    upd = fmax(upd, row_ror_f64<8>(upd));
+    upd = fmax(upd, row_ror_f64<4>(upd));
+    upd = fmax(upd, row_ror_f64<2>(upd));
+    upd = fmax(upd, row_ror_f64<1>(upd));
+    upd = fmax(fmax(readlane_f64(upd, 0), readlane_f64(upd, 16)), fmax(readlane_f64(upd, 32), readlane_f64(upd, 48)));
     converged = upd < kTol;
 #ifdef MI_NEWTON_FIXED_SWEEPS
     converged = sweep + 1 >= MI_NEWTON_FIXED_SWEEPS;         // timing experiments only
