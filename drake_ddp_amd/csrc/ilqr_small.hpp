@@ -409,6 +409,9 @@ __device__ inline void traj_cost(const WS& w, const Consts<M>& c, double eps, do
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ double lane_read_f64(double v, int src);
 
+#ifdef MI_PROF_NEWTON
+__device__ double mi_dbg_vals[8];
+#endif
 struct Aff2 {                     // x -> G x + c
   double G[2][2], c[2];
 };
@@ -420,6 +423,48 @@ __device__ __forceinline__ void aff2_compose(Aff2& o, const Aff2& l, const Aff2&
 #pragma unroll
     for (int j = 0; j < 2; ++j) o.G[i][j] = fma(l.G[i][0], e.G[0][j], l.G[i][1] * e.G[1][j]);
   }
+}
+
+// The same maps with G stored as G - I ("deviation form"): the identity is all zeros, which is what a
+// DPP move delivers to a lane without a source (bound_ctrl) - so the Kogge-Stone prefix below needs
+// neither selects nor the LDS crossbar.  later (o) earlier:
+//   G' = l.G' + e.G' + l.G' e.G',   c = l.c + e.c + l.G' e.c
+__device__ __forceinline__ void aff2_compose_dev(Aff2& o, const Aff2& l, const Aff2& e) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    o.c[i] = fma(l.G[i][0], e.c[0], fma(l.G[i][1], e.c[1], l.c[i] + e.c[i]));
+#pragma unroll
+    for (int j = 0; j < 2; ++j) o.G[i][j] = fma(l.G[i][0], e.G[0][j], fma(l.G[i][1], e.G[1][j], l.G[i][j] + e.G[i][j]));
+  }
+}
+template <int CTRL, int ROWS>
+__device__ __forceinline__ double dpp_f64_or_zero(double v) {
+  union { double d; int i[2]; } u, r;
+  u.d = v;
+  r.i[0] = __builtin_amdgcn_update_dpp(0, u.i[0], CTRL, ROWS, 0xF, true);   // no source / row not selected: 0
+  r.i[1] = __builtin_amdgcn_update_dpp(0, u.i[1], CTRL, ROWS, 0xF, true);
+  return r.d;
+}
+template <int CTRL, int ROWS>
+__device__ __forceinline__ void aff2_prefix_level(Aff2& P) {
+  Aff2 f, t_;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    f.c[i] = dpp_f64_or_zero<CTRL, ROWS>(P.c[i]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) f.G[i][j] = dpp_f64_or_zero<CTRL, ROWS>(P.G[i][j]);
+  }
+  aff2_compose_dev(t_, P, f);
+  P = t_;
+}
+// In: this lane's map (deviation form).  Out: the composition of the maps of lanes 0..lane.
+__device__ __forceinline__ void aff2_prefix_dpp(Aff2& P) {
+  aff2_prefix_level<0x111, 0xF>(P);     // row_shr:1
+  aff2_prefix_level<0x112, 0xF>(P);     // row_shr:2
+  aff2_prefix_level<0x114, 0xF>(P);     // row_shr:4
+  aff2_prefix_level<0x118, 0xF>(P);     // row_shr:8   -> prefix inside every 16-lane row
+  aff2_prefix_level<0x142, 0xA>(P);     // row_bcast:15 into rows 1 and 3
+  aff2_prefix_level<0x143, 0xC>(P);     // row_bcast:31 into rows 2 and 3
 }
 
 template <class M, int CH>
@@ -447,7 +492,13 @@ __device__ inline bool rollout_newton_impl(const WS& w, const KArgs& a, const do
   constexpr int kMaxSweeps = 7;
   constexpr double kTol = 1e-7;
   bool converged = false;
+#ifdef MI_PROF_NEWTON
+  const long long pn0 = clock64(); int nsw = 0;
+#endif
   for (int sweep = 0; sweep < kMaxSweeps && !converged; ++sweep) {
+#ifdef MI_PROF_NEWTON
+    ++nsw;
+#endif
     Aff2 loc[CH], agg;
     agg.G[0][0] = 1.0; agg.G[0][1] = 0.0; agg.G[1][0] = 0.0; agg.G[1][1] = 1.0; agg.c[0] = 0.0; agg.c[1] = 0.0;
 #pragma unroll
@@ -467,29 +518,16 @@ __device__ inline bool rollout_newton_impl(const WS& w, const KArgs& a, const do
       aff2_compose(t_, loc[k], agg);
       agg = t_;
     }
-    // inclusive prefix over the lanes: P_l = agg_l o agg_{l-1} o ... o agg_0
+    // inclusive prefix over the lanes: P_l = agg_l o agg_{l-1} o ... o agg_0, all in DPP moves
     Aff2 P = agg;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      Aff2 f;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        f.c[i] = lane_read_f64(P.c[i], lane - off);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) f.G[i][j] = lane_read_f64(P.G[i][j], lane - off);
-      }
-      if (lane >= off) {
-        Aff2 t_;
-        aff2_compose(t_, P, f);
-        P = t_;
-      }
-    }
+    P.G[0][0] -= 1.0; P.G[1][1] -= 1.0;
+    aff2_prefix_dpp(P);
     // this lane's first state = the END state of the previous lane's prefix: P_{l-1}(x0)
     double xs[n];
     {
       double ye[n];
 #pragma unroll
-      for (int i = 0; i < n; ++i) ye[i] = fma(P.G[i][0], x0r[0], fma(P.G[i][1], x0r[1], P.c[i]));
+      for (int i = 0; i < n; ++i) ye[i] = fma(P.G[i][0], x0r[0], fma(P.G[i][1], x0r[1], P.c[i] + x0r[i]));
 #pragma unroll
       for (int i = 0; i < n; ++i) { const double yp = lane_read_f64(ye[i], lane - 1); xs[i] = (lane == 0) ? x0r[i] : yp; }
     }
@@ -516,6 +554,10 @@ __device__ inline bool rollout_newton_impl(const WS& w, const KArgs& a, const do
     converged = sweep + 1 >= MI_NEWTON_FIXED_SWEEPS;         // timing experiments only
 #endif
   }
+#ifdef MI_PROF_NEWTON
+  const long long pn1 = clock64();
+  if (lane == 0) { mi_dbg_vals[0] = (double)(pn1 - pn0); mi_dbg_vals[1] = nsw; }
+#endif
   if (!converged) return false;
   // final pass: the plain fp64 step over this lane's chunk from its converged start (ilqr.py:313-316)
   if (lane == 0) {
@@ -537,6 +579,9 @@ __device__ inline bool rollout_newton_impl(const WS& w, const KArgs& a, const do
       x[0] = xn[0]; x[1] = xn[1];
     }
   }
+#ifdef MI_PROF_NEWTON
+  if (lane == 0) mi_dbg_vals[2] = (double)(clock64() - pn1);
+#endif
   return true;
 }
 
@@ -1548,6 +1593,9 @@ __global__ void __launch_bounds__(256) ilqr_small_kernel(const KArgs a) {
       if (lane == 0 && it_this < a.hist_cap) {                    // history of the LAST solve
         hist[4 * it_this + 0] = L_new; hist[4 * it_this + 1] = eps;
         hist[4 * it_this + 2] = (double)trials; hist[4 * it_this + 3] = (double)nk / (double)(N - 1) * 100.0;   // :406
+#ifdef MI_PROF_NEWTON
+        hist[4 * it_this + 0] = (double)(c1 - c0); hist[4 * it_this + 1] = mi_dbg_vals[0]; hist[4 * it_this + 2] = mi_dbg_vals[1]; hist[4 * it_this + 3] = mi_dbg_vals[2];
+#endif
       }
       improvement = L - L_new;                                    // :706
       L = L_new;
