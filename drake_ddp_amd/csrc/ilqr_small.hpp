@@ -22,6 +22,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "../../include/mi_ilqr.h"
 #include "fastmath.hpp"
@@ -441,8 +442,13 @@ template <int CTRL, int ROWS>
 __device__ __forceinline__ double dpp_f64_or_zero(double v) {
   union { double d; int i[2]; } u, r;
   u.d = v;
-  r.i[0] = __builtin_amdgcn_update_dpp(0, u.i[0], CTRL, ROWS, 0xF, true);   // no source / row not selected: 0
-  r.i[1] = __builtin_amdgcn_update_dpp(0, u.i[1], CTRL, ROWS, 0xF, true);
+  if constexpr (ROWS == 0xF) {                                              // no source lane: 0 (bound_ctrl)
+    r.i[0] = __builtin_amdgcn_mov_dpp(u.i[0], CTRL, 0xF, 0xF, true);
+    r.i[1] = __builtin_amdgcn_mov_dpp(u.i[1], CTRL, 0xF, 0xF, true);
+  } else {                                                                  // row not selected: 0 (old value)
+    r.i[0] = __builtin_amdgcn_update_dpp(0, u.i[0], CTRL, ROWS, 0xF, true);
+    r.i[1] = __builtin_amdgcn_update_dpp(0, u.i[1], CTRL, ROWS, 0xF, true);
+  }
   return r.d;
 }
 template <int CTRL, int ROWS>
@@ -529,7 +535,7 @@ __device__ inline bool rollout_newton_impl(const WS& w, const KArgs& a, const do
 #pragma unroll
       for (int i = 0; i < n; ++i) ye[i] = fma(P.G[i][0], x0r[0], fma(P.G[i][1], x0r[1], P.c[i] + x0r[i]));
 #pragma unroll
-      for (int i = 0; i < n; ++i) { const double yp = lane_read_f64(ye[i], lane - 1); xs[i] = (lane == 0) ? x0r[i] : yp; }
+      for (int i = 0; i < n; ++i) { const double yp = dpp_f64_or_zero<0x138, 0xF>(ye[i]); xs[i] = (lane == 0) ? x0r[i] : yp; }   // wave_shr:1
     }
     double upd = 0.0;
 #pragma unroll
@@ -1293,17 +1299,21 @@ __device__ __forceinline__ double lane_read_f64(double v, int src) {
   return r.d;
 }
 
-template <int n>
-__device__ __forceinline__ void ric_fetch(RicElem<n>& dst, const RicElem<n>& src, int from_lane) {
+// One Kogge-Stone level of the scan over the lanes, operands moved with DPP: `dst` = the element of
+// the source lane, or the IDENTITY element where there is none (the moves deliver zeros there, and
+// the identity is all zeros once A is sent as A - I).
+template <int CTRL, int ROWS, int n>
+__device__ __forceinline__ void ric_fetch_dpp(RicElem<n>& dst, const RicElem<n>& src) {
 #pragma unroll
   for (int i = 0; i < n; ++i) {
-    dst.b[i] = lane_read_f64(src.b[i], from_lane);
-    dst.e[i] = lane_read_f64(src.e[i], from_lane);
+    dst.b[i] = dpp_f64_or_zero<CTRL, ROWS>(src.b[i]);
+    dst.e[i] = dpp_f64_or_zero<CTRL, ROWS>(src.e[i]);
 #pragma unroll
     for (int j = 0; j < n; ++j) {
-      dst.A[i][j] = lane_read_f64(src.A[i][j], from_lane);
-      dst.C[i][j] = lane_read_f64(src.C[i][j], from_lane);
-      dst.J[i][j] = lane_read_f64(src.J[i][j], from_lane);
+      const double idm = (i == j) ? 1.0 : 0.0;
+      dst.A[i][j] = dpp_f64_or_zero<CTRL, ROWS>(src.A[i][j] - idm) + idm;
+      dst.C[i][j] = dpp_f64_or_zero<CTRL, ROWS>(src.C[i][j]);
+      dst.J[i][j] = dpp_f64_or_zero<CTRL, ROWS>(src.J[i][j]);
     }
   }
 }
@@ -1315,7 +1325,10 @@ __device__ inline void backward_scan(const WS& w, const Consts<M>& c) {
   using Ly = Lay<n, m>;
   const int N = w.N, lane = threadIdx.x & 63;
   const int chunk = (N + 63) >> 6;                          // elements 0..N-2 are steps, element N-1 is the terminal one
-  const int e0 = lane * chunk;
+  // chunks are dealt to the lanes in REVERSE time order (lane 63 owns steps 0..chunk-1), so that the
+  // suffix scan over time is a prefix scan over the lanes - the direction DPP row shifts and row
+  // broadcasts move data in
+  const int e0 = (63 - lane) * chunk;
   double Q2[n][n], R2[m][m];
 #pragma unroll
   for (int i = 0; i < n; ++i)
@@ -1386,22 +1399,28 @@ __device__ inline void backward_scan(const WS& w, const Consts<M>& c) {
       S = U;
     }
   }
-  // ---- (2) inclusive suffix scan over the lanes:  S_l <- g_l (x) g_{l+1} (x) ... (x) g_63
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    ric_fetch<n>(T, S, lane + off);                         // all lanes take part in the exchange ...
-    if (lane + off < 64) {                                  // ... lanes without a partner keep their suffix
-      ric_combine(U, S, T);
-      S = U;
-    }
-  }
-  // value function at the right edge of this chunk = (J, -eta) of the NEXT lane's suffix
+  // ---- (2) inclusive scan: S_l <- g_l (x) g_{l-1} (x) ... (x) g_0  (lane l-1 holds the LATER chunk).
+  // Combining with the identity reproduces the left operand exactly, so lanes without a partner need
+  // no select.  Four levels inside the 16-lane rows, then the row totals into the following rows.
+  auto level = [&](auto ctrl, auto rows) __attribute__((always_inline)) {
+    ric_fetch_dpp<decltype(ctrl)::value, decltype(rows)::value, n>(T, S);
+    ric_combine(U, S, T);
+    S = U;
+  };
+  using std::integral_constant;
+  level(integral_constant<int, 0x111>{}, integral_constant<int, 0xF>{});   // row_shr:1
+  level(integral_constant<int, 0x112>{}, integral_constant<int, 0xF>{});   // row_shr:2
+  level(integral_constant<int, 0x114>{}, integral_constant<int, 0xF>{});   // row_shr:4
+  level(integral_constant<int, 0x118>{}, integral_constant<int, 0xF>{});   // row_shr:8
+  level(integral_constant<int, 0x142>{}, integral_constant<int, 0xA>{});   // row_bcast:15 -> rows 1, 3
+  level(integral_constant<int, 0x143>{}, integral_constant<int, 0xC>{});   // row_bcast:31 -> rows 2, 3
+  // value function at the right edge of this chunk = (J, -eta) of the scan value one lane down
   double Vx[n], Vxx[n][n];
 #pragma unroll
   for (int i = 0; i < n; ++i) {
-    Vx[i] = -lane_read_f64(S.e[i], lane + 1);
+    Vx[i] = -dpp_f64_or_zero<0x138, 0xF>(S.e[i]);                          // wave_shr:1
 #pragma unroll
-    for (int j = 0; j < n; ++j) Vxx[i][j] = lane_read_f64(S.J[i][j], lane + 1);
+    for (int j = 0; j < n; ++j) Vxx[i][j] = dpp_f64_or_zero<0x138, 0xF>(S.J[i][j]);
   }
   // ---- (3) the reference recursion over this lane's own steps
   int t_hi = e0 + chunk - 1;                                // last element of the chunk
