@@ -492,6 +492,52 @@ __device__ inline bool rollout_newton_impl(const WS& w, const KArgs& a, const do
     for (int i = 0; i < n; ++i) { xb[k][i] = g[Ly::XB + i]; Kk[k][i] = g[Ly::KK + i]; X[k][i] = (t == 0) ? x0r[i] : xb[k][i]; }
     dd[k] = g[Ly::UB] - 1.0 * g[Ly::KAP];                   // u_bar - eps kappa, eps = 1 (ilqr.py:313)
   }
+#ifndef MI_NEWTON_NO_PREDICTOR
+  // Predictor: the first guess is the trajectory the backward pass itself predicts, the linearized
+  // closed loop  dx_{t+1} = (fx_t - fu_t K_t) dx_t - fu_t kappa_t  around the nominal one (the same
+  // scan, 6 multiply-adds per step instead of a Dual2 model evaluation) - it stands in for the first
+  // Newton sweep.
+  {
+    Aff2 loc[CH], agg;
+    agg.G[0][0] = 0.0; agg.G[0][1] = 0.0; agg.G[1][0] = 0.0; agg.G[1][1] = 0.0; agg.c[0] = 0.0; agg.c[1] = 0.0;
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      const int t = valid[k] ? t0 + k : 0;
+      const double* jr = w.J + t * Ly::JS;
+      const double kap = w.G[t * Ly::GS + Ly::KAP];
+#pragma unroll
+      for (int i = 0; i < n; ++i) {
+        const double fui = jr[Ly::FU + i];
+#pragma unroll
+        for (int j = 0; j < n; ++j) {
+          const double acl = fma(-fui, Kk[k][j], jr[Ly::FX + i * n + j]) - ((i == j) ? 1.0 : 0.0);
+          loc[k].G[i][j] = valid[k] ? acl : 0.0;
+        }
+        loc[k].c[i] = valid[k] ? -fui * kap : 0.0;
+      }
+      Aff2 t_;
+      aff2_compose_dev(t_, loc[k], agg);
+      agg = t_;
+    }
+    Aff2 P = agg;
+    aff2_prefix_dpp(P);
+    const double d0[n] = {x0r[0] - w.G[Ly::XB + 0], x0r[1] - w.G[Ly::XB + 1]};   // MPC re-solves move x0
+    double ds[n];
+#pragma unroll
+    for (int i = 0; i < n; ++i) {
+      const double ye = fma(P.G[i][0], d0[0], fma(P.G[i][1], d0[1], P.c[i] + d0[i]));
+      const double yp = dpp_f64_or_zero<0x138, 0xF>(ye);                         // wave_shr:1
+      ds[i] = (lane == 0) ? d0[i] : yp;
+    }
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      X[k][0] = xb[k][0] + ds[0]; X[k][1] = xb[k][1] + ds[1];
+      const double n0 = fma(loc[k].G[0][0], ds[0], fma(loc[k].G[0][1], ds[1], loc[k].c[0] + ds[0]));
+      const double n1 = fma(loc[k].G[1][0], ds[0], fma(loc[k].G[1][1], ds[1], loc[k].c[1] + ds[1]));
+      ds[0] = n0; ds[1] = n1;
+    }
+  }
+#endif
   // Stop when a sweep moved the guess by less than kTol: the iteration is quadratic (error after a
   // sweep ~ 0.03 x the squared error before it, measured on C2), the update of a sweep IS the error
   // before it, so an update < 1e-7 leaves an error < 1e-15 - round-off.
@@ -625,9 +671,18 @@ __device__ inline bool linesearch(const WS& w, const Consts<M>& c, const KArgs& 
       // not at the first iteration of a solve (L_last = inf: no useful guess of the trajectory yet)
       if (a.newton_rollout && L_last < __builtin_inf()) done = rollout_newton<M>(w, a, x0r);
     }
+#ifdef MI_PROF_NEWTON
+    const long long pr0 = clock64();
+#endif
     if (!done) rollout<M, false>(w, c, a, x0r, 1.0, lane == 0 ? 0 : -1, L, ex);
     wave_sync();
+#ifdef MI_PROF_NEWTON
+    const long long pr1 = clock64();
+#endif
     traj_cost<M>(w, c, 1.0, L, ex);
+#ifdef MI_PROF_NEWTON
+    if constexpr (M::n == 2 && M::m == 1) { if (!done && lane == 0) { mi_dbg_vals[0] = (double)(pr1 - pr0); mi_dbg_vals[1] = 0; mi_dbg_vals[2] = (double)(clock64() - pr1); } }
+#endif
     if ((L_last - L) > a.gamma * ex) {                         // ilqr.py:330-331
       L_out = L;
       eps_out = 1.0;
