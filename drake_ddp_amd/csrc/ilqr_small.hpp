@@ -474,7 +474,7 @@ __device__ __forceinline__ void aff2_prefix_dpp(Aff2& P) {
 }
 
 template <class M, int CH>
-__device__ inline bool rollout_newton_impl(const WS& w, const KArgs& a, const double* x0r) {
+__device__ inline bool rollout_newton_impl(const WS& w, const KArgs& a, const double* x0r, double eps) {
   constexpr int n = 2, m = 1;
   static_assert(M::n == 2 && M::m == 1, "2-state closed loop");
   using Ly = Lay<n, m>;
@@ -490,7 +490,7 @@ __device__ inline bool rollout_newton_impl(const WS& w, const KArgs& a, const do
     const double* g = w.G + (valid[k] ? t : 0) * Ly::GS;
 #pragma unroll
     for (int i = 0; i < n; ++i) { xb[k][i] = g[Ly::XB + i]; Kk[k][i] = g[Ly::KK + i]; X[k][i] = (t == 0) ? x0r[i] : xb[k][i]; }
-    dd[k] = g[Ly::UB] - 1.0 * g[Ly::KAP];                   // u_bar - eps kappa, eps = 1 (ilqr.py:313)
+    dd[k] = g[Ly::UB] - eps * g[Ly::KAP];                   // u_bar - eps kappa (ilqr.py:313)
   }
 #ifndef MI_NEWTON_NO_PREDICTOR
   // Predictor: the first guess is the trajectory the backward pass itself predicts, the linearized
@@ -504,7 +504,7 @@ __device__ inline bool rollout_newton_impl(const WS& w, const KArgs& a, const do
     for (int k = 0; k < CH; ++k) {
       const int t = valid[k] ? t0 + k : 0;
       const double* jr = w.J + t * Ly::JS;
-      const double kap = w.G[t * Ly::GS + Ly::KAP];
+      const double kap = eps * w.G[t * Ly::GS + Ly::KAP];
 #pragma unroll
       for (int i = 0; i < n; ++i) {
         const double fui = jr[Ly::FU + i];
@@ -638,12 +638,15 @@ __device__ inline bool rollout_newton_impl(const WS& w, const KArgs& a, const do
 }
 
 template <class M>
-__device__ inline bool rollout_newton(const WS& w, const KArgs& a, const double* x0r) {
+__device__ __forceinline__ bool newton_capable(const WS& w, const KArgs& a) {
+  // four steps per lane: horizons up to N = 257
+  if constexpr (M::n == 2 && M::m == 1) return a.newton_rollout != 0 && w.N - 1 <= 64 * 4;
+  return false;
+}
+template <class M>
+__device__ inline bool rollout_newton(const WS& w, const KArgs& a, const double* x0r, double eps) {
   if constexpr (M::n == 2 && M::m == 1) {
-    const int steps = w.N - 1;
-    // four steps per lane: horizons up to N = 257 (a second instantiation with eight would raise the
-    // whole kernel's register allocation past two resident waves per SIMD)
-    if (steps <= 64 * 4) return rollout_newton_impl<M, 4>(w, a, x0r);
+    if (newton_capable<M>(w, a)) return rollout_newton_impl<M, 4>(w, a, x0r, eps);
   }
   return false;
 }
@@ -664,33 +667,35 @@ __device__ inline bool linesearch(const WS& w, const Consts<M>& c, const KArgs& 
   const int lane = threadIdx.x;
   int base = 0;
   double eps_base = 1.0;
+  // the stored nominal trajectory is a usable first guess except at the first iteration of a solve
+  const bool newton = newton_capable<M>(w, a) && L_last < __builtin_inf();
   if (optimistic) {
     double L, ex;
-    bool done = false;
-    if constexpr (M::n == 2 && M::m == 1) {
-      // not at the first iteration of a solve (L_last = inf: no useful guess of the trajectory yet)
-      if (a.newton_rollout && L_last < __builtin_inf()) done = rollout_newton<M>(w, a, x0r);
+    const bool done = newton && rollout_newton<M>(w, a, x0r, 1.0);
+    // Newton tried and not converged (a step that large is about to be rejected anyway): no second,
+    // sequential attempt at eps = 1 - the candidate pass below has it in lane 0
+    if (done || !newton) {
+#ifdef MI_PROF_NEWTON
+      const long long pr0 = clock64();
+#endif
+      if (!done) rollout<M, false>(w, c, a, x0r, 1.0, lane == 0 ? 0 : -1, L, ex);
+      wave_sync();
+#ifdef MI_PROF_NEWTON
+      const long long pr1 = clock64();
+#endif
+      traj_cost<M>(w, c, 1.0, L, ex);
+#ifdef MI_PROF_NEWTON
+      if constexpr (M::n == 2 && M::m == 1) { if (!done && lane == 0) { mi_dbg_vals[0] = (double)(pr1 - pr0); mi_dbg_vals[1] = 0; mi_dbg_vals[2] = (double)(clock64() - pr1); } }
+#endif
+      if ((L_last - L) > a.gamma * ex) {                         // ilqr.py:330-331
+        L_out = L;
+        eps_out = 1.0;
+        trials = 1;
+        slot_out = 0;
+        return true;
+      }
+      wave_sync();
     }
-#ifdef MI_PROF_NEWTON
-    const long long pr0 = clock64();
-#endif
-    if (!done) rollout<M, false>(w, c, a, x0r, 1.0, lane == 0 ? 0 : -1, L, ex);
-    wave_sync();
-#ifdef MI_PROF_NEWTON
-    const long long pr1 = clock64();
-#endif
-    traj_cost<M>(w, c, 1.0, L, ex);
-#ifdef MI_PROF_NEWTON
-    if constexpr (M::n == 2 && M::m == 1) { if (!done && lane == 0) { mi_dbg_vals[0] = (double)(pr1 - pr0); mi_dbg_vals[1] = 0; mi_dbg_vals[2] = (double)(clock64() - pr1); } }
-#endif
-    if ((L_last - L) > a.gamma * ex) {                         // ilqr.py:330-331
-      L_out = L;
-      eps_out = 1.0;
-      trials = 1;
-      slot_out = 0;
-      return true;
-    }
-    wave_sync();
   }
   for (;;) {
     double eps = eps_base;
@@ -711,7 +716,22 @@ __device__ inline bool linesearch(const WS& w, const Consts<M>& c, const KArgs& 
         slot_out = k;
         return true;
       }
-      // candidate base+k wins: re-run with it in lane 0 so its trajectory is stored
+      // candidate base+k wins and its trajectory was not kept: roll it out once more, stored - parallel
+      // in time when that converges (the cost is then re-evaluated on the stored trajectory) ...
+      if (newton) {
+        const double eps_k = __shfl(eps, k);
+        wave_sync();
+        if (rollout_newton<M>(w, a, x0r, eps_k)) {
+          wave_sync();
+          double ex_;
+          traj_cost<M>(w, c, eps_k, L_out, ex_);
+          eps_out = eps_k;
+          trials = base + k + 1;
+          slot_out = 0;
+          return true;
+        }
+      }
+      // ... otherwise by another pass with it in lane 0
       for (int i = 0; i < k; ++i) eps_base *= a.beta;
       base += k;
       wave_sync();
@@ -1544,6 +1564,8 @@ __global__ void __launch_bounds__(256) ilqr_small_kernel(const KArgs a) {
     return;
   }
   lds_vint_t* team_cmd = (lds_vint_t*)w.aux;
+  // setInterval with minN = 1 (the default, ilqr.py:396): every step is a key-point, no list, no interpolation
+  const bool every_step = (MODE == MODE_SOLVE || MODE == MODE_MPC) && a.kp_method == MI_KP_SET_INTERVAL && a.minN == 1;
   const size_t oX = (size_t)b * n * N, oU = (size_t)b * m * (N - 1), oK = (size_t)b * m * n * (N - 1);
   const size_t oFx = (size_t)b * n * n * (N - 1), oFu = (size_t)b * n * m * (N - 1), oT = (size_t)b * (N - 1);
 
@@ -1644,7 +1666,8 @@ __global__ void __launch_bounds__(256) ilqr_small_kernel(const KArgs a) {
       double L_new, eps; int trials, slot = 0;
       const long long c0 = clock64();
       const bool ok = linesearch<M>(w, c, a, x0r, L, optimistic, L_new, eps, trials, slot);
-      optimistic = ok && trials == 1;
+      // expect eps = 1 next time if it was accepted now - or whenever the attempt is the cheap one
+      optimistic = (ok && trials == 1) || newton_capable<M>(w, a);
       ls_total += trials;
       if (!ok) { status = MI_STATUS_LINESEARCH_FAILED; break; }
       wave_sync();
@@ -1657,6 +1680,10 @@ __global__ void __launch_bounds__(256) ilqr_small_kernel(const KArgs a) {
         team_barrier();
         jac_rounds<M, JAC>(w, a, 0, team, lane);
         team_barrier();
+      } else if (every_step) {                                    // same, without helpers or the key-point list
+        nk = N - 1;
+        jac_rounds<M, JAC>(w, a, 0, 1, lane);
+        wave_sync();
       } else {
         nk = linearize<M, JAC>(w, a);                             // at the ACCEPTED trajectory (:370)
       }
@@ -1695,6 +1722,8 @@ __global__ void __launch_bounds__(256) ilqr_small_kernel(const KArgs a) {
   if (team > 1) {
     if (lane == 0) team_cmd[0] = TEAM_CMD_EXIT;
     team_barrier();
+  }
+  if (every_step && (MODE == MODE_SOLVE || MODE == MODE_MPC)) {
     for (int i = lane; i < N - 1; i += 64) w.kp[i] = i;          // what keypoints_set_interval(minN = 1) lists
   }
   wave_sync();
