@@ -410,6 +410,35 @@ __device__ inline void traj_cost(const WS& w, const Consts<M>& c, double eps, do
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ double lane_read_f64(double v, int src);
 
+// One column of [fx | fu] at (x, u): central differences (the build's stand-in for AutoDiff,
+// ilqr.py:233-272) or one forward-mode dual evaluation.
+template <class M, int JAC>
+__device__ __forceinline__ void jac_column(const double (&x)[M::n], const double (&u)[M::m], int col, const KArgs& a,
+                                           double (&d)[M::n]) {
+  constexpr int n = M::n, m = M::m;
+  if (JAC == MI_JAC_FD_CENTRAL) {
+    const double h = a.fd_h, inv2h = 1.0 / (2.0 * h);
+    double xp[n], up[m], xm[n], um[m], fp[n], fm_[n];
+#pragma unroll
+    for (int i = 0; i < n; ++i) { xp[i] = (col == i) ? x[i] + h : x[i]; xm[i] = (col == i) ? x[i] - h : x[i]; }
+#pragma unroll
+    for (int k = 0; k < m; ++k) { up[k] = (col == n + k) ? u[k] + h : u[k]; um[k] = (col == n + k) ? u[k] - h : u[k]; }
+    M::template step<double>(xp, up, fp, a.params, a.dt);
+    M::template step<double>(xm, um, fm_, a.params, a.dt);
+#pragma unroll
+    for (int i = 0; i < n; ++i) d[i] = (fp[i] - fm_[i]) * inv2h;
+  } else {
+    Dual1 xd[n], ud[m], fd[n];
+#pragma unroll
+    for (int i = 0; i < n; ++i) xd[i] = Dual1(x[i], (col == i) ? 1.0 : 0.0);
+#pragma unroll
+    for (int k = 0; k < m; ++k) ud[k] = Dual1(u[k], (col == n + k) ? 1.0 : 0.0);
+    M::template step<Dual1>(xd, ud, fd, a.params, a.dt);
+#pragma unroll
+    for (int i = 0; i < n; ++i) d[i] = fd[i].d;
+  }
+}
+
 #ifdef MI_PROF_NEWTON
 __device__ double mi_dbg_vals[8];
 #endif
@@ -473,8 +502,17 @@ __device__ __forceinline__ void aff2_prefix_dpp(Aff2& P) {
   aff2_prefix_level<0x143, 0xC>(P);     // row_bcast:31 into rows 2 and 3
 }
 
-template <class M, int CH>
-__device__ inline bool rollout_newton_impl(const WS& w, const KArgs& a, const double* x0r, double eps) {
+// Outcome of the time-parallel rollout.  With `fuse` = 0 it only stores the trial trajectory in T
+// (NEWTON_STORED; the caller evaluates the cost).  With fuse >= 1 the final pass also sums the cost
+// from its registers (ilqr.py:325-327), applies the acceptance test (:330-331) and, if accepted,
+// writes the trajectory straight into the nominal records (:375-376) - no T records, no separate
+// cost and commit passes; fuse = 2 additionally differentiates the dynamics at every step it holds
+// (:380-415 with every step a key-point), again from registers.
+enum { NEWTON_FAILED = 0, NEWTON_STORED = 1, NEWTON_REJECTED = 2, NEWTON_ACCEPTED = 3 };
+
+template <class M, int JAC, int CH>
+__device__ inline int rollout_newton_impl(const WS& w, const Consts<M>& c, const KArgs& a, const double* x0r, double eps,
+                                          int fuse, double L_last, double& L_out) {
   constexpr int n = 2, m = 1;
   static_assert(M::n == 2 && M::m == 1, "2-state closed loop");
   using Ly = Lay<n, m>;
@@ -610,31 +648,87 @@ __device__ inline bool rollout_newton_impl(const WS& w, const KArgs& a, const do
   const long long pn1 = clock64();
   if (lane == 0) { mi_dbg_vals[0] = (double)(pn1 - pn0); mi_dbg_vals[1] = nsw; }
 #endif
-  if (!converged) return false;
+  if (!converged) return NEWTON_FAILED;
   // final pass: the plain fp64 step over this lane's chunk from its converged start (ilqr.py:313-316)
-  if (lane == 0) {
+  if (fuse == 0) {
+    if (lane == 0) {
 #pragma unroll
-    for (int i = 0; i < n; ++i) w.T[Ly::XN + i] = x0r[i];
+      for (int i = 0; i < n; ++i) w.T[Ly::XN + i] = x0r[i];
+    }
+    double x[n] = {X[0][0], X[0][1]};
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      if (valid[k]) {
+        const int t = t0 + k;
+        double u[m], xn[n];
+        u[0] = dd[k] - (Kk[k][0] * (x[0] - xb[k][0]) + Kk[k][1] * (x[1] - xb[k][1]));
+        M::template step<double>(x, u, xn, a.params, a.dt);
+        double* tr = w.T + t * Ly::TS;
+        tr[Ly::UN] = u[0];
+        tr[Ly::TS + Ly::XN + 0] = xn[0];
+        tr[Ly::TS + Ly::XN + 1] = xn[1];
+        x[0] = xn[0]; x[1] = xn[1];
+      }
+    }
+#ifdef MI_PROF_NEWTON
+    if (lane == 0) mi_dbg_vals[2] = (double)(clock64() - pn1);
+#endif
+    return NEWTON_STORED;
   }
-  double x[n] = {X[0][0], X[0][1]};
+  double xk[CH][n], uk[CH][m], xlast[n] = {0.0, 0.0};
+  double cost = 0.0, dvs = 0.0;
+  {
+    double x[n] = {X[0][0], X[0][1]};
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      xk[k][0] = x[0]; xk[k][1] = x[1]; uk[k][0] = 0.0;
+      if (valid[k]) {
+        const int t = t0 + k;
+        double u[m], xn[n];
+        u[0] = dd[k] - (Kk[k][0] * (x[0] - xb[k][0]) + Kk[k][1] * (x[1] - xb[k][1]));
+        M::template step<double>(x, u, xn, a.params, a.dt);
+        uk[k][0] = u[0];
+        cost += stage_cost<M>(c, x, u);                        // ilqr.py:325
+        dvs += w.G[t * Ly::GS + Ly::DV];                       // :326
+        if (t == steps - 1) {                                  // :327
+          cost += terminal_cost<M>(c, xn);
+          xlast[0] = xn[0]; xlast[1] = xn[1];
+        }
+        x[0] = xn[0]; x[1] = xn[1];
+      }
+    }
+  }
+  const double L = wave_sum(cost);
+  const double ex = -eps * (1.0 - eps / 2.0) * wave_sum(dvs);
+  L_out = L;
+  if (!((L_last - L) > a.gamma * ex)) return NEWTON_REJECTED;  // ilqr.py:330-331
 #pragma unroll
   for (int k = 0; k < CH; ++k) {
     if (valid[k]) {
       const int t = t0 + k;
-      double u[m], xn[n];
-      u[0] = dd[k] - (Kk[k][0] * (x[0] - xb[k][0]) + Kk[k][1] * (x[1] - xb[k][1]));
-      M::template step<double>(x, u, xn, a.params, a.dt);
-      double* tr = w.T + t * Ly::TS;
-      tr[Ly::UN] = u[0];
-      tr[Ly::TS + Ly::XN + 0] = xn[0];
-      tr[Ly::TS + Ly::XN + 1] = xn[1];
-      x[0] = xn[0]; x[1] = xn[1];
+      double* g = w.G + t * Ly::GS;
+      g[Ly::XB + 0] = xk[k][0]; g[Ly::XB + 1] = xk[k][1];
+      g[Ly::UB] = uk[k][0];
+      if (t == steps - 1) { g[Ly::GS + Ly::XB + 0] = xlast[0]; g[Ly::GS + Ly::XB + 1] = xlast[1]; }
+      if (fuse == 2) {
+        double* j = w.J + t * Ly::JS;
+#pragma unroll
+        for (int col = 0; col < n + m; ++col) {
+          double d[n];
+          jac_column<M, JAC>(xk[k], uk[k], col, a, d);
+#pragma unroll
+          for (int i = 0; i < n; ++i) {
+            if (col < n) j[Ly::FX + i * n + col] = d[i];
+            else j[Ly::FU + i * m + (col - n)] = d[i];
+          }
+        }
+      }
     }
   }
 #ifdef MI_PROF_NEWTON
   if (lane == 0) mi_dbg_vals[2] = (double)(clock64() - pn1);
 #endif
-  return true;
+  return NEWTON_ACCEPTED;
 }
 
 template <class M>
@@ -643,12 +737,13 @@ __device__ __forceinline__ bool newton_capable(const WS& w, const KArgs& a) {
   if constexpr (M::n == 2 && M::m == 1) return a.newton_rollout != 0 && w.N - 1 <= 64 * 4;
   return false;
 }
-template <class M>
-__device__ inline bool rollout_newton(const WS& w, const KArgs& a, const double* x0r, double eps) {
+template <class M, int JAC>
+__device__ inline int rollout_newton(const WS& w, const Consts<M>& c, const KArgs& a, const double* x0r, double eps,
+                                     int fuse, double L_last, double& L_out) {
   if constexpr (M::n == 2 && M::m == 1) {
-    if (newton_capable<M>(w, a)) return rollout_newton_impl<M, 4>(w, a, x0r, eps);
+    if (newton_capable<M>(w, a)) return rollout_newton_impl<M, JAC, 4>(w, c, a, x0r, eps, fuse, L_last, L_out);
   }
-  return false;
+  return NEWTON_FAILED;
 }
 
 // ---------------------------------------------------------------------------
@@ -661,9 +756,14 @@ __device__ inline bool rollout_newton(const WS& w, const KArgs& a, const double*
 // arithmetic (a fifth of the sequential instruction stream) and its cost is evaluated
 // time-parallel afterwards; only if that trial is rejected does the speculative 64-candidate
 // pass run.  The accepted candidate is the same either way.
-template <class M>
+// `fuse` (see rollout_newton_impl): what the time-parallel rollout may do beyond the trial itself;
+// `fused_out` reports what it did for the accepted trial (0: trajectory in T slot `slot_out`;
+// 1: already committed to the nominal records; 2: committed and linearized).
+template <class M, int JAC>
 __device__ inline bool linesearch(const WS& w, const Consts<M>& c, const KArgs& a, const double* x0r,
-                                  double L_last, bool optimistic, double& L_out, double& eps_out, int& trials, int& slot_out) {
+                                  double L_last, bool optimistic, int fuse, double& L_out, double& eps_out, int& trials,
+                                  int& slot_out, int& fused_out) {
+  fused_out = 0;
   const int lane = threadIdx.x;
   int base = 0;
   double eps_base = 1.0;
@@ -671,9 +771,18 @@ __device__ inline bool linesearch(const WS& w, const Consts<M>& c, const KArgs& 
   const bool newton = newton_capable<M>(w, a) && L_last < __builtin_inf();
   if (optimistic) {
     double L, ex;
-    const bool done = newton && rollout_newton<M>(w, a, x0r, 1.0);
-    // Newton tried and not converged (a step that large is about to be rejected anyway): no second,
-    // sequential attempt at eps = 1 - the candidate pass below has it in lane 0
+    const int nr = newton ? rollout_newton<M, JAC>(w, c, a, x0r, 1.0, fuse, L_last, L) : NEWTON_FAILED;
+    if (nr == NEWTON_ACCEPTED) {
+      L_out = L;
+      eps_out = 1.0;
+      trials = 1;
+      slot_out = 0;
+      fused_out = fuse;
+      return true;
+    }
+    const bool done = nr == NEWTON_STORED;
+    // Newton tried and not converged (a step that large is about to be rejected anyway) or rejected:
+    // no second, sequential attempt at eps = 1 - the candidate pass below has it in lane 0
     if (done || !newton) {
 #ifdef MI_PROF_NEWTON
       const long long pr0 = clock64();
@@ -721,13 +830,18 @@ __device__ inline bool linesearch(const WS& w, const Consts<M>& c, const KArgs& 
       if (newton) {
         const double eps_k = __shfl(eps, k);
         wave_sync();
-        if (rollout_newton<M>(w, a, x0r, eps_k)) {
+        // (the sequential rollout of lane k already passed the acceptance test: L_last = inf here)
+        const int nr = rollout_newton<M, JAC>(w, c, a, x0r, eps_k, fuse, __builtin_inf(), L_out);
+        if (nr == NEWTON_STORED) {
           wave_sync();
           double ex_;
           traj_cost<M>(w, c, eps_k, L_out, ex_);
+        }
+        if (nr == NEWTON_STORED || nr == NEWTON_ACCEPTED) {
           eps_out = eps_k;
           trials = base + k + 1;
           slot_out = 0;
+          fused_out = (nr == NEWTON_ACCEPTED) ? fuse : 0;
           return true;
         }
       }
@@ -774,33 +888,13 @@ template <class M, int JAC>
 __device__ __forceinline__ void jac_item(const WS& w, const KArgs& a, int t, int col) {
   constexpr int n = M::n, m = M::m;
   using Ly = Lay<n, m>;
-  const double h = a.fd_h, inv2h = 1.0 / (2.0 * h);
   const double* g = w.G + t * Ly::GS;
   double x[n], u[m], d[n];
 #pragma unroll
   for (int i = 0; i < n; ++i) x[i] = g[Ly::XB + i];
 #pragma unroll
   for (int k = 0; k < m; ++k) u[k] = g[Ly::UB + k];
-  if (JAC == MI_JAC_FD_CENTRAL) {
-    double xp[n], up[m], xm[n], um[m], fp[n], fm_[n];
-#pragma unroll
-    for (int i = 0; i < n; ++i) { xp[i] = (col == i) ? x[i] + h : x[i]; xm[i] = (col == i) ? x[i] - h : x[i]; }
-#pragma unroll
-    for (int k = 0; k < m; ++k) { up[k] = (col == n + k) ? u[k] + h : u[k]; um[k] = (col == n + k) ? u[k] - h : u[k]; }
-    M::template step<double>(xp, up, fp, a.params, a.dt);
-    M::template step<double>(xm, um, fm_, a.params, a.dt);
-#pragma unroll
-    for (int i = 0; i < n; ++i) d[i] = (fp[i] - fm_[i]) * inv2h;
-  } else {
-    Dual1 xd[n], ud[m], fd[n];
-#pragma unroll
-    for (int i = 0; i < n; ++i) xd[i] = Dual1(x[i], (col == i) ? 1.0 : 0.0);
-#pragma unroll
-    for (int k = 0; k < m; ++k) ud[k] = Dual1(u[k], (col == n + k) ? 1.0 : 0.0);
-    M::template step<Dual1>(xd, ud, fd, a.params, a.dt);
-#pragma unroll
-    for (int i = 0; i < n; ++i) d[i] = fd[i].d;
-  }
+  jac_column<M, JAC>(x, u, col, a, d);
   double* j = w.J + t * Ly::JS;
   if (col < n) {
 #pragma unroll
@@ -1566,6 +1660,9 @@ __global__ void __launch_bounds__(256) ilqr_small_kernel(const KArgs a) {
   lds_vint_t* team_cmd = (lds_vint_t*)w.aux;
   // setInterval with minN = 1 (the default, ilqr.py:396): every step is a key-point, no list, no interpolation
   const bool every_step = (MODE == MODE_SOLVE || MODE == MODE_MPC) && a.kp_method == MI_KP_SET_INTERVAL && a.minN == 1;
+  // what the time-parallel rollout folds in (rollout_newton_impl): cost + commit, and the linearization
+  // unless helper wavefronts share that
+  const int fuse = (MODE == MODE_SOLVE || MODE == MODE_MPC) ? ((every_step && team == 1) ? 2 : 1) : 0;
   const size_t oX = (size_t)b * n * N, oU = (size_t)b * m * (N - 1), oK = (size_t)b * m * n * (N - 1);
   const size_t oFx = (size_t)b * n * n * (N - 1), oFu = (size_t)b * n * m * (N - 1), oT = (size_t)b * (N - 1);
 
@@ -1665,16 +1762,19 @@ __global__ void __launch_bounds__(256) ilqr_small_kernel(const KArgs a) {
       if (it_this >= a.max_iters) { status = MI_STATUS_MAX_ITERS; break; }
       double L_new, eps; int trials, slot = 0;
       const long long c0 = clock64();
-      const bool ok = linesearch<M>(w, c, a, x0r, L, optimistic, L_new, eps, trials, slot);
+      int fused = 0;
+      const bool ok = linesearch<M, JAC>(w, c, a, x0r, L, optimistic, fuse, L_new, eps, trials, slot, fused);
       // expect eps = 1 next time if it was accepted now - or whenever the attempt is the cheap one
       optimistic = (ok && trials == 1) || newton_capable<M>(w, a);
       ls_total += trials;
       if (!ok) { status = MI_STATUS_LINESEARCH_FAILED; break; }
       wave_sync();
       const long long c1 = clock64();
-      commit_trial<n, m>(w, slot);                                // u_bar <- u, x_bar <- x (:375-376)
+      if (fused == 0) commit_trial<n, m>(w, slot);                // u_bar <- u, x_bar <- x (:375-376)
       wave_sync();
-      if (team > 1) {
+      if (fused == 2) {
+        nk = N - 1;                                               // linearized by the rollout itself
+      } else if (team > 1) {
         nk = N - 1;                                               // every step is a key-point (:396, :414)
         if (lane == 0) team_cmd[0] = TEAM_CMD_LINEARIZE;
         team_barrier();
