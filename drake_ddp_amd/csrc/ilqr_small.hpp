@@ -508,6 +508,9 @@ __device__ __forceinline__ void aff2_prefix_dpp(Aff2& P) {
 // writes the trajectory straight into the nominal records (:375-376) - no T records, no separate
 // cost and commit passes; fuse = 2 additionally differentiates the dynamics at every step it holds
 // (:380-415 with every step a key-point), again from registers.
+#ifndef MI_NEWTON_MAX_SWEEPS
+#define MI_NEWTON_MAX_SWEEPS 7
+#endif
 enum { NEWTON_FAILED = 0, NEWTON_STORED = 1, NEWTON_REJECTED = 2, NEWTON_ACCEPTED = 3 };
 
 template <class M, int JAC, int CH>
@@ -579,7 +582,7 @@ __device__ inline int rollout_newton_impl(const WS& w, const Consts<M>& c, const
   // Stop when a sweep moved the guess by less than kTol: the iteration is quadratic (error after a
   // sweep ~ 0.03 x the squared error before it, measured on C2), the update of a sweep IS the error
   // before it, so an update < 1e-7 leaves an error < 1e-15 - round-off.
-  constexpr int kMaxSweeps = 7;
+  constexpr int kMaxSweeps = MI_NEWTON_MAX_SWEEPS;
   constexpr double kTol = 1e-7;
   bool converged = false;
 #ifdef MI_PROF_NEWTON

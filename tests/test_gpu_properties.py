@@ -308,3 +308,60 @@ np.savez(sys.argv[1], x=x, u=u, L=L, K=s.K, kappa=s.kappa, dV=s.dV_coeff, it=s.i
     assert np.max(rel_L) < 1e-8 and np.median(rel_L) < 1e-10
     assert np.max(np.abs(par["x"] - seq["x"])) < 1e-6 and np.max(np.abs(par["u"] - seq["u"])) < 1e-6
     assert np.max(np.abs(par["K"] - seq["K"])) < 1e-5 * np.max(np.abs(seq["K"]))
+
+
+@pytest.mark.parametrize("N", [4, 5, 64, 66, 130, 254, 257, 258, 300])
+def test_pendulum_horizons_around_the_lane_chunk_edges(N):
+    """The time-parallel passes deal 1..4 consecutive steps to each lane (up to N = 257; longer
+    horizons take the sequential rollout and a longer-chunk sweep): horizons that leave lanes empty,
+    fill them exactly, or spill over - every problem against the C oracle."""
+    from oracle import c_oracle, models_np as M
+    rng = np.random.default_rng(N)
+    dt = 2.0 / 200
+    prob = dict(model_id=0, dt=dt, N=N, x_nom=np.array([np.pi, 0.0]), Q=dt * 0.01 * np.diag([0.0, 1.0]),
+                R=dt * 0.01 * np.eye(1), Qf=100.0 * np.eye(2), delta=1e-3, beta=0.8, gamma=0.0)
+    B = 48
+    x0 = np.stack([rng.uniform(-np.pi, np.pi, B), rng.uniform(-1, 1, B)], axis=1)
+    ug = rng.uniform(-0.2, 0.2, (B, 1, N - 1))
+    s = make_solver(prob, B=B, jac="fd")
+    s.SetInitialState(x0)
+    s.SetInitialGuess(ug)
+    x, u, _, L = s.Solve()
+    r = c_oracle.solve_batch(M.Model(0, dt), prob, x0, ug)
+    ok = (r["status"] == 0) & (s.status == 0)
+    assert ok.mean() > 0.95
+    same = ok & (s.iterations == r["iters"]) & (s.ls_trials == r["ls"])
+    assert same.mean() > 0.9, (same.mean(), s.iterations[:8], r["iters"][:8])
+    assert np.max(np.abs(L[same] - r["cost"][same]) / np.abs(r["cost"][same])) < 1e-7
+    # (the shortest horizons need controls ~1e3 to reach the target in 3 steps: relative to the largest entry)
+    for got, want in ((x, r["x_bar"]), (u, r["u_bar"]), (s.K, r["K"])):
+        assert np.max(np.abs(got[same] - want[same])) < 1e-6 * max(1.0, np.max(np.abs(want[same])))
+
+
+def test_pendulum_mpc_on_device_time_parallel_vs_sequential(tmp_path):
+    """MPCRun on the n = 2 path: every re-solve moves x0 off the stored nominal trajectory (the
+    predictor and the Newton sweeps start from x0 - x_bar_0 != 0) and restarts with L = inf.  Same
+    iteration counts and logs as the kernels forced to the sequential passes."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = f"""
+import sys, numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, 'tests')!r})
+from test_gpu_parity import make_solver
+dt = 0.02
+prob = dict(model_id=0, dt=dt, N=60, x_nom=np.array([np.pi, 0.0]), Q=dt * np.diag([1.0, 0.1]), R=dt * 0.05 * np.eye(1),
+            Qf=20.0 * np.eye(2), delta=1e-3, beta=0.7, gamma=0.0)
+rng = np.random.default_rng(7)
+B = 40
+x0 = np.stack([rng.uniform(-np.pi, np.pi, B), rng.uniform(-1, 1, B)], axis=1)
+s = make_solver(prob, B=B, jac='fd')
+s.SetInitialState(x0); s.SetInitialGuess(np.zeros((1, prob['N'] - 1)))
+s.Solve()
+s.MPCRun(12, 3)
+np.savez(sys.argv[1], log=s.mpc_log, x=s.x_bar, u=s.u_bar, K=s.K, it=s.iterations, ls=s.ls_trials)
+"""
+    par = _run_variant(script, {}, str(tmp_path / "par.npz"), tmp_path)
+    seq = _run_variant(script, {"MI_ILQR_SEQ_BACKWARD": "1", "MI_ILQR_SEQ_ROLLOUT": "1"}, str(tmp_path / "seq.npz"), tmp_path)
+    same = (par["it"] == seq["it"]) & (par["ls"] == seq["ls"])
+    assert same.mean() > 0.9
+    assert np.allclose(par["log"][same], seq["log"][same], rtol=1e-7, atol=1e-9)
+    assert np.max(np.abs(par["x"][same] - seq["x"][same])) < 1e-6 and np.max(np.abs(par["u"][same] - seq["u"][same])) < 1e-6

@@ -1,17 +1,19 @@
+"""Line-search trial counts per iteration at the C2 shape: which problems backtrack, and how far."""
 import sys, numpy as np
 sys.path.insert(0, ".")
 from drake_ddp_amd import workloads as W
 from drake_ddp_amd.ilqr import BatchedIterativeLQR
 from drake_ddp_amd.models import ModelSystem
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 prob = W.pendulum_problem(); x0 = W.pendulum_batch_x0(B); N = prob["N"]
-if len(sys.argv) > 2:                       # one problem of the batch, alone (the counters are per launch)
-    x0 = x0[int(sys.argv[2]):int(sys.argv[2]) + 1]; B = 1
 s = BatchedIterativeLQR(ModelSystem(prob["model_id"], prob["dt"]), N, B, delta=prob["delta"], beta=prob["beta"], gamma=prob["gamma"])
 s.SetTargetState(prob["x_nom"]); s.SetRunningCost(prob["Q"], prob["R"]); s.SetTerminalCost(prob["Qf"])
 s.SetInitialState(x0); s.SetInitialGuess(np.zeros((1, N - 1)))
 s.Solve()
-h = s.history; it = s.iterations
-for b in sorted(set([0, B // 2, int(np.argmax(it))])):
-    print("problem", b, "iters", it[b], "stage cycles", s.stage_cycles[b].tolist())
-    for i in range(it[b]): print("   it %d: linesearch %6.0f  newton sweeps %6.0f (n=%d)  final pass %5.0f" % (i, *h[b, i]), " ls trials so far", s.ls_trials[b])
+h = s.history; it = s.iterations; cyc = s.stage_cycles
+tr = [h[b, :it[b], 2].astype(int) for b in range(B)]
+allt = np.concatenate(tr)
+print("iterations:", len(allt), " trials histogram:", {int(k): int((allt == k).sum()) for k in sorted(set(allt.tolist()))})
+order = np.argsort(-cyc[:, 3])[:8]
+for b in order:
+    print(f"problem {b}: cycles {cyc[b,3]} iters {it[b]} trials/iter {tr[b].tolist()}")
