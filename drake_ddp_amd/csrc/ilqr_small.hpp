@@ -515,7 +515,7 @@ enum { NEWTON_FAILED = 0, NEWTON_STORED = 1, NEWTON_REJECTED = 2, NEWTON_ACCEPTE
 
 template <class M, int JAC, int CH>
 __device__ inline int rollout_newton_impl(const WS& w, const Consts<M>& c, const KArgs& a, const double* x0r, double eps,
-                                          int fuse, double L_last, double& L_out) {
+                                          int fuse, double L_last, double& L_out, bool coarse) {
   constexpr int n = 2, m = 1;
   static_assert(M::n == 2 && M::m == 1, "2-state closed loop");
   using Ly = Lay<n, m>;
@@ -533,7 +533,33 @@ __device__ inline int rollout_newton_impl(const WS& w, const Consts<M>& c, const
     for (int i = 0; i < n; ++i) { xb[k][i] = g[Ly::XB + i]; Kk[k][i] = g[Ly::KK + i]; X[k][i] = (t == 0) ? x0r[i] : xb[k][i]; }
     dd[k] = g[Ly::UB] - eps * g[Ly::KAP];                   // u_bar - eps kappa (ilqr.py:313)
   }
+  if (coarse) {
+    // First iteration of a cold solve: there is no nominal trajectory to start from.  The guess is a
+    // COARSE sequential rollout - one model step of CH dt per lane chunk, control held at its value at
+    // the chunk start (ceil(steps / CH) dependent steps instead of `steps`) - refined inside every
+    // chunk by the plain steps from the coarse chunk start.  Newton's sweeps then pull the whole
+    // trajectory onto the fine recurrence; not converged -> sequential rollout as before.
+    double xc[n] = {x0r[0], x0r[1]};
+    const int nchunks = (steps + CH - 1) / CH;
+    for (int j = 0; j < nchunks; ++j) {
+      if (lane == j) { X[0][0] = xc[0]; X[0][1] = xc[1]; }
+      const double* g = w.G + (j * CH) * Ly::GS;              // wave-uniform address: LDS broadcast
+      double u[m], xn[n];
+      u[0] = (g[Ly::UB] - eps * g[Ly::KAP]) - (g[Ly::KK + 0] * (xc[0] - g[Ly::XB + 0]) + g[Ly::KK + 1] * (xc[1] - g[Ly::XB + 1]));
+      M::template step<double>(xc, u, xn, a.params, (double)CH * a.dt);
+      xc[0] = xn[0]; xc[1] = xn[1];
+    }
+    if (lane >= nchunks) { X[0][0] = xc[0]; X[0][1] = xc[1]; }
+#pragma unroll
+    for (int k = 0; k + 1 < CH; ++k) {
+      double u[m], xn[n];
+      u[0] = dd[k] - (Kk[k][0] * (X[k][0] - xb[k][0]) + Kk[k][1] * (X[k][1] - xb[k][1]));
+      M::template step<double>(X[k], u, xn, a.params, a.dt);
+      X[k + 1][0] = xn[0]; X[k + 1][1] = xn[1];
+    }
+  }
 #ifndef MI_NEWTON_NO_PREDICTOR
+  else
   // Predictor: the first guess is the trajectory the backward pass itself predicts, the linearized
   // closed loop  dx_{t+1} = (fx_t - fu_t K_t) dx_t - fu_t kappa_t  around the nominal one (the same
   // scan, 6 multiply-adds per step instead of a Dual2 model evaluation) - it stands in for the first
@@ -742,9 +768,9 @@ __device__ __forceinline__ bool newton_capable(const WS& w, const KArgs& a) {
 }
 template <class M, int JAC>
 __device__ inline int rollout_newton(const WS& w, const Consts<M>& c, const KArgs& a, const double* x0r, double eps,
-                                     int fuse, double L_last, double& L_out) {
+                                     int fuse, double L_last, double& L_out, bool coarse = false) {
   if constexpr (M::n == 2 && M::m == 1) {
-    if (newton_capable<M>(w, a)) return rollout_newton_impl<M, JAC, 4>(w, c, a, x0r, eps, fuse, L_last, L_out);
+    if (newton_capable<M>(w, a)) return rollout_newton_impl<M, JAC, 4>(w, c, a, x0r, eps, fuse, L_last, L_out, coarse);
   }
   return NEWTON_FAILED;
 }
@@ -765,7 +791,7 @@ __device__ inline int rollout_newton(const WS& w, const Consts<M>& c, const KArg
 template <class M, int JAC>
 __device__ inline bool linesearch(const WS& w, const Consts<M>& c, const KArgs& a, const double* x0r,
                                   double L_last, bool optimistic, int fuse, double& L_out, double& eps_out, int& trials,
-                                  int& slot_out, int& fused_out) {
+                                  int& slot_out, int& fused_out, bool cold_start = false) {
   fused_out = 0;
   const int lane = threadIdx.x;
   int base = 0;
@@ -774,7 +800,9 @@ __device__ inline bool linesearch(const WS& w, const Consts<M>& c, const KArgs& 
   const bool newton = newton_capable<M>(w, a) && L_last < __builtin_inf();
   if (optimistic) {
     double L, ex;
-    const int nr = newton ? rollout_newton<M, JAC>(w, c, a, x0r, 1.0, fuse, L_last, L) : NEWTON_FAILED;
+    int nr = NEWTON_FAILED;
+    if (newton) nr = rollout_newton<M, JAC>(w, c, a, x0r, 1.0, fuse, L_last, L);
+    else if (cold_start && newton_capable<M>(w, a)) nr = rollout_newton<M, JAC>(w, c, a, x0r, 1.0, fuse, L_last, L, true);
     if (nr == NEWTON_ACCEPTED) {
       L_out = L;
       eps_out = 1.0;
@@ -1766,7 +1794,9 @@ __global__ void __launch_bounds__(256) ilqr_small_kernel(const KArgs a) {
       double L_new, eps; int trials, slot = 0;
       const long long c0 = clock64();
       int fused = 0;
-      const bool ok = linesearch<M, JAC>(w, c, a, x0r, L, optimistic, fuse, L_new, eps, trials, slot, fused);
+      // first iteration of the first solve on all-zero solver state (no gains, no nominal trajectory)
+      const bool cold_start = cold && rs == 0 && it_this == 0 && (MODE == MODE_SOLVE || MODE == MODE_MPC);
+      const bool ok = linesearch<M, JAC>(w, c, a, x0r, L, optimistic, fuse, L_new, eps, trials, slot, fused, cold_start);
       // expect eps = 1 next time if it was accepted now - or whenever the attempt is the cheap one
       optimistic = (ok && trials == 1) || newton_capable<M>(w, a);
       ls_total += trials;
