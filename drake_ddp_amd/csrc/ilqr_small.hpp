@@ -541,13 +541,23 @@ __device__ inline int rollout_newton_impl(const WS& w, const Consts<M>& c, const
     // trajectory onto the fine recurrence; not converged -> sequential rollout as before.
     double xc[n] = {x0r[0], x0r[1]};
     const int nchunks = (steps + CH - 1) / CH;
-    for (int j = 0; j < nchunks; ++j) {
-      if (lane == j) { X[0][0] = xc[0]; X[0][1] = xc[1]; }
+    struct Rec { double xb[n], kk[n], ub, kap; };
+    auto fetch = [&](Rec& r, int j) __attribute__((always_inline)) {
       const double* g = w.G + (j * CH) * Ly::GS;              // wave-uniform address: LDS broadcast
+      r.xb[0] = g[Ly::XB + 0]; r.xb[1] = g[Ly::XB + 1]; r.kk[0] = g[Ly::KK + 0]; r.kk[1] = g[Ly::KK + 1];
+      r.ub = g[Ly::UB]; r.kap = g[Ly::KAP];
+    };
+    Rec cur, nxt;
+    fetch(cur, 0);
+    for (int j = 0; j < nchunks; ++j) {
+      fetch(nxt, j + 1 < nchunks ? j + 1 : j);                // one record ahead of its use
+      __builtin_amdgcn_sched_barrier(0);
+      if (lane == j) { X[0][0] = xc[0]; X[0][1] = xc[1]; }
       double u[m], xn[n];
-      u[0] = (g[Ly::UB] - eps * g[Ly::KAP]) - (g[Ly::KK + 0] * (xc[0] - g[Ly::XB + 0]) + g[Ly::KK + 1] * (xc[1] - g[Ly::XB + 1]));
+      u[0] = (cur.ub - eps * cur.kap) - (cur.kk[0] * (xc[0] - cur.xb[0]) + cur.kk[1] * (xc[1] - cur.xb[1]));
       M::template step<double>(xc, u, xn, a.params, (double)CH * a.dt);
       xc[0] = xn[0]; xc[1] = xn[1];
+      cur = nxt;
     }
     if (lane >= nchunks) { X[0][0] = xc[0]; X[0][1] = xc[1]; }
 #pragma unroll
