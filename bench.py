@@ -269,7 +269,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "ilqr_small_kernel<Pendulum,FD,SOLVE>", "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "note": "dependency-latency-bound: 2(N-1) sequential steps per iteration; state is LDS-resident"},
+                         "note": "issue-latency-bound: one wave per problem, rollout and Riccati sweep as time-parallel scans; state is LDS-resident, the launch lasts as long as its slowest problem"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(prob, x0_all, min(args.cpu_sample, B))
