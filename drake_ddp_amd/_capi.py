@@ -26,7 +26,7 @@ I_ITERS, I_STATUS, I_LS_TRIALS, I_KP_COUNT, I_KP_LIST = 100, 101, 102, 103, 104
 EXPORTS = [
     "mi_ilqr_abi_version", "mi_ilqr_strerror", "mi_ilqr_model_info", "mi_ilqr_create", "mi_ilqr_destroy",
     "mi_ilqr_set_cost", "mi_ilqr_set_initial", "mi_ilqr_reset", "mi_ilqr_rearm_initial_guess",
-    "mi_ilqr_solve", "mi_ilqr_solve_async", "mi_ilqr_collect_stats",
+    "mi_ilqr_solve", "mi_ilqr_solve_async", "mi_ilqr_collect_stats", "mi_ilqr_collect_stats_n",
     "mi_ilqr_rollout", "mi_ilqr_forward", "mi_ilqr_linearize", "mi_ilqr_backward", "mi_ilqr_mpc_shift",
     "mi_ilqr_mpc_run", "mi_ilqr_get_mpc_log",
     "mi_ilqr_get", "mi_ilqr_get_int", "mi_ilqr_set", "mi_ilqr_device_ptr", "mi_ilqr_get_stream",
@@ -86,6 +86,7 @@ def load():
         getattr(lib, name).argtypes = [H]
     lib.mi_ilqr_solve.argtypes = [H, C.POINTER(Stats)]
     lib.mi_ilqr_collect_stats.argtypes = [H, C.POINTER(Stats)]
+    lib.mi_ilqr_collect_stats_n.argtypes = [H, C.c_int32, C.POINTER(Stats)]
     lib.mi_ilqr_rollout.argtypes = [H, C.c_void_p]
     lib.mi_ilqr_forward.argtypes = [H, C.c_void_p]
     lib.mi_ilqr_mpc_shift.argtypes = [H, C.c_int32]

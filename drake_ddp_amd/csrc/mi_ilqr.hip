@@ -32,6 +32,14 @@ struct mi_ilqr {
   mi_ilqr_desc d;
   int n, m, N, B;
   hipStream_t stream = nullptr;
+  // Per-launch records (kernel start/stop events + aggregate statistics) live in a ring, so that up to
+  // kStatsRing solves can be enqueued back to back (mi_ilqr_solve_async) before anything is collected;
+  // ev0/ev1/h_stats/d_stats alias the slot of the most recent launch.
+  static constexpr int kStatsRing = 32;
+  hipEvent_t ring_ev0[kStatsRing] = {}, ring_ev1[kStatsRing] = {};
+  DevStats* h_ring = nullptr;    // pinned host memory, device-mapped
+  DevStats* d_ring = nullptr;    // its device alias
+  long long seq = 0;             // solves enqueued so far
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // double fields
   double *x_bar = nullptr, *u_bar = nullptr, *K = nullptr, *kappa = nullptr, *dV = nullptr, *fx = nullptr, *fu = nullptr;
@@ -52,6 +60,11 @@ struct mi_ilqr {
   int n_store = 1;         // line-search candidate trajectories kept in LDS
   bool batch_minor = false; // lane-per-problem path: state arrays are [t][row][b] in HBM
 };
+
+static inline void select_stats_slot(mi_ilqr* h, int slot) {
+  h->ev0 = h->ring_ev0[slot]; h->ev1 = h->ring_ev1[slot];
+  h->h_stats = h->h_ring + slot; h->d_stats = h->d_ring + slot;
+}
 
 namespace {
 
@@ -538,16 +551,23 @@ int mi_ilqr_create(const mi_ilqr_desc* desc, mi_ilqr_t** out) {
     for (size_t i = 0; i < m; ++i) cm[n * n + i * m + i] = 1.0;
     if (hipMemcpy(h->costmat, cm.data(), cm.size() * 8, hipMemcpyHostToDevice) != hipSuccess) { mi_ilqr_destroy(h); return MI_ILQR_E_HIP; }
   }
-  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
+  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
     mi_ilqr_destroy(h);
     return MI_ILQR_E_HIP;
   }
-  if (hipHostMalloc(reinterpret_cast<void**>(&h->h_stats), sizeof(DevStats), hipHostMallocMapped) != hipSuccess ||
-      hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_stats), h->h_stats, 0) != hipSuccess) {
+  for (int i = 0; i < mi_ilqr::kStatsRing; ++i) {
+    if (hipEventCreate(&h->ring_ev0[i]) != hipSuccess || hipEventCreate(&h->ring_ev1[i]) != hipSuccess) {
+      mi_ilqr_destroy(h);
+      return MI_ILQR_E_HIP;
+    }
+  }
+  if (hipHostMalloc(reinterpret_cast<void**>(&h->h_ring), sizeof(DevStats) * mi_ilqr::kStatsRing, hipHostMallocMapped) != hipSuccess ||
+      hipHostGetDevicePointer(reinterpret_cast<void**>(&h->d_ring), h->h_ring, 0) != hipSuccess) {
     mi_ilqr_destroy(h);
     return MI_ILQR_E_HIP;
   }
+  std::memset(h->h_ring, 0, sizeof(DevStats) * mi_ilqr::kStatsRing);
+  select_stats_slot(h, 0);
   h->cold = true;
   h->u_pending = false;
   *out = h;
@@ -562,10 +582,12 @@ void mi_ilqr_destroy(mi_ilqr_t* h) {
                   h->x_trial, h->u_trial, h->trial_cost, h->stage_in, h->costmat, h->iters, h->status, h->ls_trials,
                   h->kp_count, h->kp_list, h->prof};
   for (void* p : ptrs) if (p) (void)hipFree(p);
-  if (h->h_stats) (void)hipHostFree(h->h_stats);
+  if (h->h_ring) (void)hipHostFree(h->h_ring);
   if (h->mpc_log) (void)hipFree(h->mpc_log);
-  if (h->ev0) (void)hipEventDestroy(h->ev0);
-  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  for (int i = 0; i < mi_ilqr::kStatsRing; ++i) {
+    if (h->ring_ev0[i]) (void)hipEventDestroy(h->ring_ev0[i]);
+    if (h->ring_ev1[i]) (void)hipEventDestroy(h->ring_ev1[i]);
+  }
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -623,6 +645,7 @@ int mi_ilqr_synchronize(mi_ilqr_t* h) {
 
 int mi_ilqr_solve_async(mi_ilqr_t* h) {
   if (!h) return MI_ILQR_E_BAD_ARG;
+  select_stats_slot(h, (int)(h->seq++ % mi_ilqr::kStatsRing));
   int rc = launch(h, MODE_SOLVE);
   if (rc != MI_ILQR_OK) return rc;
   hipLaunchKernelGGL(stats_kernel, dim3(1), dim3(256), 0, h->stream, h->iters, h->status, h->ls_trials, h->cost, h->B, h->d_stats);
@@ -632,21 +655,33 @@ int mi_ilqr_solve_async(mi_ilqr_t* h) {
   return MI_ILQR_OK;
 }
 
-int mi_ilqr_collect_stats(mi_ilqr_t* h, mi_ilqr_stats* st) {
-  if (!h || !st) return MI_ILQR_E_BAD_ARG;
-  HIPCHK(hipSetDevice(h->d.device_id));
-  HIPCHK(hipStreamSynchronize(h->stream));
+static void fill_stats(mi_ilqr* h, int slot, mi_ilqr_stats* st) {
   std::memset(st, 0, sizeof(*st));
-  const DevStats ds = *h->h_stats;     // written by stats_kernel, visible after the stream sync above
+  const DevStats ds = h->h_ring[slot];   // written by stats_kernel, visible after a stream sync
   st->total_iters = ds.total_iters; st->total_ls_trials = ds.total_ls;
   st->n_converged = ds.n_conv; st->n_max_iters = ds.n_max; st->n_ls_failed = ds.n_fail;
   st->max_iters_seen = ds.max_iters_seen; st->best_cost = ds.best_cost; st->best_index = ds.best_index;
   float ms = 0.f;
-  if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) st->kernel_ms = ms;
+  if (hipEventElapsedTime(&ms, h->ring_ev0[slot], h->ring_ev1[slot]) == hipSuccess) st->kernel_ms = ms;
   // bytes_iter is affine in ls: sum over iterations = ls_total*roll + iters*(deriv+back)
   const double per_ls = bytes_per_iteration(h->n, h->m, h->N, 1) - bytes_per_iteration(h->n, h->m, h->N, 0);
   const double fixed = bytes_per_iteration(h->n, h->m, h->N, 0);
   st->algorithmic_bytes = per_ls * (double)st->total_ls_trials + fixed * (double)st->total_iters;
+}
+
+int mi_ilqr_collect_stats(mi_ilqr_t* h, mi_ilqr_stats* st) {
+  if (!h || !st) return MI_ILQR_E_BAD_ARG;
+  HIPCHK(hipSetDevice(h->d.device_id));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  fill_stats(h, (int)(h->h_stats - h->h_ring), st);
+  return MI_ILQR_OK;
+}
+
+int mi_ilqr_collect_stats_n(mi_ilqr_t* h, int32_t count, mi_ilqr_stats* st) {
+  if (!h || !st || count < 1 || count > mi_ilqr::kStatsRing || count > h->seq) return MI_ILQR_E_BAD_ARG;
+  HIPCHK(hipSetDevice(h->d.device_id));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  for (int i = 0; i < count; ++i) fill_stats(h, (int)((h->seq - count + i) % mi_ilqr::kStatsRing), st + i);
   return MI_ILQR_OK;
 }
 

@@ -205,6 +205,18 @@ class BatchedIterativeLQR:
         self.stats = stats
         return stats
 
+    def solve_resident_async(self):
+        """Enqueue a solve from the resident inputs on the handle's stream and return at once; up to
+        32 may be in flight before `collect(count)` (each keeps its own events and statistics)."""
+        _capi.check(self._lib.mi_ilqr_solve_async(self._h), "mi_ilqr_solve_async")
+
+    def collect(self, count=1):
+        """Wait for the stream and return the statistics of the last `count` enqueued solves, oldest first."""
+        arr = (_capi.Stats * int(count))()
+        _capi.check(self._lib.mi_ilqr_collect_stats_n(self._h, int(count), arr), "mi_ilqr_collect_stats_n")
+        self.stats = arr[count - 1]
+        return list(arr)
+
     def rearm(self, cold=True):
         if cold:
             _capi.check(self._lib.mi_ilqr_reset(self._h), "mi_ilqr_reset")

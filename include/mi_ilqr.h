@@ -159,6 +159,9 @@ int mi_ilqr_rearm_initial_guess(mi_ilqr_t* h);
 int mi_ilqr_solve(mi_ilqr_t* h, mi_ilqr_stats* stats);
 int mi_ilqr_solve_async(mi_ilqr_t* h);
 int mi_ilqr_collect_stats(mi_ilqr_t* h, mi_ilqr_stats* stats);
+/* Up to 32 solves may be enqueued with _solve_async before collecting (each keeps its own kernel
+ * events and statistics record): the statistics of the last `count` of them, oldest first. */
+int mi_ilqr_collect_stats_n(mi_ilqr_t* h, int32_t count, mi_ilqr_stats* stats);
 
 /* Stage-level entries (parity tests).
  * rollout : one line-search trial per problem with the given eps (ilqr.py:306-327)

@@ -365,3 +365,22 @@ np.savez(sys.argv[1], log=s.mpc_log, x=s.x_bar, u=s.u_bar, K=s.K, it=s.iteration
     assert same.mean() > 0.9
     assert np.allclose(par["log"][same], seq["log"][same], rtol=1e-7, atol=1e-9)
     assert np.max(np.abs(par["x"][same] - seq["x"][same])) < 1e-6 and np.max(np.abs(par["u"][same] - seq["u"][same])) < 1e-6
+
+
+def test_async_solves_keep_their_own_statistics():
+    """mi_ilqr_solve_async x k then mi_ilqr_collect_stats_n: every enqueued solve ran in full and left
+    its own record (the bench pipelines its steps this way); more than the ring holds is refused."""
+    from drake_ddp_amd._capi import MiIlqrError
+    prob, x0, s = c2_setup(64)
+    x, u, _, L = s.Solve()
+    ref = s.stats
+    for _ in range(5):
+        s.rearm(cold=True)
+        s.solve_resident_async()
+    got = s.collect(5)
+    for st in got:
+        assert st.total_iters == ref.total_iters and st.total_ls_trials == ref.total_ls_trials
+        assert st.n_converged == 64 and st.best_cost == ref.best_cost and st.kernel_ms > 0
+    assert np.array_equal(s.x_bar, x) and np.array_equal(s.cost, L)
+    with pytest.raises(MiIlqrError):
+        s.collect(33)
