@@ -1490,12 +1490,74 @@ __device__ __forceinline__ void ric_combine(RicElem<2>& o, const RicElem<2>& ei,
     o.e[i] = se;
 #pragma unroll
     for (int j = 0; j < n; ++j) {
-      double sa = 0.0, sc = ej.C[i][j], sj = ei.J[i][j];
+      double sa = 0.0;
 #pragma unroll
-      for (int k = 0; k < n; ++k) { sa += W[i][k] * ei.A[k][j]; sc += WC[i][k] * ej.A[j][k]; sj += VJ[i][k] * ei.A[k][j]; }
+      for (int k = 0; k < n; ++k) sa += W[i][k] * ei.A[k][j];
       o.A[i][j] = sa;
-      o.C[i][j] = sc;
-      o.J[i][j] = sj;
+      if (j >= i) {                                          // C and J are symmetric: upper triangle, mirrored
+        double sc = ej.C[i][j], sj = ei.J[i][j];
+#pragma unroll
+        for (int k = 0; k < n; ++k) { sc += WC[i][k] * ej.A[j][k]; sj += VJ[i][k] * ei.A[k][j]; }
+        o.C[i][j] = sc; o.C[j][i] = sc;
+        o.J[i][j] = sj; o.J[j][i] = sj;
+      }
+    }
+  }
+}
+
+// The last level of the scan: only the value function (J, eta) of the composition is read afterwards.
+__device__ __forceinline__ void ric_combine_value(RicElem<2>& o, const RicElem<2>& ei, const RicElem<2>& ej) {
+  constexpr int n = 2;
+  double P[n][n], Mi[n][n], MA[n][n];
+#pragma unroll
+  for (int i = 0; i < n; ++i)
+#pragma unroll
+    for (int j = 0; j < n; ++j) {
+      double s = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+      for (int k = 0; k < n; ++k) s += ei.C[i][k] * ej.J[k][j];
+      P[i][j] = s;
+    }
+  const double idet = fast_rcp(P[0][0] * P[1][1] - P[0][1] * P[1][0]);
+  Mi[0][0] = P[1][1] * idet; Mi[0][1] = -P[0][1] * idet; Mi[1][0] = -P[1][0] * idet; Mi[1][1] = P[0][0] * idet;
+#pragma unroll
+  for (int i = 0; i < n; ++i)
+#pragma unroll
+    for (int j = 0; j < n; ++j) {
+      double q = 0.0;
+#pragma unroll
+      for (int k = 0; k < n; ++k) q += Mi[i][k] * ei.A[k][j];
+      MA[i][j] = q;                                         // M A_i ; V = MA^T
+    }
+  double t2[n], VJ[n][n];
+#pragma unroll
+  for (int i = 0; i < n; ++i) {
+    double q = ej.e[i];
+#pragma unroll
+    for (int k = 0; k < n; ++k) q -= ej.J[i][k] * ei.b[k];
+    t2[i] = q;                                              // eta_j - J_j b_i
+  }
+#pragma unroll
+  for (int i = 0; i < n; ++i)
+#pragma unroll
+    for (int j = 0; j < n; ++j) {
+      double q = 0.0;
+#pragma unroll
+      for (int k = 0; k < n; ++k) q += MA[k][i] * ej.J[k][j];
+      VJ[i][j] = q;                                         // V J_j
+    }
+#pragma unroll
+  for (int i = 0; i < n; ++i) {
+    double se = ei.e[i];
+#pragma unroll
+    for (int k = 0; k < n; ++k) se += MA[k][i] * t2[k];
+    o.e[i] = se;
+#pragma unroll
+    for (int j = i; j < n; ++j) {
+      double sj = ei.J[i][j];
+#pragma unroll
+      for (int k = 0; k < n; ++k) sj += VJ[i][k] * ei.A[k][j];
+      o.J[i][j] = sj; o.J[j][i] = sj;
     }
   }
 }
@@ -1512,18 +1574,20 @@ __device__ __forceinline__ double lane_read_f64(double v, int src) {
 // One Kogge-Stone level of the scan over the lanes, operands moved with DPP: `dst` = the element of
 // the source lane, or the IDENTITY element where there is none (the moves deliver zeros there, and
 // the identity is all zeros once A is sent as A - I).
-template <int CTRL, int ROWS, int n>
+template <int CTRL, int ROWS, int n, bool VALUE_ONLY = false>
 __device__ __forceinline__ void ric_fetch_dpp(RicElem<n>& dst, const RicElem<n>& src) {
 #pragma unroll
   for (int i = 0; i < n; ++i) {
-    dst.b[i] = dpp_f64_or_zero<CTRL, ROWS>(src.b[i]);
     dst.e[i] = dpp_f64_or_zero<CTRL, ROWS>(src.e[i]);
+    if (!VALUE_ONLY) dst.b[i] = dpp_f64_or_zero<CTRL, ROWS>(src.b[i]);
 #pragma unroll
     for (int j = 0; j < n; ++j) {
       const double idm = (i == j) ? 1.0 : 0.0;
-      dst.A[i][j] = dpp_f64_or_zero<CTRL, ROWS>(src.A[i][j] - idm) + idm;
-      dst.C[i][j] = dpp_f64_or_zero<CTRL, ROWS>(src.C[i][j]);
-      dst.J[i][j] = dpp_f64_or_zero<CTRL, ROWS>(src.J[i][j]);
+      if (!VALUE_ONLY) dst.A[i][j] = dpp_f64_or_zero<CTRL, ROWS>(src.A[i][j] - idm) + idm;
+      if (j >= i) {                                          // symmetric blocks: upper triangle only
+        if (!VALUE_ONLY) { dst.C[i][j] = dpp_f64_or_zero<CTRL, ROWS>(src.C[i][j]); dst.C[j][i] = dst.C[i][j]; }
+        dst.J[i][j] = dpp_f64_or_zero<CTRL, ROWS>(src.J[i][j]); dst.J[j][i] = dst.J[i][j];
+      }
     }
   }
 }
@@ -1623,7 +1687,10 @@ __device__ inline void backward_scan(const WS& w, const Consts<M>& c) {
   level(integral_constant<int, 0x114>{}, integral_constant<int, 0xF>{});   // row_shr:4
   level(integral_constant<int, 0x118>{}, integral_constant<int, 0xF>{});   // row_shr:8
   level(integral_constant<int, 0x142>{}, integral_constant<int, 0xA>{});   // row_bcast:15 -> rows 1, 3
-  level(integral_constant<int, 0x143>{}, integral_constant<int, 0xC>{});   // row_bcast:31 -> rows 2, 3
+  ric_fetch_dpp<0x143, 0xC, n, true>(T, S);                                // row_bcast:31 -> rows 2, 3: only
+  ric_combine_value(U, S, T);                                              // (J, eta) are read from here on
+  S.e[0] = U.e[0]; S.e[1] = U.e[1];
+  S.J[0][0] = U.J[0][0]; S.J[0][1] = U.J[0][1]; S.J[1][0] = U.J[1][0]; S.J[1][1] = U.J[1][1];
   // value function at the right edge of this chunk = (J, -eta) of the scan value one lane down
   double Vx[n], Vxx[n][n];
 #pragma unroll
