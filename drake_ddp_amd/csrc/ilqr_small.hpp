@@ -1754,6 +1754,9 @@ __global__ void __launch_bounds__(256) ilqr_small_kernel(const KArgs a) {
   constexpr int n = M::n, m = M::m;
   using Ly = Lay<n, m>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef MI_PROF_NEWTON
+  const long long c_kstart = clock64();
+#endif
   const int b = blockIdx.x;
   const int lane = threadIdx.x;
   const int N = a.N;
@@ -1775,19 +1778,53 @@ __global__ void __launch_bounds__(256) ilqr_small_kernel(const KArgs a) {
   const size_t oFx = (size_t)b * n * n * (N - 1), oFu = (size_t)b * n * m * (N - 1), oT = (size_t)b * (N - 1);
 
   const bool cold = a.cold != 0;
-  stage_in(w.G, Ly::GS, Ly::XB, a.x_bar + oX, n, N, cold);
-  stage_in(w.G, Ly::GS, Ly::UB, (a.u_pending ? a.u_guess : a.u_bar) + oU, m, N - 1, false);
-  stage_in(w.G, Ly::GS, Ly::KK, a.K + oK, m * n, N - 1, cold);
-  stage_in(w.G, Ly::GS, Ly::KAP, a.kappa + oU, m, N - 1, cold);
-  stage_in(w.G, Ly::GS, Ly::DV, a.dV + oT, 1, N - 1, cold);
-  stage_in(w.J, Ly::JS, Ly::FX, a.fx + oFx, n * n, N - 1, cold);
-  stage_in(w.J, Ly::JS, Ly::FU, a.fu + oFu, n * m, N - 1, cold);
-
   Consts<M> c;
-  c.load(a.costmat);
   double x0r[n];
+  if constexpr (n <= 2) {
+    // Everything that comes from HBM is requested up front - cost matrices, x0, the first 256 steps of
+    // the control sequence - and consumed after the LDS arrays have been initialized: one memory
+    // latency instead of one per array (a cold solve reads nothing else).  (n = 2 only: in the
+    // larger kernels the extra live registers cost more in the line-search loops than this saves.)
+    c.load(a.costmat);
 #pragma unroll
-  for (int i = 0; i < n; ++i) x0r[i] = a.x0[(size_t)b * n + i];
+    for (int i = 0; i < n; ++i) x0r[i] = a.x0[(size_t)b * n + i];
+    constexpr int UPQ = 4;
+    const double* usrc = (a.u_pending ? a.u_guess : a.u_bar) + oU;
+    double upre[m][UPQ];
+#pragma unroll
+    for (int r = 0; r < m; ++r)
+#pragma unroll
+      for (int q = 0; q < UPQ; ++q) {
+        const int t = lane + 64 * q;
+        upre[r][q] = (t < N - 1) ? usrc[(size_t)r * (N - 1) + t] : 0.0;
+      }
+    stage_in(w.G, Ly::GS, Ly::XB, a.x_bar + oX, n, N, cold);
+    stage_in(w.G, Ly::GS, Ly::KK, a.K + oK, m * n, N - 1, cold);
+    stage_in(w.G, Ly::GS, Ly::KAP, a.kappa + oU, m, N - 1, cold);
+    stage_in(w.G, Ly::GS, Ly::DV, a.dV + oT, 1, N - 1, cold);
+    stage_in(w.J, Ly::JS, Ly::FX, a.fx + oFx, n * n, N - 1, cold);
+    stage_in(w.J, Ly::JS, Ly::FU, a.fu + oFu, n * m, N - 1, cold);
+#pragma unroll
+    for (int r = 0; r < m; ++r) {
+#pragma unroll
+      for (int q = 0; q < UPQ; ++q) {
+        const int t = lane + 64 * q;
+        if (t < N - 1) w.G[t * Ly::GS + Ly::UB + r] = upre[r][q];
+      }
+      for (int t = lane + 64 * UPQ; t < N - 1; t += 64) w.G[t * Ly::GS + Ly::UB + r] = usrc[(size_t)r * (N - 1) + t];
+    }
+  } else {
+    stage_in(w.G, Ly::GS, Ly::XB, a.x_bar + oX, n, N, cold);
+    stage_in(w.G, Ly::GS, Ly::UB, (a.u_pending ? a.u_guess : a.u_bar) + oU, m, N - 1, false);
+    stage_in(w.G, Ly::GS, Ly::KK, a.K + oK, m * n, N - 1, cold);
+    stage_in(w.G, Ly::GS, Ly::KAP, a.kappa + oU, m, N - 1, cold);
+    stage_in(w.G, Ly::GS, Ly::DV, a.dV + oT, 1, N - 1, cold);
+    stage_in(w.J, Ly::JS, Ly::FX, a.fx + oFx, n * n, N - 1, cold);
+    stage_in(w.J, Ly::JS, Ly::FU, a.fu + oFu, n * m, N - 1, cold);
+    c.load(a.costmat);
+#pragma unroll
+    for (int i = 0; i < n; ++i) x0r[i] = a.x0[(size_t)b * n + i];
+  }
   wave_sync();
 
   if (MODE == MODE_ROLLOUT) {
@@ -1937,19 +1974,68 @@ __global__ void __launch_bounds__(256) ilqr_small_kernel(const KArgs a) {
     for (int i = lane; i < N - 1; i += 64) w.kp[i] = i;          // what keypoints_set_interval(minN = 1) lists
   }
   wave_sync();
-  stage_out(a.x_bar + oX, w.G, Ly::GS, Ly::XB, n, N);
-  stage_out(a.u_bar + oU, w.G, Ly::GS, Ly::UB, m, N - 1);
-  stage_out(a.fx + oFx, w.J, Ly::JS, Ly::FX, n * n, N - 1);
-  stage_out(a.fu + oFu, w.J, Ly::JS, Ly::FU, n * m, N - 1);
-  if (MODE == MODE_SOLVE || MODE == MODE_MPC) {
-    stage_out(a.K + oK, w.G, Ly::GS, Ly::KK, m * n, N - 1);
-    stage_out(a.kappa + oU, w.G, Ly::GS, Ly::KAP, m, N - 1);
-    stage_out(a.dV + oT, w.G, Ly::GS, Ly::DV, 1, N - 1);
+#ifdef MI_PROF_NEWTON
+  const long long c_loop_end = clock64();
+#endif
+  if constexpr (n <= 2) {
+    // Write-back, one time step per lane: a step's whole G and J records are read from LDS together
+    // (one LDS latency per 64 steps instead of one per array row), then scattered to the reference's
+    // time-last arrays - every store instruction still writes 64 consecutive doubles.
+    for (int tb = 0; tb < N; tb += 64) {
+      const int t = tb + lane;
+      if (t < N) {
+        const double* g = w.G + t * Ly::GS;
+        const double* jr = w.J + t * Ly::JS;                      // t = N-1: the pad record, read but not stored
+        double xb[n], ub[m], kk[m * n], kap[m], dv, fxr[n * n], fur[n * m];
+  #pragma unroll
+        for (int i = 0; i < n; ++i) xb[i] = g[Ly::XB + i];
+  #pragma unroll
+        for (int k = 0; k < m; ++k) { ub[k] = g[Ly::UB + k]; kap[k] = g[Ly::KAP + k]; }
+  #pragma unroll
+        for (int k = 0; k < m * n; ++k) kk[k] = g[Ly::KK + k];
+        dv = g[Ly::DV];
+  #pragma unroll
+        for (int k = 0; k < n * n; ++k) fxr[k] = jr[Ly::FX + k];
+  #pragma unroll
+        for (int k = 0; k < n * m; ++k) fur[k] = jr[Ly::FU + k];
+  #pragma unroll
+        for (int i = 0; i < n; ++i) a.x_bar[oX + (size_t)i * N + t] = xb[i];
+        if (t < N - 1) {
+  #pragma unroll
+          for (int k = 0; k < m; ++k) a.u_bar[oU + (size_t)k * (N - 1) + t] = ub[k];
+  #pragma unroll
+          for (int k = 0; k < n * n; ++k) a.fx[oFx + (size_t)k * (N - 1) + t] = fxr[k];
+  #pragma unroll
+          for (int k = 0; k < n * m; ++k) a.fu[oFu + (size_t)k * (N - 1) + t] = fur[k];
+          if (MODE == MODE_SOLVE || MODE == MODE_MPC) {
+  #pragma unroll
+            for (int k = 0; k < m * n; ++k) a.K[oK + (size_t)k * (N - 1) + t] = kk[k];
+  #pragma unroll
+            for (int k = 0; k < m; ++k) a.kappa[oU + (size_t)k * (N - 1) + t] = kap[k];
+            a.dV[oT + t] = dv;
+          }
+        }
+      }
+    }
+  } else {
+    stage_out(a.x_bar + oX, w.G, Ly::GS, Ly::XB, n, N);
+    stage_out(a.u_bar + oU, w.G, Ly::GS, Ly::UB, m, N - 1);
+    stage_out(a.fx + oFx, w.J, Ly::JS, Ly::FX, n * n, N - 1);
+    stage_out(a.fu + oFu, w.J, Ly::JS, Ly::FU, n * m, N - 1);
+    if (MODE == MODE_SOLVE || MODE == MODE_MPC) {
+      stage_out(a.K + oK, w.G, Ly::GS, Ly::KK, m * n, N - 1);
+      stage_out(a.kappa + oU, w.G, Ly::GS, Ly::KAP, m, N - 1);
+      stage_out(a.dV + oT, w.G, Ly::GS, Ly::DV, 1, N - 1);
+    }
   }
   for (int i = lane; i < nk; i += 64) a.kp_list[(size_t)b * (N - 1) + i] = w.kp[i];
   if (lane == 0) {
     a.cost[b] = L; a.iters[b] = iters; a.status[b] = status; a.ls_trials[b] = ls_total; a.kp_count[b] = nk;
     a.prof[4 * b + 0] = c_ls; a.prof[4 * b + 1] = c_lin; a.prof[4 * b + 2] = c_bp; a.prof[4 * b + 3] = clock64() - c_begin;
+#ifdef MI_PROF_NEWTON
+    // debug build: launch phases instead of the stage stopwatches
+    a.prof[4 * b + 0] = c_begin - c_kstart; a.prof[4 * b + 1] = c_loop_end - c_begin; a.prof[4 * b + 2] = clock64() - c_loop_end;
+#endif
   }
 }
 
