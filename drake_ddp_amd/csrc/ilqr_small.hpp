@@ -1798,12 +1798,25 @@ __global__ void __launch_bounds__(256) ilqr_small_kernel(const KArgs a) {
         const int t = lane + 64 * q;
         upre[r][q] = (t < N - 1) ? usrc[(size_t)r * (N - 1) + t] : 0.0;
       }
-    stage_in(w.G, Ly::GS, Ly::XB, a.x_bar + oX, n, N, cold);
-    stage_in(w.G, Ly::GS, Ly::KK, a.K + oK, m * n, N - 1, cold);
-    stage_in(w.G, Ly::GS, Ly::KAP, a.kappa + oU, m, N - 1, cold);
-    stage_in(w.G, Ly::GS, Ly::DV, a.dV + oT, 1, N - 1, cold);
-    stage_in(w.J, Ly::JS, Ly::FX, a.fx + oFx, n * n, N - 1, cold);
-    stage_in(w.J, Ly::JS, Ly::FU, a.fu + oFu, n * m, N - 1, cold);
+    if (cold) {
+      // all-zero solver state: whole records at once (one pass over t instead of one per array row)
+      for (int t = lane; t < N; t += 64) {
+        double* g = w.G + t * Ly::GS;
+        double* jr = w.J + t * Ly::JS;
+#pragma unroll
+        for (int k = 0; k < Ly::GS; ++k) g[k] = 0.0;
+#pragma unroll
+        for (int k = 0; k < Ly::JS; ++k) jr[k] = 0.0;
+      }
+    } else {
+      stage_in(w.G, Ly::GS, Ly::XB, a.x_bar + oX, n, N, false);
+      stage_in(w.G, Ly::GS, Ly::KK, a.K + oK, m * n, N - 1, false);
+      stage_in(w.G, Ly::GS, Ly::KAP, a.kappa + oU, m, N - 1, false);
+      stage_in(w.G, Ly::GS, Ly::DV, a.dV + oT, 1, N - 1, false);
+      stage_in(w.J, Ly::JS, Ly::FX, a.fx + oFx, n * n, N - 1, false);
+      stage_in(w.J, Ly::JS, Ly::FU, a.fu + oFu, n * m, N - 1, false);
+    }
+    wave_sync();
 #pragma unroll
     for (int r = 0; r < m; ++r) {
 #pragma unroll
