@@ -8,15 +8,21 @@
 // algorithm:
 //   * line search (ilqr.py:300-337): lane j rolls out candidate eps = beta^(base+j)
 //     concurrently; the first accepted candidate in lane order is exactly the one
-//     the reference's sequential loop accepts.  Lane 0 also stores
-//     its trajectory, so the common case (eps=1 accepted) costs ONE rollout.
+//     the reference's sequential loop accepts.  The eps = 1 trial is
+//     attempted on its own first, so the common case costs ONE rollout.
 //   * linearization (ilqr.py:380-415, 233-272): (key-point, column) pairs are
 //     spread over the lanes; central finite differences (or one-directional
 //     forward-mode duals) replace Drake AutoDiff.
 //   * key-point selection / interpolation (ilqr.py:417-621): ballots + per-lane
 //     segments.
-//   * backward Riccati pass (ilqr.py:623-667 with :161-206 fused in): strictly
-//     sequential in t, evaluated wave-uniformly out of registers.
+//   * n = 2: TIME itself.  The rollout of a trial is Newton's method on the whole
+//     trajectory (rollout_newton: every lane owns four consecutive steps, the
+//     linearized recurrence is a prefix scan of affine maps over the lanes) and the
+//     backward Riccati pass (ilqr.py:623-667 with :161-206 fused in) is an
+//     associative scan of its second-order elements (backward_scan); both scans move
+//     their operands with DPP row shifts / row broadcasts.
+//   * n = 3..4: the backward pass stays sequential in t, each step two fp64 MFMAs
+//     (backward_mfma); the rollout is sequential, evaluated wave-uniformly.
 // Time is the fastest LDS axis (the reference's own layout), so
 // HBM<->LDS staging is a linear, fully coalesced copy per array.
 #pragma once
