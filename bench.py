@@ -189,26 +189,24 @@ def main():
     RING = 32      # solves the library lets us keep in flight (per-launch events + statistics records)
 
     def run_steps(count):
-        """`count` cold-start solves of the whole batch.  Single GPU: enqueued back to back on the
-        handle's stream (launch latency overlaps the previous solve; every solve still runs in full and
-        leaves its own statistics record), collected per group of RING.  Multi-GPU: each solve's best
-        cost feeds the path's one collective, so the steps are collected one by one."""
+        """`count` cold-start solves of the whole (per-rank) batch, enqueued back to back on the handle's
+        stream in groups of RING: launch latency overlaps the previous solve; every solve still runs in
+        full and leaves its own statistics record.  With N > 1 ranks the path's one collective - the
+        RCCL all-reduce(min) of each solve's best cost - is issued per group, one 8*RING-byte
+        reduction of the group's best costs, asynchronously (it overlaps the next group) and completed
+        inside the timed region."""
+        from drake_ddp_amd.dist import allreduce_min_vec_async
         out = []
-        if world > 1:
-            for _ in range(count):
-                s.rearm(cold=True)
-                out.append(s.solve_resident())
-                # RCCL all-reduce(min) of the best cost, 8 bytes, issued asynchronously so it overlaps
-                # the next solve; completed inside the timed region
-                pending.append(s.best_cost_allreduce_async())
-            return out
         done = 0
         while done < count:
             k = min(RING, count - done)
             for _ in range(k):
                 s.rearm(cold=True)
                 s.solve_resident_async()
-            out += s.collect(k)
+            grp = s.collect(k)
+            if world > 1:
+                pending.append(allreduce_min_vec_async([st.best_cost for st in grp], dev_index))
+            out += grp
             done += k
         return out
 

@@ -62,6 +62,31 @@ def allreduce_min_async(value, device_id=0):
     return PendingMin(t, dist.all_reduce(t, op=dist.ReduceOp.MIN, async_op=True))
 
 
+class PendingMinVec:
+    """Handle of an in-flight element-wise all-reduce(min) of several values."""
+
+    def __init__(self, tensor, work):
+        self.tensor, self.work = tensor, work
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        return self.tensor.cpu().numpy()
+
+
+def allreduce_min_vec_async(values, device_id=0):
+    """Element-wise min over ranks of a short vector (the best costs of a group of batched solves):
+    ONE collective for the group instead of one per solve."""
+    import torch
+    dist = _dist()
+    v = [float(x) for x in values]
+    if dist is None:
+        return PendingMinVec(torch.tensor(v, dtype=torch.float64), None)
+    t = torch.tensor(v, dtype=torch.float64, device=_device(device_id))
+    return PendingMinVec(t, dist.all_reduce(t, op=dist.ReduceOp.MIN, async_op=True))
+
+
 def best_of_all_ranks(local_best_cost, local_best_index, shard_lo, device_id=0):
     """(cost, global problem index, owning rank) of the best converged problem of the
     whole batch: all-gather of one {cost, global index} pair per rank + local argmin."""

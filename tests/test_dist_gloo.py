@@ -73,8 +73,11 @@ def _worker_async(rank, world, port, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    from drake_ddp_amd.dist import allreduce_min_vec_async
     hs = [allreduce_min_async(10.0 * (rank + 1) + k) for k in range(3)]     # several in flight
-    out.put((rank, [h.wait() for h in hs]))
+    # the bench's grouped form: one element-wise reduction of a group's best costs
+    hv = allreduce_min_vec_async([5.0 - rank, 7.0 + rank, 1.0, 2.0 * rank])
+    out.put((rank, [h.wait() for h in hs], [float(v) for v in hv.wait()]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -92,3 +95,4 @@ def test_world2_async_min_overlaps():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res[0][1] == [10.0, 11.0, 12.0] and res[1][1] == [10.0, 11.0, 12.0]
+    assert res[0][2] == [4.0, 7.0, 1.0, 0.0] and res[1][2] == [4.0, 7.0, 1.0, 0.0]
