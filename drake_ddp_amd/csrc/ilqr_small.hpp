@@ -1922,10 +1922,13 @@ __global__ void __launch_bounds__(256) ilqr_small_kernel(const KArgs a) {
     double improvement = __builtin_inf();
     bool optimistic = true;
     int it_this = 0;
+    long long c_prev = 0;
     while (improvement > a.delta) {
       if (it_this >= a.max_iters) { status = MI_STATUS_MAX_ITERS; break; }
       double L_new, eps; int trials, slot = 0;
-      const long long c0 = clock64();
+      // stopwatch reads cost an s_memtime round trip each: an iteration starts where the previous one
+      // ended, and a rollout that linearized on the way has no separate linearization span
+      const long long c0 = (it_this == 0) ? clock64() : c_prev;
       int fused = 0;
       // first iteration of the first solve on all-zero solver state (no gains, no nominal trajectory)
       const bool cold_start = cold && rs == 0 && it_this == 0 && (MODE == MODE_SOLVE || MODE == MODE_MPC);
@@ -1935,7 +1938,7 @@ __global__ void __launch_bounds__(256) ilqr_small_kernel(const KArgs a) {
       ls_total += trials;
       if (!ok) { status = MI_STATUS_LINESEARCH_FAILED; break; }
       wave_sync();
-      const long long c1 = clock64();
+      const long long c1 = (fused == 2) ? c0 : clock64();
       if (fused == 0) commit_trial<n, m>(w, slot);                // u_bar <- u, x_bar <- x (:375-376)
       wave_sync();
       if (fused == 2) {
@@ -1956,7 +1959,10 @@ __global__ void __launch_bounds__(256) ilqr_small_kernel(const KArgs a) {
       const long long c2 = clock64();
       if (MODE != MODE_FORWARD) { backward<M>(w, c, a.seq_backward != 0); wave_sync(); } // :697
       const long long c3 = clock64();
-      c_ls += c1 - c0; c_lin += c2 - c1; c_bp += c3 - c2;
+      c_prev = c3;
+      if (fused == 2) c_ls += c2 - c0;                            // line search + commit + linearization
+      else { c_ls += c1 - c0; c_lin += c2 - c1; }
+      c_bp += c3 - c2;
       if (lane == 0 && it_this < a.hist_cap) {                    // history of the LAST solve
         hist[4 * it_this + 0] = L_new; hist[4 * it_this + 1] = eps;
         hist[4 * it_this + 2] = (double)trials; hist[4 * it_this + 3] = (double)nk / (double)(N - 1) * 100.0;   // :406
