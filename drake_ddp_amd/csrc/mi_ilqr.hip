@@ -486,7 +486,11 @@ int mi_ilqr_create(const mi_ilqr_desc* desc, mi_ilqr_t** out) {
   {
     const bool can = !large && desc->keypoint_method == MI_KP_SET_INTERVAL && desc->minN == 1;
     if (desc->kernel_mode == MI_KERNEL_THROUGHPUT && !can) return MI_ILQR_E_UNSUPPORTED;
-    batch_minor = can && (desc->kernel_mode == MI_KERNEL_THROUGHPUT || (desc->kernel_mode == MI_KERNEL_AUTO && desc->B >= 8192));
+    // n = 2 within the time-parallel passes' horizon: the wave-per-problem kernel is the faster one at
+    // every batch size (B = 65536: 68 M vs 42 M it/s, profiles/r01l_c2_modes_batch_sweep.txt)
+    const bool time_parallel = info->n == 2 && info->m == 1 && desc->N - 1 <= 256;
+    batch_minor = can && (desc->kernel_mode == MI_KERNEL_THROUGHPUT ||
+                          (desc->kernel_mode == MI_KERNEL_AUTO && desc->B >= 8192 && !time_parallel));
     // horizons whose per-problem state exceeds the 160 KB of LDS (e.g. acrobot.py's literal N = 750) are
     // served by the HBM-streaming kernel, which has no such limit
     if (!batch_minor && lds > kMaxLds && can && desc->kernel_mode == MI_KERNEL_AUTO) batch_minor = true;

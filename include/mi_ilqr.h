@@ -70,7 +70,9 @@ enum { MI_JAC_FD_CENTRAL = 0, MI_JAC_AUTODIFF = 1 };
  *   LATENCY    wave-per-problem, state in LDS: minimal time-to-solution, up to ~2k problems/GPU in flight;
  *   THROUGHPUT lane-per-problem, batch-minor state streamed through HBM: for tens of thousands of
  *              problems (setInterval/1 key-points; stage-level entries are not available);
- *   AUTO       THROUGHPUT when B >= 8192 and the configuration allows it, else LATENCY. */
+ *   AUTO       THROUGHPUT when B >= 8192 and the configuration allows it - except n = 2 models with
+ *              N <= 257, whose LATENCY kernel (rollout and Riccati sweep parallel in time) is the faster one
+ *              at every batch size - else LATENCY. */
 enum { MI_KERNEL_AUTO = 0, MI_KERNEL_LATENCY = 1, MI_KERNEL_THROUGHPUT = 2 };
 
 /* Per-problem status written by solve/forward. */

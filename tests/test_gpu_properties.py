@@ -384,3 +384,31 @@ def test_async_solves_keep_their_own_statistics():
     assert np.array_equal(s.x_bar, x) and np.array_equal(s.cost, L)
     with pytest.raises(MiIlqrError):
         s.collect(33)
+
+
+def test_auto_kernel_selection_at_large_batches():
+    """AUTO keeps the n = 2 models on the wave-per-problem kernel at any batch size (its time-parallel
+    passes make it the faster one) and moves the other small-state models to the lane-per-problem
+    kernel at B >= 8192; both serve the same batch with the same results."""
+    from drake_ddp_amd import workloads as W
+    from drake_ddp_amd._capi import MiIlqrError
+    prob = W.pendulum_problem()
+    B = 8192
+    x0 = W.pendulum_batch_x0(B)
+    res = {}
+    for mode in ("auto", "throughput"):
+        s = make_solver(prob, B=B, jac="fd", kernel_mode=mode, hist_cap=2)
+        s.SetInitialState(x0)
+        s.SetInitialGuess(np.zeros((1, prob["N"] - 1)))
+        x, u, _, L = s.Solve()
+        res[mode] = (L, s.iterations.copy())
+        if mode == "auto":
+            s.stage_backward()                         # stage-level entries: wave-per-problem kernels only
+        else:
+            with pytest.raises(MiIlqrError):
+                s.stage_backward()
+    assert np.array_equal(res["auto"][1], res["throughput"][1])
+    assert np.max(np.abs(res["auto"][0] - res["throughput"][0]) / np.abs(res["throughput"][0])) < 5e-8   # both central FD
+    a = make_solver(W.acrobot_problem(), B=B, jac="ad", kernel_mode="auto", hist_cap=2)
+    with pytest.raises(MiIlqrError):
+        a.stage_backward()                             # n = 4 at B >= 8192: lane-per-problem kernel

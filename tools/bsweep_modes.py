@@ -4,7 +4,7 @@ from drake_ddp_amd import workloads as W
 from drake_ddp_amd.ilqr import BatchedIterativeLQR
 from drake_ddp_amd.models import ModelSystem
 prob = W.pendulum_problem(); N = prob["N"]
-for mode, Bs in (("latency", (1024, 4096, 16384)), ("throughput", (1024, 4096, 16384, 65536, 262144))):
+for mode, Bs in (("latency", (1024, 2048, 4096, 16384, 65536, 262144)), ("throughput", (4096, 16384, 65536, 262144))):
     for B in Bs:
         x0 = W.pendulum_batch_x0(B)
         s = BatchedIterativeLQR(ModelSystem(prob["model_id"], prob["dt"]), N, B, delta=prob["delta"], beta=prob["beta"], gamma=prob["gamma"], kernel_mode=mode, hist_cap=2)
