@@ -685,9 +685,6 @@ __device__ inline int rollout_newton_impl(const WS& w, const Consts<M>& c, const
     upd = fmax(upd, row_ror_f64<1>(upd));
     upd = fmax(fmax(readlane_f64(upd, 0), readlane_f64(upd, 16)), fmax(readlane_f64(upd, 32), readlane_f64(upd, 48)));
     converged = upd < kTol;
-#ifdef MI_NEWTON_FIXED_SWEEPS
-    converged = sweep + 1 >= MI_NEWTON_FIXED_SWEEPS;         // timing experiments only
-#endif
   }
 #ifdef MI_PROF_NEWTON
   const long long pn1 = clock64();

@@ -1,3 +1,4 @@
+"""Phase profile of the workgroup-per-problem backward pass (needs a -DMI_PROF_BACKWARD build): cycles per phase A/B/C/D."""
 import sys, numpy as np
 sys.path.insert(0, ".")
 from drake_ddp_amd import workloads as W

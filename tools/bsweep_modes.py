@@ -1,3 +1,4 @@
+"""C2 batch sweep of the two small-state kernel families (wave-per-problem vs lane-per-problem): kernel time, it/s, roofline fraction."""
 import sys, time, numpy as np
 sys.path.insert(0, ".")
 from drake_ddp_amd import workloads as W

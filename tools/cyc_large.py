@@ -1,3 +1,4 @@
+"""Stage cycle counters of the workgroup-per-problem kernel at the C5 shape."""
 import sys, numpy as np
 sys.path.insert(0, ".")
 from drake_ddp_amd import workloads as W

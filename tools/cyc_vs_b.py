@@ -1,3 +1,4 @@
+"""Per-iteration stage cycles of the C2 solve kernel against the batch size."""
 import sys, numpy as np
 sys.path.insert(0, ".")
 from drake_ddp_amd import workloads as W

@@ -1,3 +1,5 @@
+"""Per-iteration profile of the time-parallel rollout (needs a -DMI_PROF_NEWTON build): line-search cycles, Newton sweep
+cycles and count, final-pass cycles.  python tools/newton_prof.py B [problem index to run alone]"""
 import sys, numpy as np
 sys.path.insert(0, ".")
 from drake_ddp_amd import workloads as W

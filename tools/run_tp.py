@@ -1,3 +1,4 @@
+"""One throughput-mode (lane-per-problem) solve at the C2 shape, for rocprofv3 PMC passes: python tools/run_tp.py B"""
 import sys, numpy as np
 import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from drake_ddp_amd import workloads as W
