@@ -593,10 +593,9 @@ __device__ inline int rollout_newton_impl(const WS& w, const Consts<M>& c, const
         const double fui = jr[Ly::FU + i];
 #pragma unroll
         for (int j = 0; j < n; ++j) {
-          const double acl = fma(-fui, Kk[k][j], jr[Ly::FX + i * n + j]) - ((i == j) ? 1.0 : 0.0);
-          loc[k].G[i][j] = valid[k] ? acl : 0.0;
+          loc[k].G[i][j] = fma(-fui, Kk[k][j], jr[Ly::FX + i * n + j]) - ((i == j) ? 1.0 : 0.0);
         }
-        loc[k].c[i] = valid[k] ? -fui * kap : 0.0;
+        loc[k].c[i] = -fui * kap;
       }
       Aff2 t_;
       aff2_compose_dev(t_, loc[k], agg);
@@ -645,9 +644,11 @@ __device__ inline int rollout_newton_impl(const WS& w, const Consts<M>& c, const
       M::template step<Dual2>(xd, ud, xn, a.params, a.dt);
 #pragma unroll
       for (int i = 0; i < n; ++i) {
-        const double g0 = valid[k] ? xn[i].d0 : (i == 0 ? 1.0 : 0.0), g1 = valid[k] ? xn[i].d1 : (i == 1 ? 1.0 : 0.0);
+        // (steps past the horizon evaluate record 0's data: their maps only enter the prefixes of later
+        // lanes, which hold no valid step - nothing forces them to the identity)
+        const double g0 = xn[i].d0, g1 = xn[i].d1;
         loc[k].G[i][0] = g0; loc[k].G[i][1] = g1;
-        loc[k].c[i] = valid[k] ? (xn[i].v - (g0 * X[k][0] + g1 * X[k][1])) : 0.0;
+        loc[k].c[i] = xn[i].v - (g0 * X[k][0] + g1 * X[k][1]);
       }
       Aff2 t_;
       aff2_compose(t_, loc[k], agg);
