@@ -1918,7 +1918,7 @@ __global__ void __launch_bounds__(256) ilqr_small_kernel(const KArgs a) {
       L = __builtin_inf();
     }
     double improvement = __builtin_inf();
-    bool optimistic = true;
+    bool optimistic = true, first_try_streak = true;
     int it_this = 0;
     long long c_prev = 0;
     while (improvement > a.delta) {
@@ -1932,7 +1932,10 @@ __global__ void __launch_bounds__(256) ilqr_small_kernel(const KArgs a) {
       const bool cold_start = cold && rs == 0 && it_this == 0 && (MODE == MODE_SOLVE || MODE == MODE_MPC);
       const bool ok = linesearch<M, JAC>(w, c, a, x0r, L, optimistic, fuse, L_new, eps, trials, slot, fused, cold_start);
       // expect eps = 1 next time if it was accepted now - or whenever the attempt is the cheap one
-      optimistic = (ok && trials == 1) || newton_capable<M>(w, a);
+      // (sequential attempts: only after TWO first-trial acceptances in a row - on coarse line
+      // searches a lone one is usually followed by a backtrack, and the failed attempt costs a rollout)
+      optimistic = (ok && trials == 1 && first_try_streak) || newton_capable<M>(w, a);
+      first_try_streak = ok && trials == 1;
       ls_total += trials;
       if (!ok) { status = MI_STATUS_LINESEARCH_FAILED; break; }
       wave_sync();
