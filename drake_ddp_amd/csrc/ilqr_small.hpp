@@ -41,6 +41,14 @@ enum KernelMode { MODE_SOLVE = 0, MODE_ROLLOUT = 1, MODE_FORWARD = 2, MODE_LINEA
 
 constexpr int kMaxStateDim = 40;   // largest model state (Synth36: 36), for by-value kernel arguments
 
+// Per-solve aggregate over the batch, written into pinned, device-mapped host memory (one small host
+// read after a blocking solve instead of four D2H copies).
+struct DevStats {
+  long long total_iters, total_ls;
+  int n_conv, n_max, n_fail, max_iters_seen, best_index, pad;
+  double best_cost;
+};
+
 struct KArgs {
   // persistent per-problem solver state, reference layout with a leading batch axis
   double *x_bar, *u_bar, *K, *kappa, *dV, *fx, *fu;
@@ -66,6 +74,10 @@ struct KArgs {
   int32_t helpers;             // extra wavefronts per problem that share the linearization (0, 1 or 3), see ilqr_small_kernel
   int32_t seq_backward;        // 1: sequential Riccati sweep instead of the parallel-in-time scan (A/B measurements)
   int32_t newton_rollout;      // 1: the eps = 1 trial is rolled out parallel in time (Newton on the trajectory) when it converges
+  // MODE_SOLVE / MODE_MPC of the wave-per-problem kernels: the last workgroup to finish aggregates the
+  // batch statistics itself (no second kernel per solve).  Null: the host launches stats_kernel.
+  DevStats* stats_out;
+  int32_t* done_counter;       // zero between launches
 };
 
 __device__ __forceinline__ double bcast_lane0(double v) {
@@ -1751,6 +1763,72 @@ __device__ inline void backward(const WS& w, const Consts<M>& c, bool sequential
 }
 
 // ---------------------------------------------------------------------------
+// Batch statistics without a second kernel: every workgroup publishes its problem's results, takes a
+// ticket, and the holder of the last ticket - all other results are then visible - reduces the B
+// per-problem records (same rules as stats_kernel: best cost among the converged problems, ties to
+// the lower index) and writes the aggregate.  Called by the main wave, all 64 lanes.
+// ---------------------------------------------------------------------------
+// The four per-problem records travel as device-scope atomic stores / loads (coherent across the
+// eight XCDs' L2 caches on their own) and the ticket is taken once they are acknowledged - NOT behind a
+// device-scope release fence: that would write back the whole L2, i.e. wait for the results other
+// workgroups are streaming out at that moment (measured: +12 us per launch).
+__device__ inline void batch_stats_by_last_workgroup(const KArgs& a, int b, double L, int iters, int status, int ls_total) {
+  const int lane = threadIdx.x & 63;
+  int ticket = 0;
+  if (lane == 0) {
+    __hip_atomic_store(a.cost + b, L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(a.iters + b, iters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(a.status + b, status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(a.ls_trials + b, ls_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // stores acknowledged (s_waitcnt), no cache write-back
+    ticket = __hip_atomic_fetch_add(a.done_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  ticket = __builtin_amdgcn_readfirstlane(ticket);
+  if (ticket != (int)gridDim.x - 1) return;
+  const int B = a.B;
+  long long it = 0, ls = 0;
+  int c = 0, mxi = 0, nm = 0, nf = 0, bi = -1;
+  double bc = __builtin_inf();
+  constexpr int U = 4;                                         // 4 x 4 independent loads in flight per lane
+  for (int q0 = lane; q0 < B; q0 += 64 * U) {
+    int iq[U], sq[U], lq[U]; double cq[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int q = (q0 + 64 * u < B) ? q0 + 64 * u : 0;
+      iq[u] = __hip_atomic_load(a.iters + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      sq[u] = __hip_atomic_load(a.status + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      lq[u] = __hip_atomic_load(a.ls_trials + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      cq[u] = __hip_atomic_load(a.cost + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int q = q0 + 64 * u;
+      if (q < B) {
+        it += iq[u]; ls += lq[u];
+        mxi = iq[u] > mxi ? iq[u] : mxi;
+        if (sq[u] == MI_STATUS_CONVERGED) { c++; if (cq[u] < bc) { bc = cq[u]; bi = q; } }
+        else if (sq[u] == MI_STATUS_MAX_ITERS) nm++;
+        else nf++;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    it += __shfl_xor(it, o); ls += __shfl_xor(ls, o);
+    c += __shfl_xor(c, o); nm += __shfl_xor(nm, o); nf += __shfl_xor(nf, o);
+    const int m2 = __shfl_xor(mxi, o); mxi = m2 > mxi ? m2 : mxi;
+    const double bc2 = __shfl_xor(bc, o); const int bi2 = __shfl_xor(bi, o);
+    if (bc2 < bc || (bc2 == bc && bi2 >= 0 && (bi < 0 || bi2 < bi))) { bc = bc2; bi = bi2; }
+  }
+  if (lane == 0) {
+    DevStats* o = a.stats_out;
+    o->total_iters = it; o->total_ls = ls; o->n_conv = c; o->n_max = nm; o->n_fail = nf;
+    o->max_iters_seen = mxi; o->best_index = bi; o->best_cost = bc;
+    __hip_atomic_store(a.done_counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+  }
+}
+
+// ---------------------------------------------------------------------------
 // The kernel: stage, run MODE, write back.
 // ---------------------------------------------------------------------------
 template <class M, int JAC, int MODE>
@@ -2003,6 +2081,10 @@ __global__ void __launch_bounds__(256) ilqr_small_kernel(const KArgs a) {
 #ifdef MI_PROF_NEWTON
   const long long c_loop_end = clock64();
 #endif
+  // Batch statistics first, while this wave has next to nothing in flight (the ticket waits for the
+  // wave's outstanding stores).
+  if ((MODE == MODE_SOLVE || MODE == MODE_MPC) && a.stats_out != nullptr)
+    batch_stats_by_last_workgroup(a, b, L, iters, status, ls_total);
   if constexpr (n <= 2) {
     // Write-back, one time step per lane: a step's whole G and J records are read from LDS together
     // (one LDS latency per 64 steps instead of one per array row), then scattered to the reference's

@@ -413,3 +413,30 @@ def test_auto_kernel_selection_at_large_batches():
     a = make_solver(W.acrobot_problem(), B=B, jac="ad", kernel_mode="auto", hist_cap=2)
     with pytest.raises(MiIlqrError):
         a.stage_backward()                             # n = 4 at B >= 8192: lane-per-problem kernel
+
+
+def test_in_kernel_and_separate_statistics_agree(tmp_path):
+    """The batch statistics come from the solve kernel's own epilogue (small batches) or from
+    stats_kernel: same aggregate either way, for a batch with converged, capped and failed problems."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = f"""
+import sys, numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, 'tests')!r})
+from drake_ddp_amd import workloads as W
+from test_gpu_parity import make_solver
+prob = W.pendulum_problem()
+x0 = W.pendulum_batch_x0(1024)[:200]
+s = make_solver(prob, B=200, jac='fd', max_iters=7)
+s.SetInitialState(x0); s.SetInitialGuess(np.zeros((1, prob['N'] - 1)))
+s.Solve()
+st = s.stats
+np.savez(sys.argv[1], v=np.array([st.total_iters, st.total_ls_trials, st.n_converged, st.n_max_iters, st.n_ls_failed,
+                                  st.max_iters_seen, st.best_index, st.best_cost]), it=s.iterations, status=s.status, cost=s.cost)
+"""
+    a = _run_variant(script, {"MI_ILQR_STATS_KERNEL": "0"}, str(tmp_path / "a.npz"), tmp_path)
+    b = _run_variant(script, {"MI_ILQR_STATS_KERNEL": "1"}, str(tmp_path / "b.npz"), tmp_path)
+    assert np.array_equal(a["v"], b["v"]) and np.array_equal(a["it"], b["it"])
+    v, it, status, cost = a["v"], a["it"], a["status"], a["cost"]
+    assert v[0] == it.sum() and v[2] == (status == 0).sum() and v[3] == (status == 1).sum() and v[3] > 0 and v[5] == it.max()
+    conv = np.where(status == 0)[0]
+    assert int(v[6]) == conv[np.argmin(cost[conv])] and v[7] == cost[conv].min()
