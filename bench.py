@@ -7,7 +7,9 @@
 
 A "step" is ONE batched Solve() from a cold start (fresh solver state, the resident
 u_guess re-armed) of this rank's shard; inputs are resident in HBM before the timed
-region.  value = (sum over ranks and steps of iLQR iterations) / (max-over-ranks wall).
+region.  Steps are enqueued back to back on the solver's stream (one solve runs at a time;
+each keeps its own kernel events and statistics record) and collected per group of 32.
+value = (sum over ranks and steps of iLQR iterations) / (max-over-ranks wall).
 Prints exactly one JSON line on rank 0.
 """
 import argparse
