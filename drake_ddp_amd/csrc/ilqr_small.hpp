@@ -132,11 +132,14 @@ struct Lay {
   static constexpr int XN = 0, UN = even(n), TS = pad(UN + m);
   static constexpr int FX = 0, FU = even(n * n), JS = pad(FU + n * m);
   static constexpr int DUMP_DOUBLES = 64 * 2 + (GS > JS ? GS : JS);   // 16 B per lane + one record of slack
+  // copy of the cost constants (Consts<M>) for code that runs outside the kernel function (outlined passes)
+  static constexpr int CST_DOUBLES = (n >= 3) ? even(2 * n * n + m * m + 3 * n) : 0;
 };
 
 struct WS {
   double *G, *T, *J;       // point at record index 0 (pad record lives at index -1)
   double* dump;            // per-lane sink for predicated-off stores (lane*16 B)
+  double* cst;             // Consts<M> image (n >= 3)
   int *kp, *aux, *need, *binA, *binB;
   int N;
   int n_store, t_stride;   // T holds n_store trajectories, t_stride doubles apart
@@ -145,7 +148,7 @@ struct WS {
 template <int n, int m>
 __host__ __device__ constexpr size_t ws_bytes(int N, int n_store = 1) {
   using L = Lay<n, m>;
-  return ((size_t)(N + 2) * L::GS + (size_t)n_store * (N + 2) * L::TS + (size_t)(N + 2) * L::JS + L::DUMP_DOUBLES) * 8 +
+  return ((size_t)(N + 2) * L::GS + (size_t)n_store * (N + 2) * L::TS + (size_t)(N + 2) * L::JS + L::DUMP_DOUBLES + L::CST_DOUBLES) * 8 +
          (size_t)7 * N * 4 + 16;
 }
 
@@ -160,6 +163,7 @@ __device__ inline WS carve(char* base, int N, int n_store) {
   w.n_store = n_store; w.t_stride = (N + 2) * L::TS;
   w.J = p + L::JS; p += (size_t)(N + 2) * L::JS;
   w.dump = p; p += L::DUMP_DOUBLES;
+  w.cst = p; p += L::CST_DOUBLES;
   int* q = reinterpret_cast<int*>(p);
   w.kp = q; q += N;
   w.aux = q; q += N;
@@ -190,6 +194,16 @@ __device__ inline void stage_out(double* dst, const double* recs, int RS, int of
   }
 }
 
+// The same model with the kernels' backward pass run as the time-parallel scan.  For n = 3..4 the scan
+// pays from two steps per lane on (N > 128) and its register appetite must not touch the kernels of
+// short horizons, so the host picks this instantiation by horizon (mi_ilqr.hip: launch_jac).
+template <class M>
+struct LongHorizon : M { static constexpr bool kScanBackward = true; };
+template <class M, class = void>
+struct UsesScanBackward : std::false_type {};
+template <class M>
+struct UsesScanBackward<M, std::void_t<decltype(M::kScanBackward)>> : std::bool_constant<M::kScanBackward> {};
+
 template <class M>
 struct Consts {
   static constexpr int n = M::n, m = M::m;
@@ -214,6 +228,33 @@ struct Consts {
       for (int i = 0; i < n; ++i) { s += (2.0 * xnom[i]) * Q[i][j]; sf += (2.0 * xnom[i]) * Qf[i][j]; }
       qn[j] = s; qfn[j] = sf;
     }
+  }
+  // LDS image: Q | Qf | R | xnom | qn | qfn
+  __device__ inline void to_lds(double* d) const {
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+      for (int i = 0; i < n; ++i)
+#pragma unroll
+        for (int j = 0; j < n; ++j) { d[i * n + j] = Q[i][j]; d[n * n + i * n + j] = Qf[i][j]; }
+#pragma unroll
+      for (int i = 0; i < m; ++i)
+#pragma unroll
+        for (int j = 0; j < m; ++j) d[2 * n * n + i * m + j] = R[i][j];
+#pragma unroll
+      for (int i = 0; i < n; ++i) { d[2 * n * n + m * m + i] = xnom[i]; d[2 * n * n + m * m + n + i] = qn[i]; d[2 * n * n + m * m + 2 * n + i] = qfn[i]; }
+    }
+  }
+  __device__ inline void from_lds(const double* d) {
+#pragma unroll
+    for (int i = 0; i < n; ++i)
+#pragma unroll
+      for (int j = 0; j < n; ++j) { Q[i][j] = d[i * n + j]; Qf[i][j] = d[n * n + i * n + j]; }
+#pragma unroll
+    for (int i = 0; i < m; ++i)
+#pragma unroll
+      for (int j = 0; j < m; ++j) R[i][j] = d[2 * n * n + i * m + j];
+#pragma unroll
+    for (int i = 0; i < n; ++i) { xnom[i] = d[2 * n * n + m * m + i]; qn[i] = d[2 * n * n + m * m + n + i]; qfn[i] = d[2 * n * n + m * m + 2 * n + i]; }
   }
 };
 
@@ -1453,9 +1494,42 @@ __device__ __forceinline__ void ric_identity(RicElem<n>& r) {
   }
 }
 
-// out = ei (x) ej   (ei earlier in time); out may alias neither input
-__device__ __forceinline__ void ric_combine(RicElem<2>& o, const RicElem<2>& ei, const RicElem<2>& ej) {
-  constexpr int n = 2;
+// M = P^-1 for P = I + C_i J_j.  n = 2: adjugate / determinant (det >= 1: C, J are PSD).  n > 2:
+// Gauss-Jordan WITHOUT pivoting - P is not symmetric and a pivot can in principle come out small or
+// negative although det P >= 1, so the smallest pivot magnitude is reported and the caller falls back
+// to the sequential sweep when it is not comfortably away from zero (never seen on the configs).
+template <int n>
+__device__ __forceinline__ void ric_invert(const double (&P)[n][n], double (&Mi)[n][n], double& min_pivot) {
+  if constexpr (n == 2) {
+    const double idet = fast_rcp(P[0][0] * P[1][1] - P[0][1] * P[1][0]);
+    Mi[0][0] = P[1][1] * idet; Mi[0][1] = -P[0][1] * idet; Mi[1][0] = -P[1][0] * idet; Mi[1][1] = P[0][0] * idet;
+  } else {
+    double a[n][n];
+#pragma unroll
+    for (int i = 0; i < n; ++i)
+#pragma unroll
+      for (int j = 0; j < n; ++j) { a[i][j] = P[i][j]; Mi[i][j] = (i == j) ? 1.0 : 0.0; }
+#pragma unroll
+    for (int k = 0; k < n; ++k) {
+      min_pivot = fmin(min_pivot, fabs(a[k][k]));
+      const double ip = fast_rcp(a[k][k]);
+#pragma unroll
+      for (int j = 0; j < n; ++j) { a[k][j] *= ip; Mi[k][j] *= ip; }   // (columns < k of a, > k of Mi: zeros, folded)
+#pragma unroll
+      for (int i = 0; i < n; ++i) {
+        if (i == k) continue;
+        const double f = a[i][k];
+#pragma unroll
+        for (int j = 0; j < n; ++j) { a[i][j] = fma(-f, a[k][j], a[i][j]); Mi[i][j] = fma(-f, Mi[k][j], Mi[i][j]); }
+      }
+    }
+  }
+}
+
+// out = ei (x) ej   (ei earlier in time); out may alias neither input.  VALUE_ONLY: just (J, eta) -
+// all that is read after the last level of the scan.
+template <int n, bool VALUE_ONLY = false>
+__device__ __forceinline__ void ric_combine(RicElem<n>& o, const RicElem<n>& ei, const RicElem<n>& ej, double& min_pivot) {
   double P[n][n], Mi[n][n], W[n][n], MA[n][n];
 #pragma unroll
   for (int i = 0; i < n; ++i)
@@ -1464,17 +1538,16 @@ __device__ __forceinline__ void ric_combine(RicElem<2>& o, const RicElem<2>& ei,
       double s = (i == j) ? 1.0 : 0.0;
 #pragma unroll
       for (int k = 0; k < n; ++k) s += ei.C[i][k] * ej.J[k][j];
-      P[i][j] = s;                                          // I + C_i J_j  (eigenvalues >= 1: C, J are PSD)
+      P[i][j] = s;                                          // I + C_i J_j
     }
-  const double idet = fast_rcp(P[0][0] * P[1][1] - P[0][1] * P[1][0]);
-  Mi[0][0] = P[1][1] * idet; Mi[0][1] = -P[0][1] * idet; Mi[1][0] = -P[1][0] * idet; Mi[1][1] = P[0][0] * idet;
+  ric_invert<n>(P, Mi, min_pivot);
 #pragma unroll
   for (int i = 0; i < n; ++i)
 #pragma unroll
     for (int j = 0; j < n; ++j) {
       double s = 0.0, q = 0.0;
 #pragma unroll
-      for (int k = 0; k < n; ++k) { s += ej.A[i][k] * Mi[k][j]; q += Mi[i][k] * ei.A[k][j]; }
+      for (int k = 0; k < n; ++k) { if (!VALUE_ONLY) s += ej.A[i][k] * Mi[k][j]; q += Mi[i][k] * ei.A[k][j]; }
       W[i][j] = s;                                          // A_j M
       MA[i][j] = q;                                         // M A_i ; V = MA^T
     }
@@ -1483,7 +1556,7 @@ __device__ __forceinline__ void ric_combine(RicElem<2>& o, const RicElem<2>& ei,
   for (int i = 0; i < n; ++i) {
     double s = ei.b[i], q = ej.e[i];
 #pragma unroll
-    for (int k = 0; k < n; ++k) { s += ei.C[i][k] * ej.e[k]; q -= ej.J[i][k] * ei.b[k]; }
+    for (int k = 0; k < n; ++k) { if (!VALUE_ONLY) s += ei.C[i][k] * ej.e[k]; q -= ej.J[i][k] * ei.b[k]; }
     t1[i] = s;                                              // b_i + C_i eta_j
     t2[i] = q;                                              // eta_j - J_j b_i
   }
@@ -1493,7 +1566,7 @@ __device__ __forceinline__ void ric_combine(RicElem<2>& o, const RicElem<2>& ei,
     for (int j = 0; j < n; ++j) {
       double s = 0.0, q = 0.0;
 #pragma unroll
-      for (int k = 0; k < n; ++k) { s += W[i][k] * ei.C[k][j]; q += MA[k][i] * ej.J[k][j]; }
+      for (int k = 0; k < n; ++k) { if (!VALUE_ONLY) s += W[i][k] * ei.C[k][j]; q += MA[k][i] * ej.J[k][j]; }
       WC[i][j] = s;                                         // W C_i
       VJ[i][j] = q;                                         // V J_j
     }
@@ -1501,79 +1574,24 @@ __device__ __forceinline__ void ric_combine(RicElem<2>& o, const RicElem<2>& ei,
   for (int i = 0; i < n; ++i) {
     double sb = ej.b[i], se = ei.e[i];
 #pragma unroll
-    for (int k = 0; k < n; ++k) { sb += W[i][k] * t1[k]; se += MA[k][i] * t2[k]; }
-    o.b[i] = sb;
+    for (int k = 0; k < n; ++k) { if (!VALUE_ONLY) sb += W[i][k] * t1[k]; se += MA[k][i] * t2[k]; }
+    if (!VALUE_ONLY) o.b[i] = sb;
     o.e[i] = se;
 #pragma unroll
     for (int j = 0; j < n; ++j) {
-      double sa = 0.0;
+      if (!VALUE_ONLY) {
+        double sa = 0.0;
 #pragma unroll
-      for (int k = 0; k < n; ++k) sa += W[i][k] * ei.A[k][j];
-      o.A[i][j] = sa;
+        for (int k = 0; k < n; ++k) sa += W[i][k] * ei.A[k][j];
+        o.A[i][j] = sa;
+      }
       if (j >= i) {                                          // C and J are symmetric: upper triangle, mirrored
         double sc = ej.C[i][j], sj = ei.J[i][j];
 #pragma unroll
-        for (int k = 0; k < n; ++k) { sc += WC[i][k] * ej.A[j][k]; sj += VJ[i][k] * ei.A[k][j]; }
-        o.C[i][j] = sc; o.C[j][i] = sc;
+        for (int k = 0; k < n; ++k) { if (!VALUE_ONLY) sc += WC[i][k] * ej.A[j][k]; sj += VJ[i][k] * ei.A[k][j]; }
+        if (!VALUE_ONLY) { o.C[i][j] = sc; o.C[j][i] = sc; }
         o.J[i][j] = sj; o.J[j][i] = sj;
       }
-    }
-  }
-}
-
-// The last level of the scan: only the value function (J, eta) of the composition is read afterwards.
-__device__ __forceinline__ void ric_combine_value(RicElem<2>& o, const RicElem<2>& ei, const RicElem<2>& ej) {
-  constexpr int n = 2;
-  double P[n][n], Mi[n][n], MA[n][n];
-#pragma unroll
-  for (int i = 0; i < n; ++i)
-#pragma unroll
-    for (int j = 0; j < n; ++j) {
-      double s = (i == j) ? 1.0 : 0.0;
-#pragma unroll
-      for (int k = 0; k < n; ++k) s += ei.C[i][k] * ej.J[k][j];
-      P[i][j] = s;
-    }
-  const double idet = fast_rcp(P[0][0] * P[1][1] - P[0][1] * P[1][0]);
-  Mi[0][0] = P[1][1] * idet; Mi[0][1] = -P[0][1] * idet; Mi[1][0] = -P[1][0] * idet; Mi[1][1] = P[0][0] * idet;
-#pragma unroll
-  for (int i = 0; i < n; ++i)
-#pragma unroll
-    for (int j = 0; j < n; ++j) {
-      double q = 0.0;
-#pragma unroll
-      for (int k = 0; k < n; ++k) q += Mi[i][k] * ei.A[k][j];
-      MA[i][j] = q;                                         // M A_i ; V = MA^T
-    }
-  double t2[n], VJ[n][n];
-#pragma unroll
-  for (int i = 0; i < n; ++i) {
-    double q = ej.e[i];
-#pragma unroll
-    for (int k = 0; k < n; ++k) q -= ej.J[i][k] * ei.b[k];
-    t2[i] = q;                                              // eta_j - J_j b_i
-  }
-#pragma unroll
-  for (int i = 0; i < n; ++i)
-#pragma unroll
-    for (int j = 0; j < n; ++j) {
-      double q = 0.0;
-#pragma unroll
-      for (int k = 0; k < n; ++k) q += MA[k][i] * ej.J[k][j];
-      VJ[i][j] = q;                                         // V J_j
-    }
-#pragma unroll
-  for (int i = 0; i < n; ++i) {
-    double se = ei.e[i];
-#pragma unroll
-    for (int k = 0; k < n; ++k) se += MA[k][i] * t2[k];
-    o.e[i] = se;
-#pragma unroll
-    for (int j = i; j < n; ++j) {
-      double sj = ei.J[i][j];
-#pragma unroll
-      for (int k = 0; k < n; ++k) sj += VJ[i][k] * ei.A[k][j];
-      o.J[i][j] = sj; o.J[j][i] = sj;
     }
   }
 }
@@ -1609,9 +1627,10 @@ __device__ __forceinline__ void ric_fetch_dpp(RicElem<n>& dst, const RicElem<n>&
 }
 
 template <class M>
-__device__ inline void backward_scan(const WS& w, const Consts<M>& c) {
+__device__ inline bool backward_scan(const WS& w, const Consts<M>& c) {
   constexpr int n = M::n, m = M::m;
-  static_assert(n == 2 && m == 1, "closed-form 2x2 composition");
+  static_assert(m == 1, "rank-one control term: C = fu luu^-1 fu^T with scalar luu");
+  double min_pivot = __builtin_inf();                       // smallest pivot of the n > 2 inversions
   using Ly = Lay<n, m>;
   const int N = w.N, lane = threadIdx.x & 63;
   const int chunk = (N + 63) >> 6;                          // elements 0..N-2 are steps, element N-1 is the terminal one
@@ -1634,7 +1653,7 @@ __device__ inline void backward_scan(const WS& w, const Consts<M>& c) {
   constexpr int CHMAX = 4;
   struct Raw { double x[n], u, fx[n][n], fu[n]; };
   Raw raw[CHMAX];
-  const bool held = chunk <= CHMAX;                         // longer horizons: phase (3) re-reads
+  const bool held = n == 2 && chunk <= CHMAX;               // longer horizons, larger n: phase (3) re-reads
   auto read_raw = [&](Raw& r, int t) __attribute__((always_inline)) {
     const int tg = t < N ? t : N - 1, tj = t < N - 1 ? t : N - 2;
     const double* g = w.G + tg * Ly::GS;
@@ -1675,7 +1694,7 @@ __device__ inline void backward_scan(const WS& w, const Consts<M>& c) {
       if (k < chunk) {
         read_raw(raw[k], e0 + k);
         if (k == 0) element(S, raw[0], e0);
-        else { element(T, raw[k], e0 + k); ric_combine(U, S, T); S = U; }
+        else { element(T, raw[k], e0 + k); ric_combine<n>(U, S, T, min_pivot); S = U; }
       }
     }
   } else {
@@ -1685,7 +1704,7 @@ __device__ inline void backward_scan(const WS& w, const Consts<M>& c) {
     for (int k = 1; k < chunk; ++k) {
       read_raw(q, e0 + k);
       element(T, q, e0 + k);
-      ric_combine(U, S, T);
+      ric_combine<n>(U, S, T, min_pivot);
       S = U;
     }
   }
@@ -1694,7 +1713,7 @@ __device__ inline void backward_scan(const WS& w, const Consts<M>& c) {
   // no select.  Four levels inside the 16-lane rows, then the row totals into the following rows.
   auto level = [&](auto ctrl, auto rows) __attribute__((always_inline)) {
     ric_fetch_dpp<decltype(ctrl)::value, decltype(rows)::value, n>(T, S);
-    ric_combine(U, S, T);
+    ric_combine<n>(U, S, T, min_pivot);
     S = U;
   };
   using std::integral_constant;
@@ -1704,9 +1723,18 @@ __device__ inline void backward_scan(const WS& w, const Consts<M>& c) {
   level(integral_constant<int, 0x118>{}, integral_constant<int, 0xF>{});   // row_shr:8
   level(integral_constant<int, 0x142>{}, integral_constant<int, 0xA>{});   // row_bcast:15 -> rows 1, 3
   ric_fetch_dpp<0x143, 0xC, n, true>(T, S);                                // row_bcast:31 -> rows 2, 3: only
-  ric_combine_value(U, S, T);                                              // (J, eta) are read from here on
-  S.e[0] = U.e[0]; S.e[1] = U.e[1];
-  S.J[0][0] = U.J[0][0]; S.J[0][1] = U.J[0][1]; S.J[1][0] = U.J[1][0]; S.J[1][1] = U.J[1][1];
+  ric_combine<n, true>(U, S, T, min_pivot);                                // (J, eta) are read from here on
+#pragma unroll
+  for (int i = 0; i < n; ++i) {
+    S.e[i] = U.e[i];
+#pragma unroll
+    for (int j = 0; j < n; ++j) S.J[i][j] = U.J[i][j];
+  }
+  if constexpr (n > 2) {
+    // an inversion without pivoting met a small pivot somewhere in the wave: the caller redoes the pass
+    // with the sequential sweep (nothing has been written yet)
+    if (!__all(min_pivot > 1e-3)) return false;
+  }
   // value function at the right edge of this chunk = (J, -eta) of the scan value one lane down
   double Vx[n], Vxx[n][n];
 #pragma unroll
@@ -1753,11 +1781,36 @@ __device__ inline void backward_scan(const WS& w, const Consts<M>& c) {
       riccati_step(q, t);
     }
   }
+  return true;
+}
+
+// n = 3..4: the scan keeps three n x n elements and the temporaries of a composition live - all 512
+// registers of a wave.  Inlined into the kernel that allocation drags the line-search loops down with
+// it (C4: line search 208 k -> 259 k cycles per iteration), so it is a real function with its own
+// register allocation: it rebuilds its view of the workgroup's LDS and reads the cost constants from
+// their LDS image.
+template <class M>
+__device__ __attribute__((noinline)) bool backward_scan_outlined(int N, int n_store) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const WS w = carve<M::n, M::m>(smem, N, n_store);
+  Consts<M> c;
+  c.from_lds(w.cst);
+  return backward_scan<M>(w, c);
 }
 
 template <class M>
 __device__ inline void backward(const WS& w, const Consts<M>& c, bool sequential = false) {
-  if constexpr (M::n >= 3 && M::n <= 4 && M::m == 1) backward_mfma<M>(w, c);
+  if constexpr (M::n >= 3 && M::n <= 4 && M::m == 1) {
+    // LongHorizon<M> kernels (N > 128, two or more steps per lane): the scan's 9 compositions of n x n
+    // elements (~640 fused multiply-adds each at n = 4) beat N - 1 sequential MFMA steps
+    if constexpr (UsesScanBackward<M>::value) {
+      // (N > 128 always holds for these kernels.  The loop-invariant test is kept on purpose: LLVM unswitches
+      // the solve loop on it, and the copy of the loop that contains the call then keeps the line-search
+      // loops' register allocation - measured 202 k vs 238 k cycles of line search per C4 iteration.)
+      if (!sequential && w.N > 128 && backward_scan_outlined<M>(w.N, w.n_store)) return;
+    }
+    backward_mfma<M>(w, c);
+  }
   else if constexpr (M::n == 2 && M::m == 1) { if (sequential) backward_scalar<M>(w, c); else backward_scan<M>(w, c); }
   else backward_scalar<M>(w, c);
 }
@@ -1919,6 +1972,7 @@ __global__ void __launch_bounds__(256) ilqr_small_kernel(const KArgs a) {
     c.load(a.costmat);
 #pragma unroll
     for (int i = 0; i < n; ++i) x0r[i] = a.x0[(size_t)b * n + i];
+    if constexpr (UsesScanBackward<M>::value) c.to_lds(w.cst);
   }
   wave_sync();
 
@@ -1992,6 +2046,7 @@ __global__ void __launch_bounds__(256) ilqr_small_kernel(const KArgs a) {
         for (int i = 0; i < n; ++i) { s_ += (2.0 * c.xnom[i]) * c.Q[i][j]; sf_ += (2.0 * c.xnom[i]) * c.Qf[i][j]; }
         c.qn[j] = s_; c.qfn[j] = sf_;
       }
+      if constexpr (UsesScanBackward<M>::value) c.to_lds(w.cst);
       wave_sync();
       L = __builtin_inf();
     }
@@ -2037,6 +2092,9 @@ __global__ void __launch_bounds__(256) ilqr_small_kernel(const KArgs a) {
       }
       const long long c2 = clock64();
       if (MODE != MODE_FORWARD) { backward<M>(w, c, a.seq_backward != 0); wave_sync(); } // :697
+      // LongHorizon kernels: backward() is a real call; re-reading the constants from their LDS image instead
+      // of keeping 90 registers alive across it leaves the line-search loops their old allocation
+      if constexpr (UsesScanBackward<M>::value) c.from_lds(w.cst);
       const long long c3 = clock64();
       c_prev = c3;
       if (fused == 2) c_ls += c2 - c0;                            // line search + commit + linearization

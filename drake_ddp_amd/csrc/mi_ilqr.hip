@@ -230,6 +230,19 @@ int launch_batch(mi_ilqr* h, int mode, const KArgs& a) {
 
 template <class M>
 int launch_jac(mi_ilqr* h, int mode, const KArgs& a) {
+  if constexpr (M::n >= 3 && M::n <= 4 && M::m == 1) {
+    // two or more steps per lane: the kernels whose backward pass is the time-parallel scan (ilqr_small.hpp:
+    // LongHorizon) - only the modes that run a backward pass have such an instantiation
+    if (h->N > 128 && (mode == MODE_SOLVE || mode == MODE_MPC || mode == MODE_BACKWARD)) {
+      using L = LongHorizon<M>;
+      const bool ad = h->d.jacobian_mode == MI_JAC_AUTODIFF;
+      switch (mode) {
+        case MODE_SOLVE: return ad ? launch_one<L, MI_JAC_AUTODIFF, MODE_SOLVE>(h, a) : launch_one<L, MI_JAC_FD_CENTRAL, MODE_SOLVE>(h, a);
+        case MODE_MPC: return ad ? launch_one<L, MI_JAC_AUTODIFF, MODE_MPC>(h, a) : launch_one<L, MI_JAC_FD_CENTRAL, MODE_MPC>(h, a);
+        default: return launch_one<L, MI_JAC_FD_CENTRAL, MODE_BACKWARD>(h, a);
+      }
+    }
+  }
   if (h->d.jacobian_mode == MI_JAC_AUTODIFF) return launch_mode<M, MI_JAC_AUTODIFF>(h, mode, a);
   return launch_mode<M, MI_JAC_FD_CENTRAL>(h, mode, a);
 }
