@@ -510,7 +510,7 @@ int mi_ilqr_create(const mi_ilqr_desc* desc, mi_ilqr_t** out) {
     const bool can = !large && desc->keypoint_method == MI_KP_SET_INTERVAL && desc->minN == 1;
     if (desc->kernel_mode == MI_KERNEL_THROUGHPUT && !can) return MI_ILQR_E_UNSUPPORTED;
     // n = 2 within the time-parallel passes' horizon: the wave-per-problem kernel is the faster one at
-    // every batch size (B = 65536: 68 M vs 42 M it/s, profiles/r01m_c2_modes_batch_sweep.txt)
+    // every batch size (B = 65536: 68 M vs 42 M it/s, profiles/r01n_c2_modes_batch_sweep.txt)
     const bool time_parallel = info->n == 2 && info->m == 1 && desc->N - 1 <= 256;
     batch_minor = can && (desc->kernel_mode == MI_KERNEL_THROUGHPUT ||
                           (desc->kernel_mode == MI_KERNEL_AUTO && desc->B >= 8192 && !time_parallel));
