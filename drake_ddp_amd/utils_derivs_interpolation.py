@@ -8,20 +8,21 @@ same positional construction order — callers such as acrobot.py:115 do
 keypoint_method is one of 'setInterval' | 'adaptiveJerk' | 'iterativeError'
 (/root/reference/ilqr.py:396-400); the solver maps it onto MI_KP_* of include/mi_ilqr.h.
 """
-import dataclasses as _dc
-
-_KP_FIELDS = (
-    ("keypoint_method", str),            # which key-point selection rule
-    ("minN", int),                       # minimum spacing between key-points
-    ("maxN", int),                       # maximum spacing (adaptiveJerk only)
-    ("jerk_threshold", float),           # adaptiveJerk trigger
-    ("iterative_error_threshold", float),  # iterativeError trigger
-)
-_SPAN_FIELDS = (("start_index", int), ("end_index", int))
-
-derivs_interpolation = _dc.make_dataclass("derivs_interpolation", _KP_FIELDS)
-index_tuple = _dc.make_dataclass("index_tuple", _SPAN_FIELDS)
-for _cls in (derivs_interpolation, index_tuple):
-    _cls.__module__ = __name__
+from dataclasses import dataclass
 
 KEYPOINT_METHODS = ("setInterval", "adaptiveJerk", "iterativeError")
+
+
+@dataclass
+class derivs_interpolation:
+    keypoint_method: str               # which key-point selection rule (KEYPOINT_METHODS)
+    minN: int                          # minimum spacing between key-points
+    maxN: int                          # maximum spacing (adaptiveJerk only)
+    jerk_threshold: float              # adaptiveJerk trigger
+    iterative_error_threshold: float   # iterativeError trigger
+
+
+@dataclass
+class index_tuple:
+    start_index: int
+    end_index: int

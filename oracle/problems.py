@@ -1,3 +1,102 @@
-"""Workload definitions are shared with the product (pure-NumPy data, no solver
-code): re-exported here so oracle scripts read ``oracle.problems``."""
-from drake_ddp_amd.workloads import *  # noqa: F401,F403
+"""ORACLE-side workload definitions (test infrastructure): the cost matrices, horizons and
+line-search parameters of the five BASELINE.json configs, restated here from the reference's
+example scripts so that the golden generator (oracle/gen_golden.py) does not depend on product
+code for its inputs.  tests/test_oracle_vs_golden.py::test_oracle_and_product_workloads_agree
+holds these equal to drake_ddp_amd/workloads.py, value for value.
+
+Model ids follow include/mi_ilqr.h / oracle/models_np.py.
+"""
+import numpy as np
+
+PENDULUM, ACROBOT, CARTPOLE, CARTPOLE_WALL, SYNTH36 = range(5)
+SYNTH_TARGET_VEL = 1.0
+
+
+def _problem(name, model_id, dt, N, x_nom, Q, R, Qf, beta):
+    # every example keeps delta = 1e-2, gamma = 0 (pendulum.py:85-86, acrobot.py:118-120, ...)
+    return dict(name=name, model_id=model_id, dt=dt, N=N, x_nom=np.asarray(x_nom, dtype=np.float64),
+                Q=Q, R=R, Qf=Qf, delta=1e-2, beta=beta, gamma=0.0)
+
+
+def pendulum_problem():
+    """/root/reference/pendulum.py:18-19 (T=2.0, dt=1e-2), :29 target, :32-34 cost, :93-94 (dt*Q, dt*R, Qf)."""
+    T, dt = 2.0, 1e-2
+    Q = 0.01 * np.diag([0.0, 1.0])
+    R = 0.01 * np.eye(1)
+    return _problem("pendulum", PENDULUM, dt, int(T / dt), [np.pi, 0.0], dt * Q, dt * R, 100.0 * np.eye(2), 0.95)
+
+
+def pendulum_batch_x0(B, seed=0):
+    rng = np.random.default_rng(seed)
+    theta = rng.uniform(-np.pi, np.pi, B)
+    omega = rng.uniform(-1.0, 1.0, B)
+    return np.column_stack([theta, omega])
+
+
+def acrobot_problem(N=40):
+    """/root/reference/acrobot.py:20 (dt=0.004), :40 target, :43-45 cost, :118-120 beta=0.5; N=40 per the config."""
+    dt = 0.004
+    Q = 0.01 * np.diag([0.0, 0.0, 1.0, 1.0])
+    R = 0.01 * np.eye(1)
+    return _problem("acrobot", ACROBOT, dt, N, [np.pi, 0.0, 0.0, 0.0], dt * Q, dt * R, 100.0 * np.eye(4), 0.5)
+
+
+def acrobot_batch_x0(B, seed=1):
+    return np.random.default_rng(seed).uniform(-0.1, 0.1, (B, 4))
+
+
+def cartpole_problem(N=100):
+    """/root/reference/cart_pole.py:21-22,44-46, beta=0.9 (:106-108)."""
+    dt = 1e-2
+    Q = np.diag([10.0, 10.0, 0.1, 0.1])
+    R = 0.001 * np.eye(1)
+    return _problem("cart_pole", CARTPOLE, dt, N, [0.0, np.pi, 0.0, 0.0], dt * Q, dt * R,
+                    np.diag([100.0, 100.0, 10.0, 10.0]), 0.9)
+
+
+def cartpole_wall_problem(N=200):
+    """/root/reference/cart_pole_with_wall.py:23 (dt), :38 target, :41-43 cost, :148 beta=0.5; N=200 per the config."""
+    dt = 1e-2
+    Q = np.diag([0.1, 1.0, 0.01, 0.01])
+    R = 0.001 * np.eye(1)
+    return _problem("cart_pole_with_wall", CARTPOLE_WALL, dt, N, [0.0, np.pi, 0.0, 0.0], dt * Q, dt * R,
+                    np.diag([200.0, 200.0, 10.0, 10.0]), 0.5)
+
+
+def cartpole_wall_batch_x0(B, seed=2):
+    x0 = np.zeros((B, 4))
+    x0[:, 1] = np.pi + 0.5 + np.random.default_rng(seed).uniform(-0.2, 0.2, B)
+    return x0
+
+
+def synth36_problem(N=40):
+    """C5 shape: diagonal weights patterned on /root/reference/mini_cheetah.py:60-69 (6 'base' + 12 'leg'
+    dofs), dt=4e-3 (:23), beta=0.5 (:168-169), forward-velocity target (:55-57)."""
+    dt = 4e-3
+    q_base = np.array([3.0, 3.0, 3.0, 1.0, 1.0, 1.0])
+    v_base = np.ones(6)
+    q_leg = np.zeros(12)
+    v_leg = np.full(12, 0.01)
+    Q = np.diag(np.concatenate([q_base, q_leg, 0.01 * v_base, v_leg]))
+    R = 0.01 * np.eye(12)
+    Qf = np.diag(np.concatenate([5.0 * q_base, 0.1 + q_leg, v_base, v_leg]))
+    x_nom = np.zeros(36)
+    x_nom[0] = SYNTH_TARGET_VEL * N * dt
+    x_nom[18] = SYNTH_TARGET_VEL
+    return _problem("synth36", SYNTH36, dt, N, x_nom, dt * Q, dt * R, Qf, 0.5)
+
+
+def synth36_batch_x0(B, seed=3):
+    x0 = np.zeros((B, 36))
+    x0[:, :18] = np.random.default_rng(seed).uniform(-0.1, 0.1, (B, 18))
+    return x0
+
+
+def synth36_u_guess(N):
+    return np.full((12, N - 1), 0.05)
+
+
+def mpc_shift(x, u, replan):
+    """acrobot.py:147-152 / mini_cheetah.py:193-198: drop `replan` controls, repeat the last, restart at x[:, replan]."""
+    u_next = np.concatenate([u[..., replan:], np.repeat(u[..., -1:], replan, axis=-1)], axis=-1)
+    return np.array(x[..., replan]), u_next

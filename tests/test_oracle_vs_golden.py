@@ -95,3 +95,27 @@ def test_bytes_per_iteration_matches_survey():
     assert bytes_per_iteration(4, 1, 40, 1) == 22288
     assert bytes_per_iteration(4, 1, 200, 1) == 113168
     assert bytes_per_iteration(36, 12, 40, 1) == 1416704
+
+
+def test_oracle_and_product_workloads_agree():
+    """oracle/problems.py (inputs of the golden generator) and drake_ddp_amd/workloads.py (inputs of
+    bench.py / the examples) are written independently from the reference's scripts: bitwise the same
+    problems, batches and warm starts."""
+    from oracle import problems as P
+    from drake_ddp_amd import workloads as W
+    for name, args in (("pendulum_problem", ()), ("acrobot_problem", (40,)), ("cartpole_problem", (100,)),
+                       ("cartpole_wall_problem", (200,)), ("cartpole_wall_problem", (100,)), ("synth36_problem", (40,))):
+        a, b = getattr(P, name)(*args), getattr(W, name)(*args)
+        assert a.keys() == b.keys()
+        for k in a:
+            if isinstance(a[k], np.ndarray):
+                assert np.array_equal(a[k], b[k]), (name, k)
+            else:
+                assert a[k] == b[k], (name, k)
+    for name, B in (("pendulum_batch_x0", 1024), ("acrobot_batch_x0", 512), ("cartpole_wall_batch_x0", 256), ("synth36_batch_x0", 64)):
+        assert np.array_equal(getattr(P, name)(B), getattr(W, name)(B)), name
+    assert np.array_equal(P.synth36_u_guess(40), W.synth36_u_guess(40)) and P.SYNTH_TARGET_VEL == W.SYNTH_TARGET_VEL
+    rng = np.random.default_rng(0)
+    x, u = rng.standard_normal((3, 4, 40)), rng.standard_normal((3, 1, 39))
+    for got, want in zip(P.mpc_shift(x, u, 2), W.mpc_shift(x, u, 2)):
+        assert np.array_equal(got, want)
