@@ -5,12 +5,18 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+With --gpus N > 1 and no launcher environment (WORLD_SIZE unset) the script launches its own N ranks
+(one process per GPU, torch.distributed.run on 127.0.0.1, RCCL) and rank 0 prints the line.
+
 A "step" is ONE batched Solve() from a cold start (fresh solver state, the resident
 u_guess re-armed) of this rank's shard; inputs are resident in HBM before the timed
 region.  Steps are enqueued back to back on the solver's stream (one solve runs at a time;
 each keeps its own kernel events and statistics record) and collected per group of 32.
 value = (sum over ranks and steps of iLQR iterations) / (max-over-ranks wall).
-Prints exactly one JSON line on rank 0.
+After the headline the same line carries `configs` (BASELINE.json's other configs C1, C3, C4, C5 at
+their full sizes, sharded over the ranks: iterations/s, ms per solve, kernel ms, algorithmic GB/s and
+roofline fraction, fp64 FLOP/s for C5) and `boundary_inclusive` (C2 through the class surface:
+Solve() with the host copy-in and the x_bar/u_bar/cost copy-out).  Prints exactly one JSON line on rank 0.
 """
 import argparse
 import json
@@ -60,7 +66,7 @@ def pmc_traffic_live(batch):
         try:
             cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", out, "--",
                    sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1",
-                   "--batch", str(batch), "--no-cpu-baseline"]
+                   "--batch", str(batch), "--no-cpu-baseline", "--no-configs"]
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
                            timeout=180, check=True)
             rows = []
@@ -138,6 +144,183 @@ def cpu_baseline(prob, x0, sample, budget_s=8.0):
     return out
 
 
+FP64_PEAK_TFLOPS = 78.6  # /opt/skills/guides/MI355X_MICROARCH.md: dense fp64 vector / matrix peak
+
+
+def backward_flops_per_iteration(n, m, N):
+    """fp64 flops of one backward pass (ilqr.py:651-667 per step): fx^T Vxx (2n^3), (.) fx (2n^3), fu^T Vxx (2n^2 m),
+    Quu (2nm^2), Qux (2n^2 m), the m x m inverse (~2/3 m^3), K (2m^2 n), Qux^T K (2n^2 m), vectors (~6nm + 4n^2)."""
+    per_step = 4.0 * n ** 3 + 6.0 * n * n * m + 2.0 * n * m * m + 2.0 * m * m * n + (2.0 / 3.0) * m ** 3 + 6.0 * n * m + 4.0 * n * n
+    return per_step * (N - 1)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks here (one process per GPU,
+    torch.distributed.run, rendezvous on 127.0.0.1) and let rank 0 print the JSON line."""
+    import socket
+    import subprocess
+    import torch
+    backend = os.environ.get("MI_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if ndev < 1:
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the hot path)")
+    if backend == "nccl" and ndev < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {ndev} GPU(s) visible on this node")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "8"))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+class Ranks:
+    """The launch contract's rank plumbing: fence = barrier + device sync; reductions over ranks."""
+
+    def __init__(self, world, rank, backend, dist, torch):
+        self.world, self.rank, self.backend, self.dist, self.torch = world, rank, backend, dist, torch
+
+    def fence(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def reduce(self, values, op):
+        if self.world == 1:
+            return [float(v) for v in values]
+        t = self.torch.tensor([float(v) for v in values], dtype=self.torch.float64,
+                              device="cuda" if self.backend == "nccl" else "cpu")
+        self.dist.all_reduce(t, op={"max": self.dist.ReduceOp.MAX, "sum": self.dist.ReduceOp.SUM}[op])
+        return [float(v) for v in t.cpu()]
+
+
+def make_solver(prob, B, dev_index, **kw):
+    from drake_ddp_amd.ilqr import BatchedIterativeLQR
+    from drake_ddp_amd.models import ModelSystem
+    s = BatchedIterativeLQR(ModelSystem(prob["model_id"], prob["dt"]), prob["N"], B, delta=prob["delta"], beta=prob["beta"],
+                            gamma=prob["gamma"], jacobian_mode="fd", fd_step=1e-5, device=dev_index, hist_cap=8, **kw)
+    s.SetTargetState(prob["x_nom"])
+    s.SetRunningCost(prob["Q"], prob["R"])
+    s.SetTerminalCost(prob["Qf"])
+    return s
+
+
+def run_config(rk, dev_index, name, prob, x0_all, u_guess, reps, mpc=None):
+    """One of BASELINE.json's configs at its full (global) batch, sharded contiguously over the ranks.
+    `mpc` = (resolves, replan, (index, step) of the moving target or None): the cold solve plus the whole
+    receding-horizon loop on the device (mi_ilqr_mpc_run) is one repetition; otherwise a repetition is
+    one cold-start batched solve.  Inputs are resident before the timed region; one host synchronization
+    per repetition.  Returns the aggregated record (rank 0's is printed)."""
+    from drake_ddp_amd.dist import shard_range
+    n, m, N = x0_all.shape[1], prob["R"].shape[0], prob["N"]
+    Bg = len(x0_all)
+    lo, hi = shard_range(Bg, rk.rank, rk.world)
+    B = hi - lo
+    s = make_solver(prob, B, dev_index) if B > 0 else None
+    step = None
+    if mpc is not None and mpc[2] is not None:
+        step = np.zeros(n)
+        step[mpc[2][0]] = mpc[2][1]
+
+    def once():
+        it = kms = ab = 0.0
+        conv = mx = 0
+        if s is None:
+            return it, kms, ab, conv, mx
+        if mpc is not None:
+            s.Reset()
+            s.SetTargetState(np.array(prob["x_nom"], float))
+            s.SetInitialState(x0_all[lo:hi])
+            s.SetInitialGuess(u_guess)
+            s._push_problem()
+            st = s.solve_resident()
+            it += st.total_iters; kms += st.kernel_ms; ab += st.algorithmic_bytes
+            st = s.MPCRun(mpc[0], mpc[1], target_step=step)
+        else:
+            s.rearm(cold=True)
+            st = s.solve_resident()
+        it += st.total_iters; kms += st.kernel_ms; ab += st.algorithmic_bytes
+        return it, kms, ab, st.n_converged, st.max_iters_seen
+
+    if s is not None and mpc is None:
+        s.SetInitialState(x0_all[lo:hi])
+        s.SetInitialGuess(u_guess)
+        s._push_problem()
+    once()                                           # warm-up (module load, first-touch)
+    rk.fence()
+    t0 = time.perf_counter()
+    it = kms = ab = 0.0
+    for _ in range(reps):
+        a_, b_, c_, conv, mx = once()
+        it += a_; kms += b_; ab += c_
+    rk.fence()
+    wall = time.perf_counter() - t0
+    wall, kms_max, mx = rk.reduce([wall, kms, mx], "max")
+    it, ab, conv = rk.reduce([it, ab, conv], "sum")
+    solves = reps * (1 + (mpc[0] if mpc is not None else 0))
+    gbps = ab / (kms_max * 1e-3) / 1e9 / max(rk.world, 1) if kms_max > 0 else 0.0     # per-GPU average rate
+    out = {"name": name, "batch": Bg, "batch_per_gpu": -(-Bg // rk.world),
+           "n": n, "m": m, "N": N, "solves": solves, "iterations": it / reps, "iterations_per_s": it / wall,
+           "ms_per_solve": 1e3 * wall / solves, "kernel_ms_per_solve": kms_max / solves,
+           "max_iterations_per_problem": int(mx), "converged": int(conv),
+           "algorithmic_GBps_per_gpu": gbps, "hbm_frac": gbps / HBM_PEAK_GBS}
+    if n >= 16:                                      # C5: the backward pass is matrix-core work
+        tf = backward_flops_per_iteration(n, m, N) * it / (kms_max * 1e-3) / 1e12 / max(rk.world, 1)
+        out["backward_fp64_TFLOPs_per_gpu"] = tf
+        out["fp64_frac"] = tf / FP64_PEAK_TFLOPS
+    del s
+    return out
+
+
+def all_configs(rk, dev_index):
+    """C1, C3, C4, C5 of BASELINE.json (C2 is the headline), SURVEY.md 8(d) inputs."""
+    from drake_ddp_amd import workloads as W
+    out = []
+    p = W.pendulum_problem()
+    out.append(run_config(rk, dev_index, "C1 pendulum swing-up, single problem (pendulum.py literal)", p,
+                          np.zeros((1, 2)), np.zeros((1, p["N"] - 1)), reps=20))
+    a = W.acrobot_problem()
+    out.append(run_config(rk, dev_index, "C3 acrobot MPC N=40: 1 + 50 receding-horizon re-solves x batch 512, device loop", a,
+                          W.acrobot_batch_x0(512), np.zeros((1, a["N"] - 1)), reps=3, mpc=(50, 2, None)))
+    c = W.cartpole_wall_problem()
+    out.append(run_config(rk, dev_index, "C4 cart-pole with wall N=200, batch 256, central-FD Jacobians", c,
+                          W.cartpole_wall_batch_x0(256), np.zeros((1, c["N"] - 1)), reps=5))
+    q = W.synth36_problem()
+    out.append(run_config(rk, dev_index, "C5 n=36 m=12 N=40 MPC: 1 + 100 re-solves x batch 64, moving target, device loop", q,
+                          W.synth36_batch_x0(64), W.synth36_u_guess(q["N"]), reps=2,
+                          mpc=(100, 4, (0, W.SYNTH_TARGET_VEL * q["dt"] * 4))))
+    if rk.world == 1:
+        out.append(run_config(rk, dev_index, "C5 shard of an 8-GPU run: batch 8 on this GPU", q,
+                              W.synth36_batch_x0(64)[:8], W.synth36_u_guess(q["N"]), reps=2,
+                              mpc=(100, 4, (0, W.SYNTH_TARGET_VEL * q["dt"] * 4))))
+    return out
+
+
+def boundary_inclusive(prob, x0, dev_index, reps=5):
+    """C2 through the class surface, host buffers in and out: SetInitialState/SetInitialGuess + Solve()
+    (copy-in of x0 and u_guess, the solve, copy-out of x_bar, u_bar, cost) - the PCIe-inclusive rate.
+    Never `value`."""
+    B, N = len(x0), prob["N"]
+    s = make_solver(prob, B, dev_index)
+    ug = np.zeros((B, 1, N - 1))
+    it = 0
+    t0 = 0.0
+    for r in range(reps + 1):
+        if r == 1:
+            t0 = time.perf_counter()
+            it = 0
+        s.Reset()
+        s.SetInitialState(x0)
+        s.SetInitialGuess(ug)
+        x, u, _, L = s.Solve()
+        it += s.stats.total_iters
+    wall = time.perf_counter() - t0
+    return {"workload": "C2 through Solve(): host x0 + u_guess in, x_bar + u_bar + cost out", "iterations_per_s": it / wall,
+            "ms_per_solve": 1e3 * wall / reps, "bytes_in": int(x0.nbytes + ug.nbytes), "bytes_out": int(x.nbytes + u.nbytes + L.nbytes)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -145,8 +328,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1024, help="problems per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="headline only (skip C1/C3/C4/C5 and the boundary-inclusive run)")
     ap.add_argument("--cpu-sample", type=int, default=24)
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
 
     import torch
     import torch.distributed as dist
@@ -154,11 +341,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the hot path)")
     # MI_BENCH_BACKEND=gloo lets the N>1 code path be exercised on a single-GPU box (all ranks
     # share device 0); the driver's multi-GPU runs use the default: nccl (= RCCL over xGMI).
     backend = os.environ.get("MI_BENCH_BACKEND", "nccl")
+    if backend == "nccl" and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py --gpus {world}: only {torch.cuda.device_count()} GPU(s) visible on this node")
     dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     if world > 1:
@@ -167,10 +358,9 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend=backend)
+    rk = Ranks(world, rank, backend, dist, torch)
 
     from drake_ddp_amd import workloads as W
-    from drake_ddp_amd.ilqr import BatchedIterativeLQR
-    from drake_ddp_amd.models import ModelSystem
 
     prob = W.pendulum_problem()
     B = args.batch
@@ -178,11 +368,7 @@ def main():
     x0_all = W.pendulum_batch_x0(B * world, seed=0)       # global batch; rank r owns a contiguous block
     x0 = x0_all[rank * B:(rank + 1) * B]
 
-    s = BatchedIterativeLQR(ModelSystem(prob["model_id"], prob["dt"]), N, B, delta=prob["delta"], beta=prob["beta"],
-                            gamma=prob["gamma"], jacobian_mode="fd", fd_step=1e-5, device=dev_index)
-    s.SetTargetState(prob["x_nom"])
-    s.SetRunningCost(prob["Q"], prob["R"])
-    s.SetTerminalCost(prob["Qf"])
+    s = make_solver(prob, B, dev_index)
     s.SetInitialState(x0)
     s.SetInitialGuess(np.zeros((1, N - 1)))
     s._push_problem()                                      # inputs resident in HBM from here on
@@ -216,36 +402,29 @@ def main():
         while pending:
             pending.pop().wait()
 
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     run_steps(args.warmup)
     drain()
-    fence()
+    rk.fence()
     t0 = time.perf_counter()
     per_step = run_steps(args.steps)
     drain()
-    fence()
+    rk.fence()
     elapsed = time.perf_counter() - t0
     iters = sum(st.total_iters for st in per_step)
     ls_trials = sum(st.total_ls_trials for st in per_step)
     kernel_ms = sum(st.kernel_ms for st in per_step)
     alg_bytes = sum(st.algorithmic_bytes for st in per_step)
     last = per_step[-1]
+    elapsed = rk.reduce([elapsed], "max")[0]
+    iters_all = rk.reduce([iters], "sum")[0]
+    del s
 
-    tot = torch.tensor([elapsed, float(iters), kernel_ms, alg_bytes], dtype=torch.float64,
-                       device="cuda" if backend == "nccl" else "cpu")
-    if world > 1:
-        mx = tot.clone()
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        sm = tot.clone()
-        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
-        elapsed = float(mx[0])
-        iters_all = float(sm[1])
-    else:
-        iters_all = float(iters)
+    configs = boundary = None
+    if not args.no_configs and not os.environ.get("MI_BENCH_NESTED"):
+        configs = all_configs(rk, dev_index)
+        if rank == 0:
+            boundary = boundary_inclusive(prob, x0, dev_index)
+        rk.fence()
 
     if rank == 0:
         k_ms = kernel_ms / args.steps                       # avg launch duration of the dominant kernel (HIP events)
@@ -285,6 +464,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(prob, x0_all, min(args.cpu_sample, B))
         else:
             out["cpu_baseline"] = None
+        out["configs"] = configs
+        out["boundary_inclusive"] = boundary
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -984,6 +984,7 @@ __global__ void __launch_bounds__(kLargeThreads) ilqr_large_kernel(const KArgs a
       }
       __syncthreads();
       L = __builtin_inf();
+      status = MI_STATUS_CONVERGED;                          // per re-solve, as a host loop of Solve() calls would leave it
     }
     double improvement = __builtin_inf();
     int it_this = 0;

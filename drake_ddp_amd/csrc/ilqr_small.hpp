@@ -72,7 +72,7 @@ struct KArgs {
   double mpc_target_step[kMaxStateDim];   // added to x_nom before every re-solve (mini_cheetah.py:151-156); zeros = fixed target
   double* mpc_log;             // (B, mpc_resolves, n+2): x0 of the re-solve | cost | iterations
   int32_t helpers;             // extra wavefronts per problem that share the linearization (0, 1 or 3), see ilqr_small_kernel
-  int32_t seq_backward;        // 1: sequential Riccati sweep instead of the parallel-in-time scan (A/B measurements)
+  int32_t seq_backward;        // 0: fastest backward pass; 1: sequential sweep (A/B measurements); 2: the reference's scalar recursion verbatim (asymmetric / indefinite costs)
   int32_t newton_rollout;      // 1: the eps = 1 trial is rolled out parallel in time (Newton on the trajectory) when it converges
   // MODE_SOLVE / MODE_MPC of the wave-per-problem kernels: the last workgroup to finish aggregates the
   // batch statistics itself (no second kernel per solve).  Null: the host launches stats_kernel.
@@ -203,6 +203,15 @@ template <class M, class = void>
 struct UsesScanBackward : std::false_type {};
 template <class M>
 struct UsesScanBackward<M, std::void_t<decltype(M::kScanBackward)>> : std::bool_constant<M::kScanBackward> {};
+
+// The same model with the kernels' backward pass run as the reference's scalar recursion verbatim
+// (cost matrices the MFMA / scan forms do not cover: asymmetric or indefinite Q, Qf, R).
+template <class M>
+struct ExactCost : M { static constexpr bool kExactBackward = true; };
+template <class M, class = void>
+struct UsesExactBackward : std::false_type {};
+template <class M>
+struct UsesExactBackward<M, std::void_t<decltype(M::kExactBackward)>> : std::bool_constant<M::kExactBackward> {};
 
 template <class M>
 struct Consts {
@@ -745,6 +754,27 @@ __device__ inline int rollout_newton_impl(const WS& w, const Consts<M>& c, const
   if (lane == 0) { mi_dbg_vals[0] = (double)(pn1 - pn0); mi_dbg_vals[1] = nsw; }
 #endif
   if (!converged) return NEWTON_FAILED;
+  // A-posteriori guard of the stopping rule: the final pass re-steps every lane chunk exactly from its
+  // converged start, so the only place the stored trajectory can fail to be a rollout of u under f
+  // (ilqr.py:313-316) is a chunk edge - this lane's end state against the next lane's start.  The update
+  // test above leaves that defect at round-off when the sweeps contract quadratically with a moderate
+  // constant (measured on C2); for dynamics or gains where they do not, the defect shows it and the
+  // caller falls back to the sequential rollout.  One wave_shl DPP move + one wave maximum.
+  auto edges_closed = [&](const double (&xe)[n]) __attribute__((always_inline)) -> bool {
+    constexpr double kEdgeTol = 1e-11;
+    const double nx0 = dpp_f64_or_zero<0x130, 0xF>(X[0][0]), nx1 = dpp_f64_or_zero<0x130, 0xF>(X[0][1]);   // wave_shl:1
+    double dfc = 0.0;
+    if (t0 + CH < steps) {                                     // the next lane holds a valid step
+      const double d = fmax(fabs(xe[0] - nx0), fabs(xe[1] - nx1));
+      const double sc = fmax(1.0, fmax(fabs(xe[0]), fabs(xe[1])));
+      dfc = (d <= kEdgeTol * sc) ? 0.0 : 1.0;                  // NaN -> open
+    }
+    dfc = fmax(dfc, row_ror_f64<8>(dfc));
+    dfc = fmax(dfc, row_ror_f64<4>(dfc));
+    dfc = fmax(dfc, row_ror_f64<2>(dfc));
+    dfc = fmax(dfc, row_ror_f64<1>(dfc));
+    return fmax(fmax(readlane_f64(dfc, 0), readlane_f64(dfc, 16)), fmax(readlane_f64(dfc, 32), readlane_f64(dfc, 48))) == 0.0;
+  };
   // final pass: the plain fp64 step over this lane's chunk from its converged start (ilqr.py:313-316)
   if (fuse == 0) {
     if (lane == 0) {
@@ -766,6 +796,7 @@ __device__ inline int rollout_newton_impl(const WS& w, const Consts<M>& c, const
         x[0] = xn[0]; x[1] = xn[1];
       }
     }
+    if (!edges_closed(x)) return NEWTON_FAILED;                // (the caller's sequential rollout rewrites T)
 #ifdef MI_PROF_NEWTON
     if (lane == 0) mi_dbg_vals[2] = (double)(clock64() - pn1);
 #endif
@@ -793,6 +824,7 @@ __device__ inline int rollout_newton_impl(const WS& w, const Consts<M>& c, const
         x[0] = xn[0]; x[1] = xn[1];
       }
     }
+    if (!edges_closed(x)) return NEWTON_FAILED;
   }
   const double L = wave_sum(cost);
   const double ex = -eps * (1.0 - eps / 2.0) * wave_sum(dvs);
@@ -1798,8 +1830,18 @@ __device__ __attribute__((noinline)) bool backward_scan_outlined(int N, int n_st
   return backward_scan<M>(w, c);
 }
 
+// `mode` (KArgs::seq_backward): 0 the fastest form; 1 sequential in time (A/B measurements); 2 the
+// reference's recursion verbatim (backward_scalar: no use of Vxx = Vxx^T, no scan elements that assume
+// symmetric positive semi-definite Q/Qf) - chosen by the host for asymmetric or indefinite cost matrices,
+// which the reference accepts without symmetrizing (ilqr.py:182,653-667).  For n = 3..4 that form lives in
+// its own kernel instantiations (ExactCost<M>, picked by the host like LongHorizon<M>), so the regular
+// kernels carry neither its code nor its registers.
 template <class M>
-__device__ inline void backward(const WS& w, const Consts<M>& c, bool sequential = false) {
+__device__ inline void backward(const WS& w, const Consts<M>& c, int mode = 0) {
+  const bool sequential = mode != 0;
+  if constexpr (UsesExactBackward<M>::value) {
+    backward_scalar<M>(w, c);
+  } else
   if constexpr (M::n >= 3 && M::n <= 4 && M::m == 1) {
     // LongHorizon<M> kernels (N > 128, two or more steps per lane): the scan's 9 compositions of n x n
     // elements (~640 fused multiply-adds each at n = 4) beat N - 1 sequential MFMA steps
@@ -1821,10 +1863,13 @@ __device__ inline void backward(const WS& w, const Consts<M>& c, bool sequential
 // per-problem records (same rules as stats_kernel: best cost among the converged problems, ties to
 // the lower index) and writes the aggregate.  Called by the main wave, all 64 lanes.
 // ---------------------------------------------------------------------------
-// The four per-problem records travel as device-scope atomic stores / loads (coherent across the
-// eight XCDs' L2 caches on their own) and the ticket is taken once they are acknowledged - NOT behind a
-// device-scope release fence: that would write back the whole L2, i.e. wait for the results other
-// workgroups are streaming out at that moment (measured: +12 us per launch).
+// The four per-problem records travel as device-scope atomic stores / loads (write-through sc1 stores,
+// coherent across the eight XCDs' L2 caches on their own) and the ticket is taken once they are
+// ACKNOWLEDGED: an explicit s_waitcnt vmcnt(0) between the stores and the ticket's atomic add (stores
+// count in vmcnt on gfx9; a workgroup-scope fence alone emits no wait, and the stores and the counter
+// live in different L2 channels).  NOT a device-scope release fence: that would write back the whole
+// L2, i.e. wait for the results other workgroups are streaming out at that moment (measured: +12 us per
+// launch).
 __device__ inline void batch_stats_by_last_workgroup(const KArgs& a, int b, double L, int iters, int status, int ls_total) {
   const int lane = threadIdx.x & 63;
   int ticket = 0;
@@ -1833,7 +1878,8 @@ __device__ inline void batch_stats_by_last_workgroup(const KArgs& a, int b, doub
     __hip_atomic_store(a.iters + b, iters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(a.status + b, status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(a.ls_trials + b, ls_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // stores acknowledged (s_waitcnt), no cache write-back
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // compiler ordering; no cache write-back
+    __builtin_amdgcn_s_waitcnt(0x0F70);                        // vmcnt(0): the four write-through stores are acknowledged
     ticket = __hip_atomic_fetch_add(a.done_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   ticket = __builtin_amdgcn_readfirstlane(ticket);
@@ -1994,7 +2040,7 @@ __global__ void __launch_bounds__(256) ilqr_small_kernel(const KArgs a) {
     return;
   }
   if (MODE == MODE_BACKWARD) {
-    backward<M>(w, c, a.seq_backward != 0);
+    backward<M>(w, c, a.seq_backward);
     wave_sync();
     stage_out(a.K + oK, w.G, Ly::GS, Ly::KK, m * n, N - 1);
     stage_out(a.kappa + oU, w.G, Ly::GS, Ly::KAP, m, N - 1);
@@ -2049,6 +2095,7 @@ __global__ void __launch_bounds__(256) ilqr_small_kernel(const KArgs a) {
       if constexpr (UsesScanBackward<M>::value) c.to_lds(w.cst);
       wave_sync();
       L = __builtin_inf();
+      status = MI_STATUS_CONVERGED;                // per re-solve, as a host loop of Solve() calls would leave it
     }
     double improvement = __builtin_inf();
     bool optimistic = true, first_try_streak = true;
@@ -2091,7 +2138,7 @@ __global__ void __launch_bounds__(256) ilqr_small_kernel(const KArgs a) {
         nk = linearize<M, JAC>(w, a);                             // at the ACCEPTED trajectory (:370)
       }
       const long long c2 = clock64();
-      if (MODE != MODE_FORWARD) { backward<M>(w, c, a.seq_backward != 0); wave_sync(); } // :697
+      if (MODE != MODE_FORWARD) { backward<M>(w, c, a.seq_backward); wave_sync(); } // :697
       // LongHorizon kernels: backward() is a real call; re-reading the constants from their LDS image instead
       // of keeping 90 registers alive across it leaves the line-search loops their old allocation
       if constexpr (UsesScanBackward<M>::value) c.from_lds(w.cst);

@@ -50,6 +50,11 @@ struct mi_ilqr {
   double mpc_target_step[mi::kMaxStateDim] = {};
   bool cold = true;        // persistent state is known to be all zero (fresh object / after reset)
   bool u_pending = false;  // SetInitialGuess input waiting in u_guess
+  bool u_zero = false;     // u_bar is to read as all zero (after reset, until a guess is set or re-armed): ilqr.py:71
+  int exact_backward = 0;  // cost matrices the fast backward forms do not cover (asymmetric / indefinite): reference recursion
+  std::vector<double> h_costmat;   // host mirror of costmat (Q | R | Qf | x_nom)
+  double* scratch = nullptr;       // device staging area of the boundary's layout conversions (grow-only)
+  size_t scratch_bytes = 0;
   size_t lds = 0;
   bool large = false;      // workgroup-per-problem path: state arrays are TIME-MAJOR in HBM
   int n_store = 1;         // line-search candidate trajectories kept in LDS
@@ -83,6 +88,8 @@ namespace {
     }                                                                                     \
   } while (0)
 
+constexpr size_t kMaxLds = 160 * 1024;
+
 struct ModelInfo { int n, m, n_params; double defaults[MI_ILQR_MAX_PARAMS]; };
 
 const ModelInfo* model_info(int id) {
@@ -114,8 +121,6 @@ size_t large_lds(int model_id, int N) {
   }
 }
 
-constexpr size_t kMaxLds = 160 * 1024;
-
 KArgs make_args(const mi_ilqr* h) {
   KArgs a;
   std::memset(&a, 0, sizeof(a));
@@ -146,7 +151,7 @@ KArgs make_args(const mi_ilqr* h) {
       (h->N - 1) * (h->n + h->m) > 128)
     a.helpers = h->B <= 256 ? 3 : (h->B <= 512 ? 1 : 0);
   static const bool seq_bp = [] { const char* e = std::getenv("MI_ILQR_SEQ_BACKWARD"); return e && e[0] == '1'; }();
-  a.seq_backward = seq_bp ? 1 : 0;
+  a.seq_backward = h->exact_backward ? 2 : (seq_bp ? 1 : 0);
   static const bool seq_ro = [] { const char* e = std::getenv("MI_ILQR_SEQ_ROLLOUT"); return e && e[0] == '1'; }();
   a.newton_rollout = seq_ro ? 0 : 1;
   // wave-per-problem kernels aggregate the batch statistics themselves (MODE_SOLVE / MODE_MPC)
@@ -156,10 +161,22 @@ KArgs make_args(const mi_ilqr* h) {
   return a;
 }
 
+// The dynamic-LDS ceiling of a kernel is raised once per (kernel, device), to the hardware maximum - not
+// on every launch.
+constexpr int kMaxDevices = 64;
+template <class Kern>
+int allow_max_lds(Kern kern, bool (&done)[kMaxDevices], int device) {
+  if (device >= 0 && device < kMaxDevices && done[device]) return MI_ILQR_OK;
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
+  if (device >= 0 && device < kMaxDevices) done[device] = true;
+  return MI_ILQR_OK;
+}
+
 template <class M, int JAC, int MODE>
 int launch_one(mi_ilqr* h, const KArgs& a) {
   auto kern = ilqr_small_kernel<M, JAC, MODE>;
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
+  static bool lds_ok[kMaxDevices] = {};
+  { const int rc = allow_max_lds(kern, lds_ok, h->d.device_id); if (rc != MI_ILQR_OK) return rc; }
   HIPCHK(hipEventRecord(h->ev0, h->stream));
   const int waves = (a.helpers > 0 && (MODE == MODE_SOLVE || MODE == MODE_MPC)) ? 1 + a.helpers : 1;
   hipLaunchKernelGGL(kern, dim3(h->B), dim3(64 * waves), h->lds, h->stream, a);
@@ -184,7 +201,8 @@ int launch_mode(mi_ilqr* h, int mode, const KArgs& a) {
 template <class M, int JAC, int MODE>
 int launch_one_large(mi_ilqr* h, const KArgs& a) {
   auto kern = ilqr_large_kernel<M, JAC, MODE>;
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds));
+  static bool lds_ok[kMaxDevices] = {};
+  { const int rc = allow_max_lds(kern, lds_ok, h->d.device_id); if (rc != MI_ILQR_OK) return rc; }
   HIPCHK(hipEventRecord(h->ev0, h->stream));
   hipLaunchKernelGGL(kern, dim3(h->B), dim3(kLargeThreads), h->lds, h->stream, a);
   HIPCHK(hipGetLastError());
@@ -231,6 +249,16 @@ int launch_batch(mi_ilqr* h, int mode, const KArgs& a) {
 template <class M>
 int launch_jac(mi_ilqr* h, int mode, const KArgs& a) {
   if constexpr (M::n >= 3 && M::n <= 4 && M::m == 1) {
+    // cost matrices outside the symmetric-PSD class: the kernels whose backward pass is the reference's recursion
+    if (h->exact_backward && (mode == MODE_SOLVE || mode == MODE_MPC || mode == MODE_BACKWARD)) {
+      using E = ExactCost<M>;
+      const bool ad = h->d.jacobian_mode == MI_JAC_AUTODIFF;
+      switch (mode) {
+        case MODE_SOLVE: return ad ? launch_one<E, MI_JAC_AUTODIFF, MODE_SOLVE>(h, a) : launch_one<E, MI_JAC_FD_CENTRAL, MODE_SOLVE>(h, a);
+        case MODE_MPC: return ad ? launch_one<E, MI_JAC_AUTODIFF, MODE_MPC>(h, a) : launch_one<E, MI_JAC_FD_CENTRAL, MODE_MPC>(h, a);
+        default: return launch_one<E, MI_JAC_FD_CENTRAL, MODE_BACKWARD>(h, a);
+      }
+    }
     // two or more steps per lane: the kernels whose backward pass is the time-parallel scan (ilqr_small.hpp:
     // LongHorizon) - only the modes that run a backward pass have such an instantiation
     if (h->N > 128 && (mode == MODE_SOLVE || mode == MODE_MPC || mode == MODE_BACKWARD)) {
@@ -251,6 +279,8 @@ int launch_jac(mi_ilqr* h, int mode, const KArgs& a) {
 // longer known-zero for the fields the mode writes, and u_bar is materialized.
 int launch(mi_ilqr* h, int mode) {
   HIPCHK(hipSetDevice(h->d.device_id));
+  if (h->u_zero && !h->u_pending) HIPCHK(hipMemsetAsync(h->u_bar, 0, (size_t)h->B * h->m * (h->N - 1) * 8, h->stream));
+  h->u_zero = false;
   const KArgs a = make_args(h);
   int rc;
   if (h->batch_minor) {
@@ -289,6 +319,8 @@ int materialize_zero_state(mi_ilqr* h) {
 }
 
 int materialize_u(mi_ilqr* h) {
+  if (h->u_zero && !h->u_pending) HIPCHK(hipMemsetAsync(h->u_bar, 0, (size_t)h->B * h->m * (h->N - 1) * 8, h->stream));
+  h->u_zero = false;
   if (!h->u_pending) return MI_ILQR_OK;
   HIPCHK(hipMemcpyAsync(h->u_bar, h->u_guess, (size_t)h->B * h->m * (h->N - 1) * 8, hipMemcpyDeviceToDevice, h->stream));
   h->u_pending = false;
@@ -333,16 +365,73 @@ __global__ void mpc_shift_kernel_bm(const double* x_bar, const double* u_bar, do
   }
 }
 
-// batch-minor [t][row][b]  <->  reference time-last (b, row, t)
-void bm_to_time_last(const double* bmv, double* tl, int B, int rows, int len) {
-  for (int t = 0; t < len; ++t)
-    for (int r = 0; r < rows; ++r)
-      for (int b = 0; b < B; ++b) tl[((size_t)b * rows + r) * len + t] = bmv[((size_t)t * rows + r) * B + b];
+// Layouts of a (B, rows, len) trajectory array: TL time-last [b][row][t] (the reference's, SURVEY F5 - what
+// crosses the C ABI); TM time-major [b][t][row] (workgroup-per-problem kernels); BM batch-minor
+// [t][row][b] (lane-per-problem kernels).  The conversions run on the DEVICE, between the field and a
+// staging buffer; the host copy is then one linear transfer.
+enum { LAYOUT_TL = 0, LAYOUT_TM = 1, LAYOUT_BM = 2 };
+
+// TL <-> TM: a per-problem (rows x len) transpose; both sides of a problem fit the caches, a gather is enough.
+__global__ void __launch_bounds__(256) relayout_tm_kernel(const double* __restrict__ src, double* __restrict__ dst,
+                                                            int rows, int len, int to_tm) {
+  const size_t base = (size_t)blockIdx.x * rows * len;
+  for (int e = threadIdx.x; e < rows * len; e += 256) {
+    int r, t;
+    if (to_tm) { t = e / rows; r = e - t * rows; dst[base + e] = src[base + (size_t)r * len + t]; }
+    else { r = e / len; t = e - r * len; dst[base + e] = src[base + (size_t)t * rows + r]; }
+  }
 }
-void time_last_to_bm(const double* tl, double* bmv, int B, int rows, int len) {
-  for (int t = 0; t < len; ++t)
-    for (int r = 0; r < rows; ++r)
-      for (int b = 0; b < B; ++b) bmv[((size_t)t * rows + r) * B + b] = tl[((size_t)b * rows + r) * len + t];
+
+// TL <-> BM: for every row r a (B x len) <-> (len x B) transpose with pitches; 32 x 32 tiles through LDS
+// so that both the reads and the writes are coalesced.  grid = (ceil(len/32), ceil(B/32), rows).
+__global__ void __launch_bounds__(256) relayout_bm_kernel(const double* __restrict__ src, double* __restrict__ dst,
+                                                            int B, int rows, int len, int to_bm) {
+  __shared__ double tile[32][33];
+  const int r = blockIdx.z, t0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8 threads
+  if (to_bm) {
+    for (int j = ty; j < 32; j += 8) {                             // read TL: t fastest
+      const int b = b0 + j, t = t0 + tx;
+      if (b < B && t < len) tile[j][tx] = src[((size_t)b * rows + r) * len + t];
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {                             // write BM: b fastest
+      const int t = t0 + j, b = b0 + tx;
+      if (b < B && t < len) dst[((size_t)t * rows + r) * B + b] = tile[tx][j];
+    }
+  } else {
+    for (int j = ty; j < 32; j += 8) {                             // read BM: b fastest
+      const int t = t0 + j, b = b0 + tx;
+      if (b < B && t < len) tile[j][tx] = src[((size_t)t * rows + r) * B + b];
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {                             // write TL: t fastest
+      const int b = b0 + j, t = t0 + tx;
+      if (b < B && t < len) dst[((size_t)b * rows + r) * len + t] = tile[tx][j];
+    }
+  }
+}
+
+int ensure_scratch(mi_ilqr* h, size_t bytes) {
+  if (h->scratch_bytes >= bytes) return MI_ILQR_OK;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (h->scratch) HIPCHK(hipFree(h->scratch));
+  h->scratch = nullptr; h->scratch_bytes = 0;
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&h->scratch), bytes));
+  h->scratch_bytes = bytes;
+  return MI_ILQR_OK;
+}
+
+// Convert between the handle's kernel layout and time-last, on the handle's stream.
+int relayout(mi_ilqr* h, const double* src, double* dst, int rows, int len, bool to_kernel_layout) {
+  if (h->batch_minor) {
+    const dim3 grid((len + 31) / 32, (h->B + 31) / 32, rows);
+    hipLaunchKernelGGL(relayout_bm_kernel, grid, dim3(256), 0, h->stream, src, dst, h->B, rows, len, to_kernel_layout ? 1 : 0);
+  } else {
+    hipLaunchKernelGGL(relayout_tm_kernel, dim3(h->B), dim3(256), 0, h->stream, src, dst, rows, len, to_kernel_layout ? 1 : 0);
+  }
+  HIPCHK(hipGetLastError());
+  return MI_ILQR_OK;
 }
 
 // rows of the (rows,len) time-last view of a double field; 0 = not a trajectory array
@@ -358,18 +447,6 @@ int traj_rows(const mi_ilqr* h, int which, int* len) {
   }
   *len = 0;
   return 0;
-}
-
-// host-side layout conversion for the time-major (large-state) path
-void to_time_last(const double* tm, double* tl, int B, int rows, int len) {
-  for (int b = 0; b < B; ++b)
-    for (int t = 0; t < len; ++t)
-      for (int r = 0; r < rows; ++r) tl[((size_t)b * rows + r) * len + t] = tm[((size_t)b * len + t) * rows + r];
-}
-void to_time_major(const double* tl, double* tm, int B, int rows, int len) {
-  for (int b = 0; b < B; ++b)
-    for (int t = 0; t < len; ++t)
-      for (int r = 0; r < rows; ++r) tm[((size_t)b * len + t) * rows + r] = tl[((size_t)b * rows + r) * len + t];
 }
 
 // Aggregate per-problem results on the device so a blocking solve costs ONE small host read
@@ -578,6 +655,7 @@ int mi_ilqr_create(const mi_ilqr_desc* desc, mi_ilqr_t** out) {
     for (size_t i = 0; i < n; ++i) { cm[i * n + i] = 1.0; cm[n * n + m * m + i * n + i] = 1.0; }
     for (size_t i = 0; i < m; ++i) cm[n * n + i * m + i] = 1.0;
     if (hipMemcpy(h->costmat, cm.data(), cm.size() * 8, hipMemcpyHostToDevice) != hipSuccess) { mi_ilqr_destroy(h); return MI_ILQR_E_HIP; }
+    h->h_costmat = cm;
   }
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
     mi_ilqr_destroy(h);
@@ -612,6 +690,7 @@ void mi_ilqr_destroy(mi_ilqr_t* h) {
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->h_ring) (void)hipHostFree(h->h_ring);
   if (h->mpc_log) (void)hipFree(h->mpc_log);
+  if (h->scratch) (void)hipFree(h->scratch);
   for (int i = 0; i < mi_ilqr::kStatsRing; ++i) {
     if (h->ring_ev0[i]) (void)hipEventDestroy(h->ring_ev0[i]);
     if (h->ring_ev1[i]) (void)hipEventDestroy(h->ring_ev1[i]);
@@ -620,10 +699,50 @@ void mi_ilqr_destroy(mi_ilqr_t* h) {
   delete h;
 }
 
+// Symmetric positive semi-definite (definite with `strict`)?  Cholesky of A + eps*I; the matrices are tiny.
+static bool is_sym_psd(const double* A, int k, bool strict) {
+  double scale = 0.0;
+  for (int i = 0; i < k * k; ++i) { if (!(std::fabs(A[i]) < INFINITY)) return false; scale = std::fmax(scale, std::fabs(A[i])); }
+  for (int i = 0; i < k; ++i)
+    for (int j = 0; j < i; ++j) if (A[i * k + j] != A[j * k + i]) return false;
+  std::vector<double> L((size_t)k * k, 0.0);
+  const double eps = strict ? 0.0 : 1e-12 * scale * k;
+  for (int j = 0; j < k; ++j) {
+    double d = A[j * k + j] + eps;
+    for (int q = 0; q < j; ++q) d -= L[j * k + q] * L[j * k + q];
+    if (strict ? !(d > 0.0) : !(d >= 0.0)) return false;
+    const double ld = std::sqrt(d);
+    L[j * k + j] = ld;
+    for (int i = j + 1; i < k; ++i) {
+      double v = A[i * k + j];
+      for (int q = 0; q < j; ++q) v -= L[i * k + q] * L[j * k + q];
+      if (ld > 0.0) L[i * k + j] = v / ld;
+      else if (std::fabs(v) > 1e-12 * scale) return false;      // zero pivot with a non-zero column: indefinite
+    }
+  }
+  return true;
+}
+
 int mi_ilqr_set_cost(mi_ilqr_t* h, const double* Q, const double* R, const double* Qf, const double* x_nom) {
   if (!h) return MI_ILQR_E_BAD_ARG;
   HIPCHK(hipSetDevice(h->d.device_id));
   const size_t n = h->n, m = h->m;
+  {
+    // The time-parallel / matrix-core backward passes use Vxx = Vxx^T and (scan) PSD second-order terms; the
+    // reference accepts ANY Q, R, Qf and never symmetrizes (ilqr.py:182,653-667).  Matrices outside that
+    // class are served by the reference's recursion verbatim (wave- and lane-per-problem kernels); the
+    // workgroup-per-problem kernel factorizes Quu = L D L^T and has no such form.
+    std::vector<double> cm = h->h_costmat;
+    if (Q) std::memcpy(cm.data(), Q, n * n * 8);
+    if (R) std::memcpy(cm.data() + n * n, R, m * m * 8);
+    if (Qf) std::memcpy(cm.data() + n * n + m * m, Qf, n * n * 8);
+    if (x_nom) std::memcpy(cm.data() + 2 * n * n + m * m, x_nom, n * 8);
+    const bool regular = is_sym_psd(cm.data(), (int)n, false) && is_sym_psd(cm.data() + n * n + m * m, (int)n, false) &&
+                         is_sym_psd(cm.data() + n * n, (int)m, true);
+    if (!regular && h->large) return MI_ILQR_E_UNSUPPORTED;
+    h->exact_backward = regular ? 0 : 1;
+    h->h_costmat.swap(cm);
+  }
   HIPCHK(hipStreamSynchronize(h->stream));
   if (Q) HIPCHK(hipMemcpy(h->costmat, Q, n * n * 8, hipMemcpyHostToDevice));
   if (R) HIPCHK(hipMemcpy(h->costmat + n * n, R, m * m * 8, hipMemcpyHostToDevice));
@@ -639,15 +758,17 @@ int mi_ilqr_set_initial(mi_ilqr_t* h, const double* x0, const double* u_guess) {
   if (x0) HIPCHK(hipMemcpy(h->x0, x0, (size_t)h->B * h->n * 8, hipMemcpyHostToDevice));
   if (u_guess) {
     const size_t cnt = (size_t)h->B * h->m * (h->N - 1);
-    if (h->large || h->batch_minor) {
-      std::vector<double> tm(cnt);
-      if (h->large) to_time_major(u_guess, tm.data(), h->B, h->m, h->N - 1);
-      else time_last_to_bm(u_guess, tm.data(), h->B, h->m, h->N - 1);
-      HIPCHK(hipMemcpy(h->u_guess, tm.data(), cnt * 8, hipMemcpyHostToDevice));
+    if ((h->large || h->batch_minor) && (h->m > 1 || h->batch_minor)) {
+      int rc = ensure_scratch(h, cnt * 8);
+      if (rc != MI_ILQR_OK) return rc;
+      HIPCHK(hipMemcpy(h->scratch, u_guess, cnt * 8, hipMemcpyHostToDevice));
+      if ((rc = relayout(h, h->scratch, h->u_guess, h->m, h->N - 1, true)) != MI_ILQR_OK) return rc;
+      HIPCHK(hipStreamSynchronize(h->stream));
     } else {
       HIPCHK(hipMemcpy(h->u_guess, u_guess, cnt * 8, hipMemcpyHostToDevice));
     }
     h->u_pending = true;
+    h->u_zero = false;
   }
   return MI_ILQR_OK;
 }
@@ -655,12 +776,15 @@ int mi_ilqr_set_initial(mi_ilqr_t* h, const double* x0, const double* u_guess) {
 int mi_ilqr_reset(mi_ilqr_t* h) {
   if (!h) return MI_ILQR_E_BAD_ARG;
   h->cold = true;          // zeros are materialized lazily (the kernels skip the HBM read)
+  h->u_zero = true;        // a fresh reference object has u_bar = 0 until SetInitialGuess (ilqr.py:71,148-156)
+  h->u_pending = false;
   return MI_ILQR_OK;
 }
 
 int mi_ilqr_rearm_initial_guess(mi_ilqr_t* h) {
   if (!h) return MI_ILQR_E_BAD_ARG;
   h->u_pending = true;     // next kernel takes u_bar from the resident u_guess again
+  h->u_zero = false;
   return MI_ILQR_OK;
 }
 
@@ -864,14 +988,16 @@ int mi_ilqr_get(mi_ilqr_t* h, int which, double* dst, size_t bytes) {
   HIPCHK(hipSetDevice(h->d.device_id));
   HIPCHK(hipStreamSynchronize(h->stream));
   if (h->cold && is_state_field(which)) { std::memset(dst, 0, bytes); return MI_ILQR_OK; }
-  const void* src = (h->u_pending && which == MI_F_U_BAR) ? (const void*)h->u_guess : f.ptr;
+  if (which == MI_F_U_BAR && h->u_zero && !h->u_pending) { std::memset(dst, 0, bytes); return MI_ILQR_OK; }
+  const double* src = (h->u_pending && which == MI_F_U_BAR) ? h->u_guess : static_cast<const double*>(f.ptr);
   int len = 0;
   const int rows = (h->large || h->batch_minor) ? traj_rows(h, which, &len) : 0;
   if (rows > 1 || (h->batch_minor && rows == 1)) {
-    std::vector<double> tm(bytes / 8);
-    HIPCHK(hipMemcpy(tm.data(), src, bytes, hipMemcpyDeviceToHost));
-    if (h->batch_minor) bm_to_time_last(tm.data(), dst, h->B, rows, len);
-    else to_time_last(tm.data(), dst, h->B, rows, len);
+    int rc = ensure_scratch(h, bytes);
+    if (rc != MI_ILQR_OK) return rc;
+    if ((rc = relayout(h, src, h->scratch, rows, len, false)) != MI_ILQR_OK) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(dst, h->scratch, bytes, hipMemcpyDeviceToHost));
     return MI_ILQR_OK;
   }
   HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
@@ -900,14 +1026,15 @@ int mi_ilqr_set(mi_ilqr_t* h, int which, const double* src, size_t bytes) {
   int len = 0;
   const int rows = (h->large || h->batch_minor) ? traj_rows(h, which, &len) : 0;
   if (rows > 1 || (h->batch_minor && rows == 1)) {
-    std::vector<double> tm(bytes / 8);
-    if (h->batch_minor) time_last_to_bm(src, tm.data(), h->B, rows, len);
-    else to_time_major(src, tm.data(), h->B, rows, len);
-    HIPCHK(hipMemcpy(f.ptr, tm.data(), bytes, hipMemcpyHostToDevice));
+    int rc = ensure_scratch(h, bytes);
+    if (rc != MI_ILQR_OK) return rc;
+    HIPCHK(hipMemcpy(h->scratch, src, bytes, hipMemcpyHostToDevice));
+    if ((rc = relayout(h, h->scratch, static_cast<double*>(f.ptr), rows, len, true)) != MI_ILQR_OK) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
   } else {
     HIPCHK(hipMemcpy(f.ptr, src, bytes, hipMemcpyHostToDevice));
   }
-  if (which == MI_F_U_BAR) h->u_pending = false;
+  if (which == MI_F_U_BAR) { h->u_pending = false; h->u_zero = false; }
   return MI_ILQR_OK;
 }
 

@@ -20,6 +20,7 @@ def load():
         subprocess.check_call(["make", "-C", HERE, "-s"])
     lib = C.CDLL(LIB)
     lib.oracle_solve_batch.restype = C.c_int
+    lib.oracle_mpc_batch.restype = C.c_int
     return lib
 
 
@@ -44,5 +45,33 @@ def solve_batch(model, prob, x0, u_guess=None, minN=1, fd_h=1e-5, nthreads=0, wa
     used = lib.oracle_solve_batch(C.byref(cfg), B, p(Q), p(R), p(Qf), p(xn), p(x0), p(ug),
                                   p(out.get("x_bar")), p(out.get("u_bar")), p(out.get("K")), p(out.get("kappa")),
                                   p(out["cost"]), p(out["iters"]), p(out["ls"]), p(out["status"]), int(nthreads))
+    out["threads"] = used
+    return out
+
+
+def mpc_batch(model, prob, x0, u_guess, resolves, replan, target_step=None, minN=1, fd_h=1e-5, nthreads=0):
+    """Cold solve + `resolves` receding-horizon re-solves per problem with the solver state persisting
+    (acrobot.py:131-162, mini_cheetah.py:186-213).  Returns log (B,resolves,n+2), first (B,2) and the
+    final arrays."""
+    lib = load()
+    n, m, N = model.n, model.m, prob["N"]
+    x0 = np.ascontiguousarray(x0, dtype=np.float64).reshape(-1, n)
+    B = x0.shape[0]
+    cfg = Cfg(n=n, m=m, N=N, model_id=model.model_id, dt=model.dt, delta=prob["delta"], beta=prob["beta"],
+              gamma=prob["gamma"], minN=minN, fd_h=fd_h, max_iters=100000)
+    for i, v in enumerate(model.params):
+        cfg.params[i] = float(v)
+    f = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    Q, R, Qf, xn = f(prob["Q"]), f(prob["R"]), f(prob["Qf"]), f(prob["x_nom"])
+    ug = None if u_guess is None else f(np.broadcast_to(u_guess, (B, m, N - 1)))
+    ts = None if target_step is None else f(target_step)
+    out = dict(log=np.empty((B, resolves, n + 2)), first=np.empty((B, 2)), x_bar=np.empty((B, n, N)),
+               u_bar=np.empty((B, m, N - 1)), K=np.empty((B, m, n, N - 1)), kappa=np.empty((B, m, N - 1)),
+               ls=np.empty(B, np.int32), status=np.empty(B, np.int32))
+    p = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
+    used = lib.oracle_mpc_batch(C.byref(cfg), B, p(Q), p(R), p(Qf), p(xn), p(x0), p(ug), int(resolves), int(replan), p(ts),
+                                p(out["log"]), p(out["first"]), p(out["x_bar"]), p(out["u_bar"]), p(out["K"]), p(out["kappa"]),
+                                p(out["ls"]), p(out["status"]), int(nthreads))
+    assert used > 0
     out["threads"] = used
     return out

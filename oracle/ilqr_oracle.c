@@ -5,8 +5,9 @@
  * Follows /root/reference/ilqr.py function by function (lines cited below); pinned
  * against the NumPy oracle (oracle/ilqr_np.py, itself pinned against the unmodified
  * reference through tests/golden/) by tests/test_c_oracle.py.  Jacobians use the
- * same central finite differences as the HIP path.  Covered: cold-start Solve()
- * with key-point method 'setInterval' (any minN, with interpolation).  Problems of
+ * same central finite differences as the HIP path.  Covered: Solve() from a cold start
+ * or from persistent solver state (the receding-horizon loops of acrobot.py / mini_cheetah.py,
+ * oracle_mpc_batch), key-point method 'setInterval' (any minN, with interpolation).  Problems of
  * a batch are independent and run on OpenMP threads.
  *
  * NOT part of the product: only tests/, __graft_entry__.smoke() and bench.py's
@@ -228,17 +229,25 @@ static void backward(const oracle_cfg* c, const double* Q, const double* R, cons
   }
 }
 
-/* Solve (ilqr.py:669-710) for one problem from a cold start. status: 0 ok, 1 max_iters, 2 linesearch failed */
-static int solve_one(const oracle_cfg* c, const double* Q, const double* R, const double* Qf, const double* xnom,
-                     const double* x0, const double* u_guess, work* w, double* cost, int* iters, int* ls_trials) {
+/* The persistent solver state of a freshly constructed reference object: all zero (ilqr.py:70-83). */
+static void fresh_state(const oracle_cfg* c, work* w) {
   const int n = c->n, m = c->m, N = c->N;
   memset(w->x_bar, 0, sizeof(double) * n * N);
+  memset(w->u_bar, 0, sizeof(double) * m * (N - 1));
   memset(w->K, 0, sizeof(double) * m * n * (N - 1));
   memset(w->kappa, 0, sizeof(double) * m * (N - 1));
   memset(w->dV, 0, sizeof(double) * (N - 1));
   memset(w->fx, 0, sizeof(double) * n * n * (N - 1));
   memset(w->fu, 0, sizeof(double) * n * m * (N - 1));
-  if (u_guess) memcpy(w->u_bar, u_guess, sizeof(double) * m * (N - 1)); else memset(w->u_bar, 0, sizeof(double) * m * (N - 1));
+}
+
+/* Solve (ilqr.py:669-710) for one problem FROM THE STATE IN `w` (x_bar, u_bar, K, kappa, dV persist across
+ * calls exactly as the attributes of the reference object do - SURVEY F10: the first rollout of a re-solve
+ * applies the previous solve's gains about the previous x_bar and is accepted unconditionally, L_last = inf).
+ * status: 0 ok, 1 max_iters, 2 linesearch failed */
+static int solve_one(const oracle_cfg* c, const double* Q, const double* R, const double* Qf, const double* xnom,
+                     const double* x0, work* w, double* cost, int* iters, int* ls_trials) {
+  const int n = c->n, m = c->m, N = c->N;
   double L = INFINITY, improvement = INFINITY;
   int it = 0, ls = 0, status = 0;
   while (improvement > c->delta) {
@@ -294,10 +303,75 @@ int oracle_solve_batch(const oracle_cfg* c, int B, const double* Q, const double
 #endif
     for (int b = 0; b < B; ++b) {
       double L; int it, ls;
-      const int st = solve_one(c, Q, R, Qf, xnom, x0 + (size_t)b * n, u_guess ? u_guess + (size_t)b * m * (N - 1) : NULL, &w, &L, &it, &ls);
+      fresh_state(c, &w);
+      if (u_guess) memcpy(w.u_bar, u_guess + (size_t)b * m * (N - 1), sizeof(double) * m * (N - 1));   /* SetInitialGuess (:148-156) */
+      const int st = solve_one(c, Q, R, Qf, xnom, x0 + (size_t)b * n, &w, &L, &it, &ls);
       if (cost) cost[b] = L;
       if (iters) iters[b] = it;
       if (ls_trials) ls_trials[b] = ls;
+      if (status) status[b] = st;
+      if (x_bar) memcpy(x_bar + (size_t)b * n * N, w.x_bar, sizeof(double) * n * N);
+      if (u_bar) memcpy(u_bar + (size_t)b * m * (N - 1), w.u_bar, sizeof(double) * m * (N - 1));
+      if (K) memcpy(K + (size_t)b * m * n * (N - 1), w.K, sizeof(double) * m * n * (N - 1));
+      if (kappa) memcpy(kappa + (size_t)b * m * (N - 1), w.kappa, sizeof(double) * m * (N - 1));
+    }
+    work_free(&w);
+  }
+  return used;
+}
+
+/* The receding-horizon loop of the reference's callers (acrobot.py:131-162, mini_cheetah.py:186-213) for every
+ * problem of a batch: a cold Solve() from u_guess, then `resolves` times
+ *     u_guess <- [u[:, replan:], repeat(u[:, -1], replan)];  x0 <- x[:, replan]     (acrobot.py:147-152)
+ *     x_nom  += target_step (NULL = fixed target; mini_cheetah.py:151-156)
+ *     Solve() on the SAME solver object: gains, x_bar and dV persist.
+ * log: (B, resolves, n+2) = x0 of the re-solve | cost | iterations, like mi_ilqr_get_mpc_log; first: (B,2) cost and
+ * iterations of the cold solve; the final x_bar/u_bar/K/kappa are optional.  Returns the threads used. */
+int oracle_mpc_batch(const oracle_cfg* c, int B, const double* Q, const double* R, const double* Qf, const double* xnom,
+                     const double* x0, const double* u_guess, int resolves, int replan, const double* target_step,
+                     double* log, double* first, double* x_bar, double* u_bar, double* K, double* kappa,
+                     int* ls_trials, int* status, int nthreads) {
+  const int n = c->n, m = c->m, N = c->N;
+  if (n > MAXN || m > MAXM || replan < 1 || replan >= N - 1) return -1;
+  int used = 1;
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel
+#endif
+  {
+    work w;
+    work_alloc(&w, n, m, N);
+#ifdef _OPENMP
+#pragma omp single
+    used = omp_get_num_threads();
+#pragma omp for schedule(dynamic, 1)
+#endif
+    for (int b = 0; b < B; ++b) {
+      double L, x0b[MAXN], xn[MAXN], ush[MAXM];
+      int it, ls, ls_sum = 0, st;
+      memcpy(x0b, x0 + (size_t)b * n, sizeof(double) * n);
+      memcpy(xn, xnom, sizeof(double) * n);
+      fresh_state(c, &w);
+      if (u_guess) memcpy(w.u_bar, u_guess + (size_t)b * m * (N - 1), sizeof(double) * m * (N - 1));
+      st = solve_one(c, Q, R, Qf, xn, x0b, &w, &L, &it, &ls);
+      ls_sum += ls;
+      if (first) { first[2 * b] = L; first[2 * b + 1] = (double)it; }
+      for (int r = 0; r < resolves && st != 2; ++r) {
+        for (int i = 0; i < n; ++i) x0b[i] = X(w.x_bar, i, replan);
+        for (int k = 0; k < m; ++k) {
+          ush[k] = U(w.u_bar, k, N - 2);
+          for (int t = 0; t < N - 1; ++t) U(w.u_bar, k, t) = (t + replan < N - 1) ? U(w.u_bar, k, t + replan) : ush[k];
+        }
+        if (target_step) for (int i = 0; i < n; ++i) xn[i] += target_step[i];
+        st = solve_one(c, Q, R, Qf, xn, x0b, &w, &L, &it, &ls);
+        ls_sum += ls;
+        if (log) {
+          double* lg = log + ((size_t)b * resolves + r) * (n + 2);
+          for (int i = 0; i < n; ++i) lg[i] = x0b[i];
+          lg[n] = L; lg[n + 1] = (double)it;
+        }
+      }
+      if (ls_trials) ls_trials[b] = ls_sum;
       if (status) status[b] = st;
       if (x_bar) memcpy(x_bar + (size_t)b * n * N, w.x_bar, sizeof(double) * n * N);
       if (u_bar) memcpy(u_bar + (size_t)b * m * (N - 1), w.u_bar, sizeof(double) * m * (N - 1));

@@ -1,0 +1,74 @@
+"""bench.py's launch contract: `--gpus N` starts N ranks by itself when no launcher did, the N > 1
+path runs (gloo stand-in for RCCL on a single-GPU box: all ranks share device 0), and the one JSON
+line carries the headline, `roofline`, `cpu_baseline`, `configs` and `boundary_inclusive`."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, env=None, timeout=900):
+    return subprocess.run([sys.executable, BENCH] + args, capture_output=True, text=True, timeout=timeout,
+                          env=dict(os.environ, **(env or {})), cwd=ROOT)
+
+
+def _json_line(stdout):
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_fails_loudly_without_a_gpu_or_with_too_few():
+    """No CPU fallback: without a device (this container) every form of the command exits non-zero with a
+    message; on a GPU box asking for more GPUs than the node has does."""
+    import torch
+    if torch.cuda.is_available():
+        r = _run(["--gpus", str(torch.cuda.device_count() + 1), "--steps", "1", "--warmup", "0"])
+        assert r.returncode != 0 and "GPU(s) visible" in (r.stderr + r.stdout)
+    else:
+        for a in (["--steps", "1"], ["--gpus", "2", "--steps", "1"]):
+            r = _run(a)
+            assert r.returncode != 0 and "needs an MI355X" in (r.stderr + r.stdout)
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_launches_its_own_ranks():
+    r = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-configs"],
+             env={"MI_BENCH_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 2048 and d["value"] > 0
+    one = _json_line(_run(["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-configs"]).stdout)
+    assert one["n_gpus"] == 1 and one["config"]["global_batch"] == 1024
+    # weak scaling: every rank solves 1024 problems per step (its block of the 2048-problem global draw), so
+    # rank 0's iterations per step stay within a few percent of the single-rank batch's
+    assert abs(d["iterations_per_step_rank0"] - one["iterations_per_step_rank0"]) < 0.05 * one["iterations_per_step_rank0"]
+    assert d["converged_rank0"] == 1024
+
+
+@pytest.mark.gpu
+def test_bench_line_carries_every_config_and_the_boundary():
+    r = _run(["--steps", "5", "--warmup", "2", "--cpu-sample", "4"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _json_line(r.stdout)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "configs", "boundary_inclusive"):
+        assert k in d, k
+    assert d["dtype"] == "f64" and d["vs_baseline"] is None and "workload" in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["kernel_ms"] > 0
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 0
+    names = [c["name"][:2] for c in d["configs"]]
+    assert names[:4] == ["C1", "C3", "C4", "C5"]
+    for c in d["configs"]:
+        assert c["iterations_per_s"] > 0 and c["ms_per_solve"] > 0 and c["kernel_ms_per_solve"] > 0 and 0 < c["hbm_frac"] < 1
+        assert c["converged"] == c["batch"] or c["name"].startswith("C4")       # (C4: long contact solves may hit no cap, all converge too)
+    assert d["configs"][3]["backward_fp64_TFLOPs_per_gpu"] > 0
+    b = d["boundary_inclusive"]
+    assert b["ms_per_solve"] > d["ms_per_step"] and b["bytes_out"] > b["bytes_in"]

@@ -42,3 +42,32 @@ def test_c_oracle_vs_reference_golden_and_threads():
         assert abs(r1["cost"][b] - g["L"]) < 1e-8 * abs(g["L"])
         assert np.max(np.abs(r1["x_bar"][b] - g["x_bar"])) < 1e-6
         assert rel_err(r1["K"][b], g["K"]) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["acrobot_mpc_0", "acrobot_mpc_1", "synth36_mpc_0"])
+def test_c_oracle_mpc_loop_vs_reference_golden(name):
+    """oracle_mpc_batch (shift warm start, moving target, gains persisting across solves - SURVEY F10)
+    against MPC sequences recorded from the unmodified reference (exact Jacobians there, central FD here:
+    FD tolerances; iteration counts exact)."""
+    from oracle import c_oracle, models_np as M, problems as P
+    g, prob = load_golden(name)
+    n, N = g["xs"].shape[1], prob["N"]
+    m = g["us"].shape[1]
+    replan, R = int(g["replan"]), len(g["Ls"]) - 1
+    step = None
+    ug = np.zeros((m, N - 1))
+    if "move_target" in g:
+        step = np.zeros(n)
+        step[int(g["move_target"][0])] = g["move_target"][1]
+        ug = P.synth36_u_guess(N)
+    r = c_oracle.mpc_batch(M.Model(prob["model_id"], prob["dt"]), prob, g["x0"][None], ug, R, replan, target_step=step)
+    assert r["status"][0] == 0
+    assert int(r["first"][0, 1]) == g["iters"][0] and abs(r["first"][0, 0] - g["Ls"][0]) < 1e-8 * abs(g["Ls"][0])
+    log = r["log"][0]
+    assert np.array_equal(log[:, -1].astype(int), g["iters"][1:])
+    assert rel_err(log[:, -2], g["Ls"][1:]) < 1e-8
+    for k in range(R):
+        want = g["xs"][k + 1][:, 0]                # (the acrobot optimum is flat: x moves at FD-noise level, 1e-6 relative)
+        assert np.max(np.abs(log[k, :n] - want)) < 1e-6 * max(1.0, np.max(np.abs(want)))
+    assert rel_err(r["x_bar"][0], g["xs"][-1]) < 1e-6 and rel_err(r["u_bar"][0], g["us"][-1]) < 1e-5
+    assert rel_err(r["K"][0], g["Ks"][-1]) < 1e-5

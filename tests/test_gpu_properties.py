@@ -233,15 +233,18 @@ def test_randomized_configs_vs_c_oracle(seed):
     s.SetInitialGuess(ug)
     x, u, _, L = s.Solve()
     r = c_oracle.solve_batch(M.Model(model_id, dt), prob, x0, ug)
-    ok = (r["status"] == 0) & (s.status == 0)
-    assert ok.mean() > 0.9
+    assert np.array_equal(s.status, r["status"]) and (s.status == 0).all()       # every problem converges on both sides
     it, ls = s.iterations, s.ls_trials
-    same = ok & (it == r["iters"]) & (ls == r["ls"])
-    # long or ill-conditioned solves may flip a line-search decision at round-off level; they must be rare
-    assert same.mean() > 0.9, (same.mean(), it[:10], r["iters"][:10])
-    assert np.max(np.abs(L[same] - r["cost"][same]) / np.abs(r["cost"][same])) < 1e-7
+    same = (it == r["iters"]) & (ls == r["ls"])
+    # a long or ill-conditioned solve may flip one line-search decision at round-off level: rare (none on these
+    # seeds today), and such a problem must still land on the oracle's optimum
+    assert same.mean() >= 0.97, (same.mean(), it[~same][:10], r["iters"][~same][:10])
+    rel = np.abs(L - r["cost"]) / np.abs(r["cost"])
+    assert np.max(rel[same]) < 1e-7
+    assert np.all(rel[~same] < 1e-3)
     assert np.max(np.abs(x[same] - r["x_bar"][same])) < 1e-4
-    assert (ls[ok] > it[ok]).any() or prob["beta"] > 0.8 or True
+    if prob["beta"] <= 0.8:
+        assert (ls > it).any()                               # backtracking really happened (coarse line searches)
 
 
 @pytest.mark.parametrize("cfg,B", [("pendulum", 300), ("wall", 5)])
@@ -329,11 +332,11 @@ def test_pendulum_horizons_around_the_lane_chunk_edges(N):
     s.SetInitialGuess(ug)
     x, u, _, L = s.Solve()
     r = c_oracle.solve_batch(M.Model(0, dt), prob, x0, ug)
-    ok = (r["status"] == 0) & (s.status == 0)
-    assert ok.mean() > 0.95
-    same = ok & (s.iterations == r["iters"]) & (s.ls_trials == r["ls"])
-    assert same.mean() > 0.9, (same.mean(), s.iterations[:8], r["iters"][:8])
-    assert np.max(np.abs(L[same] - r["cost"][same]) / np.abs(r["cost"][same])) < 1e-7
+    assert np.array_equal(s.status, r["status"]) and (s.status == 0).all()
+    same = (s.iterations == r["iters"]) & (s.ls_trials == r["ls"])
+    assert same.mean() >= 0.97, (same.mean(), s.iterations[~same][:8], r["iters"][~same][:8])
+    rel = np.abs(L - r["cost"]) / np.abs(r["cost"])
+    assert np.max(rel[same]) < 1e-7 and np.all(rel[~same] < 1e-3)          # a flipped decision still reaches the same optimum
     # (the shortest horizons need controls ~1e3 to reach the target in 3 steps: relative to the largest entry)
     for got, want in ((x, r["x_bar"]), (u, r["u_bar"]), (s.K, r["K"])):
         assert np.max(np.abs(got[same] - want[same])) < 1e-6 * max(1.0, np.max(np.abs(want[same])))
@@ -363,7 +366,9 @@ np.savez(sys.argv[1], log=s.mpc_log, x=s.x_bar, u=s.u_bar, K=s.K, it=s.iteration
     par = _run_variant(script, {}, str(tmp_path / "par.npz"), tmp_path)
     seq = _run_variant(script, {"MI_ILQR_SEQ_BACKWARD": "1", "MI_ILQR_SEQ_ROLLOUT": "1"}, str(tmp_path / "seq.npz"), tmp_path)
     same = (par["it"] == seq["it"]) & (par["ls"] == seq["ls"])
-    assert same.mean() > 0.9
+    assert same.mean() >= 0.95
+    # (a problem whose counts differ flipped one decision in one of 12 re-solves: its final costs still agree)
+    assert np.allclose(par["log"][~same][:, -1, -2], seq["log"][~same][:, -1, -2], rtol=1e-3)
     assert np.allclose(par["log"][same], seq["log"][same], rtol=1e-7, atol=1e-9)
     assert np.max(np.abs(par["x"][same] - seq["x"][same])) < 1e-6 and np.max(np.abs(par["u"][same] - seq["u"][same])) < 1e-6
 
