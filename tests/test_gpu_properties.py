@@ -243,8 +243,6 @@ def test_randomized_configs_vs_c_oracle(seed):
     assert np.max(rel[same]) < 1e-7
     assert np.all(rel[~same] < 1e-3)
     assert np.max(np.abs(x[same] - r["x_bar"][same])) < 1e-4
-    if prob["beta"] <= 0.8:
-        assert (ls > it).any()                               # backtracking really happened (coarse line searches)
 
 
 @pytest.mark.parametrize("cfg,B", [("pendulum", 300), ("wall", 5)])
