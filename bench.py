@@ -374,6 +374,12 @@ def main():
     s._push_problem()                                      # inputs resident in HBM from here on
 
     pending = []
+    # MI_BENCH_NATIVE_RCCL=1: the collective goes through the library's own RCCL communicator
+    # (mi_ilqr_allreduce_min_start/_wait, the C caller's path) instead of torch.distributed
+    native = None
+    if world > 1 and backend == "nccl" and os.environ.get("MI_BENCH_NATIVE_RCCL") == "1":
+        from drake_ddp_amd.dist import NativeComm
+        native = NativeComm.from_torch(dev_index)
     RING = 32      # solves the library lets us keep in flight (per-launch events + statistics records)
 
     def run_steps(count):
@@ -393,7 +399,11 @@ def main():
                 s.solve_resident_async()
             grp = s.collect(k)
             if world > 1:
-                pending.append(allreduce_min_vec_async([st.best_cost for st in grp], dev_index))
+                if native is not None:
+                    drain()                                 # (one reduction in flight per communicator)
+                    pending.append(native.start([st.best_cost for st in grp]))
+                else:
+                    pending.append(allreduce_min_vec_async([st.best_cost for st in grp], dev_index))
             out += grp
             done += k
         return out
@@ -449,7 +459,9 @@ def main():
             "config": {"workload": "C2 pendulum swing-up n=2 m=1 N=200, batch=1024 random initial states per GPU "
                                    "(rng seed 0), fp64, central-FD Jacobians h=1e-5, cold-start Solve per step",
                        "batch_per_gpu": B, "global_batch": B * world, "N": N, "n": 2, "m": 1,
-                       "parallelism": f"batch-shard x{world}"},
+                       "parallelism": f"batch-shard x{world}",
+                       "collective": None if world == 1 else ("librccl all-reduce(min) via mi_ilqr_allreduce_min_start" if native is not None
+                                                              else f"torch.distributed all_reduce(MIN), backend {backend}")},
             "iterations_per_step_rank0": iters / args.steps,
             "max_iterations_per_problem": int(last.max_iters_seen),
             "converged_rank0": int(last.n_converged),

@@ -12,10 +12,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmi_ilqr.so")
 
 MAX_PARAMS = 16
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # enums (include/mi_ilqr.h)
-OK, E_BAD_SHAPE, E_BAD_METHOD, E_LINESEARCH, E_HIP, E_NO_DEVICE, E_BAD_ARG, E_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6, -7
+OK, E_BAD_SHAPE, E_BAD_METHOD, E_LINESEARCH, E_HIP, E_NO_DEVICE, E_BAD_ARG, E_UNSUPPORTED, E_RCCL = 0, -1, -2, -3, -4, -5, -6, -7, -8
+COMM_ID_BYTES, COMM_MAX_COUNT = 128, 64
 KP_SET_INTERVAL, KP_ADAPTIVE_JERK, KP_ITERATIVE_ERROR = 0, 1, 2
 JAC_FD_CENTRAL, JAC_AUTODIFF = 0, 1
 KERNEL_AUTO, KERNEL_LATENCY, KERNEL_THROUGHPUT = 0, 1, 2
@@ -31,6 +32,8 @@ EXPORTS = [
     "mi_ilqr_mpc_run", "mi_ilqr_get_mpc_log",
     "mi_ilqr_get", "mi_ilqr_get_int", "mi_ilqr_set", "mi_ilqr_device_ptr", "mi_ilqr_get_stream",
     "mi_ilqr_synchronize", "mi_ilqr_last_kernel_ms", "mi_ilqr_get_cycles", "mi_ilqr_bytes_per_iteration", "mi_ilqr_lds_bytes",
+    "mi_ilqr_comm_unique_id", "mi_ilqr_comm_create", "mi_ilqr_comm_destroy", "mi_ilqr_allreduce_min",
+    "mi_ilqr_allreduce_min_start", "mi_ilqr_allreduce_min_wait",
 ]
 
 
@@ -103,6 +106,13 @@ def load():
     lib.mi_ilqr_bytes_per_iteration.argtypes = [C.c_int32] * 4
     lib.mi_ilqr_lds_bytes.restype = C.c_size_t
     lib.mi_ilqr_lds_bytes.argtypes = [C.POINTER(Desc)]
+    lib.mi_ilqr_comm_unique_id.argtypes = [C.c_void_p]
+    lib.mi_ilqr_comm_create.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(H)]
+    lib.mi_ilqr_comm_destroy.argtypes = [H]
+    lib.mi_ilqr_comm_destroy.restype = None
+    lib.mi_ilqr_allreduce_min.argtypes = [H, C.c_void_p, C.c_int32]
+    lib.mi_ilqr_allreduce_min_start.argtypes = [H, C.c_void_p, C.c_int32]
+    lib.mi_ilqr_allreduce_min_wait.argtypes = [H, C.c_void_p, C.c_int32]
     if lib.mi_ilqr_abi_version() != ABI_VERSION:
         raise ImportError("libmi_ilqr.so ABI version mismatch")
     _lib = lib

@@ -32,7 +32,7 @@ def build(force=False, verbose=True, extra=()):
     os.makedirs(LIBDIR, exist_ok=True)
     if not force and not needs_build():
         return LIB
-    cmd = [HIPCC] + FLAGS + list(extra) + SOURCES + ["-o", LIB]
+    cmd = [HIPCC] + FLAGS + list(extra) + SOURCES + ["-o", LIB, "-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -7,6 +7,8 @@
 // MI_ILQR_E_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -536,7 +538,8 @@ const char* mi_ilqr_strerror(int code) {
     case MI_ILQR_E_HIP: return "HIP runtime error";
     case MI_ILQR_E_NO_DEVICE: return "no usable gfx950 device (there is no CPU fallback)";
     case MI_ILQR_E_BAD_ARG: return "bad argument";
-    case MI_ILQR_E_UNSUPPORTED: return "model/size combination not supported by any kernel";
+    case MI_ILQR_E_UNSUPPORTED: return "model/size/cost combination not supported by any kernel";
+    case MI_ILQR_E_RCCL: return "RCCL error (librccl missing, or a communicator / collective call failed)";
   }
   return "unknown error";
 }
@@ -1068,6 +1071,146 @@ int mi_ilqr_get_stream(mi_ilqr_t* h, void** hip_stream) {
   if (!h || !hip_stream) return MI_ILQR_E_BAD_ARG;
   *hip_stream = reinterpret_cast<void*>(h->stream);
   return MI_ILQR_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------
+// The path's one collective: all-reduce(min) of the best costs over the ranks, RCCL over xGMI.
+// librccl is bound at run time (dlopen), so libmi_ilqr.so has no link-time dependency on it; a
+// process that already holds an RCCL (e.g. PyTorch's) shares that instance.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+struct RcclApi {
+  // the few entry points used, with the types of rccl.h (ncclResult_t = int, ncclComm_t = opaque pointer,
+  // ncclUniqueId = 128 bytes by value, ncclDataType_t / ncclRedOp_t = int enums: ncclFloat64 = 8, ncclMin = 4)
+  struct UniqueId { char internal[MI_ILQR_COMM_ID_BYTES]; };
+  int (*GetUniqueId)(UniqueId*) = nullptr;
+  int (*CommInitRank)(void**, int, UniqueId, int) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  bool ok = false;
+};
+constexpr int kNcclFloat64 = 8, kNcclMin = 4;
+
+const RcclApi& rccl() {
+  static const RcclApi api = [] {
+    RcclApi a;
+    void* lib = nullptr;
+    for (const char* name : {"librccl.so.1", "librccl.so"})            // an instance already in the process first
+      if (!lib) lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+      if (!lib) lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+    if (!lib) return a;
+    a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
+    a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
+    a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+    a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(dlsym(lib, "ncclAllReduce"));
+    a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+    a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllReduce;
+    return a;
+  }();
+  return api;
+}
+#define RCCLCHK(expr)                                                                               \
+  do {                                                                                              \
+    const int r_ = (expr);                                                                          \
+    if (r_ != 0) {                                                                                  \
+      std::fprintf(stderr, "mi_ilqr: %s failed: %s (%s:%d)\n", #expr,                               \
+                   rccl().GetErrorString ? rccl().GetErrorString(r_) : "?", __FILE__, __LINE__);    \
+      return MI_ILQR_E_RCCL;                                                                        \
+    }                                                                                               \
+  } while (0)
+}  // namespace
+
+struct mi_ilqr_comm {
+  void* comm = nullptr;
+  int rank = 0, world = 1, device = 0;
+  hipStream_t stream = nullptr;     // the collective's own stream: it overlaps the solves of the handles
+  hipEvent_t done = nullptr;
+  double* d_buf = nullptr;          // MI_ILQR_COMM_MAX_COUNT doubles on the device
+  double* h_buf = nullptr;          // pinned staging
+  int in_flight = 0;                // count of the reduction started and not yet waited for
+};
+
+extern "C" {
+
+int mi_ilqr_comm_unique_id(void* id_bytes) {
+  if (!id_bytes) return MI_ILQR_E_BAD_ARG;
+  if (!rccl().ok) return MI_ILQR_E_RCCL;
+  RcclApi::UniqueId id;
+  RCCLCHK(rccl().GetUniqueId(&id));
+  std::memcpy(id_bytes, id.internal, MI_ILQR_COMM_ID_BYTES);
+  return MI_ILQR_OK;
+}
+
+int mi_ilqr_comm_create(const void* id_bytes, int32_t rank, int32_t world, int32_t device_id, mi_ilqr_comm_t** out) {
+  if (!id_bytes || !out || world < 1 || rank < 0 || rank >= world) return MI_ILQR_E_BAD_ARG;
+  *out = nullptr;
+  if (!rccl().ok) return MI_ILQR_E_RCCL;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) return MI_ILQR_E_NO_DEVICE;
+  HIPCHK(hipSetDevice(device_id));
+  mi_ilqr_comm* c = new (std::nothrow) mi_ilqr_comm();
+  if (!c) return MI_ILQR_E_BAD_ARG;
+  c->rank = rank; c->world = world; c->device = device_id;
+  RcclApi::UniqueId id;
+  std::memcpy(id.internal, id_bytes, MI_ILQR_COMM_ID_BYTES);
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->done) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&c->d_buf), MI_ILQR_COMM_MAX_COUNT * 8) != hipSuccess ||
+      hipHostMalloc(reinterpret_cast<void**>(&c->h_buf), MI_ILQR_COMM_MAX_COUNT * 8, hipHostMallocDefault) != hipSuccess) {
+    mi_ilqr_comm_destroy(c);
+    return MI_ILQR_E_HIP;
+  }
+  const int r = rccl().CommInitRank(&c->comm, world, id, rank);
+  if (r != 0) {
+    std::fprintf(stderr, "mi_ilqr: ncclCommInitRank failed: %s\n", rccl().GetErrorString ? rccl().GetErrorString(r) : "?");
+    c->comm = nullptr;
+    mi_ilqr_comm_destroy(c);
+    return MI_ILQR_E_RCCL;
+  }
+  *out = c;
+  return MI_ILQR_OK;
+}
+
+void mi_ilqr_comm_destroy(mi_ilqr_comm_t* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->comm && rccl().ok) (void)rccl().CommDestroy(c->comm);
+  if (c->d_buf) (void)hipFree(c->d_buf);
+  if (c->h_buf) (void)hipHostFree(c->h_buf);
+  if (c->done) (void)hipEventDestroy(c->done);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int mi_ilqr_allreduce_min_start(mi_ilqr_comm_t* c, const double* values, int32_t count) {
+  if (!c || !values || count < 1 || count > MI_ILQR_COMM_MAX_COUNT || c->in_flight) return MI_ILQR_E_BAD_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  std::memcpy(c->h_buf, values, (size_t)count * 8);
+  HIPCHK(hipMemcpyAsync(c->d_buf, c->h_buf, (size_t)count * 8, hipMemcpyHostToDevice, c->stream));
+  RCCLCHK(rccl().AllReduce(c->d_buf, c->d_buf, (size_t)count, kNcclFloat64, kNcclMin, c->comm, c->stream));
+  HIPCHK(hipMemcpyAsync(c->h_buf, c->d_buf, (size_t)count * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipEventRecord(c->done, c->stream));
+  c->in_flight = count;
+  return MI_ILQR_OK;
+}
+
+int mi_ilqr_allreduce_min_wait(mi_ilqr_comm_t* c, double* values, int32_t count) {
+  if (!c || !values || count != c->in_flight || count < 1) return MI_ILQR_E_BAD_ARG;
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipEventSynchronize(c->done));
+  std::memcpy(values, c->h_buf, (size_t)count * 8);
+  c->in_flight = 0;
+  return MI_ILQR_OK;
+}
+
+int mi_ilqr_allreduce_min(mi_ilqr_comm_t* c, double* values, int32_t count) {
+  const int rc = mi_ilqr_allreduce_min_start(c, values, count);
+  if (rc != MI_ILQR_OK) return rc;
+  return mi_ilqr_allreduce_min_wait(c, values, count);
 }
 
 }  // extern "C"

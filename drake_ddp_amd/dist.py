@@ -111,3 +111,68 @@ def allreduce_sum(values, device_id=0):
     if dist is not None:
         dist.all_reduce(v, op=dist.ReduceOp.SUM)
     return v.cpu().numpy()
+
+
+class NativeComm:
+    """The same collective without torch in the data path: an RCCL communicator owned by libmi_ilqr.so
+    (include/mi_ilqr.h: mi_ilqr_comm_*), the way a C caller of the library reduces its best costs.  The
+    128-byte communicator id is created on rank 0 and shipped by whatever channel the launcher has
+    (`exchange`: a callable bytes-or-None -> bytes; from_torch() uses the process group's object broadcast)."""
+
+    def __init__(self, rank, world, device_id, exchange=None):
+        import ctypes as C
+        from . import _capi
+        self._capi, self._C = _capi, C
+        self._lib = _capi.load()
+        ident = None
+        if rank == 0:
+            buf = (C.c_char * _capi.COMM_ID_BYTES)()
+            _capi.check(self._lib.mi_ilqr_comm_unique_id(buf), "mi_ilqr_comm_unique_id")
+            ident = bytes(buf.raw)
+        if world > 1:
+            if exchange is None:
+                raise ValueError("world > 1 needs an `exchange` callable to ship the communicator id")
+            ident = exchange(ident)
+        h = C.c_void_p()
+        idbuf = C.create_string_buffer(ident, _capi.COMM_ID_BYTES)
+        _capi.check(self._lib.mi_ilqr_comm_create(idbuf, int(rank), int(world), int(device_id), C.byref(h)), "mi_ilqr_comm_create")
+        self._h = h
+        self.rank, self.world = int(rank), int(world)
+        self._pending = 0
+
+    @classmethod
+    def from_torch(cls, device_id):
+        """Ranks and id exchange taken from the initialized torch.distributed process group (any backend)."""
+        dist = _dist()
+        if dist is None:
+            return cls(0, 1, device_id)
+
+        def exchange(ident):
+            box = [ident]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+        return cls(dist.get_rank(), dist.get_world_size(), device_id, exchange)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.mi_ilqr_comm_destroy(h)
+
+    def allreduce_min(self, values):
+        v = np.ascontiguousarray(values, dtype=np.float64).copy()
+        self._capi.check(self._lib.mi_ilqr_allreduce_min(self._h, self._capi.ptr(v), int(v.size)), "mi_ilqr_allreduce_min")
+        return v
+
+    def start(self, values):
+        """Enqueue the reduction on the communicator's own stream (overlaps the next solves); wait() completes it."""
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        self._capi.check(self._lib.mi_ilqr_allreduce_min_start(self._h, self._capi.ptr(v), int(v.size)), "mi_ilqr_allreduce_min_start")
+        self._pending = int(v.size)
+        return self
+
+    def wait(self):
+        out = np.empty(self._pending, dtype=np.float64)
+        if self._pending:
+            self._capi.check(self._lib.mi_ilqr_allreduce_min_wait(self._h, self._capi.ptr(out), self._pending), "mi_ilqr_allreduce_min_wait")
+            self._pending = 0
+        return out

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MI_ILQR_ABI_VERSION 2
+#define MI_ILQR_ABI_VERSION 3
 #define MI_ILQR_MAX_PARAMS 16
 
 /* Error codes (0 = OK).  The Python wrapper maps them onto the exception types
@@ -45,7 +45,8 @@ enum {
   MI_ILQR_E_HIP = -4,
   MI_ILQR_E_NO_DEVICE = -5,
   MI_ILQR_E_BAD_ARG = -6,
-  MI_ILQR_E_UNSUPPORTED = -7     /* model / size combination no kernel covers */
+  MI_ILQR_E_UNSUPPORTED = -7,    /* model / size / cost-matrix combination no kernel covers */
+  MI_ILQR_E_RCCL = -8            /* librccl missing, or a collective / communicator call failed */
 };
 
 /* Device dynamics models (the `system` argument of ilqr.py:21 becomes a model
@@ -140,15 +141,20 @@ int mi_ilqr_create(const mi_ilqr_desc* desc, mi_ilqr_t** out);
 void mi_ilqr_destroy(mi_ilqr_t* h);
 
 /* SetRunningCost / SetTerminalCost / SetTargetState (ilqr.py:111-146): Q (n,n), R (m,m),
- * Qf (n,n), x_nom (n), shared by the batch.  Any pointer may be NULL = keep. */
+ * Qf (n,n), x_nom (n), shared by the batch.  Any pointer may be NULL = keep.  Any matrices are accepted,
+ * like the reference (lxx = 2Q, never symmetrized - ilqr.py:182): symmetric positive semi-definite Q, Qf and
+ * positive definite R take the time-parallel / matrix-core backward passes, anything else the reference's
+ * recursion verbatim (n <= 4), or MI_ILQR_E_UNSUPPORTED on the workgroup-per-problem kernel (n = 36), whose
+ * Quu = L D L^T factorization has no such form. */
 int mi_ilqr_set_cost(mi_ilqr_t* h, const double* Q, const double* R, const double* Qf, const double* x_nom);
 
 /* SetInitialState / SetInitialGuess (ilqr.py:102-109,148-156): x0 (B,n), u_guess (B,m,N-1).
  * u_guess becomes u_bar (the reference aliases it, ilqr.py:156).  NULL = keep. */
 int mi_ilqr_set_initial(mi_ilqr_t* h, const double* x0, const double* u_guess);
 
-/* Zero the persistent solver state (x_bar,K,kappa,dV,fx,fu) = a freshly constructed
- * reference object (ilqr.py:70-83).  Without it the state persists across solves (F10). */
+/* Zero the persistent solver state (x_bar,u_bar,K,kappa,dV,fx,fu) = a freshly constructed
+ * reference object (ilqr.py:70-83): a solve after it without mi_ilqr_set_initial(u_guess) /
+ * mi_ilqr_rearm_initial_guess starts from u_bar = 0.  Without it the state persists across solves (F10). */
 int mi_ilqr_reset(mi_ilqr_t* h);
 
 /* Benchmark/MPC helper: make the resident u_guess (last mi_ilqr_set_initial or
@@ -187,8 +193,12 @@ int mi_ilqr_mpc_shift(mi_ilqr_t* h, int32_t replan_steps);
  * For the wave-per-problem kernels this is ONE launch and the solver state stays in LDS between
  * re-solves; the workgroup-per-problem kernel (n = 36) runs the loop in one launch as well.  Per
  * re-solve the log keeps (x0 (n), cost, iterations) for every problem:
- * mi_ilqr_get_mpc_log -> (B, num_resolves, n+2).  stats aggregate the whole loop.  (The
- * lane-per-problem "throughput" kernels loop shift + solve on the host and keep no log.) */
+ * mi_ilqr_get_mpc_log -> (B, num_resolves, n+2).  stats aggregate the whole loop; the per-problem status
+ * is that of the LAST re-solve (a loop that hits a line-search failure stops there).
+ * Limits of the single-launch form: wave-per-problem kernels N <= 512 (the in-kernel shift holds eight
+ * controls per lane), workgroup-per-problem kernel m*(N-1) <= 2048.  Beyond them, and for the
+ * lane-per-problem "throughput" kernels, the same loop runs as shift + solve launches from the host:
+ * same results, no log (mi_ilqr_get_mpc_log then returns MI_ILQR_E_BAD_ARG). */
 int mi_ilqr_mpc_run(mi_ilqr_t* h, int32_t num_resolves, int32_t replan_steps, const double* target_step, mi_ilqr_stats* stats);
 int mi_ilqr_get_mpc_log(mi_ilqr_t* h, double* dst, size_t bytes);
 
@@ -202,6 +212,28 @@ int mi_ilqr_set(mi_ilqr_t* h, int which, const double* src, size_t bytes);
 int mi_ilqr_device_ptr(mi_ilqr_t* h, int which, void** ptr, size_t* bytes);
 int mi_ilqr_get_stream(mi_ilqr_t* h, void** hip_stream);
 int mi_ilqr_synchronize(mi_ilqr_t* h);
+
+/* ---- multi-GPU: the path's one collective -------------------------------------------
+ * Problems are independent: every rank (one process per GPU) owns a handle over its contiguous shard of
+ * the batch and no kernel ever exchanges data.  The only cross-rank step is the reduction of the best
+ * total cost at the end of a batched solve: ONE RCCL all-reduce(min) of a few doubles over xGMI, here so
+ * that a C caller needs nothing but this header.  librccl is loaded on first use (dlopen); without it
+ * these entries return MI_ILQR_E_RCCL and everything else keeps working.
+ *   rank 0:  mi_ilqr_comm_unique_id(id)  ->  ship the MI_ILQR_COMM_ID_BYTES bytes to every rank over the
+ *            launcher's own channel (MPI_Bcast, a file, a TCP store)
+ *   all:     mi_ilqr_comm_create(id, rank, world, device_id, &comm)          (collective call)
+ *   all:     mi_ilqr_allreduce_min(comm, values, count)                      (blocking; in place)
+ *        or  mi_ilqr_allreduce_min_start / _wait: the reduction runs on the communicator's own stream and
+ *            overlaps the next solve; at most one in flight per communicator; count <= 64. */
+#define MI_ILQR_COMM_ID_BYTES 128
+#define MI_ILQR_COMM_MAX_COUNT 64
+typedef struct mi_ilqr_comm mi_ilqr_comm_t;
+int mi_ilqr_comm_unique_id(void* id_bytes);
+int mi_ilqr_comm_create(const void* id_bytes, int32_t rank, int32_t world, int32_t device_id, mi_ilqr_comm_t** out);
+void mi_ilqr_comm_destroy(mi_ilqr_comm_t* c);
+int mi_ilqr_allreduce_min(mi_ilqr_comm_t* c, double* values, int32_t count);
+int mi_ilqr_allreduce_min_start(mi_ilqr_comm_t* c, const double* values, int32_t count);
+int mi_ilqr_allreduce_min_wait(mi_ilqr_comm_t* c, double* values, int32_t count);
 
 /* Per-problem in-kernel stopwatches of the last solve, shader-clock cycles, (B,4):
  * line search, linearization, backward pass, whole Solve loop — the device counterpart

@@ -369,3 +369,27 @@ def test_layout_conversions_round_trip(path):
     s.SetInitialGuess(ug)
     s._push_problem()
     assert np.array_equal(s.u_bar, ug)
+
+
+def test_native_rccl_collective_single_rank():
+    """mi_ilqr_comm_* / mi_ilqr_allreduce_min: the library's own RCCL communicator (what a C caller uses for the
+    best-cost reduction).  One GPU here, so one rank: the id is created, the communicator initialized and real
+    ncclAllReduce(min) calls run on the device, blocking and start/wait; argument errors are refused."""
+    from drake_ddp_amd.dist import NativeComm
+    from drake_ddp_amd._capi import MiIlqrError
+    c = NativeComm(0, 1, 0)
+    v = np.array([3.5, -1.25, 7.0])
+    assert np.array_equal(c.allreduce_min(v), v)
+    assert np.array_equal(c.start(v[:2]).wait(), v[:2])
+    with pytest.raises(MiIlqrError):
+        c.allreduce_min(np.zeros(65))                                  # MI_ILQR_COMM_MAX_COUNT
+    # and together with a solve: the reduction of the batch's best cost
+    from drake_ddp_amd import workloads as W
+    prob = W.pendulum_problem()
+    s = make_solver(prob, B=8, jac="fd")
+    s.SetInitialState(W.pendulum_batch_x0(8))
+    s.SetInitialGuess(np.zeros((1, prob["N"] - 1)))
+    s.Solve()
+    assert c.allreduce_min([s.stats.best_cost])[0] == s.cost.min()
+    c2 = NativeComm.from_torch(0)                                      # no process group: a one-rank communicator
+    assert c2.world == 1 and c2.allreduce_min([2.0])[0] == 2.0
