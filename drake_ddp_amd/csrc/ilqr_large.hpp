@@ -89,6 +89,18 @@ __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+// Models whose step is an articulated-body algorithm cut into chains (models.hpp: PlanarQuad): cooperative
+// step in the rollout, accessor-driven whole-tree evaluation in the linearization.
+template <class M, class = void>
+struct IsChainModel { static constexpr bool value = false; };
+template <class M>
+struct IsChainModel<M, decltype((void)M::kChainCooperative)> { static constexpr bool value = M::kChainCooperative; };
+// Models that can declare a step infeasible (Drake's update throwing -> L = inf, ilqr.py:315-323).
+template <class M, class = void>
+struct CanFail { static constexpr bool value = false; };
+template <class M>
+struct CanFail<M, decltype((void)M::kCanFail)> { static constexpr bool value = M::kCanFail; };
+
 __device__ __forceinline__ double block_sum(double v, double* red) {
   // deterministic fixed-order tree: 64-lane butterfly, then 4 wave partials
 #pragma unroll
@@ -134,6 +146,7 @@ __device__ inline double large_rollout(const LView<M::n, M::m>& v, double* lds, 
   static_assert(Ly::oQc - Ly::oXb >= n, "second state buffer");
   if (tid < n) { xs[tid] = x0g[tid]; v.Xn[tid] = x0g[tid]; }
   double acc = 0.0;                    // per-thread cost partial over all time steps
+  bool bad = false;                    // this thread saw an infeasible step (models that can fail)
   // Operands of the control law (K_t row slice, x_bar_t slice, u_bar_t, kappa_t) come from
   // L2/MALL: they are requested TWO steps ahead into two alternating register sets (a step is
   // ~1.5 k cycles of work; an Infinity-Cache hit costs about that much on its own).
@@ -169,13 +182,62 @@ __device__ inline double large_rollout(const LView<M::n, M::m>& v, double* lds, 
     }
     if (t + 2 < N - 1) prefetch(f, t + 2);       // this set is free again
     lds_barrier();
-    // dynamics: one lane per degree of freedom (ilqr.py:316); cost rows on the other waves (:325)
-    if (tid < M::nq) {
-      double qn_ = 0.0, vn_ = 0.0;
-      M::template dof<double>(tid, xc, us, qn_, vn_, a.params, a.dt);
-      xn_[tid] = qn_; xn_[M::nq + tid] = vn_;
-      v.Xn[(size_t)(t + 1) * n + tid] = qn_;
-      v.Xn[(size_t)(t + 1) * n + M::nq + tid] = vn_;
+    // dynamics (ilqr.py:316); cost rows on the other waves (:325)
+    bool dyn_done = false;
+    if constexpr (IsChainModel<M>::value) {
+      // articulated body: ONE LANE PER CHAIN of the tree (lanes 0..kChains-1 of wave 0; the other lanes of the
+      // first 16-lane row shadow the last chain and contribute zeros).  Leaves-to-root pass per chain, the
+      // chains' articulated inertias / bias forces summed over the row with DPP rotations, the trunk's 3x3
+      // system solved redundantly in every lane, root-to-leaves pass per chain.  No LDS traffic, no barrier.
+      if (tid < 16) {
+        const int ch = tid < M::kChains ? tid : M::kChains - 1;
+        typename M::template Trunk<double> tr;
+        M::template trunk_state<double>(xc, tr);
+        typename M::template Agg<double> ag;
+        typename M::template Saved<double> sv;
+        M::template chain_up<double>(ch, tr, xc, us, a.params, ag, sv);
+        const double keep = tid < M::kChains ? 1.0 : 0.0;
+        typename M::template Agg<double> tot;
+        M::template trunk_agg<double>(a.params, tot);
+        tot.J += row16_sum(keep * ag.J); tot.hx += row16_sum(keep * ag.hx); tot.hz += row16_sum(keep * ag.hz);
+        tot.mxx += row16_sum(keep * ag.mxx); tot.mxz += row16_sum(keep * ag.mxz); tot.mzz += row16_sum(keep * ag.mzz);
+        tot.bn += row16_sum(keep * ag.bn); tot.bx += row16_sum(keep * ag.bx); tot.bz += row16_sum(keep * ag.bz);
+        double ax, az, alpha;
+        M::template base_solve<double>(tot, ax, az, alpha);
+        double q3[3];
+        M::template chain_down<double>(sv, alpha, ax, az, q3);
+        if (tid < M::kChains) {
+#pragma unroll
+          for (int b_ = 0; b_ < 3; ++b_) {
+            const int i = 3 + 3 * tid + b_;
+            const double vn_ = xc[M::nq + i] + a.dt * q3[b_];
+            const double qn_ = xc[i] + a.dt * vn_;
+            xn_[i] = qn_; xn_[M::nq + i] = vn_;
+            v.Xn[(size_t)(t + 1) * n + i] = qn_; v.Xn[(size_t)(t + 1) * n + M::nq + i] = vn_;
+            bad = bad || M::infeasible_velocity(vn_, a.params);
+          }
+        }
+        if (tid < 3) {                                     // the trunk's own coordinates: x, z, pitch
+          const double acc_ = tid == 0 ? ax : (tid == 1 ? az : alpha);
+          const double vn_ = xc[M::nq + tid] + a.dt * acc_;
+          const double qn_ = xc[tid] + a.dt * vn_;
+          xn_[tid] = qn_; xn_[M::nq + tid] = vn_;
+          v.Xn[(size_t)(t + 1) * n + tid] = qn_; v.Xn[(size_t)(t + 1) * n + M::nq + tid] = vn_;
+          bad = bad || M::infeasible_velocity(vn_, a.params);
+        }
+        dyn_done = true;
+      }
+    } else {
+      if (tid < M::nq) {                                   // one lane per degree of freedom
+        double qn_ = 0.0, vn_ = 0.0;
+        M::template dof<double>(tid, xc, us, qn_, vn_, a.params, a.dt);
+        xn_[tid] = qn_; xn_[M::nq + tid] = vn_;
+        v.Xn[(size_t)(t + 1) * n + tid] = qn_;
+        v.Xn[(size_t)(t + 1) * n + M::nq + tid] = vn_;
+        dyn_done = true;
+      }
+    }
+    if (dyn_done) {
     } else if (qrole) {
       const int i = tid - 64;
       double r = 0.0;
@@ -211,9 +273,17 @@ __device__ inline double large_rollout(const LView<M::n, M::m>& v, double* lds, 
   double dvp = 0.0;
   for (int t = tid; t < N - 1; t += kLargeThreads) dvp += v.dV[t];
   double* red = lds + Ly::oRed;
-  const double L = block_sum(acc, red);
+  double L = block_sum(acc, red);
   const double dvs = block_sum(dvp, red);
   expd_out = -eps * (1.0 - eps / 2.0) * dvs;             // ilqr.py:326
+  if constexpr (CanFail<M>::value) {
+    // a step was declared infeasible: the trial's cost is +inf (ilqr.py:317-323; the reference stops simulating
+    // there - what this rollout computed past that step is never looked at: L = inf is never accepted, :330)
+    // (workgroup-wide OR through the reduction scratch: HIP's __syncthreads_or carries a static LDS variable,
+    // which would take the kernel's dynamic LDS below the 160 KB the layout is sized for)
+    const double flagged = block_sum(bad ? 1.0 : 0.0, red);
+    if (flagged > 0.0) L = __builtin_inf();
+  }
   return L;
 }
 
@@ -292,6 +362,47 @@ __device__ __forceinline__ void large_jac_at_sparse(const LView<M::n, M::m>& v, 
         }
         o[i * stride] = dq;                       // same thread, same address as the zero above: program order holds
         o[(nq + i) * stride] = dv;
+      }
+    }
+  }
+}
+
+// Chain models: the whole tree is evaluated per (key-point, column) item on one thread, its inputs read
+// through the perturbing / seeding accessors (no per-thread copy of x, u); every entry of the column is written.
+template <class M, int JAC>
+__device__ __forceinline__ void large_jac_at_tree(const LView<M::n, M::m>& v, const KArgs& a, const int* list, int count,
+                                                  const double* Xsrc, const double* Usrc) {
+  constexpr int n = M::n, m = M::m, nc = n + m, nq = M::nq;
+  const double h = a.fd_h, inv2h = 1.0 / (2.0 * h), dt = a.dt;
+  for (int it = threadIdx.x; it < count * nc; it += kLargeThreads) {
+    const int ki = it / nc, col = it - ki * nc;
+    const int t = list[ki];
+    const double* xg = Xsrc + (size_t)t * n;
+    const double* ug = Usrc + (size_t)t * m;
+    double* o;
+    int stride;
+    if (col < n) { o = v.Fx + (size_t)t * n * n + col; stride = n; }
+    else { o = v.Fu + (size_t)t * n * m + (col - n); stride = m; }
+    if (JAC == MI_JAC_FD_CENTRAL) {
+      double ap[nq], am[nq];
+      const PertAcc xp{xg, col, h}, up{ug, col - n, h}, xm{xg, col, -h}, um{ug, col - n, -h};
+      M::template accel<double>(xp, up, a.params, ap);
+      M::template accel<double>(xm, um, a.params, am);
+      for (int i = 0; i < nq; ++i) {                       // (f(x+h e) - f(x-h e)) / 2h on v+ = v + dt a, q+ = q + dt v+
+        const double vp = xp[nq + i] + dt * ap[i], vm = xm[nq + i] + dt * am[i];
+        const double qp = xp[i] + dt * vp, qm = xm[i] + dt * vm;
+        o[i * stride] = (qp - qm) * inv2h;
+        o[(nq + i) * stride] = (vp - vm) * inv2h;
+      }
+    } else {
+      Dual1 ad[nq];
+      const SeedAcc xs{xg, col}, us{ug, col - n};
+      M::template accel<Dual1>(xs, us, a.params, ad);
+      for (int i = 0; i < nq; ++i) {
+        const Dual1 vn = xs[nq + i] + dt * ad[i];
+        const Dual1 qn = xs[i] + dt * vn;
+        o[i * stride] = qn.d;
+        o[(nq + i) * stride] = vn.d;
       }
     }
   }
@@ -902,12 +1013,13 @@ __global__ void __launch_bounds__(kLargeThreads) ilqr_large_kernel(const KArgs a
   // The sparse Jacobian code reads a handful of x/u entries per evaluation: it takes them from an
   // LDS copy of the nominal trajectory (the backward pass's T1|H and F areas are idle during the
   // linearization) instead of paying an L2 round trip per dependent access.
-  const bool lin_staged = HasSparsity<M>::value && (size_t)n * N <= (size_t)(n + Ly::NMP) * Ly::TS &&
+  const bool lin_staged = (HasSparsity<M>::value || IsChainModel<M>::value) && (size_t)n * N <= (size_t)(n + Ly::NMP) * Ly::TS &&
                           (size_t)m * (N - 1) <= (size_t)n * Ly::NMP;
   const double* lin_X = lin_staged ? lds + Ly::oT1 : v.X;
   const double* lin_U = lin_staged ? lds + Ly::oF : v.U;
   auto jac = [&](const int* list, int count) __attribute__((always_inline)) {
     if constexpr (HasSparsity<M>::value) large_jac_at_sparse<M, JAC>(v, a, list, count, lin_X, lin_U);
+    else if constexpr (IsChainModel<M>::value) large_jac_at_tree<M, JAC>(v, a, list, count, lin_X, lin_U);
     else large_jac_at<M, JAC>(v, a, list, count);
   };
   auto do_linearize = [&](bool have_copy) __attribute__((always_inline)) {

@@ -101,8 +101,9 @@ const ModelInfo* model_info(int id) {
       {4, 1, 4, {10.0, 1.0, 0.5, 9.81}},
       {4, 1, 8, {10.0, 1.0, 0.5, 9.81, -0.45, 0.05, 2000.0, 0.01}},
       {36, 12, 4, {4.0, 0.5, 6.0, 0.1}},
+      {36, 12, 9, {9.81, 4000.0, 0.004, 0.3, 0.15, 0.05, 0.02, 2.0, 60.0}},
   };
-  if (id < 0 || id > 4) return nullptr;
+  if (id < 0 || id > 5) return nullptr;
   return &table[id];
 }
 
@@ -119,6 +120,7 @@ size_t small_lds_bytes(int model_id, int N, int n_store = 1) {
 size_t large_lds(int model_id, int N) {
   switch (model_id) {
     case MI_MODEL_SYNTH36: return large_lds_bytes<Synth36::n, Synth36::m>(N);
+    case MI_MODEL_PLANAR_QUAD: return large_lds_bytes<PlanarQuad::n, PlanarQuad::m>(N);
     default: return 0;
   }
 }
@@ -300,6 +302,7 @@ int launch(mi_ilqr* h, int mode) {
     case MI_MODEL_CARTPOLE: rc = launch_jac<CartPole>(h, mode, a); break;
     case MI_MODEL_CARTPOLE_WALL: rc = launch_jac<CartPoleWall>(h, mode, a); break;
     case MI_MODEL_SYNTH36: rc = launch_jac_large<Synth36>(h, mode, a); break;
+    case MI_MODEL_PLANAR_QUAD: rc = launch_jac_large<PlanarQuad>(h, mode, a); break;
     default: return MI_ILQR_E_UNSUPPORTED;
   }
   return rc;

@@ -131,4 +131,193 @@ struct Synth36 {             // params [ks, c, kc, bu]; 18 coupled pendula, dofs
   }
 };
 
+// Planar floating-base articulated body of the mini-cheetah's SHAPE (mini_cheetah.py:41-52: 18 positions,
+// 18 velocities, 12 actuators): trunk (x, z, pitch) + four 3-link legs (hip, knee, ankle: the actuated joints) +
+// a passive 3-link tail; compliant ground contact at the four feet and the tail tip.  Accelerations by the
+// articulated-body algorithm in world-aligned planar coordinates (a body's spatial quantities: moment about /
+// rotation at its joint axis, x, z; transforms between bodies are pure translations) - the same formulas as
+// oracle/models_np.py:quad_accel and oracle/ilqr_oracle.c.  params [g, k, sigma, dn, mu, b_leg, b_tail, k_tail, v_max].
+//   q = [x, z, pitch | leg0 hip,knee,ankle | leg1 | leg2 | leg3 | tail 1,2,3],  u -> the 12 leg joints.
+// The tree is five 3-body CHAINS hanging off the trunk, which is how the work is cut: a chain's leaves-to-root
+// pass yields its articulated inertia and bias force at the trunk (chain_up), the trunk's 3x3 system gives the
+// base acceleration (base_solve), a chain's root-to-leaves pass its joint accelerations (chain_down).  One
+// lane per chain in the rollout (cooperative step of the workgroup-per-problem kernel), all five chains on
+// one thread in the linearization's finite differences.
+// The model can FAIL: a step that leaves |v| <= v_max is declared infeasible - the device analogue of Drake's
+// discrete update throwing, which the reference's line search turns into L = inf (ilqr.py:315-323).
+struct PlanarQuad {
+  static constexpr int n = 36, m = 12, n_params = 9, nq = 18, kChains = 5;
+  static constexpr bool kChainCooperative = true;
+  static constexpr bool kCanFail = true;
+  template <class T> struct Trunk { T sn, cs, om, pz, vx, vz; };
+  template <class T> struct Agg { T J, hx, hz, mxx, mxz, mzz, bn, bx, bz; };
+  template <class T> struct Saved { T D[3], Ux[3], Uz[3], uu[3], dx[3], dz[3], cbx[3], cbz[3]; };
+  __device__ static constexpr double len(int c, int b) { return c < 4 ? (b == 0 ? 0.20 : (b == 1 ? 0.18 : 0.14)) : 0.12; }
+  __device__ static constexpr double mass(int c, int b) { return c < 4 ? (b == 0 ? 0.60 : (b == 1 ? 0.40 : 0.30)) : 0.10; }
+  __device__ static constexpr double atx(int c) { return c < 2 ? 0.19 : (c < 4 ? -0.19 : -0.25); }
+  __device__ static constexpr double atz(int c) { return c < 4 ? 0.0 : 0.02; }
+  __device__ static constexpr double tail_rest(int b) { return b == 0 ? -1.2 : -0.2; }
+  static constexpr double kTrunkMass = 4.0, kTrunkInertia = 0.06;
+
+  template <class T, class XA>
+  __device__ static inline void trunk_state(const XA& x, Trunk<T>& tr) {
+    const T th = x[2];
+    tr.sn = mi_sin(th); tr.cs = mi_cos(th); tr.om = x[nq + 2]; tr.pz = x[1]; tr.vx = x[nq + 0]; tr.vz = x[nq + 1];
+  }
+  // trunk's own inertia about its origin (= its COM) and bias (gravity only: no centripetal term at the COM)
+  template <class T>
+  __device__ static inline void trunk_agg(const double* p, Agg<T>& a) {
+    a.J = kTrunkInertia; a.hx = 0.0; a.hz = 0.0; a.mxx = kTrunkMass; a.mxz = 0.0; a.mzz = kTrunkMass;
+    a.bn = 0.0; a.bx = 0.0; a.bz = kTrunkMass * p[0];
+  }
+  template <class T>
+  __device__ static inline void agg_add(Agg<T>& a, const Agg<T>& b) {
+    a.J = a.J + b.J; a.hx = a.hx + b.hx; a.hz = a.hz + b.hz; a.mxx = a.mxx + b.mxx; a.mxz = a.mxz + b.mxz; a.mzz = a.mzz + b.mzz;
+    a.bn = a.bn + b.bn; a.bx = a.bx + b.bx; a.bz = a.bz + b.bz;
+  }
+  // Chain c (0..3 legs, 4 tail): kinematics, joint torques, contact at the tip, leaves-to-root pass.
+  // `agg`: the chain's contribution to the trunk's articulated inertia / bias; `sv`: what chain_down needs.
+  template <class T, class XA, class UA>
+  __device__ static inline void chain_up(int c, const Trunk<T>& tr, const XA& x, const UA& u, const double* p, Agg<T>& agg, Saved<T>& sv) {
+    const double g = p[0], kc = p[1], sig = p[2], dn = p[3], mu = p[4], b_leg = p[5], b_tail = p[6], k_tail = p[7];
+    const double inv_sig = 1.0 / sig;
+    const int j0 = 3 + 3 * c;                      // first joint dof of the chain
+    T sn[3], cs[3], om[3], rx[3], rz[3], tau[3];
+    T J[3], hx[3], hz[3], mxx[3], mxz[3], mzz[3], bn[3], bx[3], bz[3];
+    // ---- pass 1 (root to leaves)
+    T th_par = x[2], om_par = tr.om, sn_par = tr.sn, cs_par = tr.cs;
+    T pz = tr.pz, vx = tr.vx, vz = tr.vz;
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      if (b == 0) { sv.dx[0] = cs_par * atx(c) - sn_par * atz(c); sv.dz[0] = sn_par * atx(c) + cs_par * atz(c); }
+      else { const double lp = len(c, b - 1); sv.dx[b] = lp * sn_par; sv.dz[b] = -lp * cs_par; }
+      const T qj = x[j0 + b], vj = x[nq + j0 + b];
+      const T th = th_par + qj;
+      om[b] = om_par + vj;
+      sn[b] = mi_sin(th); cs[b] = mi_cos(th);
+      pz = pz + sv.dz[b];
+      vx = vx - om_par * sv.dz[b]; vz = vz + om_par * sv.dx[b];
+      const double hl = 0.5 * len(c, b);
+      rx[b] = hl * sn[b]; rz[b] = -hl * cs[b];
+      const T w2p = om_par * om_par;
+      sv.cbx[b] = -w2p * sv.dx[b]; sv.cbz[b] = -w2p * sv.dz[b];
+      if (c < 4) tau[b] = u[3 * c + b] - b_leg * vj;
+      else tau[b] = -b_tail * vj - k_tail * (qj - tail_rest(b));
+      const double m_ = mass(c, b), ic = m_ * len(c, b) * len(c, b) / 12;
+      const T w2 = om[b] * om[b];
+      J[b] = ic + m_ * (rx[b] * rx[b] + rz[b] * rz[b]);
+      hx[b] = -m_ * rz[b]; hz[b] = m_ * rx[b];
+      mxx[b] = m_; mxz[b] = 0.0; mzz[b] = m_;
+      bn[b] = m_ * g * rx[b];
+      bx[b] = -m_ * w2 * rx[b];
+      bz[b] = -m_ * w2 * rz[b] + m_ * g;
+      if (b == 2) {                                  // ground contact at the tip of the last link
+        const T ex = 2.0 * rx[2], ez = 2.0 * rz[2];
+        const T tz = pz + ez;
+        const T tvx = vx - om[2] * ez, tvz = vz + om[2] * ex;
+        const T fn0 = (kc * sig) * mi_softplus(-tz * inv_sig);
+        const T fn = fn0 * (1.0 - dn * tvz);
+        const T ft = -mu * fn0 * tvx;
+        bn[2] = bn[2] - (ex * fn - ez * ft);
+        bx[2] = bx[2] - ft;
+        bz[2] = bz[2] - fn;
+      }
+      th_par = th; om_par = om[b]; sn_par = sn[b]; cs_par = cs[b];
+    }
+    // ---- pass 2 (leaves to root): eliminate joint b, shift what is left to the parent's axis
+#pragma unroll
+    for (int b = 2; b >= 0; --b) {
+      sv.D[b] = J[b]; sv.Ux[b] = hx[b]; sv.Uz[b] = hz[b];
+      sv.uu[b] = tau[b] - bn[b];
+      const T invD = mi_rcp(sv.D[b]);
+      const T exx = mxx[b] - sv.Ux[b] * sv.Ux[b] * invD;
+      const T exz = mxz[b] - sv.Ux[b] * sv.Uz[b] * invD;
+      const T ezz = mzz[b] - sv.Uz[b] * sv.Uz[b] * invD;
+      const T s_ = sv.uu[b] * invD;
+      const T fx = bx[b] + exx * sv.cbx[b] + exz * sv.cbz[b] + sv.Ux[b] * s_;
+      const T fz = bz[b] + exz * sv.cbx[b] + ezz * sv.cbz[b] + sv.Uz[b] * s_;
+      const T gx = -exx * sv.dz[b] + exz * sv.dx[b];
+      const T gz = -exz * sv.dz[b] + ezz * sv.dx[b];
+      const T dJ = -sv.dz[b] * gx + sv.dx[b] * gz;
+      const T dn_ = tau[b] - sv.dz[b] * fx + sv.dx[b] * fz;
+      if (b > 0) {
+        J[b - 1] = J[b - 1] + dJ; hx[b - 1] = hx[b - 1] + gx; hz[b - 1] = hz[b - 1] + gz;
+        mxx[b - 1] = mxx[b - 1] + exx; mxz[b - 1] = mxz[b - 1] + exz; mzz[b - 1] = mzz[b - 1] + ezz;
+        bn[b - 1] = bn[b - 1] + dn_; bx[b - 1] = bx[b - 1] + fx; bz[b - 1] = bz[b - 1] + fz;
+      } else {
+        agg.J = dJ; agg.hx = gx; agg.hz = gz; agg.mxx = exx; agg.mxz = exz; agg.mzz = ezz;
+        agg.bn = dn_; agg.bx = fx; agg.bz = fz;
+      }
+    }
+  }
+  // Floating base: I_A a = -p_A (3x3 symmetric, LDL^T in the order x, z, pitch).
+  template <class T>
+  __device__ static inline void base_solve(const Agg<T>& t, T& ax, T& az, T& alpha) {
+    const T a11 = t.mxx, a12 = t.mxz, a13 = t.hx, a22 = t.mzz, a23 = t.hz, a33 = t.J;
+    const T r1 = -t.bx, r2 = -t.bz, r3 = -t.bn;
+    const T i11 = mi_rcp(a11);
+    const T l21 = a12 * i11, l31 = a13 * i11;
+    const T d2 = a22 - l21 * a12, e23 = a23 - l21 * a13;
+    const T i22 = mi_rcp(d2);
+    const T l32 = e23 * i22;
+    const T d3 = a33 - l31 * a13 - l32 * e23;
+    const T y2 = r2 - l21 * r1;
+    const T y3 = r3 - l31 * r1 - l32 * y2;
+    alpha = y3 * mi_rcp(d3);
+    az = (y2 - e23 * alpha) * i22;
+    ax = (r1 - a12 * az - a13 * alpha) * i11;
+  }
+  // Root-to-leaves pass of one chain: joint accelerations from the base acceleration.
+  template <class T>
+  __device__ static inline void chain_down(const Saved<T>& sv, T alpha, T ax, T az, T (&qdd)[3]) {
+    T al = alpha, acx = ax, acz = az;
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      const T apx = acx - al * sv.dz[b] + sv.cbx[b];
+      const T apz = acz + al * sv.dx[b] + sv.cbz[b];
+      const T qi = (sv.uu[b] - (sv.D[b] * al + sv.Ux[b] * apx + sv.Uz[b] * apz)) * mi_rcp(sv.D[b]);
+      qdd[b] = qi;
+      al = al + qi; acx = apx; acz = apz;
+    }
+  }
+  // All 18 generalized accelerations on one thread.  The chains' up-passes are run twice (once for the trunk's
+  // aggregate, once more right before their down-pass) instead of keeping 5 x 24 saved values alive.
+  template <class T, class XA, class UA>
+  __device__ static inline void accel(const XA& x, const UA& u, const double* p, T (&qdd)[nq]) {
+    Trunk<T> tr;
+    trunk_state<T>(x, tr);
+    Agg<T> tot;
+    trunk_agg<T>(p, tot);
+    for (int c = 0; c < kChains; ++c) {
+      Agg<T> a; Saved<T> sv;
+      chain_up<T>(c, tr, x, u, p, a, sv);
+      agg_add(tot, a);
+    }
+    T ax, az, alpha;
+    base_solve<T>(tot, ax, az, alpha);
+    qdd[0] = ax; qdd[1] = az; qdd[2] = alpha;
+    for (int c = 0; c < kChains; ++c) {
+      Agg<T> a; Saved<T> sv;
+      chain_up<T>(c, tr, x, u, p, a, sv);
+      T q3[3];
+      chain_down<T>(sv, alpha, ax, az, q3);
+      qdd[3 + 3 * c] = q3[0]; qdd[4 + 3 * c] = q3[1]; qdd[5 + 3 * c] = q3[2];
+    }
+  }
+  // semi-implicit Euler: v+ = v + dt a(q, v, u); q+ = q + dt v+
+  template <class T, class XA, class UA>
+  __device__ static inline void step_acc(const XA& x, const UA& u, T* xn, const double* p, double dt) {
+    T qdd[nq];
+    accel<T>(x, u, p, qdd);
+    for (int i = 0; i < nq; ++i) {
+      const T vn = x[nq + i] + dt * qdd[i];
+      xn[nq + i] = vn;
+      xn[i] = x[i] + dt * vn;
+    }
+  }
+  template <class T>
+  __device__ static inline void step(const T* x, const T* u, T* xn, const double* p, double dt) { step_acc<T>(x, u, xn, p, dt); }
+  __device__ static inline bool infeasible_velocity(double vn, const double* p) { return !(fabs(vn) <= p[8]); }
+};
+
 }  // namespace mi

@@ -8,17 +8,18 @@ import numpy as np
 
 from . import _capi
 
-PENDULUM, ACROBOT, CARTPOLE, CARTPOLE_WALL, SYNTH36 = 0, 1, 2, 3, 4
-_DIMS = {PENDULUM: (2, 1), ACROBOT: (4, 1), CARTPOLE: (4, 1), CARTPOLE_WALL: (4, 1), SYNTH36: (36, 12)}
+PENDULUM, ACROBOT, CARTPOLE, CARTPOLE_WALL, SYNTH36, PLANAR_QUAD = 0, 1, 2, 3, 4, 5
+_DIMS = {PENDULUM: (2, 1), ACROBOT: (4, 1), CARTPOLE: (4, 1), CARTPOLE_WALL: (4, 1), SYNTH36: (36, 12), PLANAR_QUAD: (36, 12)}
 _DEFAULTS = {
     PENDULUM: [0.25, 0.1, 4.905],
     ACROBOT: [1.0, 1.0, 1.0, 0.5, 1.0, 0.083, 0.33, 0.1, 0.1, 9.81],
     CARTPOLE: [10.0, 1.0, 0.5, 9.81],
     CARTPOLE_WALL: [10.0, 1.0, 0.5, 9.81, -0.45, 0.05, 2000.0, 0.01],
     SYNTH36: [4.0, 0.5, 6.0, 0.1],
+    PLANAR_QUAD: [9.81, 4000.0, 0.004, 0.3, 0.15, 0.05, 0.02, 2.0, 60.0],
 }
 _NAMES = {"pendulum": PENDULUM, "acrobot": ACROBOT, "cart_pole": CARTPOLE,
-          "cart_pole_with_wall": CARTPOLE_WALL, "synth36": SYNTH36}
+          "cart_pole_with_wall": CARTPOLE_WALL, "synth36": SYNTH36, "planar_quadruped": PLANAR_QUAD}
 
 
 class _InputPort:
@@ -83,3 +84,8 @@ def CartPoleWithWall(dt=1e-2, **kw):
 
 def Synth36(dt=4e-3, **kw):
     return ModelSystem(SYNTH36, dt, **kw)
+
+
+def PlanarQuadruped(dt=4e-3, **kw):
+    """Planar floating-base quadruped with ground contact; the one model that can declare a step infeasible."""
+    return ModelSystem(PLANAR_QUAD, dt, **kw)

@@ -8,7 +8,7 @@ Pure NumPy, importable without a GPU.
 """
 import numpy as np
 
-PENDULUM, ACROBOT, CARTPOLE, CARTPOLE_WALL, SYNTH36 = 0, 1, 2, 3, 4
+PENDULUM, ACROBOT, CARTPOLE, CARTPOLE_WALL, SYNTH36, PLANAR_QUAD = 0, 1, 2, 3, 4, 5
 SYNTH_TARGET_VEL = 1.0
 
 
@@ -99,6 +99,54 @@ def synth36_batch_x0(B, seed=3):
 def synth36_u_guess(N):
     """Constant initial tape (the 'u_stand' analogue of mini_cheetah.py:47-49,177)."""
     return np.full((12, N - 1), 0.05)
+
+
+
+
+# ---- planar quadruped: articulated body + ground contact (csrc/models.hpp: PlanarQuad), n=36 m=12
+QUAD_TARGET_VEL = 0.5
+_QUAD_LEG = np.array([0.6, -1.2, 0.6])         # hip, knee, ankle
+_QUAD_TAIL = np.array([-1.2, -0.2, -0.2])
+_QUAD_U_STAND = np.array([0.1743, 1.7505, -0.0176, 0.1743, 1.7505, -0.0176, 0.2331, 1.7024, -0.0176, 0.2331, 1.7024, -0.0176])
+
+
+def planar_quad_stand():
+    """Standing state (feet 4.5 mm into the compliant ground), zero velocity."""
+    x = np.zeros(36)
+    x[1] = 0.20 * np.cos(0.6) + 0.18 * np.cos(0.6) + 0.14 - 0.0045
+    x[3:15] = np.tile(_QUAD_LEG, 4)
+    x[15:18] = _QUAD_TAIL
+    return x
+
+
+def planar_quad_problem(N=40):
+    """C5's shape on a physically meaningful model: weights patterned on /root/reference/mini_cheetah.py:60-69,
+    passed as dt*Q, dt*R, Qf (:172-173); forward-velocity target (:55-57); dt=4e-3, beta=.5, delta=1e-2."""
+    dt = 4e-3
+    qb, vb = np.array([1.0, 1.0, 3.0]), np.ones(3)
+    qj, vj = np.zeros(15), 0.01 * np.ones(15)
+    Q = np.diag(np.hstack([qb, qj, 0.01 * vb, vj]))
+    R = 0.01 * np.eye(12)
+    Qf = np.diag(np.hstack([5 * qb, 0.1 + qj, vb, vj]))
+    x_nom = planar_quad_stand()
+    x_nom[0] = QUAD_TARGET_VEL * N * dt
+    x_nom[18] = QUAD_TARGET_VEL
+    return dict(name="planar_quadruped", model_id=PLANAR_QUAD, dt=dt, N=N, x_nom=x_nom,
+                Q=dt * Q, R=dt * R, Qf=Qf, delta=1e-2, beta=0.5, gamma=0.0)
+
+
+def planar_quad_batch_x0(B, seed=4):
+    rng = np.random.default_rng(seed)
+    x0 = np.tile(planar_quad_stand(), (B, 1))
+    x0[:, 1] += rng.uniform(0.0, 0.01, B)
+    x0[:, 2] += rng.uniform(-0.03, 0.03, B)
+    x0[:, 3:18] += rng.uniform(-0.05, 0.05, (B, 15))
+    return x0
+
+
+def planar_quad_u_guess(N):
+    """Constant standing torques (the 'u_stand' of mini_cheetah.py:47-49,177)."""
+    return np.repeat(_QUAD_U_STAND[:, None], N - 1, axis=1)
 
 
 def mpc_shift(x, u, replan):

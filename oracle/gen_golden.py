@@ -218,6 +218,22 @@ def main():
         move_target=(0, P.SYNTH_TARGET_VEL * c5["dt"] * 4))
     stage_level("synth36_stage", c5, sx0[0], ug, n_iters=2)
 
+    # (f)4: the planar quadruped (articulated-body dynamics + ground contact), C5's shape on a physical model.
+    # quad_infeasible_*: |v| bound tightened to 27.5 so that line-search trials are declared INFEASIBLE by the
+    # model (RuntimeError out of the Drake-shaped update, caught at ilqr.py:315-323: L = inf) and the accepted
+    # step sizes differ from the unconstrained run's.
+    cq = P.planar_quad_problem()
+    qx0 = P.planar_quad_batch_x0(8)
+    qug = P.planar_quad_u_guess(cq["N"])
+    stage_level("quad_stage", cq, qx0[0], qug, n_iters=2)
+    single_solve("quad_solve_0", cq, qx0[0], qug)
+    mpc("quad_mpc_0", cq, qx0[1], qug, resolves=2, replan=4, move_target=(0, P.QUAD_TARGET_VEL * cq["dt"] * 4))
+    tight = np.array(M.DEFAULT_PARAMS[M.PLANAR_QUAD], float)
+    tight[8] = 27.5
+    cqt = dict(cq, params=tight)
+    for k, i in enumerate((6, 7)):
+        single_solve(f"quad_infeasible_{k}", cqt, qx0[i], qug)
+
 
 if __name__ == "__main__":
     main()

@@ -35,6 +35,118 @@ typedef struct {
 /* ---- models: same formulas / operation order as oracle/models_np.py ---- */
 static double softplus(double z) { return z > 0.0 ? z + log1p(exp(-z)) : log1p(exp(z)); }
 
+/* ---- PLANAR_QUAD (model 5): planar floating-base quadruped, articulated-body algorithm in world-aligned planar
+ * coordinates - the same formulas, body table and operation order as oracle/models_np.py:quad_accel ---- */
+#define QNB 16
+static const int q_parent[QNB] = {-1, 0, 1, 2, 0, 4, 5, 0, 7, 8, 0, 10, 11, 0, 13, 14};
+static const double q_len[QNB] = {0.0, 0.20, 0.18, 0.14, 0.20, 0.18, 0.14, 0.20, 0.18, 0.14, 0.20, 0.18, 0.14, 0.12, 0.12, 0.12};
+static const double q_mass[QNB] = {4.0, 0.60, 0.40, 0.30, 0.60, 0.40, 0.30, 0.60, 0.40, 0.30, 0.60, 0.40, 0.30, 0.10, 0.10, 0.10};
+static const double q_atx[QNB] = {0, 0.19, 0, 0, 0.19, 0, 0, -0.19, 0, 0, -0.19, 0, 0, -0.25, 0, 0};
+static const double q_atz[QNB] = {0, 0.0, 0, 0, 0.0, 0, 0, 0.0, 0, 0, 0.0, 0, 0, 0.02, 0, 0};
+static const double q_tail_rest[3] = {-1.2, -0.2, -0.2};
+
+static void quad_accel(const double* x, const double* u, const double* p, double* qdd) {
+  const double g = p[0], kc = p[1], sig = p[2], dn = p[3], mu = p[4], b_leg = p[5], b_tail = p[6], k_tail = p[7];
+  const int nq = 18;
+  const double *q = x, *v = x + nq;
+  double th[QNB], om[QNB], px[QNB], pz[QNB], vx[QNB], vz[QNB], sn[QNB], cs[QNB], rx[QNB], rz[QNB];
+  double dx[QNB], dz[QNB], cbx[QNB], cbz[QNB], tau[QNB], inert[QNB];
+  double J[QNB], hx[QNB], hz[QNB], mxx[QNB], mxz[QNB], mzz[QNB], bn[QNB], bx[QNB], bz[QNB];
+  double Dj[QNB], Ux[QNB], Uz[QNB], uu[QNB], al[QNB], acx[QNB], acz[QNB];
+  inert[0] = 0.06;
+  for (int i = 1; i < QNB; ++i) inert[i] = q_mass[i] * q_len[i] * q_len[i] / 12;
+  th[0] = q[2]; om[0] = v[2]; px[0] = q[0]; pz[0] = q[1]; vx[0] = v[0]; vz[0] = v[1];
+  sn[0] = sin(th[0]); cs[0] = cos(th[0]); rx[0] = 0.0; rz[0] = 0.0;
+  dx[0] = dz[0] = cbx[0] = cbz[0] = tau[0] = 0.0;
+  for (int i = 1; i < QNB; ++i) {
+    const int par = q_parent[i];
+    if (par != 0) { const double lp = q_len[par]; dx[i] = lp * sn[par]; dz[i] = -lp * cs[par]; }
+    else { dx[i] = cs[0] * q_atx[i] - sn[0] * q_atz[i]; dz[i] = sn[0] * q_atx[i] + cs[0] * q_atz[i]; }
+    th[i] = th[par] + q[2 + i];
+    om[i] = om[par] + v[2 + i];
+    sn[i] = sin(th[i]); cs[i] = cos(th[i]);
+    px[i] = px[par] + dx[i]; pz[i] = pz[par] + dz[i];
+    vx[i] = vx[par] - om[par] * dz[i]; vz[i] = vz[par] + om[par] * dx[i];
+    const double hl = 0.5 * q_len[i];
+    rx[i] = hl * sn[i]; rz[i] = -hl * cs[i];
+    const double w2 = om[par] * om[par];
+    cbx[i] = -w2 * dx[i]; cbz[i] = -w2 * dz[i];
+  }
+  for (int i = 1; i < 13; ++i) tau[i] = u[i - 1] - b_leg * v[2 + i];
+  for (int k = 0; k < 3; ++k) { const int i = 13 + k; tau[i] = -b_tail * v[2 + i] - k_tail * (q[2 + i] - q_tail_rest[k]); }
+  for (int i = 0; i < QNB; ++i) {
+    const double m_ = q_mass[i], w2 = om[i] * om[i];
+    J[i] = inert[i] + m_ * (rx[i] * rx[i] + rz[i] * rz[i]);
+    hx[i] = -m_ * rz[i]; hz[i] = m_ * rx[i];
+    mxx[i] = m_; mxz[i] = 0.0; mzz[i] = m_;
+    bn[i] = m_ * g * rx[i];
+    bx[i] = -m_ * w2 * rx[i];
+    bz[i] = -m_ * w2 * rz[i] + m_ * g;
+  }
+  static const int tips[5] = {3, 6, 9, 12, 15};
+  for (int c = 0; c < 5; ++c) {
+    const int i = tips[c];
+    const double ex = 2.0 * rx[i], ez = 2.0 * rz[i];
+    const double tz = pz[i] + ez;
+    const double tvx = vx[i] - om[i] * ez, tvz = vz[i] + om[i] * ex;
+    const double fn0 = kc * sig * softplus(-tz / sig);
+    const double fn = fn0 * (1.0 - dn * tvz);
+    const double ft = -mu * fn0 * tvx;
+    bn[i] = bn[i] - (ex * fn - ez * ft);
+    bx[i] = bx[i] - ft;
+    bz[i] = bz[i] - fn;
+  }
+  for (int i = QNB - 1; i >= 1; --i) {
+    const int par = q_parent[i];
+    Dj[i] = J[i]; Ux[i] = hx[i]; Uz[i] = hz[i];
+    uu[i] = tau[i] - bn[i];
+    const double invD = 1.0 / Dj[i];
+    const double exx = mxx[i] - Ux[i] * Ux[i] * invD;
+    const double exz = mxz[i] - Ux[i] * Uz[i] * invD;
+    const double ezz = mzz[i] - Uz[i] * Uz[i] * invD;
+    const double s_ = uu[i] * invD;
+    const double fx = bx[i] + exx * cbx[i] + exz * cbz[i] + Ux[i] * s_;
+    const double fz = bz[i] + exz * cbx[i] + ezz * cbz[i] + Uz[i] * s_;
+    const double gx = -exx * dz[i] + exz * dx[i];
+    const double gz = -exz * dz[i] + ezz * dx[i];
+    J[par] = J[par] + (-dz[i] * gx + dx[i] * gz);
+    hx[par] = hx[par] + gx; hz[par] = hz[par] + gz;
+    mxx[par] = mxx[par] + exx; mxz[par] = mxz[par] + exz; mzz[par] = mzz[par] + ezz;
+    bn[par] = bn[par] + tau[i] - dz[i] * fx + dx[i] * fz;
+    bx[par] = bx[par] + fx; bz[par] = bz[par] + fz;
+  }
+  {
+    const double a11 = mxx[0], a12 = mxz[0], a13 = hx[0], a22 = mzz[0], a23 = hz[0], a33 = J[0];
+    const double r1 = -bx[0], r2 = -bz[0], r3 = -bn[0];
+    const double l21 = a12 / a11, l31 = a13 / a11;
+    const double d2 = a22 - l21 * a12, e23 = a23 - l21 * a13;
+    const double l32 = e23 / d2;
+    const double d3 = a33 - l31 * a13 - l32 * e23;
+    const double y2 = r2 - l21 * r1;
+    const double y3 = r3 - l31 * r1 - l32 * y2;
+    const double alpha = y3 / d3;
+    const double az = (y2 - e23 * alpha) / d2;
+    const double ax = (r1 - a12 * az - a13 * alpha) / a11;
+    al[0] = alpha; acx[0] = ax; acz[0] = az;
+    qdd[0] = ax; qdd[1] = az; qdd[2] = alpha;
+  }
+  for (int i = 1; i < QNB; ++i) {
+    const int par = q_parent[i];
+    const double apx = acx[par] - al[par] * dz[i] + cbx[i];
+    const double apz = acz[par] + al[par] * dx[i] + cbz[i];
+    const double qi = (uu[i] - (Dj[i] * al[par] + Ux[i] * apx + Uz[i] * apz)) / Dj[i];
+    qdd[2 + i] = qi;
+    al[i] = al[par] + qi; acx[i] = apx; acz[i] = apz;
+  }
+}
+
+/* A model may declare a step infeasible (Drake's discrete update throwing, caught at ilqr.py:315-323). */
+static int step_infeasible(const oracle_cfg* c, const double* xn) {
+  if (c->model_id != 5) return 0;
+  for (int i = 18; i < 36; ++i) if (!(fabs(xn[i]) <= c->params[8])) return 1;
+  return 0;
+}
+
 static void step(const oracle_cfg* c, const double* x, const double* u, double* xn) {
   const double* p = c->params;
   const double dt = c->dt;
@@ -77,6 +189,12 @@ static void step(const oracle_cfg* c, const double* x, const double* u, double* 
       xn[0] = px + dt * vxn; xn[1] = th + dt * wn; xn[2] = vxn; xn[3] = wn;
       break;
     }
+    case 5: { /* planar quadruped */
+      double qdd[18];
+      quad_accel(x, u, p, qdd);
+      for (int i = 0; i < 18; ++i) { const double vn = x[18 + i] + dt * qdd[i]; xn[18 + i] = vn; xn[i] = x[i] + dt * vn; }
+      break;
+    }
     default: { /* synth36 */
       const double ks = p[0], cd = p[1], kc = p[2], bu = p[3];
       const int nq = 18;
@@ -117,6 +235,12 @@ static double rollout(const oracle_cfg* c, const double* Q, const double* R, con
       U(w->u, k, t) = ut[k];
     }
     step(c, xt, ut, xn);                                              /* :316 */
+    if (step_infeasible(c, xn)) {                                     /* :317-323: L = inf, stop simulating ... */
+      double qT = 0.0;                                                /* ... the terminal term is still added, at x[:,-1] = 0 (:327) */
+      for (int i = 0; i < n; ++i) { double s = 0.0; for (int j = 0; j < n; ++j) s += Qf[i * n + j] * (0.0 - xnom[j]); qT += (0.0 - xnom[i]) * s; }
+      *expected = ex;
+      return INFINITY + qT;
+    }
     double q = 0.0, r = 0.0;
     for (int i = 0; i < n; ++i) { double s = 0.0; for (int j = 0; j < n; ++j) s += Q[i * n + j] * (xt[j] - xnom[j]); q += (xt[i] - xnom[i]) * s; }
     for (int i = 0; i < m; ++i) { double s = 0.0; for (int j = 0; j < m; ++j) s += R[i * m + j] * ut[j]; r += ut[i] * s; }

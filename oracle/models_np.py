@@ -18,18 +18,22 @@ Model ids / parameter vectors (must match include/mi_ilqr.h and models.hpp):
   2 CARTPOLE       n=4  m=1   [mc, mp, l, g]
   3 CARTPOLE_WALL  n=4  m=1   [mc, mp, l, g, wall_face_x, ball_radius, k, sigma]
   4 SYNTH36        n=36 m=12  [ks, c, kc, bu]
+  5 PLANAR_QUAD    n=36 m=12  [g, k, sigma, dn, mu, b_leg, b_tail, k_tail, v_max]   (articulated, contact, can FAIL)
+
+A model may declare a step INFEASIBLE (the analogue of Drake's discrete update throwing): ``Model.step``
+then raises RuntimeError, which the reference's line search catches (ilqr.py:315-323).
 """
 import numpy as np
 
 from . import dual as D
 
-PENDULUM, ACROBOT, CARTPOLE, CARTPOLE_WALL, SYNTH36 = 0, 1, 2, 3, 4
+PENDULUM, ACROBOT, CARTPOLE, CARTPOLE_WALL, SYNTH36, PLANAR_QUAD = 0, 1, 2, 3, 4, 5
 
 MODEL_DIMS = {PENDULUM: (2, 1), ACROBOT: (4, 1), CARTPOLE: (4, 1),
-              CARTPOLE_WALL: (4, 1), SYNTH36: (36, 12)}
+              CARTPOLE_WALL: (4, 1), SYNTH36: (36, 12), PLANAR_QUAD: (36, 12)}
 
 MODEL_NAMES = {PENDULUM: "pendulum", ACROBOT: "acrobot", CARTPOLE: "cart_pole",
-               CARTPOLE_WALL: "cart_pole_with_wall", SYNTH36: "synth36"}
+               CARTPOLE_WALL: "cart_pole_with_wall", SYNTH36: "synth36", PLANAR_QUAD: "planar_quadruped"}
 
 DEFAULT_PARAMS = {
     # m=1, l=0.5, b=0.1, g=9.81 (the shape of pendulum.py's plant; SURVEY.md §8c anchor)
@@ -42,6 +46,9 @@ DEFAULT_PARAMS = {
     # hydroelastics: F = k*sigma*softplus(-phi/sigma)
     CARTPOLE_WALL: [10.0, 1.0, 0.5, 9.81, -0.45, 0.05, 2000.0, 0.01],
     SYNTH36: [4.0, 0.5, 6.0, 0.1],
+    # gravity; ground penalty k*sigma*softplus(-z/sigma) with normal damping dn and load-proportional viscous
+    # friction mu; joint damping of the legs / tail, tail spring; |v| bound beyond which a step is infeasible
+    PLANAR_QUAD: [9.81, 4000.0, 0.004, 0.3, 0.15, 0.05, 0.02, 2.0, 60.0],
 }
 
 
@@ -146,8 +153,180 @@ def synth36_step(x, u, p, dt):
     return out_q + out_v
 
 
+# ----------------------------------------------------------------------------------------------------
+# PLANAR_QUAD: a planar floating-base articulated body of the mini-cheetah's SHAPE (mini_cheetah.py:41-52:
+# 18 positions + 18 velocities, 12 actuators): trunk (x, z, pitch) + four 3-link legs (hip, knee, ankle:
+# the 12 actuated joints) + a passive 3-link tail, 16 bodies, compliant ground contact at the four feet and
+# the tail tip.  Accelerations come from the articulated-body algorithm (Featherstone) written in
+# world-aligned planar coordinates: a body's spatial quantities are (moment about / rotation at its joint
+# axis p_i, x, z), transforms between bodies are pure translations.  Build-owned like every model here.
+#   q = [x, z, pitch | leg0 hip,knee,ankle | leg1 | leg2 | leg3 | tail 1,2,3],  u -> the 12 leg joints.
+# ----------------------------------------------------------------------------------------------------
+QUAD_NQ = 18
+# body table: (parent, attach offset in the parent's frame (x, z), length, mass, inertia about the COM)
+_TH, _SH, _FT, _TL = (0.20, 0.60, 0.60 * 0.20 ** 2 / 12), (0.18, 0.40, 0.40 * 0.18 ** 2 / 12), \
+    (0.14, 0.30, 0.30 * 0.14 ** 2 / 12), (0.12, 0.10, 0.10 * 0.12 ** 2 / 12)
+QUAD_TRUNK = (4.0, 0.06)                       # mass, inertia
+QUAD_HIPS = [(0.19, 0.0), (0.19, 0.0), (-0.19, 0.0), (-0.19, 0.0)]
+QUAD_TAIL_AT = (-0.25, 0.02)
+QUAD_TAIL_REST = (-1.2, -0.2, -0.2)
+
+
+def quad_bodies():
+    """[(parent, (ax, az) or None = parent's tip, length, mass, Ic)] for bodies 1..15 (body 0 = trunk)."""
+    out = []
+    for leg in range(4):
+        base = 1 + 3 * leg
+        out.append((0, QUAD_HIPS[leg]) + _TH)
+        out.append((base, None) + _SH)
+        out.append((base + 1, None) + _FT)
+    out.append((0, QUAD_TAIL_AT) + _TL)
+    out.append((13, None) + _TL)
+    out.append((14, None) + _TL)
+    return out
+
+
+def quad_accel(x, u, p):
+    """Generalized accelerations (18) of the planar quadruped, float-or-Dual."""
+    g, kc, sig, dn, mu, b_leg, b_tail, k_tail = p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]
+    nq = QUAD_NQ
+    q, v = x[:nq], x[nq:]
+    bodies = quad_bodies()
+    nb = 16
+    th = [None] * nb; om = [None] * nb; px = [None] * nb; pz = [None] * nb; vx = [None] * nb; vz = [None] * nb
+    sn = [None] * nb; cs = [None] * nb; rx = [None] * nb; rz = [None] * nb
+    dx = [None] * nb; dz = [None] * nb; cbx = [None] * nb; cbz = [None] * nb
+    mass = [QUAD_TRUNK[0]] + [b[3] for b in bodies]
+    inert = [QUAD_TRUNK[1]] + [b[4] for b in bodies]
+    length = [0.0] + [b[2] for b in bodies]
+    th[0], om[0], px[0], pz[0], vx[0], vz[0] = q[2], v[2], q[0], q[1], v[0], v[1]
+    sn[0], cs[0] = D.sin(th[0]), D.cos(th[0])
+    rx[0], rz[0] = 0.0, 0.0
+    # ---- pass 1: kinematics (joint axis positions / velocities, COM offsets, velocity-product accelerations)
+    for i in range(1, nb):
+        par, at = bodies[i - 1][0], bodies[i - 1][1]
+        if at is None:                                   # at the parent's tip: (0, -l_par) in its frame
+            lp = length[par]
+            dx[i], dz[i] = lp * sn[par], -lp * cs[par]
+        else:
+            dx[i] = cs[par] * at[0] - sn[par] * at[1]
+            dz[i] = sn[par] * at[0] + cs[par] * at[1]
+        th[i] = th[par] + q[2 + i]
+        om[i] = om[par] + v[2 + i]
+        sn[i], cs[i] = D.sin(th[i]), D.cos(th[i])
+        px[i], pz[i] = px[par] + dx[i], pz[par] + dz[i]
+        vx[i], vz[i] = vx[par] - om[par] * dz[i], vz[par] + om[par] * dx[i]
+        hl = 0.5 * length[i]
+        rx[i], rz[i] = hl * sn[i], -hl * cs[i]
+        w2 = om[par] * om[par]
+        cbx[i], cbz[i] = -w2 * dx[i], -w2 * dz[i]
+    # ---- joint torques: actuation, damping, tail spring
+    tau = [None] * nb
+    for i in range(1, 13):
+        tau[i] = u[i - 1] - b_leg * v[2 + i]
+    for k in range(3):
+        i = 13 + k
+        tau[i] = -b_tail * v[2 + i] - k_tail * (q[2 + i] - QUAD_TAIL_REST[k])
+    # ---- articulated inertias (symmetric 3x3: [J, hx, hz; hx, mxx, mxz; hz, mxz, mzz]) and bias forces about p_i
+    J = [None] * nb; hx = [None] * nb; hz = [None] * nb; mxx = [None] * nb; mxz = [None] * nb; mzz = [None] * nb
+    bn = [None] * nb; bx = [None] * nb; bz = [None] * nb
+    for i in range(nb):
+        m_, w2 = mass[i], om[i] * om[i]
+        J[i] = inert[i] + m_ * (rx[i] * rx[i] + rz[i] * rz[i])
+        hx[i], hz[i] = -m_ * rz[i], m_ * rx[i]
+        mxx[i], mxz[i], mzz[i] = m_, 0.0, m_
+        # centripetal term of the COM minus gravity (force (0, -m g) at the COM)
+        bn[i] = m_ * g * rx[i]
+        bx[i] = -m_ * w2 * rx[i]
+        bz[i] = -m_ * w2 * rz[i] + m_ * g
+    # ---- ground contact at the feet (bodies 3, 6, 9, 12) and the tail tip (15)
+    for i in (3, 6, 9, 12, 15):
+        ex, ez = 2.0 * rx[i], 2.0 * rz[i]                 # tip relative to the joint axis
+        tz = pz[i] + ez
+        tvx, tvz = vx[i] - om[i] * ez, vz[i] + om[i] * ex
+        fn0 = kc * sig * D.softplus(-tz / sig)
+        fn = fn0 * (1.0 - dn * tvz)
+        ft = -mu * fn0 * tvx
+        bn[i] = bn[i] - (ex * fn - ez * ft)
+        bx[i] = bx[i] - ft
+        bz[i] = bz[i] - fn
+    # ---- pass 2: leaves to root
+    Dj = [None] * nb; Ux = [None] * nb; Uz = [None] * nb; uu = [None] * nb
+    for i in range(nb - 1, 0, -1):
+        par = bodies[i - 1][0]
+        Dj[i] = J[i]
+        Ux[i], Uz[i] = hx[i], hz[i]
+        uu[i] = tau[i] - bn[i]
+        invD = 1.0 / Dj[i]
+        # articulated inertia seen through the joint: only the translational block survives
+        exx = mxx[i] - Ux[i] * Ux[i] * invD
+        exz = mxz[i] - Ux[i] * Uz[i] * invD
+        ezz = mzz[i] - Uz[i] * Uz[i] * invD
+        s_ = uu[i] * invD
+        fx = bx[i] + exx * cbx[i] + exz * cbz[i] + Ux[i] * s_
+        fz = bz[i] + exz * cbx[i] + ezz * cbz[i] + Uz[i] * s_
+        # shift to the parent's axis: G = [perp(d) | I], perp(d) = (-dz, dx)
+        gx = -exx * dz[i] + exz * dx[i]                  # E perp(d)
+        gz = -exz * dz[i] + ezz * dx[i]
+        J[par] = J[par] + (-dz[i] * gx + dx[i] * gz)
+        hx[par] = hx[par] + gx
+        hz[par] = hz[par] + gz
+        mxx[par] = mxx[par] + exx
+        mxz[par] = mxz[par] + exz
+        mzz[par] = mzz[par] + ezz
+        bn[par] = bn[par] + tau[i] - dz[i] * fx + dx[i] * fz
+        bx[par] = bx[par] + fx
+        bz[par] = bz[par] + fz
+    # ---- floating base: I_A a = -p_A  (3x3 symmetric, eliminated in the order x, z, pitch... by Cramer-free LDL^T)
+    a11, a12, a13, a22, a23, a33 = mxx[0], mxz[0], hx[0], mzz[0], hz[0], J[0]      # unknowns (ax, az, alpha)
+    r1, r2, r3 = -bx[0], -bz[0], -bn[0]
+    l21 = a12 / a11
+    l31 = a13 / a11
+    d2 = a22 - l21 * a12
+    e23 = a23 - l21 * a13
+    l32 = e23 / d2
+    d3 = a33 - l31 * a13 - l32 * e23
+    y2 = r2 - l21 * r1
+    y3 = r3 - l31 * r1 - l32 * y2
+    alpha = y3 / d3
+    az = (y2 - e23 * alpha) / d2
+    ax = (r1 - a12 * az - a13 * alpha) / a11
+    # ---- pass 3: root to leaves
+    al = [None] * nb; acx = [None] * nb; acz = [None] * nb; qdd = [None] * nq
+    al[0], acx[0], acz[0] = alpha, ax, az
+    qdd[0], qdd[1], qdd[2] = ax, az, alpha
+    for i in range(1, nb):
+        par = bodies[i - 1][0]
+        apx = acx[par] - al[par] * dz[i] + cbx[i]
+        apz = acz[par] + al[par] * dx[i] + cbz[i]
+        qi = (uu[i] - (Dj[i] * al[par] + Ux[i] * apx + Uz[i] * apz)) / Dj[i]
+        qdd[2 + i] = qi
+        al[i], acx[i], acz[i] = al[par] + qi, apx, apz
+    return qdd
+
+
+def planar_quad_step(x, u, p, dt):
+    nq = QUAD_NQ
+    qdd = quad_accel(x, u, p)
+    vn = [x[nq + i] + dt * qdd[i] for i in range(nq)]
+    qn = [x[i] + dt * vn[i] for i in range(nq)]
+    return qn + vn
+
+
+def planar_quad_infeasible(xn, p):
+    """The step is declared infeasible (Drake's update would throw: ilqr.py:315-323) when a velocity leaves
+    [-v_max, v_max] or is not finite - the regime where the penalty contact model means nothing."""
+    vmax = p[8]
+    for i in range(QUAD_NQ, 2 * QUAD_NQ):
+        val = xn[i].v if isinstance(xn[i], D.Dual) else xn[i]
+        if not (abs(val) <= vmax):
+            return True
+    return False
+
+
 STEP_FUNCS = {PENDULUM: pendulum_step, ACROBOT: acrobot_step, CARTPOLE: cartpole_step,
-              CARTPOLE_WALL: cartpole_wall_step, SYNTH36: synth36_step}
+              CARTPOLE_WALL: cartpole_wall_step, SYNTH36: synth36_step, PLANAR_QUAD: planar_quad_step}
+INFEASIBLE_FUNCS = {PLANAR_QUAD: planar_quad_infeasible}
 
 
 class Model:
@@ -160,14 +339,26 @@ class Model:
         self.params = np.array(DEFAULT_PARAMS[self.model_id] if params is None else params,
                                dtype=float)
         self._f = STEP_FUNCS[self.model_id]
+        self._bad = INFEASIBLE_FUNCS.get(self.model_id)
 
     def step(self, x, u):
-        """Next state for float inputs -> (n,) float array."""
+        """Next state for float inputs -> (n,) float array.  RuntimeError when the model declares the step
+        infeasible (the reference's line search catches it: ilqr.py:315-323)."""
+        xn = self._f(list(x), list(u), self.params, self.dt)
+        if self._bad is not None and self._bad(xn, self.params):
+            raise RuntimeError("infeasible simulation step")
+        return np.array(xn, dtype=float)
+
+    def step_unchecked(self, x, u):
+        """The formula alone (finite differences probe it on both sides of a feasibility boundary)."""
         return np.array(self._f(list(x), list(u), self.params, self.dt), dtype=float)
 
     def step_generic(self, x, u):
-        """Next state for float-or-Dual inputs -> list."""
-        return self._f(list(x), list(u), self.params, self.dt)
+        """Next state for float-or-Dual inputs -> list (the duck-typed Drake system's update)."""
+        xn = self._f(list(x), list(u), self.params, self.dt)
+        if self._bad is not None and self._bad(xn, self.params):
+            raise RuntimeError("infeasible simulation step")
+        return xn
 
     def jac_ad(self, x, u):
         """Exact (fx, fu) by forward-mode duals — AutoDiffXd analogue
@@ -192,5 +383,5 @@ class Model:
             else:
                 up[c - n] = u[c - n] + h
                 um[c - n] = u[c - n] - h
-            G[:, c] = (self.step(xp, up) - self.step(xm, um)) * inv2h
+            G[:, c] = (self.step_unchecked(xp, up) - self.step_unchecked(xm, um)) * inv2h
         return G[:, :n].copy(), G[:, n:].copy()

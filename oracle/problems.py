@@ -8,7 +8,7 @@ Model ids follow include/mi_ilqr.h / oracle/models_np.py.
 """
 import numpy as np
 
-PENDULUM, ACROBOT, CARTPOLE, CARTPOLE_WALL, SYNTH36 = range(5)
+PENDULUM, ACROBOT, CARTPOLE, CARTPOLE_WALL, SYNTH36, PLANAR_QUAD = range(6)
 SYNTH_TARGET_VEL = 1.0
 
 
@@ -100,3 +100,52 @@ def mpc_shift(x, u, replan):
     """acrobot.py:147-152 / mini_cheetah.py:193-198: drop `replan` controls, repeat the last, restart at x[:, replan]."""
     u_next = np.concatenate([u[..., replan:], np.repeat(u[..., -1:], replan, axis=-1)], axis=-1)
     return np.array(x[..., replan]), u_next
+
+
+# ---- planar quadruped (articulated body + ground contact, the model that can declare a step infeasible)
+QUAD_TARGET_VEL = 0.5
+QUAD_STANCE = (0.6, -1.2, 0.6)            # hip, knee, ankle of every leg
+QUAD_TAIL = (-1.2, -0.2, -0.2)
+QUAD_U_STAND = (0.1743, 1.7505, -0.0176, 0.1743, 1.7505, -0.0176, 0.2331, 1.7024, -0.0176, 0.2331, 1.7024, -0.0176)
+
+
+def planar_quad_stand():
+    """Standing state: feet 4.5 mm into the compliant ground (that carries the weight), zero velocity."""
+    q = np.zeros(18)
+    q[1] = 0.20 * np.cos(0.6) + 0.18 * np.cos(0.6) + 0.14 - 0.0045
+    q[3:15] = np.tile(QUAD_STANCE, 4)
+    q[15:18] = QUAD_TAIL
+    return np.concatenate([q, np.zeros(18)])
+
+
+def planar_quad_problem(N=40):
+    """Weights patterned on /root/reference/mini_cheetah.py:60-69 (base pose 1, orientation +2, legs 0, base
+    velocities 0.01, joint velocities 0.01; Qf = 5x / 0.1+ / 1x), passed as dt*Q, dt*R, Qf (:172-173); target =
+    the stance moving forward at QUAD_TARGET_VEL (:55-57); dt = 4e-3 (:23), beta = 0.5, delta = 1e-2 (:168-169)."""
+    dt = 4e-3
+    q_base = np.array([1.0, 1.0, 3.0])
+    v_base = np.ones(3)
+    q_jnt = np.zeros(15)
+    v_jnt = np.full(15, 0.01)
+    Q = np.diag(np.concatenate([q_base, q_jnt, 0.01 * v_base, v_jnt]))
+    R = 0.01 * np.eye(12)
+    Qf = np.diag(np.concatenate([5.0 * q_base, 0.1 + q_jnt, v_base, v_jnt]))
+    x_nom = planar_quad_stand()
+    x_nom[0] = QUAD_TARGET_VEL * N * dt
+    x_nom[18] = QUAD_TARGET_VEL
+    return _problem("planar_quadruped", PLANAR_QUAD, dt, N, x_nom, dt * Q, dt * R, Qf, 0.5)
+
+
+def planar_quad_batch_x0(B, seed=4):
+    """The stance with every joint angle and the trunk's height / pitch moved a little (rng seed 4)."""
+    rng = np.random.default_rng(seed)
+    x0 = np.tile(planar_quad_stand(), (B, 1))
+    x0[:, 1] += rng.uniform(0.0, 0.01, B)
+    x0[:, 2] += rng.uniform(-0.03, 0.03, B)
+    x0[:, 3:18] += rng.uniform(-0.05, 0.05, (B, 15))
+    return x0
+
+
+def planar_quad_u_guess(N):
+    """Constant standing torques (the u_stand of mini_cheetah.py:47-49,177)."""
+    return np.repeat(np.array(QUAD_U_STAND)[:, None], N - 1, axis=1)

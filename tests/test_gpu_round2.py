@@ -393,3 +393,107 @@ def test_native_rccl_collective_single_rank():
     assert c.allreduce_min([s.stats.best_cost])[0] == s.cost.min()
     c2 = NativeComm.from_torch(0)                                      # no process group: a one-rank communicator
     assert c2.world == 1 and c2.allreduce_min([2.0])[0] == 2.0
+
+
+# ----------------------------------------------------------------------------------
+# (f)4: planar quadruped - articulated-body dynamics + ground contact on the workgroup-per-problem kernels,
+# and the model that can declare a step infeasible (ilqr.py:315-323)
+# ----------------------------------------------------------------------------------
+@pytest.mark.parametrize("jac", ["ad", "fd"])
+def test_quad_stage_level(jac):
+    g, prob = load_golden("quad_stage")
+    s = make_solver(prob, jac=jac)
+    s.SetInitialState(g["x0"][None])
+    s.SetInitialGuess(g["pre_u_bar"])
+    s.set_state(x_bar=g["pre_x_bar"][None], K=g["pre_K"][None], kappa=g["pre_kappa"][None], dV_coeff=g["pre_dV"][None])
+    x, u, L, ex = s.stage_rollout(1.0)                       # cooperative step: one lane per chain of the tree
+    assert rel_err(x[0], g["roll_x"]) < 1e-10 and rel_err(u[0], g["roll_u"]) < 1e-10
+    assert abs(L[0] - g["roll_L"]) < 1e-10 * abs(g["roll_L"])
+    s.set_state(x_bar=x, u_bar=u)
+    s.stage_linearize()                                      # whole-tree evaluation per (step, column) item
+    tolj = 1e-10 if jac == "ad" else 1e-6                    # (contact curvature k/sigma^2 = 2.5e8: FD truncation ~1e-7 relative)
+    assert rel_err(s.fx[0], g["fx"]) < tolj and rel_err(s.fu[0], g["fu"]) < tolj
+    s.stage_backward()
+    tolk = 1e-7 if jac == "ad" else 1e-4                     # (Quu is ill-conditioned: cond ~1e5 on this model)
+    assert rel_err(s.K[0], g["post_K"]) < tolk
+    assert rel_err(s.kappa[0], g["post_kappa"]) < (1e-7 if jac == "ad" else 1e-3)
+    assert rel_err(s.dV_coeff[0], g["post_dV"]) < (1e-7 if jac == "ad" else 1e-3)
+
+
+@pytest.mark.parametrize("name", ["quad_solve_0", "quad_infeasible_0", "quad_infeasible_1"])
+def test_quad_solve_vs_reference_golden(name):
+    """Whole solves recorded from the unmodified reference.  quad_infeasible_*: line-search trials are declared
+    infeasible by the model (|v| bound 27.5), the reference turns them into L = inf and backs off - the
+    device must take exactly the same step sizes."""
+    g, prob = load_golden(name)
+    s = make_solver(prob, jac="ad", single=True, hist_cap=32)
+    s.SetInitialState(g["x0"])
+    s.SetInitialGuess(g["u_guess"])
+    x, u, _, L = s.Solve()
+    iters = int(s.iterations[0])
+    assert iters == len(g["hist"])
+    h = s.history[0][:iters]
+    assert np.array_equal(h[:, 1:3], g["hist"][:, 1:3])              # eps and trial count of every iteration
+    assert rel_err(h[:, 0], g["hist"][:, 0]) < 1e-8 and abs(L - g["L"]) < 1e-8 * abs(g["L"])
+    assert np.max(np.abs(x - g["x_bar"])) < 1e-7 and np.max(np.abs(u - g["u_bar"])) < 1e-6
+    # (Jacobians at the FINAL trajectory, which agrees to ~1e-8: the contact curvature k/sigma^2 = 2.5e8 turns
+    # that into ~1e-8 relative on fx)
+    assert rel_err(s.K, g["K"]) < 1e-5 and rel_err(s.fx, g["fx"]) < 1e-6
+
+
+def test_quad_batch_fd_vs_c_oracle_with_infeasible_trials():
+    """64 seeded quadruped problems, central differences, default and tightened velocity bound, against the C
+    oracle (pinned to the reference's quad goldens): iteration and line-search-trial counts of every problem,
+    costs, trajectories; with the tight bound the counts must differ from the free run for some problems
+    (the infeasibility rule is really exercised on the device)."""
+    from drake_ddp_amd import workloads as W
+    from oracle import c_oracle, models_np as M
+    prob = W.planar_quad_problem()
+    B = 64
+    x0, ug = W.planar_quad_batch_x0(B), W.planar_quad_u_guess(prob["N"])
+    res = {}
+    for tag, vmax in (("free", 60.0), ("tight", 27.5)):
+        par = np.array(M.DEFAULT_PARAMS[M.PLANAR_QUAD], float)
+        par[8] = vmax
+        p = dict(prob, params=par)
+        s = make_solver(p, B=B, jac="fd")
+        s.SetInitialState(x0)
+        s.SetInitialGuess(ug)
+        x, u, _, L = s.Solve()
+        r = c_oracle.solve_batch(M.Model(p["model_id"], p["dt"], par), p, x0, ug)
+        assert np.array_equal(s.status, r["status"])
+        ok = s.status == 0
+        same = ok & (s.iterations == r["iters"]) & (s.ls_trials == r["ls"])
+        assert ok.mean() > 0.9 and same[ok].mean() >= 0.95, (tag, ok.mean(), same.mean())
+        rel = np.abs(L - r["cost"]) / np.abs(r["cost"])
+        assert np.max(rel[same]) < 1e-6 and np.all(rel[ok & ~same] < 1e-2)
+        assert np.max(np.abs(x[same] - r["x_bar"][same])) < 1e-4
+        res[tag] = (s.iterations.copy(), s.ls_trials.copy())
+    assert (res["free"][1] != res["tight"][1]).any()
+
+
+@pytest.mark.parametrize("device_loop", [False, True])
+def test_quad_mpc_moving_target(device_loop):
+    from drake_ddp_amd.workloads import mpc_shift, planar_quad_u_guess
+    g, prob = load_golden("quad_mpc_0")
+    s = make_solver(prob, jac="ad")
+    N, replan, R = prob["N"], int(g["replan"]), len(g["Ls"]) - 1
+    s.SetInitialState(g["x0"][None])
+    s.SetInitialGuess(planar_quad_u_guess(N))
+    x, u, _, L = s.Solve()
+    assert s.iterations[0] == g["iters"][0] and abs(L[0] - g["Ls"][0]) < 1e-8 * abs(g["Ls"][0])
+    step = np.zeros(36)
+    step[int(g["move_target"][0])] = g["move_target"][1]
+    if device_loop:
+        s.MPCRun(R, replan, target_step=step)
+        log = s.mpc_log[0]
+        assert np.array_equal(log[:, -1].astype(int), g["iters"][1:]) and rel_err(log[:, -2], g["Ls"][1:]) < 1e-8
+    else:
+        x_nom = prob["x_nom"].copy()
+        for r in range(1, R + 1):
+            x_nom = x_nom + step
+            x0, ug = mpc_shift(x, u, replan)
+            s.SetInitialState(x0); s.SetInitialGuess(ug); s.SetTargetState(x_nom)
+            x, u, _, L = s.Solve()
+            assert s.iterations[0] == g["iters"][r] and abs(L[0] - g["Ls"][r]) < 1e-8 * abs(g["Ls"][r])
+    assert rel_err(s.x_bar[0], g["xs"][-1]) < 1e-7 and rel_err(s.K[0], g["Ks"][-1]) < 1e-5
