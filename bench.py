@@ -291,6 +291,11 @@ def all_configs(rk, dev_index):
     out.append(run_config(rk, dev_index, "C5 n=36 m=12 N=40 MPC: 1 + 100 re-solves x batch 64, moving target, device loop", q,
                           W.synth36_batch_x0(64), W.synth36_u_guess(q["N"]), reps=2,
                           mpc=(100, 4, (0, W.SYNTH_TARGET_VEL * q["dt"] * 4))))
+    pq = W.planar_quad_problem()
+    out.append(run_config(rk, dev_index, "C5q planar quadruped (articulated-body dynamics + ground contact) n=36 m=12 N=40 MPC: "
+                          "1 + 100 re-solves x batch 64, moving target, device loop", pq,
+                          W.planar_quad_batch_x0(64), W.planar_quad_u_guess(pq["N"]), reps=2,
+                          mpc=(100, 4, (0, W.QUAD_TARGET_VEL * pq["dt"] * 4))))
     if rk.world == 1:
         out.append(run_config(rk, dev_index, "C5 shard of an 8-GPU run: batch 8 on this GPU", q,
                               W.synth36_batch_x0(64)[:8], W.synth36_u_guess(q["N"]), reps=2,

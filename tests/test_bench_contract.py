@@ -65,7 +65,7 @@ def test_bench_line_carries_every_config_and_the_boundary():
     assert rf["bound"] == "hbm" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["kernel_ms"] > 0
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 0
     names = [c["name"][:2] for c in d["configs"]]
-    assert names[:4] == ["C1", "C3", "C4", "C5"]
+    assert names[:5] == ["C1", "C3", "C4", "C5", "C5"]
     for c in d["configs"]:
         assert c["iterations_per_s"] > 0 and c["ms_per_solve"] > 0 and c["kernel_ms_per_solve"] > 0 and 0 < c["hbm_frac"] < 1
         assert c["converged"] == c["batch"] or c["name"].startswith("C4")       # (C4: long contact solves may hit no cap, all converge too)

@@ -497,3 +497,25 @@ def test_quad_mpc_moving_target(device_loop):
             x, u, _, L = s.Solve()
             assert s.iterations[0] == g["iters"][r] and abs(L[0] - g["Ls"][r]) < 1e-8 * abs(g["Ls"][r])
     assert rel_err(s.x_bar[0], g["xs"][-1]) < 1e-7 and rel_err(s.K[0], g["Ks"][-1]) < 1e-5
+
+
+def test_quad_full_size_mpc_run_vs_oracle():
+    """The benchmarked planar-quadruped config: B=64, cold solve + MPCRun(100, 4, moving target) in one launch,
+    every problem and re-solve against the C oracle's receding-horizon loop."""
+    from drake_ddp_amd import workloads as W
+    from oracle import c_oracle, models_np as M
+    q = W.planar_quad_problem()
+    B = 64
+    x0, ug = W.planar_quad_batch_x0(B), W.planar_quad_u_guess(q["N"])
+    step = np.zeros(36)
+    step[0] = W.QUAD_TARGET_VEL * q["dt"] * 4
+    s = make_solver(q, B=B, jac="fd")
+    s.SetInitialState(x0)
+    s.SetInitialGuess(ug)
+    s.Solve()
+    first_it, first_L, ls0 = s.iterations.copy(), s.cost.copy(), s.ls_trials.copy()
+    st = s.MPCRun(100, 4, target_step=step)
+    r = c_oracle.mpc_batch(M.Model(q["model_id"], q["dt"]), q, x0, ug, 100, 4, target_step=step)
+    r["ls"] = r["ls"] - ls0
+    log = _check_mpc_against_oracle(s, r, first_it, first_L, 36, tol_L=1e-6, tol_x=1e-5)
+    assert st.n_converged == B and np.all(log[:, -1, 0] > 0.3)        # the trunk moved forward by 0.3 m or more
