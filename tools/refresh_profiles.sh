@@ -9,11 +9,17 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 REPO=$PWD
 python bench.py > $OUT/${TAG}_bench_c2.json 2> $OUT/${TAG}_bench_c2.err
-( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -- python $REPO/bench.py --no-cpu-baseline > $OUT/${TAG}_prof.log 2>&1 )
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -- python $REPO/bench.py --no-cpu-baseline --no-configs > $OUT/${TAG}_prof.log 2>&1 )
 for C in FETCH_SIZE WRITE_SIZE; do
   ( cd /tmp && MI_BENCH_NESTED=1 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_$C -- python $REPO/bench.py --no-cpu-baseline --steps 5 --warmup 1 > $OUT/${TAG}_pmc_$C.log 2>&1 )
 done
-python tools/run_configs.py > $OUT/${TAG}_all_configs.jsonl 2> $OUT/${TAG}_all_configs.err
+python - > $OUT/${TAG}_all_configs.jsonl <<PY
+import json
+d = json.loads(open("$OUT/${TAG}_bench_c2.json").read().strip().splitlines()[-1])
+for c in d["configs"]:
+    print(json.dumps(c))
+print(json.dumps({"boundary_inclusive": d["boundary_inclusive"]}))
+PY
 find $OUT/${TAG}_prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/${TAG}_bench_c2_kernel_stats.csv
 python - <<PY
 import csv, glob, json
