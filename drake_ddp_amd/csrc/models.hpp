@@ -158,7 +158,19 @@ struct PlanarQuad {
   __device__ static constexpr double atz(int c) { return c < 4 ? 0.0 : 0.02; }
   __device__ static constexpr double tail_rest(int b) { return b == 0 ? -1.2 : -0.2; }
   static constexpr double kTrunkMass = 4.0, kTrunkInertia = 0.06;
+  // which chain an input column of [x | u] belongs to (-1: the trunk's own coordinates - every chain reads them)
+  __device__ static constexpr int chain_of_input(int col) {
+    return col < 3 ? -1 : (col < nq ? (col - 3) / 3 : (col < nq + 3 ? -1 : (col < n ? (col - nq - 3) / 3 : (col - n) / 3)));
+  }
 
+  // the n + m input columns ordered by owner: legs 0..3 (3 angles, 3 velocities, 3 torques each), the tail
+  // (3 angles, 3 velocities), the trunk (x, z, pitch and their velocities)
+  __device__ static constexpr int input_by_owner(int rank) {
+    if (rank < 36) { const int c = rank / 9, r = rank - 9 * c; return r < 3 ? 3 + 3 * c + r : (r < 6 ? nq + 3 + 3 * c + (r - 3) : n + 3 * c + (r - 6)); }
+    if (rank < 42) { const int r = rank - 36; return r < 3 ? 15 + r : nq + 15 + (r - 3); }
+    const int r = rank - 42;
+    return r < 3 ? r : nq + (r - 3);
+  }
   template <class T, class XA>
   __device__ static inline void trunk_state(const XA& x, Trunk<T>& tr) {
     const T th = x[2];
