@@ -1228,6 +1228,8 @@ __global__ void __launch_bounds__(kLargeThreads) ilqr_large_kernel(const KArgs a
       if (tid == 0 && it_this < a.hist_cap) {                                        // history of the LAST solve
         hist[4 * it_this + 0] = L_new; hist[4 * it_this + 1] = eps;
         hist[4 * it_this + 2] = (double)trials; hist[4 * it_this + 3] = (double)nk / (double)(N - 1) * 100.0;
+        double* ic = a.iter_cyc + ((size_t)b * a.hist_cap + it_this) * 4;             // per-iteration stopwatches (ilqr.py:364-372,696-702)
+        ic[0] = (double)(c1 - c0); ic[1] = (double)(c2 - c1); ic[2] = (double)(c3 - c2); ic[3] = (double)(c3 - c0);
       }
       improvement = L - L_new;
       L = L_new;

@@ -56,6 +56,7 @@ struct KArgs {
   const double* u_guess;   // (B,m,N-1) pending SetInitialGuess input (used when u_pending)
   double* cost;            // (B,)
   double* hist;            // (B,hist_cap,4)
+  double* iter_cyc;        // (B,hist_cap,4) per-iteration stopwatches: line search, linearization, backward pass, whole iteration (cycles)
   double *x_trial, *u_trial, *trial_cost;   // stage outputs
   const double* stage_in;  // (B,) eps (ROLLOUT) or L_last (FORWARD)
   const double* costmat;   // Q[n*n] R[m*m] Qf[n*n] x_nom[n]
@@ -2150,6 +2151,10 @@ __global__ void __launch_bounds__(256) ilqr_small_kernel(const KArgs a) {
       if (lane == 0 && it_this < a.hist_cap) {                    // history of the LAST solve
         hist[4 * it_this + 0] = L_new; hist[4 * it_this + 1] = eps;
         hist[4 * it_this + 2] = (double)trials; hist[4 * it_this + 3] = (double)nk / (double)(N - 1) * 100.0;   // :406
+        // the reference's per-iteration stopwatches (ilqr.py:364-372, 696-702), in shader-clock cycles
+        double* ic = a.iter_cyc + ((size_t)b * a.hist_cap + it_this) * 4;
+        ic[0] = (double)((fused == 2 ? c2 : c1) - c0); ic[1] = (fused == 2) ? 0.0 : (double)(c2 - c1);
+        ic[2] = (double)(c3 - c2); ic[3] = (double)(c3 - c0);
 #ifdef MI_PROF_NEWTON
         hist[4 * it_this + 0] = (double)(c1 - c0); hist[4 * it_this + 1] = mi_dbg_vals[0]; hist[4 * it_this + 2] = mi_dbg_vals[1]; hist[4 * it_this + 3] = mi_dbg_vals[2];
 #endif

@@ -39,7 +39,7 @@ struct mi_ilqr {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // double fields
   double *x_bar = nullptr, *u_bar = nullptr, *K = nullptr, *kappa = nullptr, *dV = nullptr, *fx = nullptr, *fu = nullptr;
-  double *x0 = nullptr, *u_guess = nullptr, *cost = nullptr, *hist = nullptr;
+  double *x0 = nullptr, *u_guess = nullptr, *cost = nullptr, *hist = nullptr, *iter_cyc = nullptr;
   double *x_trial = nullptr, *u_trial = nullptr, *trial_cost = nullptr, *stage_in = nullptr, *costmat = nullptr;
   int32_t *iters = nullptr, *status = nullptr, *ls_trials = nullptr, *kp_count = nullptr, *kp_list = nullptr;
   long long* prof = nullptr;
@@ -129,7 +129,7 @@ KArgs make_args(const mi_ilqr* h) {
   KArgs a;
   std::memset(&a, 0, sizeof(a));
   a.x_bar = h->x_bar; a.u_bar = h->u_bar; a.K = h->K; a.kappa = h->kappa; a.dV = h->dV; a.fx = h->fx; a.fu = h->fu;
-  a.x0 = h->x0; a.u_guess = h->u_guess; a.cost = h->cost; a.hist = h->hist;
+  a.x0 = h->x0; a.u_guess = h->u_guess; a.cost = h->cost; a.hist = h->hist; a.iter_cyc = h->iter_cyc;
   a.x_trial = h->x_trial; a.u_trial = h->u_trial; a.trial_cost = h->trial_cost; a.stage_in = h->stage_in;
   a.costmat = h->costmat;
   a.iters = h->iters; a.status = h->status; a.ls_trials = h->ls_trials; a.kp_count = h->kp_count; a.kp_list = h->kp_list;
@@ -503,6 +503,7 @@ Field field_of(mi_ilqr* h, int which) {
     case MI_F_COST: return {h->cost, B * 8, false};
     case MI_F_X0: return {h->x0, B * n * 8, false};
     case MI_F_HIST: return {h->hist, B * (size_t)h->d.hist_cap * 4 * 8, false};
+    case MI_F_ITER_CYCLES: return {h->iter_cyc, B * (size_t)h->d.hist_cap * 4 * 8, false};
     case MI_F_X_TRIAL: return {h->x_trial, B * n * N * 8, false};
     case MI_F_U_TRIAL: return {h->u_trial, B * m * (N - 1) * 8, false};
     case MI_F_TRIAL_COST: return {h->trial_cost, B * 2 * 8, false};
@@ -642,6 +643,7 @@ int mi_ilqr_create(const mi_ilqr_desc* desc, mi_ilqr_t** out) {
   ALLOC(h->u_guess, B * m * (N - 1), double);
   ALLOC(h->cost, B, double);
   ALLOC(h->hist, B * (size_t)h->d.hist_cap * 4, double);
+  ALLOC(h->iter_cyc, B * (size_t)h->d.hist_cap * 4, double);
   ALLOC(h->x_trial, B * n * N, double);
   ALLOC(h->u_trial, B * m * (N - 1), double);
   ALLOC(h->trial_cost, B * 2, double);
@@ -690,7 +692,7 @@ void mi_ilqr_destroy(mi_ilqr_t* h) {
   if (!h) return;
   (void)hipSetDevice(h->d.device_id);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  void* ptrs[] = {h->x_bar, h->u_bar, h->K, h->kappa, h->dV, h->fx, h->fu, h->x0, h->u_guess, h->cost, h->hist,
+  void* ptrs[] = {h->x_bar, h->u_bar, h->K, h->kappa, h->dV, h->fx, h->fu, h->x0, h->u_guess, h->cost, h->hist, h->iter_cyc,
                   h->x_trial, h->u_trial, h->trial_cost, h->stage_in, h->costmat, h->iters, h->status, h->ls_trials,
                   h->kp_count, h->kp_list, h->prof, h->done_counter};
   for (void* p : ptrs) if (p) (void)hipFree(p);

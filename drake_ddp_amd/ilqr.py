@@ -151,6 +151,7 @@ class BatchedIterativeLQR:
     fu = property(lambda s: s._get(_capi.F_FU, (s.B, s.n, s.m, s.N - 1)))
     cost = property(lambda s: s._get(_capi.F_COST, (s.B,)))
     history = property(lambda s: s._get(_capi.F_HIST, (s.B, s.hist_cap, 4)))
+    iteration_cycles = property(lambda s: s._get(_capi.F_ITER_CYCLES, (s.B, s.hist_cap, 4)))
     iterations = property(lambda s: s._get_int(_capi.I_ITERS, (s.B,)))
     status = property(lambda s: s._get_int(_capi.I_STATUS, (s.B,)))
     ls_trials = property(lambda s: s._get_int(_capi.I_LS_TRIALS, (s.B,)))
@@ -333,23 +334,26 @@ class IterativeLinearQuadraticRegulator(BatchedIterativeLQR):
         iters = int(self.iterations[0])
         hist = self.history[0]
         status = int(self.status[0])
-        # the reference's stopwatches (ilqr.py:364-372,696-699) from the in-kernel cycle counters:
-        # per-iteration AVERAGES of the last solve (the fused kernel does not log per-iteration clocks)
+        # the reference's stopwatches (ilqr.py:364-372,696-702) from the in-kernel cycle counters, PER ITERATION:
+        # cycles of the whole solve loop (stage_cycles[3]) span the kernel's HIP-event time
         cyc = self.stage_cycles[0].astype(np.float64)
         sec_per_cycle = stats.kernel_ms * 1e-3 / max(cyc[3], 1.0)
-        self.time_fp = cyc[0] * sec_per_cycle / max(iters, 1)
-        self.time_getDerivs = cyc[1] * sec_per_cycle / max(iters, 1)
-        self.time_backwardsPass = cyc[2] * sec_per_cycle / max(iters, 1)
+        rows = min(iters, self.hist_cap)
+        t_iter = self.iteration_cycles[0][:rows] * sec_per_cycle      # columns: fp (line search), derivs, bp, iteration
+        if rows:                                                      # like the reference: the LAST iteration's stopwatches
+            self.time_fp, self.time_getDerivs, self.time_backwardsPass = (float(v) for v in t_iter[-1, :3])
         if self.verbose:
             # same table as ilqr.py:685-704
             print("----------------------------------------------------------------------------------------------------------------------------------")
             print("|    iter    |    cost    |    eps    |    ls    | derivs time | derivs '%'  | bp time  | fp time  |   iter time    |    time    |")
             print("----------------------------------------------------------------------------------------------------------------------------------")
-            per_iter = stats.kernel_ms * 1e-3 / max(iters, 1)
-            for i in range(min(iters, self.hist_cap)):
+            elapsed = 0.0
+            for i in range(rows):
                 L_new, eps, ls, pct = hist[i]
-                print(f"{i + 1:^14}{L_new:11.4f}  {eps:^12.4f}{int(ls):^11}   {self.time_getDerivs:1.5f}         {pct:.1f}       "
-                      f"{self.time_backwardsPass:1.5f}    {self.time_fp:1.5f}      {per_iter:1.5f}          {per_iter * (i + 1):4.2f}")
+                t_fp, t_derivs, t_bp, t_it = t_iter[i]
+                elapsed += t_it
+                print(f"{i + 1:^14}{L_new:11.4f}  {eps:^12.4f}{int(ls):^11}   {t_derivs:1.5f}         {pct:.1f}       "
+                      f"{t_bp:1.5f}    {t_fp:1.5f}      {t_it:1.5f}          {elapsed:4.2f}")
         if status == _capi.STATUS_LINESEARCH_FAILED:
             raise RuntimeError("linesearch failed after %s iterations" % int(self.ls_trials[0]))   # ilqr.py:337
         return self.x_bar, self.u_bar, total_time, float(self.cost[0])

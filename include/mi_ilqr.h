@@ -91,6 +91,10 @@ enum {
   MI_F_X_TRIAL = 10,    /* (B,n,N)   last mi_ilqr_rollout trajectory                    */
   MI_F_U_TRIAL = 11,    /* (B,m,N-1)                                                    */
   MI_F_TRIAL_COST = 12, /* (B,2) (L, expected_improvement) of the last rollout          */
+  MI_F_ITER_CYCLES = 13,/* (B,hist_cap,4) per-iteration stopwatches of the last solve, shader-clock cycles: line search,
+                           linearization (0 when the rollout linearized on its way), backward pass, whole iteration - the
+                           reference's time_fp / time_getDerivs / time_backwardsPass / iter time (ilqr.py:364-372,696-702);
+                           wave- and workgroup-per-problem kernels */
   /* int32 fields (mi_ilqr_get_int) */
   MI_I_ITERS = 100,     /* (B,) iterations of the last solve                            */
   MI_I_STATUS = 101,    /* (B,)                                                         */

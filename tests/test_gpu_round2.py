@@ -519,3 +519,36 @@ def test_quad_full_size_mpc_run_vs_oracle():
     r["ls"] = r["ls"] - ls0
     log = _check_mpc_against_oracle(s, r, first_it, first_L, 36, tol_L=1e-6, tol_x=1e-5)
     assert st.n_converged == B and np.all(log[:, -1, 0] > 0.3)        # the trunk moved forward by 0.3 m or more
+
+
+def test_per_iteration_stopwatches_and_console_table(capsys):
+    """The reference times every iteration's line search, derivatives and backward pass (ilqr.py:364-372,696-702) and
+    prints them per row; the device logs the same three spans per iteration in shader-clock cycles
+    (MI_F_ITER_CYCLES): they add up to the solve's stage totals, and the single-problem Solve() prints one row per
+    iteration with that iteration's own times (and keeps the last iteration's in time_fp / time_getDerivs /
+    time_backwardsPass like the reference's attributes)."""
+    from drake_ddp_amd import workloads as W
+    from drake_ddp_amd.ilqr import IterativeLinearQuadraticRegulator
+    from drake_ddp_amd.models import ModelSystem
+    for prob, x0, ug in ((W.acrobot_problem(), W.acrobot_batch_x0(1)[0], np.zeros((1, 39))),
+                         (W.synth36_problem(), W.synth36_batch_x0(1)[0], W.synth36_u_guess(40))):
+        s = IterativeLinearQuadraticRegulator(ModelSystem(prob["model_id"], prob["dt"]), prob["N"], delta=prob["delta"],
+                                              beta=prob["beta"], gamma=prob["gamma"], jacobian_mode="fd", verbose=True)
+        s.SetTargetState(prob["x_nom"]); s.SetRunningCost(prob["Q"], prob["R"]); s.SetTerminalCost(prob["Qf"])
+        s.SetInitialState(x0); s.SetInitialGuess(ug)
+        s.Solve()
+        it = int(s.iterations[0])
+        ic = s.iteration_cycles[0][:it]
+        tot = s.stage_cycles[0]
+        assert np.all(ic[:, 3] > 0) and np.all(ic[:, 0] > 0) and np.all(ic[:, 2] > 0)
+        assert abs(ic[:, 0].sum() - tot[0]) <= 1e-9 * tot[0] and abs(ic[:, 1].sum() - tot[1]) <= 1e-9 * max(tot[1], 1)
+        assert abs(ic[:, 2].sum() - tot[2]) <= 1e-9 * tot[2] and ic[:, 3].sum() <= tot[3]
+        assert np.all(ic[:, 3] >= ic[:, 0] + ic[:, 1] + ic[:, 2] - 1)
+        out = capsys.readouterr().out
+        rows = [l for l in out.splitlines() if l.strip() and l.strip()[0].isdigit()]
+        assert len(rows) == it
+        times = np.array([[float(v) for v in r.split()[4:]] for r in rows])      # derivs, pct, bp, fp, iter, cumulative
+        assert np.all(np.diff(times[:, 5]) >= 0)                                  # cumulative time column
+        assert it == 1 or len(set(ic[:, 3])) > 1                                  # real per-iteration times, not one average
+        assert np.allclose(times[:, 4], ic[:, 3] * (s.stats.kernel_ms * 1e-3 / tot[3]), atol=6e-6)   # (5 printed decimals)
+        assert s.time_backwardsPass > 0 and s.time_fp > 0
