@@ -75,10 +75,11 @@ __device__ inline Dual2 mi_rcp(Dual2 a) { const double r = fast_rcp(a.v), q = -(
 
 // log(1+exp(z)) = max(z,0) + log1p(exp(-|z|)), overflow-safe and branch-free; same value as the
 // two-branch form of oracle/dual.py:softplus.  d/dz = logistic(z).
-__device__ inline double mi_softplus(double z) {
-  const double t = fast_exp_nonpos(-fabs(z));
-  return fmax(z, 0.0) + fast_log1p01(t);
+__device__ inline double mi_softplus(double z, const SoftplusPool& c) {
+  const double t = fast_exp_nonpos(-fabs(z), c);
+  return fmax(z, 0.0) + fast_log1p01(t, c);
 }
+__device__ inline double mi_softplus(double z) { return mi_softplus(z, SoftplusPool::literals()); }
 __device__ inline Dual1 mi_softplus(Dual1 z) {
   const double t = fast_exp_nonpos(-fabs(z.v));
   const double r = fast_rcp(1.0 + t);

@@ -103,32 +103,64 @@ __device__ __forceinline__ double fast_rcp(double x) {
   return r;
 }
 
+// The constants of exp / log1p as an argument.  fp64 VALU instructions cannot encode 64-bit literals, so each
+// constant of a polynomial costs two s_mov_b32 - and the contact model's softplus brings 25 of them on top of the
+// trig ones, more than the scalar file holds next to the kernel arguments: inside the rollout loop the compiler
+// re-materializes them every step (26 constants = 52 scalar moves per two steps, 13 % of the loop's issue slots
+// at one wave per SIMD).  A caller with a long loop loads a pool ONCE into vector registers (opaque to the
+// optimizer, see SoftplusPool::in_vgprs) and passes it down; everybody else passes the literals.
+struct SoftplusPool {
+  double E[11], L[8], ln2;
+  __device__ __forceinline__ static SoftplusPool literals() {
+    SoftplusPool p;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) p.E[k] = fm::kE[k];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) p.L[k] = fm::kL[k];
+    p.ln2 = fm::kLn2;
+    return p;
+  }
+  // the same values pinned in VGPRs at this point of the program (volatile: not hoisted to the kernel entry,
+  // where they would be live across everything and end up in AGPRs)
+  __device__ __forceinline__ static SoftplusPool in_vgprs() {
+    SoftplusPool p = literals();
+#pragma unroll
+    for (int k = 0; k < 11; ++k) asm volatile("" : "+v"(p.E[k]));
+#pragma unroll
+    for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(p.L[k]));
+    asm volatile("" : "+v"(p.ln2));
+    return p;
+  }
+};
+
 // exp(x) for x <= 0 (the only range the contact model needs): Cody-Waite reduction by ln2,
 // degree-10 polynomial, scale by 2^n (underflows cleanly to 0 for very negative x).
-__device__ __forceinline__ double fast_exp_nonpos(double x) {
+__device__ __forceinline__ double fast_exp_nonpos(double x, const SoftplusPool& c) {
   x = fmax(x, -745.0);
   const Rounded kn = round_mul(x, fm::kLog2e);
   const double nd = kn.n;
   double r = fma(-nd, fm::kLn2Hi, x);
   r = fma(-nd, fm::kLn2Lo, r);
-  double p = fm::kE[10];
+  double p = c.E[10];
 #pragma unroll
-  for (int k = 9; k >= 0; --k) p = fma(p, r, fm::kE[k]);
+  for (int k = 9; k >= 0; --k) p = fma(p, r, c.E[k]);
   const double e = 1.0 + fma(r * r, p, r);
   return ldexp(e, kn.lo);
 }
+__device__ __forceinline__ double fast_exp_nonpos(double x) { return fast_exp_nonpos(x, SoftplusPool::literals()); }
 
 // log1p(y) for 0 <= y <= 1: fold 1+y into [sqrt(1/2), sqrt 2] exactly, then 2 atanh(s).
-__device__ __forceinline__ double fast_log1p01(double y) {
+__device__ __forceinline__ double fast_log1p01(double y, const SoftplusPool& c) {
   const bool hi = y > fm::kSqrt2m1;
   const double f = hi ? 0.5 * (y - 1.0) : y;           // 1+y = 2(1+f) resp. 1+f, both exact
   const double s = f * fast_rcp(2.0 + f);
   const double w = s * s;
-  double R = fm::kL[7];
+  double R = c.L[7];
 #pragma unroll
-  for (int k = 6; k >= 0; --k) R = fma(R, w, fm::kL[k]);
+  for (int k = 6; k >= 0; --k) R = fma(R, w, c.L[k]);
   const double l = fma(s * w, R, 2.0 * s);
-  return hi ? l + fm::kLn2 : l;
+  return hi ? l + c.ln2 : l;
 }
+__device__ __forceinline__ double fast_log1p01(double y) { return fast_log1p01(y, SoftplusPool::literals()); }
 
 }  // namespace mi

@@ -335,9 +335,20 @@ struct GRegs {
   }
 };
 
+template <class M, class = void>
+struct HasStepPool : std::false_type {};
+template <class M>
+struct HasStepPool<M, std::void_t<decltype(M::kHasStepPool)>> : std::bool_constant<M::kHasStepPool> {};
+struct NoPool {};
+template <class M, bool = HasStepPool<M>::value>
+struct PoolOf { using type = NoPool; __device__ __forceinline__ static NoPool make() { return {}; } };
+template <class M>
+struct PoolOf<M, true> { using type = typename M::StepPool; __device__ __forceinline__ static type make() { return M::StepPool::in_vgprs(); } };
+
 template <class M, bool COST>
 __device__ __forceinline__ void rollout_step(const GRegs<M>& r, const Consts<M>& c, const KArgs& a, double eps,
-                                             double ce, double (&x)[M::n], double& L, double& expd, double* tw) {
+                                             double ce, double (&x)[M::n], double& L, double& expd, double* tw,
+                                             const typename PoolOf<M>::type& pool) {
   constexpr int n = M::n, m = M::m;
   using Ly = Lay<n, m>;
   // u_t = u_bar_t - eps*kappa_t - K_t (x_t - x_bar_t)          (ilqr.py:313)
@@ -350,7 +361,8 @@ __device__ __forceinline__ void rollout_step(const GRegs<M>& r, const Consts<M>&
     u[k] = (r.ub[k] - eps * r.kap[k]) - acc;
   }
   double xnext[n];
-  M::template step<double>(x, u, xnext, a.params, a.dt);        // ilqr.py:316
+  if constexpr (HasStepPool<M>::value) M::step_pooled(x, u, xnext, a.params, a.dt, pool);   // ilqr.py:316
+  else M::template step<double>(x, u, xnext, a.params, a.dt);
   if (COST) {
     // stage cost (no 1/2 factor, ilqr.py:325) and expected improvement (:326)
     L += stage_cost<M>(c, x, u);
@@ -390,19 +402,20 @@ __device__ inline void rollout(const WS& w, const Consts<M>& c, const KArgs& a, 
   const double* g = w.G;
   GRegs<M> A, B;
   A.load(g);
+  const typename PoolOf<M>::type pool = PoolOf<M>::make();   // the model's polynomial constants in VGPRs for the loop
   int t = 0;
   for (; t + 1 < N - 1; t += 2) {
     B.load(g + Ly::GS);
     __builtin_amdgcn_sched_barrier(0);      // keep the prefetch a full step ahead of its first use
-    rollout_step<M, COST>(A, c, a, eps, ce, x, L, expd, tw);
+    rollout_step<M, COST>(A, c, a, eps, ce, x, L, expd, tw, pool);
     tw += tstep;
     A.load(g + 2 * Ly::GS);                 // t+2 <= N-1: a real record (or the pad at N)
     __builtin_amdgcn_sched_barrier(0);
-    rollout_step<M, COST>(B, c, a, eps, ce, x, L, expd, tw);
+    rollout_step<M, COST>(B, c, a, eps, ce, x, L, expd, tw, pool);
     tw += tstep;
     g += 2 * Ly::GS;
   }
-  if (t < N - 1) rollout_step<M, COST>(A, c, a, eps, ce, x, L, expd, tw);
+  if (t < N - 1) rollout_step<M, COST>(A, c, a, eps, ce, x, L, expd, tw, pool);
   if (COST) L += terminal_cost<M>(c, x);            // ilqr.py:327
   L_out = L;
   exp_out = expd;

@@ -59,8 +59,19 @@ struct Acrobot {             // params [m1,m2,l1,lc1,lc2,Ic1,Ic2,b1,b2,g]
 template <bool WALL>
 struct CartPoleT {           // params [mc, mp, l, g, wall_face_x, ball_radius, k, sigma]
   static constexpr int n = 4, m = 1, n_params = WALL ? 8 : 4;
+  // The contact model's exp / log1p constants can be handed in by a caller that keeps them in vector registers
+  // across a long loop (fastmath.hpp: SoftplusPool) - the plain-double rollout of the wave-per-problem kernels.
+  static constexpr bool kHasStepPool = WALL;
+  using StepPool = SoftplusPool;
+  __device__ static inline void step_pooled(const double* x, const double* u, double* xn, const double* p, double dt, const SoftplusPool& pool) {
+    step_impl<double>(x, u, xn, p, dt, [&](double z) __attribute__((always_inline)) { return mi_softplus(z, pool); });
+  }
   template <class T>
   __device__ static inline void step(const T* x, const T* u, T* xn, const double* p, double dt) {
+    step_impl<T>(x, u, xn, p, dt, [](T z) __attribute__((always_inline)) { return mi_softplus(z); });
+  }
+  template <class T, class SP>
+  __device__ static inline void step_impl(const T* x, const T* u, T* xn, const double* p, double dt, SP softplus) {
     const double mc = p[0], mp = p[1], l = p[2], g = p[3];
     const T px = x[0], th = x[1], vx = x[2], w = x[3];
     const T s = mi_sin(th), c = mi_cos(th);
@@ -74,7 +85,7 @@ struct CartPoleT {           // params [mc, mp, l, g, wall_face_x, ball_radius, 
       const double inv_sig = 1.0 / sig;      // loop-invariant: hoisted (a full fp64 division is ~12 instructions)
       const T tip = px + l * s;
       const T phi = tip - rad - face;
-      const T F = k * sig * mi_softplus(-phi * inv_sig);
+      const T F = k * sig * softplus(-phi * inv_sig);
       r1 = r1 + F;
       r2 = r2 + F * l * c;
     }
