@@ -20,7 +20,7 @@ COMM_ID_BYTES, COMM_MAX_COUNT = 128, 64
 KP_SET_INTERVAL, KP_ADAPTIVE_JERK, KP_ITERATIVE_ERROR = 0, 1, 2
 JAC_FD_CENTRAL, JAC_AUTODIFF = 0, 1
 KERNEL_AUTO, KERNEL_LATENCY, KERNEL_THROUGHPUT = 0, 1, 2
-STATUS_CONVERGED, STATUS_MAX_ITERS, STATUS_LINESEARCH_FAILED = 0, 1, 2
+STATUS_CONVERGED, STATUS_MAX_ITERS, STATUS_LINESEARCH_FAILED, STATUS_INTERNAL = 0, 1, 2, 3
 F_X_BAR, F_U_BAR, F_K, F_KAPPA, F_DV, F_FX, F_FU, F_COST, F_X0, F_HIST, F_X_TRIAL, F_U_TRIAL, F_TRIAL_COST, F_ITER_CYCLES = range(14)
 I_ITERS, I_STATUS, I_LS_TRIALS, I_KP_COUNT, I_KP_LIST = 100, 101, 102, 103, 104
 

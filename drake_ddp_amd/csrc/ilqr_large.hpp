@@ -89,6 +89,20 @@ __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+// Data that crosses workgroups of one launch (cluster handshake): write-through stores / cache-bypassing loads at
+// device scope - coherent across the XCDs' L2 caches access by access, so no cache-wide write-back is needed to
+// publish them (a device-scope release fence writes back the whole L2 of the XCD: measured ~130 k cycles per
+// handshake with 256 workgroups doing it).
+template <bool COHERENT>
+__device__ __forceinline__ void st_shared(double* p, double v) {
+  if constexpr (COHERENT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+__device__ __forceinline__ double ld_shared(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void wait_stores() { __builtin_amdgcn_s_waitcnt(0x0F70); }   // vmcnt(0): this thread's stores acknowledged
+
 // Models whose step is an articulated-body algorithm cut into chains (models.hpp: PlanarQuad): cooperative
 // step in the rollout, accessor-driven whole-tree evaluation in the linearization.
 template <class M, class = void>
@@ -322,12 +336,12 @@ struct HasSparsity<M, decltype((void)M::kMaxAffected)> { static constexpr bool v
 
 // Sparse variant: only the dofs that read input column `col` are evaluated (M::affected); the
 // rest of the column is written as the exact zeros the dense evaluation produces.
-template <class M, int JAC>
+template <class M, int JAC, bool COH = false>
 __device__ __forceinline__ void large_jac_at_sparse(const LView<M::n, M::m>& v, const KArgs& a, const int* list, int count,
-                                                    const double* Xsrc, const double* Usrc) {
+                                                    const double* Xsrc, const double* Usrc, int first = 0, int stride = 1) {
   constexpr int n = M::n, m = M::m, nc = n + m, nq = M::nq;
   const double h = a.fd_h, inv2h = 1.0 / (2.0 * h);
-  for (int it = threadIdx.x; it < count * nc; it += kLargeThreads) {
+  for (int it = first * kLargeThreads + threadIdx.x; it < count * nc; it += stride * kLargeThreads) {
     const int ki = it / nc, col = it - ki * nc;
     const int t = list[ki];
     const double* xg = Xsrc + (size_t)t * n;
@@ -340,7 +354,7 @@ __device__ __forceinline__ void large_jac_at_sparse(const LView<M::n, M::m>& v, 
     // separate coalesced zero-fill pass was measured slower: the CU's 64 B/clk store path is the
     // floor for the 540 KB of Jacobians either way, and here it hides under the arithmetic)
 #pragma unroll
-    for (int i = 0; i < n; ++i) o[i * stride] = 0.0;
+    for (int i = 0; i < n; ++i) st_shared<COH>(o + i * stride, 0.0);
     int dofs[M::kMaxAffected];
     const int na = M::affected(col, dofs);
 #pragma unroll
@@ -360,8 +374,8 @@ __device__ __forceinline__ void large_jac_at_sparse(const LView<M::n, M::m>& v, 
           dq = qd.d;
           dv = vd.d;
         }
-        o[i * stride] = dq;                       // same thread, same address as the zero above: program order holds
-        o[(nq + i) * stride] = dv;
+        st_shared<COH>(o + i * stride, dq);       // same thread, same address as the zero above: program order holds
+        st_shared<COH>(o + (nq + i) * stride, dv);
       }
     }
   }
@@ -376,9 +390,10 @@ __device__ __forceinline__ void large_jac_at_sparse(const LView<M::n, M::m>& v, 
 // 6 chain passes instead of 20 for 42 of the 48 columns; bitwise the same Jacobians as evaluating the whole tree
 // for every perturbation (a chain's pass reads nothing but the trunk state and its own joints).
 // Results go to memory chain by chain: no per-thread arrays, no scratch.
-template <class M, int JAC>
+template <class M, int JAC, bool COH = false>
 __device__ __forceinline__ void large_jac_at_tree(const LView<M::n, M::m>& v, const KArgs& a, const int* list, int count,
-                                                  const double* Xsrc, const double* Usrc, int xstride, int ustride, double* cache) {
+                                                  const double* Xsrc, const double* Usrc, int xstride, int ustride, double* cache,
+                                                  int first = 0, int stride = 1) {
   constexpr int n = M::n, m = M::m, nc = n + m, nq = M::nq, NCH = M::kChains;
   const double h = a.fd_h, inv2h = 1.0 / (2.0 * h), dt = a.dt;
   using AggD = typename M::template Agg<double>;
@@ -401,7 +416,7 @@ __device__ __forceinline__ void large_jac_at_tree(const LView<M::n, M::m>& v, co
   // items are dealt key-point fastest, columns in the order "chain by chain, then the trunk's": the lanes of a
   // wavefront then share the owner of their column (two owners at most), so the per-chain branches below are
   // wave-uniform - dealt column-fastest they diverge and every wave runs both sides of every branch
-  for (int it = threadIdx.x; it < count * nc; it += kLargeThreads) {
+  for (int it = first * kLargeThreads + threadIdx.x; it < count * nc; it += stride * kLargeThreads) {
     const int rank = it / count, ki = it - rank * count;
     const int col = M::input_by_owner(rank);
     const int t = list[ki];
@@ -442,8 +457,8 @@ __device__ __forceinline__ void large_jac_at_tree(const LView<M::n, M::m>& v, co
       auto emit = [&](int i, double accp, double accm) __attribute__((always_inline)) {   // (f(x+h e) - f(x-h e)) / 2h on
         const double vp = xp[nq + i] + dt * accp, vm = xm[nq + i] + dt * accm;          //  v+ = v + dt a, q+ = q + dt v+
         const double qp = xp[i] + dt * vp, qm = xm[i] + dt * vm;
-        o[i * stride] = (qp - qm) * inv2h;
-        o[(nq + i) * stride] = (vp - vm) * inv2h;
+        st_shared<COH>(o + i * stride, (qp - qm) * inv2h);
+        st_shared<COH>(o + (nq + i) * stride, (vp - vm) * inv2h);
       };
       emit(0, axp, axm); emit(1, azp, azm); emit(2, alp, alm);
       for (int c = 0; c < NCH; ++c) {
@@ -479,8 +494,8 @@ __device__ __forceinline__ void large_jac_at_tree(const LView<M::n, M::m>& v, co
       auto emit = [&](int i, Dual1 acc) __attribute__((always_inline)) {
         const Dual1 vn = xs[nq + i] + dt * acc;
         const Dual1 qn = xs[i] + dt * vn;
-        o[i * stride] = qn.d;
-        o[(nq + i) * stride] = vn.d;
+        st_shared<COH>(o + i * stride, qn.d);
+        st_shared<COH>(o + (nq + i) * stride, vn.d);
       };
       emit(0, ax); emit(1, az); emit(2, al);
       for (int c = 0; c < NCH; ++c) {
@@ -1049,7 +1064,10 @@ __global__ void __launch_bounds__(kLargeThreads) ilqr_large_kernel(const KArgs a
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* lds = reinterpret_cast<double*>(smem);
   int* ilds = reinterpret_cast<int*>(lds + Ly::doubles + (size_t)a.N * (n + m));
-  const int b = blockIdx.x, tid = threadIdx.x, N = a.N;
+  // `cluster` workgroups per problem (MODE_SOLVE / MODE_MPC): workgroup 0 of a cluster is the leader and runs the
+  // solve, the others only help with its linearizations (cluster handshake below)
+  const int G = ((MODE == MODE_SOLVE || MODE == MODE_MPC) && a.cluster > 1) ? a.cluster : 1;
+  const int b = blockIdx.x / G, role = blockIdx.x - b * G, tid = threadIdx.x, N = a.N;
   LView<n, m> v;
   v.N = N;
   v.X = a.x_bar + (size_t)b * n * N;
@@ -1082,8 +1100,8 @@ __global__ void __launch_bounds__(kLargeThreads) ilqr_large_kernel(const KArgs a
       lds[Ly::oQn + tid] = s; lds[Ly::oQfn + tid] = sf;
     }
   }
-  // lazily-zero persistent state / pending initial guess
-  if (a.cold) {
+  // lazily-zero persistent state / pending initial guess (the cluster's leader only: helpers never write solver state)
+  if (a.cold && role == 0) {
     for (int e = tid; e < n * N; e += kLargeThreads) v.X[e] = 0.0;
     for (int e = tid; e < m * n * (N - 1); e += kLargeThreads) v.K[e] = 0.0;
     for (int e = tid; e < m * (N - 1); e += kLargeThreads) v.kap[e] = 0.0;
@@ -1091,7 +1109,7 @@ __global__ void __launch_bounds__(kLargeThreads) ilqr_large_kernel(const KArgs a
     for (int e = tid; e < n * n * (N - 1); e += kLargeThreads) v.Fx[e] = 0.0;
     for (int e = tid; e < n * m * (N - 1); e += kLargeThreads) v.Fu[e] = 0.0;
   }
-  if (a.u_pending) {
+  if (a.u_pending && role == 0) {
     const double* ug = a.u_guess + (size_t)b * m * (N - 1);
     for (int e = tid; e < m * (N - 1); e += kLargeThreads) v.U[e] = ug[e];
   }
@@ -1113,6 +1131,105 @@ __global__ void __launch_bounds__(kLargeThreads) ilqr_large_kernel(const KArgs a
     if constexpr (HasSparsity<M>::value) large_jac_at_sparse<M, JAC>(v, a, list, count, lin_X, lin_U);
     else if constexpr (IsChainModel<M>::value) large_jac_at_tree<M, JAC>(v, a, list, count, lin_X, lin_U, lin_xs, lin_us, lds + Ly::doubles);   // (the cost-gradient area of the backward pass is idle here)
     else large_jac_at<M, JAC>(v, a, list, count);
+  };
+  // ---- cluster handshake (G > 1; every step a key-point, models with an LDS-staged linearization) -------------
+  // The linearization is the one stage of an iteration whose (step, column) items are independent, and with few
+  // problems per GPU most CUs idle: the leader of a problem's cluster shares them with its helper workgroups.
+  //   sync words (global, zero at launch): [0] command = round << 32 | participants, [1] done (chunk shares
+  //   finished, monotonic), [2] alive (helpers that have started), [3] exit.
+  // A helper registers when it starts running (role by arrival); the leader snapshots `alive` when it publishes a
+  // round and only counts on those helpers - a workgroup that is not resident yet is never waited for, so the
+  // scheme cannot deadlock on an oversubscribed device.  Items are dealt in chunks of 256 to the participants
+  // round-robin (static: every Jacobian entry is written by exactly one workgroup, with the arithmetic of the
+  // single-workgroup path - bitwise the same fx, fu).  Trajectory and Jacobians cross workgroups through global
+  // memory under device-scope release / acquire fences.
+  unsigned long long* csync = a.cluster_sync + (size_t)4 * b;
+  constexpr bool kClusterable = HasSparsity<M>::value || IsChainModel<M>::value;
+  const bool clustered = kClusterable && G > 1 && lin_staged && a.kp_method == MI_KP_SET_INTERVAL && a.minN == 1;
+  auto stage_trajectory = [&]() __attribute__((always_inline)) {          // helper: the leader's x_bar / u_bar -> LDS
+    double* xs_ = lds + Ly::oT1;
+    double* us_ = lds + Ly::oF;
+    for (int e = tid; e < n * N; e += kLargeThreads) xs_[(e / n) * kXS + e % n] = ld_shared(v.X + e);
+    for (int e = tid; e < m * (N - 1); e += kLargeThreads) us_[(e / m) * kUS + e % m] = ld_shared(v.U + e);
+    for (int i = tid; i < N - 1; i += kLargeThreads) acc.kp[i] = i;          // keypoints_set_interval(minN = 1)
+    __syncthreads();
+  };
+  auto jac_share = [&](int first, int stride, auto coherent) __attribute__((always_inline)) {
+    constexpr bool COH = decltype(coherent)::value;
+    if constexpr (HasSparsity<M>::value) large_jac_at_sparse<M, JAC, COH>(v, a, acc.kp, N - 1, lin_X, lin_U, first, stride);
+    else if constexpr (IsChainModel<M>::value) large_jac_at_tree<M, JAC, COH>(v, a, acc.kp, N - 1, lin_X, lin_U, lin_xs, lin_us, lds + Ly::doubles, first, stride);
+  };
+  constexpr long long kSpinCap = 1ll << 22;                 // x s_sleep(4) ~ 1 s: a lost partner ends the wait, not the device
+  if (role > 0) {
+    // ---- helper workgroup
+    if (!clustered) return;
+    if (tid == 0) acc.aux[1] = (int)__hip_atomic_fetch_add(csync + 2, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+    __syncthreads();
+    const int my = acc.aux[1];                              // 1, 2, ...: order of arrival
+    unsigned last_round = 0;
+    for (;;) {
+      if (tid == 0) {
+        unsigned long long cmd = 0;
+        long long spins = 0;
+        int go = -1;
+        for (; spins < kSpinCap; ++spins) {
+          cmd = __hip_atomic_load(csync + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((unsigned)(cmd >> 32) != last_round) { go = 1; break; }
+          if (__hip_atomic_load(csync + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) break;
+          __builtin_amdgcn_s_sleep(4);
+        }
+        acc.aux[0] = go;
+        acc.aux[2] = (int)(unsigned)(cmd >> 32);
+        acc.aux[3] = (int)(unsigned)(cmd & 0xffffffffull);
+      }
+      __syncthreads();
+      const int go = acc.aux[0], parts = acc.aux[3];
+      last_round = (unsigned)acc.aux[2];
+      __syncthreads();
+      if (go < 0) return;                                   // exit flag (or nobody spoke for a second)
+      if (my >= parts) continue;                            // arrived after this round's snapshot: not counted on
+      stage_trajectory();                                   // (cache-bypassing loads: no acquire fence)
+      jac_share(my, parts, std::true_type{});               // this share of fx / fu: write-through stores ...
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");    // ... and a release: nothing of it is left dirty, so the
+      __syncthreads();                                      //     write-back it implies finds next to nothing to do
+      if (tid == 0) __hip_atomic_fetch_add(csync + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  unsigned cl_round = 0;
+  unsigned long long cl_expected = 0;                       // done-counter value after the helpers of all rounds so far
+  // leader: one clustered linearization of the committed trajectory (LDS copy in place).  Returns false on a lost helper.
+  auto linearize_clustered = [&]() __attribute__((always_inline)) -> bool {
+    for (int i = tid; i < N - 1; i += kLargeThreads) acc.kp[i] = i;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // the write-through x_bar / u_bar stores of the commit
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned long long alive = __hip_atomic_load(csync + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned parts = 1u + (unsigned)(alive < (unsigned long long)(G - 1) ? alive : (unsigned long long)(G - 1));
+      cl_round += 1;
+      acc.aux[3] = (int)parts;
+      __hip_atomic_store(csync + 0, ((unsigned long long)cl_round << 32) | parts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const int parts = acc.aux[3];
+    jac_share(0, parts, std::false_type{});                 // (own share: read back by this workgroup only)
+    __syncthreads();
+    if (tid == 0) {
+      cl_expected += (unsigned long long)(parts - 1);
+      long long spins = 0;
+      int ok = 1;
+      while (__hip_atomic_load(csync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < cl_expected) {
+        if (++spins >= kSpinCap) { ok = 0; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      acc.aux[0] = ok;
+    }
+    __syncthreads();
+    const bool ok = acc.aux[0] != 0;
+    // the helpers' shares of fx / fu are in memory; drop this XCD's cached copies of last iteration's (invalidate
+    // only - nothing of this workgroup needs writing back for anybody)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+    return ok;
   };
   auto do_linearize = [&](bool have_copy) __attribute__((always_inline)) {
     if (lin_staged && !have_copy) {
@@ -1204,11 +1321,21 @@ __global__ void __launch_bounds__(kLargeThreads) ilqr_large_kernel(const KArgs a
       {                                                                              // :375-376 (+ the LDS copy the
         double* xs_ = lds + Ly::oT1;                                                 //  linearization reads)
         double* us_ = lds + Ly::oF;
-        for (int e = tid; e < n * N; e += kLargeThreads) { const double x_ = v.Xn[e]; v.X[e] = x_; if (lin_staged) xs_[(e / n) * kXS + e % n] = x_; }
-        for (int e = tid; e < m * (N - 1); e += kLargeThreads) { const double u_ = v.Un[e]; v.U[e] = u_; if (lin_staged) us_[(e / m) * kUS + e % m] = u_; }
+        if (clustered) {                                                             // (the helpers read x_bar / u_bar: write-through)
+          for (int e = tid; e < n * N; e += kLargeThreads) { const double x_ = v.Xn[e]; st_shared<true>(v.X + e, x_); xs_[(e / n) * kXS + e % n] = x_; }
+          for (int e = tid; e < m * (N - 1); e += kLargeThreads) { const double u_ = v.Un[e]; st_shared<true>(v.U + e, u_); us_[(e / m) * kUS + e % m] = u_; }
+        } else {
+          for (int e = tid; e < n * N; e += kLargeThreads) { const double x_ = v.Xn[e]; v.X[e] = x_; if (lin_staged) xs_[(e / n) * kXS + e % n] = x_; }
+          for (int e = tid; e < m * (N - 1); e += kLargeThreads) { const double u_ = v.Un[e]; v.U[e] = u_; if (lin_staged) us_[(e / m) * kUS + e % m] = u_; }
+        }
       }
       __syncthreads();
-      nk = do_linearize(true);                                                       // :370
+      if (clustered) {                                                               // :370, shared with the helper workgroups
+        nk = N - 1;
+        if (!linearize_clustered()) { status = MI_STATUS_INTERNAL; break; }
+      } else {
+        nk = do_linearize(true);                                                     // :370
+      }
       __syncthreads();
       const long long c2 = clock64();
 #ifdef MI_PROF_BACKWARD
@@ -1241,9 +1368,10 @@ __global__ void __launch_bounds__(kLargeThreads) ilqr_large_kernel(const KArgs a
       double* lg = a.mpc_log + ((size_t)b * a.mpc_resolves + rs) * (n + 2);
       if (tid < n) lg[tid] = x0g[tid];
       if (tid == 0) { lg[n] = L; lg[n + 1] = (double)it_this; }
-      if (status == MI_STATUS_LINESEARCH_FAILED) break;
+      if (status >= MI_STATUS_LINESEARCH_FAILED) break;
     }
   }
+  if (G > 1 && tid == 0) __hip_atomic_store(csync + 3, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // helpers: go home
   for (int i = tid; i < nk; i += kLargeThreads) a.kp_list[(size_t)b * (N - 1) + i] = acc.kp[i];
   if (tid == 0) {
     a.cost[b] = L; a.iters[b] = iters; a.status[b] = status; a.ls_trials[b] = ls_total; a.kp_count[b] = nk;

@@ -79,6 +79,11 @@ struct KArgs {
   // batch statistics itself (no second kernel per solve).  Null: the host launches stats_kernel.
   DevStats* stats_out;
   int32_t* done_counter;       // zero between launches
+  // workgroup-per-problem kernels, MODE_SOLVE / MODE_MPC with every step a key-point: `cluster` workgroups per
+  // problem - one leader that runs the solve and cluster-1 helpers that share its linearizations
+  // (ilqr_large.hpp: cluster handshake).  cluster_sync: 4 x 64-bit words per problem, zero at launch.
+  int32_t cluster;
+  unsigned long long* cluster_sync;
 };
 
 __device__ __forceinline__ double bcast_lane0(double v) {

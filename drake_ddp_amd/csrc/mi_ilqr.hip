@@ -55,6 +55,8 @@ struct mi_ilqr {
   bool u_zero = false;     // u_bar is to read as all zero (after reset, until a guess is set or re-armed): ilqr.py:71
   int exact_backward = 0;  // cost matrices the fast backward forms do not cover (asymmetric / indefinite): reference recursion
   std::vector<double> h_costmat;   // host mirror of costmat (Q | R | Qf | x_nom)
+  unsigned long long* cluster_sync = nullptr;   // workgroup-per-problem kernels: 4 handshake words per problem
+  int n_cus = 0;                   // compute units of the device
   double* scratch = nullptr;       // device staging area of the boundary's layout conversions (grow-only)
   size_t scratch_bytes = 0;
   size_t lds = 0;
@@ -162,6 +164,22 @@ KArgs make_args(const mi_ilqr* h) {
   const bool own_stats = stats_in_kernel(h);
   a.stats_out = own_stats ? h->d_stats : nullptr;
   a.done_counter = own_stats ? h->done_counter : nullptr;
+  // workgroup-per-problem kernels: with few problems per GPU most CUs idle - up to 8 workgroups per problem share the
+  // linearization (ilqr_large.hpp: cluster handshake), as many as keep every workgroup of the launch on its own CU.
+  // MI_ILQR_CLUSTER=k forces k (1 = off) for A/B runs.
+  a.cluster = 1;
+  a.cluster_sync = h->cluster_sync;
+  if (h->large && h->cluster_sync && h->d.keypoint_method == MI_KP_SET_INTERVAL && h->d.minN == 1) {
+    static const int forced = [] { const char* e = std::getenv("MI_ILQR_CLUSTER"); return e ? std::atoi(e) : 0; }();
+    int g = forced > 0 ? forced : (h->n_cus > 0 ? h->n_cus / h->B : 1);
+    // a handshake costs ~40 k cycles when a few hundred workgroups fence at once: worth it for the articulated
+    // model at any batch (its linearization is 450 k cycles), for the sparse chain model (75 k) only while the
+    // launch stays small
+    if (forced <= 0 && h->d.model_id != MI_MODEL_PLANAR_QUAD && h->B > 16) g = 1;
+    if (g > 8) g = 8;
+    if (g < 1) g = 1;
+    a.cluster = g;
+  }
   return a;
 }
 
@@ -207,8 +225,10 @@ int launch_one_large(mi_ilqr* h, const KArgs& a) {
   auto kern = ilqr_large_kernel<M, JAC, MODE>;
   static bool lds_ok[kMaxDevices] = {};
   { const int rc = allow_max_lds(kern, lds_ok, h->d.device_id); if (rc != MI_ILQR_OK) return rc; }
+  const int cluster = (MODE == MODE_SOLVE || MODE == MODE_MPC) ? a.cluster : 1;
+  if (cluster > 1) HIPCHK(hipMemsetAsync(h->cluster_sync, 0, (size_t)h->B * 4 * sizeof(unsigned long long), h->stream));
   HIPCHK(hipEventRecord(h->ev0, h->stream));
-  hipLaunchKernelGGL(kern, dim3(h->B), dim3(kLargeThreads), h->lds, h->stream, a);
+  hipLaunchKernelGGL(kern, dim3(h->B * cluster), dim3(kLargeThreads), h->lds, h->stream, a);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(h->ev1, h->stream));
   return MI_ILQR_OK;
@@ -656,7 +676,12 @@ int mi_ilqr_create(const mi_ilqr_desc* desc, mi_ilqr_t** out) {
   ALLOC(h->kp_list, B * (N - 1), int32_t);
   ALLOC(h->prof, B * 4, long long);
   ALLOC(h->done_counter, 1, int32_t);
+  if (large) ALLOC(h->cluster_sync, B * 4, unsigned long long);
 #undef ALLOC
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, desc->device_id) == hipSuccess) h->n_cus = cus;
+  }
   // defaults Q=I, R=I, Qf=I, x_nom=0 (ilqr.py:61-67)
   {
     std::vector<double> cm(2 * n * n + m * m + n, 0.0);
@@ -694,7 +719,7 @@ void mi_ilqr_destroy(mi_ilqr_t* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   void* ptrs[] = {h->x_bar, h->u_bar, h->K, h->kappa, h->dV, h->fx, h->fu, h->x0, h->u_guess, h->cost, h->hist, h->iter_cyc,
                   h->x_trial, h->u_trial, h->trial_cost, h->stage_in, h->costmat, h->iters, h->status, h->ls_trials,
-                  h->kp_count, h->kp_list, h->prof, h->done_counter};
+                  h->kp_count, h->kp_list, h->prof, h->done_counter, h->cluster_sync};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->h_ring) (void)hipHostFree(h->h_ring);
   if (h->mpc_log) (void)hipFree(h->mpc_log);

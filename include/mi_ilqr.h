@@ -80,7 +80,8 @@ enum { MI_JAC_FD_CENTRAL = 0, MI_JAC_AUTODIFF = 1 };
 enum { MI_KERNEL_AUTO = 0, MI_KERNEL_LATENCY = 1, MI_KERNEL_THROUGHPUT = 2 };
 
 /* Per-problem status written by solve/forward. */
-enum { MI_STATUS_CONVERGED = 0, MI_STATUS_MAX_ITERS = 1, MI_STATUS_LINESEARCH_FAILED = 2 };
+enum { MI_STATUS_CONVERGED = 0, MI_STATUS_MAX_ITERS = 1, MI_STATUS_LINESEARCH_FAILED = 2,
+       MI_STATUS_INTERNAL = 3 /* a helper workgroup of the problem's cluster stopped answering (never seen) */ };
 
 /* Selector for mi_ilqr_get / mi_ilqr_set / mi_ilqr_device_ptr. */
 enum {

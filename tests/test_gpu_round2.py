@@ -552,3 +552,42 @@ def test_per_iteration_stopwatches_and_console_table(capsys):
         assert it == 1 or len(set(ic[:, 3])) > 1                                  # real per-iteration times, not one average
         assert np.allclose(times[:, 4], ic[:, 3] * (s.stats.kernel_ms * 1e-3 / tot[3]), atol=6e-6)   # (5 printed decimals)
         assert s.time_backwardsPass > 0 and s.time_fp > 0
+
+
+@pytest.mark.parametrize("cfg,B,forced", [("quad", 8, None), ("synth36", 8, None), ("quad", 64, "8"), ("quad", 3, "5")])
+def test_cluster_linearization_is_bitwise_the_single_workgroup_one(cfg, B, forced, tmp_path):
+    """With few problems per GPU the linearization of ONE problem is shared by a cluster of workgroups (leader +
+    helpers, handshake through global memory, ilqr_large.hpp).  Every Jacobian entry is still computed by the
+    same code on the same inputs, so everything the solve returns must be bitwise what a single workgroup per
+    problem returns (MI_ILQR_CLUSTER=1) - including when the launch is oversubscribed (512 workgroups on 256 CUs:
+    helpers that are not resident are never waited for) and for cluster sizes that do not divide anything."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = f"""
+import sys, numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, 'tests')!r})
+from drake_ddp_amd import workloads as W
+from test_gpu_parity import make_solver
+if {cfg!r} == 'quad':
+    prob, x0, ug = W.planar_quad_problem(), W.planar_quad_batch_x0(64)[:{B}], W.planar_quad_u_guess(40)
+    step = np.zeros(36); step[0] = W.QUAD_TARGET_VEL * prob['dt'] * 4
+else:
+    prob, x0, ug = W.synth36_problem(), W.synth36_batch_x0(64)[:{B}], W.synth36_u_guess(40)
+    step = np.zeros(36); step[0] = W.SYNTH_TARGET_VEL * prob['dt'] * 4
+s = make_solver(prob, B={B}, jac='fd')
+s.SetInitialState(x0); s.SetInitialGuess(ug)
+x, u, _, L = s.Solve()
+fx0, it0 = s.fx.copy(), s.iterations.copy()
+s.MPCRun(6, 4, target_step=step)
+np.savez(sys.argv[1], x=x, u=u, L=L, fx0=fx0, it0=it0, log=s.mpc_log, xm=s.x_bar, K=s.K, fx=s.fx, fu=s.fu, it=s.iterations, st=s.status)
+"""
+    outs = []
+    for tag, env in (("cluster", {} if forced is None else {"MI_ILQR_CLUSTER": forced}), ("single", {"MI_ILQR_CLUSTER": "1"})):
+        f = str(tmp_path / f"{tag}.npz")
+        r = subprocess.run([sys.executable, "-c", script, f], capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(f))
+    assert (outs[0]["st"] == 0).all()
+    for k in outs[0].files:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
