@@ -178,7 +178,8 @@ def test_c3_c4_c5_configs_converge_at_full_size():
     assert (s.status == 0).all() and np.all(np.isfinite(L))
 
 
-@pytest.mark.parametrize("script", ["swingup_pendulum.py", "mpc_acrobot.py", "wall_cartpole.py", "mpc_many_legs.py"])
+@pytest.mark.parametrize("script", ["swingup_pendulum.py", "mpc_acrobot.py", "wall_cartpole.py", "mpc_many_legs.py",
+                                    "mpc_planar_quadruped.py"])
 def test_example_scripts_run(script):
     import subprocess
     import sys
@@ -186,6 +187,7 @@ def test_example_scripts_run(script):
     out = subprocess.run([sys.executable, os.path.join(root, "examples", script)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert any(k in out.stdout for k in ("Optimal cost: 0.23997", "device loop", "derivatives evaluated at", "iLQR iterations in the re-solves"))
+    assert "all converged: False" not in out.stdout
 
 
 def test_long_horizon_falls_back_to_streaming_kernel():

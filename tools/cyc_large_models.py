@@ -1,5 +1,7 @@
+"""Per-stage cycles of the workgroup-per-problem kernels (planar quadruped, synthetic chain) at B = 64 and 8:
+line search, linearization, backward pass per iteration (in-kernel stopwatches)."""
 import sys, os, numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from drake_ddp_amd import workloads as W
 from test_gpu_parity import make_solver
