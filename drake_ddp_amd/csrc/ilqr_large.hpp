@@ -1172,7 +1172,7 @@ __global__ void __launch_bounds__(kLargeThreads) ilqr_large_kernel(const KArgs a
         unsigned long long cmd = 0;
         long long spins = 0;
         int go = -1;
-        for (; spins < kSpinCap; ++spins) {
+        for (; spins < 16 * kSpinCap; ++spins) {           // (a helper may be resident long before its leader speaks)
           cmd = __hip_atomic_load(csync + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if ((unsigned)(cmd >> 32) != last_round) { go = 1; break; }
           if (__hip_atomic_load(csync + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) break;

@@ -274,7 +274,7 @@ static void linearize(const oracle_cfg* c, const work* w) {
   const int n = c->n, m = c->m, N = c->N, minN = c->minN;
   const double h = c->fd_h, inv2h = 1.0 / (2.0 * h);
   int nk = (N - 2) / minN + 1;
-  int* kp = (int*)malloc(sizeof(int) * nk);
+  int* kp = (int*)calloc((size_t)nk + 1, sizeof(int));
   for (int i = 0; i < nk; ++i) kp[i] = i * minN;
   if (kp[nk - 1] != N - 2) kp[nk - 1] = N - 2;                        /* overwrite, not append (:428-430) */
   double xt[MAXN], ut[MAXM], xp[MAXN], up[MAXM], fp[MAXN], fm[MAXN];
