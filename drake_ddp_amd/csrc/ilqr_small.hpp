@@ -179,6 +179,13 @@ __device__ inline WS carve(char* base, int N, int n_store) {
   return w;
 }
 
+// Result write-back store that goes THROUGH the L2 (device-scope relaxed store = sc1): most waves of a launch
+// finish long before its slowest problem, and lines they leave dirty would all be written back by the
+// end-of-kernel release, i.e. inside the gap before the next dispatch.
+__device__ __forceinline__ void wt_store(double* p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // HBM (rows,len) time-last  ->  LDS records rec[t*RS + off + row]   (and back)
 __device__ inline void stage_in(double* recs, int RS, int off, const double* src, int rows, int len, bool zero) {
   for (int r = 0; r < rows; ++r) {
@@ -2235,20 +2242,20 @@ __global__ void __launch_bounds__(256) ilqr_small_kernel(const KArgs a) {
   #pragma unroll
         for (int k = 0; k < n * m; ++k) fur[k] = jr[Ly::FU + k];
   #pragma unroll
-        for (int i = 0; i < n; ++i) a.x_bar[oX + (size_t)i * N + t] = xb[i];
+        for (int i = 0; i < n; ++i) wt_store(&a.x_bar[oX + (size_t)i * N + t], xb[i]);
         if (t < N - 1) {
   #pragma unroll
-          for (int k = 0; k < m; ++k) a.u_bar[oU + (size_t)k * (N - 1) + t] = ub[k];
+          for (int k = 0; k < m; ++k) wt_store(&a.u_bar[oU + (size_t)k * (N - 1) + t], ub[k]);
   #pragma unroll
-          for (int k = 0; k < n * n; ++k) a.fx[oFx + (size_t)k * (N - 1) + t] = fxr[k];
+          for (int k = 0; k < n * n; ++k) wt_store(&a.fx[oFx + (size_t)k * (N - 1) + t], fxr[k]);
   #pragma unroll
-          for (int k = 0; k < n * m; ++k) a.fu[oFu + (size_t)k * (N - 1) + t] = fur[k];
+          for (int k = 0; k < n * m; ++k) wt_store(&a.fu[oFu + (size_t)k * (N - 1) + t], fur[k]);
           if (MODE == MODE_SOLVE || MODE == MODE_MPC) {
   #pragma unroll
-            for (int k = 0; k < m * n; ++k) a.K[oK + (size_t)k * (N - 1) + t] = kk[k];
+            for (int k = 0; k < m * n; ++k) wt_store(&a.K[oK + (size_t)k * (N - 1) + t], kk[k]);
   #pragma unroll
-            for (int k = 0; k < m; ++k) a.kappa[oU + (size_t)k * (N - 1) + t] = kap[k];
-            a.dV[oT + t] = dv;
+            for (int k = 0; k < m; ++k) wt_store(&a.kappa[oU + (size_t)k * (N - 1) + t], kap[k]);
+            wt_store(&a.dV[oT + t], dv);
           }
         }
       }

@@ -6,6 +6,7 @@
 // happens on the host: without a usable device every compute entry fails with
 // MI_ILQR_E_NO_DEVICE.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <dlfcn.h>
 
@@ -194,16 +195,23 @@ int allow_max_lds(Kern kern, bool (&done)[kMaxDevices], int device) {
   return MI_ILQR_OK;
 }
 
+// One dispatch packet per solve: the launch carries the handle's start/stop events itself (the kernel's own
+// begin/end timestamps, what rocprofv3 reports for it) instead of two hipEventRecord marker packets around it.
+template <class Kern>
+int launch_timed(mi_ilqr* h, Kern kern, dim3 grid, dim3 block, size_t lds, const KArgs& a) {
+  KArgs args = a;
+  void* argv[] = {&args};
+  HIPCHK(hipExtLaunchKernel(reinterpret_cast<const void*>(kern), grid, block, argv, lds, h->stream, h->ev0, h->ev1, 0));
+  return MI_ILQR_OK;
+}
+
 template <class M, int JAC, int MODE>
 int launch_one(mi_ilqr* h, const KArgs& a) {
   auto kern = ilqr_small_kernel<M, JAC, MODE>;
   static bool lds_ok[kMaxDevices] = {};
   { const int rc = allow_max_lds(kern, lds_ok, h->d.device_id); if (rc != MI_ILQR_OK) return rc; }
-  HIPCHK(hipEventRecord(h->ev0, h->stream));
   const int waves = (a.helpers > 0 && (MODE == MODE_SOLVE || MODE == MODE_MPC)) ? 1 + a.helpers : 1;
-  hipLaunchKernelGGL(kern, dim3(h->B), dim3(64 * waves), h->lds, h->stream, a);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(h->ev1, h->stream));
+  return launch_timed(h, kern, dim3(h->B), dim3(64 * waves), h->lds, a);
   return MI_ILQR_OK;
 }
 
@@ -227,11 +235,7 @@ int launch_one_large(mi_ilqr* h, const KArgs& a) {
   { const int rc = allow_max_lds(kern, lds_ok, h->d.device_id); if (rc != MI_ILQR_OK) return rc; }
   const int cluster = (MODE == MODE_SOLVE || MODE == MODE_MPC) ? a.cluster : 1;
   if (cluster > 1) HIPCHK(hipMemsetAsync(h->cluster_sync, 0, (size_t)h->B * 4 * sizeof(unsigned long long), h->stream));
-  HIPCHK(hipEventRecord(h->ev0, h->stream));
-  hipLaunchKernelGGL(kern, dim3(h->B * cluster), dim3(kLargeThreads), h->lds, h->stream, a);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(h->ev1, h->stream));
-  return MI_ILQR_OK;
+  return launch_timed(h, kern, dim3(h->B * cluster), dim3(kLargeThreads), h->lds, a);
 }
 
 template <class M, int JAC>
@@ -256,11 +260,7 @@ int launch_jac_large(mi_ilqr* h, int mode, const KArgs& a) {
 template <class M, int JAC>
 int launch_batch_one(mi_ilqr* h, const KArgs& a) {
   auto kern = ilqr_batch_kernel<M, JAC>;
-  HIPCHK(hipEventRecord(h->ev0, h->stream));
-  hipLaunchKernelGGL(kern, dim3((h->B + 63) / 64), dim3(64), 0, h->stream, a);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(h->ev1, h->stream));
-  return MI_ILQR_OK;
+  return launch_timed(h, kern, dim3((h->B + 63) / 64), dim3(64), 0, a);
 }
 
 template <class M>
