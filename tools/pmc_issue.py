@@ -1,0 +1,66 @@
+"""Issue-side hardware counters of the solve kernels (run on the GPU box):  python tools/pmc_issue.py <tag>
+rocprofv3 --pmc passes (one counter group per pass, kernel trace only) over tools/run_configs.py, which runs the
+five BASELINE configs; per kernel, the counters are averaged over its launches after the first.  Writes
+gpurun_out/<tag>_pmc_issue.json.  Units (MI355X_MICROARCH.md): SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count
+quad-cycles summed over waves; SQ_BUSY_CYCLES, GRBM_GUI_ACTIVE, SQ_VALU_MFMA_BUSY_CYCLES count cycles."""
+import csv, glob, json, os, subprocess, sys, tempfile, shutil
+tag = sys.argv[1] if len(sys.argv) > 1 else "rXX"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GROUPS = [
+    ["GRBM_GUI_ACTIVE", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES"],
+    ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_SALU", "SQ_WAIT_INST_ANY"],
+    ["SQ_INSTS_LDS", "SQ_ACTIVE_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"],
+    ["SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_TRANS_F64"],
+    ["SQ_INSTS_VALU_MFMA_MOPS_F64", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_MFMA", "SQ_INSTS_VMEM"],
+]
+env = dict(os.environ, TMPDIR="/tmp")
+acc = {}
+for grp in GROUPS:
+    out = tempfile.mkdtemp(prefix="mi_pmc_", dir="/tmp")
+    cmd = ["rocprofv3", "--pmc"] + grp + ["--kernel-trace", "--output-format", "csv", "-d", out, "--",
+                                           sys.executable, os.path.join(ROOT, "tools", "run_configs.py")]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    rows = []
+    for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+        rows += list(csv.DictReader(open(f)))
+    if not rows:
+        print("no counters for", grp, r.stdout.decode()[-400:], file=sys.stderr)
+    per = {}
+    for row in rows:
+        k = row["Kernel_Name"].split("(")[0]
+        if "ilqr_" not in k:
+            continue
+        k = "%s  grid=%s x %s threads" % (k.replace("void ", ""), int(row["Grid_Size"]) // max(1, int(row["Workgroup_Size"])), row["Workgroup_Size"])
+        per.setdefault((k, row["Counter_Name"]), []).append((int(row["Dispatch_Id"]), float(row["Counter_Value"])))
+    for (k, c), v in per.items():
+        v.sort()
+        vals = [x for _, x in v][1:] or [x for _, x in v]
+        acc.setdefault(k, {})[c] = sum(vals) / len(vals)
+        acc[k]["launches_averaged"] = len(vals)
+    shutil.rmtree(out, ignore_errors=True)
+N_SIMD = 1024
+N_XCD = 8           # GRBM_GUI_ACTIVE comes back summed over the eight XCDs (checked against the kernel's duration)
+for k, c in acc.items():
+    g = c.get("GRBM_GUI_ACTIVE", 0) / N_XCD
+    c["kernel_cycles (GRBM_GUI_ACTIVE / 8 XCDs)"] = g
+    if g:
+        c["derived"] = {
+            "wave_slots_occupied: SQ_WAVE_CYCLES*4 / (kernel_cycles * 1024 SIMDs)  [1.0 = one wave on every SIMD for the whole launch]": 4 * c.get("SQ_WAVE_CYCLES", 0) / (g * N_SIMD),
+            "valu_issue_fraction_of_resident_time (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES)": c.get("SQ_ACTIVE_INST_VALU", 0) / max(1.0, c.get("SQ_WAVE_CYCLES", 0)),
+            "waiting_fraction_of_resident_time (SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES)": c.get("SQ_WAIT_INST_ANY", 0) / max(1.0, c.get("SQ_WAVE_CYCLES", 0)),
+            "valu_busy_fraction_of_chip: SQ_ACTIVE_INST_VALU*4 / (kernel_cycles * 1024 SIMDs)": 4 * c.get("SQ_ACTIVE_INST_VALU", 0) / (g * N_SIMD),
+            "fp64_valu_share_of_valu_instructions": (c.get("SQ_INSTS_VALU_FMA_F64", 0) + c.get("SQ_INSTS_VALU_ADD_F64", 0) + c.get("SQ_INSTS_VALU_MUL_F64", 0)
+                                                     + c.get("SQ_INSTS_VALU_TRANS_F64", 0)) / max(1.0, c.get("SQ_INSTS_VALU", 0)),
+            "mfma_busy_cycles_per_mfma_instruction": c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / max(1.0, c.get("SQ_INSTS_MFMA", 0)),
+            "cycles_per_valu_instruction_of_a_resident_wave (4 * SQ_WAVE_CYCLES / SQ_INSTS_VALU)": 4 * c.get("SQ_WAVE_CYCLES", 0) / max(1.0, c.get("SQ_INSTS_VALU", 0)),
+            "lds_bank_conflict_fraction (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE)": c.get("SQ_LDS_BANK_CONFLICT", 0) / max(1.0, c.get("SQ_LDS_IDX_ACTIVE", 0)),
+            "mfma_busy_fraction_of_chip: SQ_VALU_MFMA_BUSY_CYCLES / (kernel_cycles * 1024 SIMDs)": c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (g * N_SIMD),
+        }
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+path = os.path.join(ROOT, "gpurun_out", tag + "_pmc_issue.json")
+json.dump({"command": "rocprofv3 --pmc <group> --kernel-trace --output-format csv -- python tools/run_configs.py (one pass per group)",
+           "groups": GROUPS, "kernels": acc}, open(path, "w"), indent=1)
+for k, c in acc.items():
+    print(k)
+    for name, v in c.get("derived", {}).items():
+        print("   %-120s %.4f" % (name, v))
