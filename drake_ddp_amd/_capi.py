@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmi_ilqr.so")
 
 MAX_PARAMS = 16
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # enums (include/mi_ilqr.h)
 OK, E_BAD_SHAPE, E_BAD_METHOD, E_LINESEARCH, E_HIP, E_NO_DEVICE, E_BAD_ARG, E_UNSUPPORTED, E_RCCL = 0, -1, -2, -3, -4, -5, -6, -7, -8
@@ -31,7 +31,7 @@ EXPORTS = [
     "mi_ilqr_rollout", "mi_ilqr_forward", "mi_ilqr_linearize", "mi_ilqr_backward", "mi_ilqr_mpc_shift",
     "mi_ilqr_mpc_run", "mi_ilqr_get_mpc_log",
     "mi_ilqr_get", "mi_ilqr_get_int", "mi_ilqr_set", "mi_ilqr_device_ptr", "mi_ilqr_get_stream",
-    "mi_ilqr_synchronize", "mi_ilqr_last_kernel_ms", "mi_ilqr_get_cycles", "mi_ilqr_bytes_per_iteration", "mi_ilqr_lds_bytes",
+    "mi_ilqr_synchronize", "mi_ilqr_last_kernel_ms", "mi_ilqr_set_timing", "mi_ilqr_get_cycles", "mi_ilqr_bytes_per_iteration", "mi_ilqr_lds_bytes",
     "mi_ilqr_comm_unique_id", "mi_ilqr_comm_create", "mi_ilqr_comm_destroy", "mi_ilqr_allreduce_min",
     "mi_ilqr_allreduce_min_start", "mi_ilqr_allreduce_min_wait",
 ]
@@ -101,6 +101,7 @@ def load():
     lib.mi_ilqr_device_ptr.argtypes = [H, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     lib.mi_ilqr_get_stream.argtypes = [H, C.POINTER(C.c_void_p)]
     lib.mi_ilqr_last_kernel_ms.argtypes = [H, C.POINTER(C.c_float)]
+    lib.mi_ilqr_set_timing.argtypes = [H, C.c_int32]
     lib.mi_ilqr_get_cycles.argtypes = [H, C.c_void_p, C.c_size_t]
     lib.mi_ilqr_bytes_per_iteration.restype = C.c_double
     lib.mi_ilqr_bytes_per_iteration.argtypes = [C.c_int32] * 4

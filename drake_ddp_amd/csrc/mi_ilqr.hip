@@ -38,11 +38,25 @@ struct mi_ilqr {
   DevStats* d_ring = nullptr;    // its device alias
   long long seq = 0;             // solves enqueued so far
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  unsigned long long seq_timed = 0;
+  int time_every = 1;              // mi_ilqr_set_timing: events on one solve in `time_every` (0 = never)
+  bool timed_launch = true;        // this launch carries the events
+  bool last_timed = true;          // ... and so did the most recent launch
+  int cur_slot = 0;
+  bool ring_timed[kStatsRing] = {};
   // double fields
   double *x_bar = nullptr, *u_bar = nullptr, *K = nullptr, *kappa = nullptr, *dV = nullptr, *fx = nullptr, *fu = nullptr;
   double *x0 = nullptr, *u_guess = nullptr, *cost = nullptr, *hist = nullptr, *iter_cyc = nullptr;
   double *x_trial = nullptr, *u_trial = nullptr, *trial_cost = nullptr, *stage_in = nullptr, *costmat = nullptr;
   int32_t *iters = nullptr, *status = nullptr, *ls_trials = nullptr, *kp_count = nullptr, *kp_list = nullptr;
+  // cost / iters / status / ls_trials above alias the CURRENT slot of these rings (kStatsRing x B each): every
+  // pipelined solve leaves its per-problem results in its own slot, so their reduction to a DevStats record can
+  // wait until somebody collects - one stats_kernel launch over all pending slots - instead of one dispatch
+  // (6 us + its gap) behind every solve.
+  double* cost_ring = nullptr;
+  int32_t *iters_ring = nullptr, *status_ring = nullptr, *ls_ring = nullptr;
+  long long stats_done = 0;      // solves with sequence number < stats_done have their DevStats record
+  bool in_async_solve = false;
   long long* prof = nullptr;
   int32_t* done_counter = nullptr;   // wave-per-problem kernels: tickets of the in-kernel statistics epilogue
   DevStats* h_stats = nullptr;   // pinned host memory, device-mapped
@@ -80,6 +94,9 @@ static inline bool stats_in_kernel(const mi_ilqr* h) {
 static inline void select_stats_slot(mi_ilqr* h, int slot) {
   h->ev0 = h->ring_ev0[slot]; h->ev1 = h->ring_ev1[slot];
   h->h_stats = h->h_ring + slot; h->d_stats = h->d_ring + slot;
+  h->cur_slot = slot;
+  const size_t o = (size_t)slot * h->B;
+  h->cost = h->cost_ring + o; h->iters = h->iters_ring + o; h->status = h->status_ring + o; h->ls_trials = h->ls_ring + o;
 }
 
 namespace {
@@ -197,10 +214,14 @@ int allow_max_lds(Kern kern, bool (&done)[kMaxDevices], int device) {
 
 // One dispatch packet per solve: the launch carries the handle's start/stop events itself (the kernel's own
 // begin/end timestamps, what rocprofv3 reports for it) instead of two hipEventRecord marker packets around it.
+// A profiled dispatch still costs the stream ~5 us of serialization in a pipelined sequence
+// (tools/ubench/gap.hip), so mi_ilqr_set_timing can restrict the events to one launch in k.
 template <class Kern>
 int launch_timed(mi_ilqr* h, Kern kern, dim3 grid, dim3 block, size_t lds, const KArgs& a) {
   KArgs args = a;
   void* argv[] = {&args};
+  h->ring_timed[h->cur_slot] = h->last_timed = h->timed_launch;
+  if (!h->timed_launch) { HIPCHK(hipLaunchKernel(reinterpret_cast<const void*>(kern), grid, block, argv, lds, h->stream)); return MI_ILQR_OK; }
   HIPCHK(hipExtLaunchKernel(reinterpret_cast<const void*>(kern), grid, block, argv, lds, h->stream, h->ev0, h->ev1, 0));
   return MI_ILQR_OK;
 }
@@ -301,8 +322,12 @@ int launch_jac(mi_ilqr* h, int mode, const KArgs& a) {
 
 // Launch `mode` for the handle's model; afterwards the persistent state is no
 // longer known-zero for the fields the mode writes, and u_bar is materialized.
+int reduce_pending_stats(mi_ilqr* h);
+
 int launch(mi_ilqr* h, int mode) {
   HIPCHK(hipSetDevice(h->d.device_id));
+  // any launch other than a pipelined solve reuses the current ring slot: settle the statistics still owed first
+  if (!h->in_async_solve) { const int rc = reduce_pending_stats(h); if (rc != MI_ILQR_OK) return rc; }
   if (h->u_zero && !h->u_pending) HIPCHK(hipMemsetAsync(h->u_bar, 0, (size_t)h->B * h->m * (h->N - 1) * 8, h->stream));
   h->u_zero = false;
   const KArgs a = make_args(h);
@@ -477,8 +502,14 @@ int traj_rows(const mi_ilqr* h, int which, int* len) {
 // Aggregate per-problem results on the device so a blocking solve costs ONE small host read
 // (pinned, device-mapped) instead of four D2H copies.
 
+// One workgroup per ring slot: blockIdx.x-th of `first, first+1, ...` (mod ring); the arrays are the slot-0 bases.
 __global__ void __launch_bounds__(256) stats_kernel(const int32_t* iters, const int32_t* status, const int32_t* ls,
-                                                    const double* cost, int B, DevStats* out) {
+                                                    const double* cost, int B, DevStats* out, int first, int ring) {
+  {
+    const int slot = (first + (int)blockIdx.x) % ring;
+    const size_t o = (size_t)slot * B;
+    iters += o; status += o; ls += o; cost += o; out += slot;
+  }
   __shared__ long long s_it[256], s_ls[256];
   __shared__ int s_c[256], s_m[256], s_f[256], s_mx[256], s_bi[256];
   __shared__ double s_bc[256];
@@ -506,6 +537,20 @@ __global__ void __launch_bounds__(256) stats_kernel(const int32_t* iters, const 
     out->total_iters = s_it[0]; out->total_ls = s_ls[0]; out->n_conv = s_c[0]; out->n_max = s_m[0]; out->n_fail = s_f[0];
     out->max_iters_seen = s_mx[0]; out->best_index = s_bi[0]; out->best_cost = s_bc[0];
   }
+}
+
+// DevStats records of every enqueued solve that has none yet: ONE launch, a workgroup per pending ring slot.
+int reduce_pending_stats(mi_ilqr* h) {
+  long long first = h->stats_done;
+  if (h->seq - first > mi_ilqr::kStatsRing) first = h->seq - mi_ilqr::kStatsRing;    // older slots were overwritten
+  const int count = (int)(h->seq - first);
+  if (count > 0) {
+    hipLaunchKernelGGL(stats_kernel, dim3(count), dim3(256), 0, h->stream, h->iters_ring, h->status_ring, h->ls_ring, h->cost_ring,
+                       h->B, h->d_ring, (int)(first % mi_ilqr::kStatsRing), (int)mi_ilqr::kStatsRing);
+    HIPCHK(hipGetLastError());
+  }
+  h->stats_done = h->seq;
+  return MI_ILQR_OK;
 }
 
 struct Field { void* ptr; size_t bytes; bool is_int; };
@@ -661,7 +706,7 @@ int mi_ilqr_create(const mi_ilqr_desc* desc, mi_ilqr_t** out) {
   ALLOC(h->fu, B * n * m * (N - 1), double);
   ALLOC(h->x0, B * n, double);
   ALLOC(h->u_guess, B * m * (N - 1), double);
-  ALLOC(h->cost, B, double);
+  ALLOC(h->cost_ring, B * mi_ilqr::kStatsRing, double);
   ALLOC(h->hist, B * (size_t)h->d.hist_cap * 4, double);
   ALLOC(h->iter_cyc, B * (size_t)h->d.hist_cap * 4, double);
   ALLOC(h->x_trial, B * n * N, double);
@@ -669,9 +714,9 @@ int mi_ilqr_create(const mi_ilqr_desc* desc, mi_ilqr_t** out) {
   ALLOC(h->trial_cost, B * 2, double);
   ALLOC(h->stage_in, B, double);
   ALLOC(h->costmat, 2 * n * n + m * m + n, double);
-  ALLOC(h->iters, B, int32_t);
-  ALLOC(h->status, B, int32_t);
-  ALLOC(h->ls_trials, B, int32_t);
+  ALLOC(h->iters_ring, B * mi_ilqr::kStatsRing, int32_t);
+  ALLOC(h->status_ring, B * mi_ilqr::kStatsRing, int32_t);
+  ALLOC(h->ls_ring, B * mi_ilqr::kStatsRing, int32_t);
   ALLOC(h->kp_count, B, int32_t);
   ALLOC(h->kp_list, B * (N - 1), int32_t);
   ALLOC(h->prof, B * 4, long long);
@@ -717,8 +762,8 @@ void mi_ilqr_destroy(mi_ilqr_t* h) {
   if (!h) return;
   (void)hipSetDevice(h->d.device_id);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  void* ptrs[] = {h->x_bar, h->u_bar, h->K, h->kappa, h->dV, h->fx, h->fu, h->x0, h->u_guess, h->cost, h->hist, h->iter_cyc,
-                  h->x_trial, h->u_trial, h->trial_cost, h->stage_in, h->costmat, h->iters, h->status, h->ls_trials,
+  void* ptrs[] = {h->x_bar, h->u_bar, h->K, h->kappa, h->dV, h->fx, h->fu, h->x0, h->u_guess, h->cost_ring, h->hist, h->iter_cyc,
+                  h->x_trial, h->u_trial, h->trial_cost, h->stage_in, h->costmat, h->iters_ring, h->status_ring, h->ls_ring,
                   h->kp_count, h->kp_list, h->prof, h->done_counter, h->cluster_sync};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->h_ring) (void)hipHostFree(h->h_ring);
@@ -830,13 +875,17 @@ int mi_ilqr_synchronize(mi_ilqr_t* h) {
 
 int mi_ilqr_solve_async(mi_ilqr_t* h) {
   if (!h) return MI_ILQR_E_BAD_ARG;
-  select_stats_slot(h, (int)(h->seq++ % mi_ilqr::kStatsRing));
+  const int slot = (int)(h->seq++ % mi_ilqr::kStatsRing);
+  select_stats_slot(h, slot);
+  // pipelined solves: the events ride on one launch in `time_every` (every other entry point times its launches)
+  h->timed_launch = h->time_every > 0 && (h->seq_timed++ % h->time_every) == 0;
+  h->in_async_solve = true;
   int rc = launch(h, MODE_SOLVE);
+  h->in_async_solve = false;
+  h->timed_launch = true;
   if (rc != MI_ILQR_OK) return rc;
-  if (!stats_in_kernel(h)) {
-    hipLaunchKernelGGL(stats_kernel, dim3(1), dim3(256), 0, h->stream, h->iters, h->status, h->ls_trials, h->cost, h->B, h->d_stats);
-    HIPCHK(hipGetLastError());
-  }
+  // (the batch statistics of this solve: by the kernel itself, or by reduce_pending_stats when somebody collects)
+  if (stats_in_kernel(h) && h->stats_done == h->seq - 1) h->stats_done = h->seq;
   h->cold = false;
   h->u_pending = false;
   return MI_ILQR_OK;
@@ -849,7 +898,7 @@ static void fill_stats(mi_ilqr* h, int slot, mi_ilqr_stats* st) {
   st->n_converged = ds.n_conv; st->n_max_iters = ds.n_max; st->n_ls_failed = ds.n_fail;
   st->max_iters_seen = ds.max_iters_seen; st->best_cost = ds.best_cost; st->best_index = ds.best_index;
   float ms = 0.f;
-  if (hipEventElapsedTime(&ms, h->ring_ev0[slot], h->ring_ev1[slot]) == hipSuccess) st->kernel_ms = ms;
+  if (h->ring_timed[slot] && hipEventElapsedTime(&ms, h->ring_ev0[slot], h->ring_ev1[slot]) == hipSuccess) st->kernel_ms = ms;
   // bytes_iter is affine in ls: sum over iterations = ls_total*roll + iters*(deriv+back)
   const double per_ls = bytes_per_iteration(h->n, h->m, h->N, 1) - bytes_per_iteration(h->n, h->m, h->N, 0);
   const double fixed = bytes_per_iteration(h->n, h->m, h->N, 0);
@@ -859,6 +908,7 @@ static void fill_stats(mi_ilqr* h, int slot, mi_ilqr_stats* st) {
 int mi_ilqr_collect_stats(mi_ilqr_t* h, mi_ilqr_stats* st) {
   if (!h || !st) return MI_ILQR_E_BAD_ARG;
   HIPCHK(hipSetDevice(h->d.device_id));
+  { const int rc = reduce_pending_stats(h); if (rc != MI_ILQR_OK) return rc; }
   HIPCHK(hipStreamSynchronize(h->stream));
   fill_stats(h, (int)(h->h_stats - h->h_ring), st);
   return MI_ILQR_OK;
@@ -867,6 +917,7 @@ int mi_ilqr_collect_stats(mi_ilqr_t* h, mi_ilqr_stats* st) {
 int mi_ilqr_collect_stats_n(mi_ilqr_t* h, int32_t count, mi_ilqr_stats* st) {
   if (!h || !st || count < 1 || count > mi_ilqr::kStatsRing || count > h->seq) return MI_ILQR_E_BAD_ARG;
   HIPCHK(hipSetDevice(h->d.device_id));
+  { const int rc = reduce_pending_stats(h); if (rc != MI_ILQR_OK) return rc; }
   HIPCHK(hipStreamSynchronize(h->stream));
   for (int i = 0; i < count; ++i) fill_stats(h, (int)((h->seq - count + i) % mi_ilqr::kStatsRing), st + i);
   return MI_ILQR_OK;
@@ -990,7 +1041,8 @@ int mi_ilqr_mpc_run(mi_ilqr_t* h, int32_t num_resolves, int32_t replan_steps, co
   rc = launch(h, MODE_MPC);
   if (rc != MI_ILQR_OK) return rc;
   if (!stats_in_kernel(h)) {
-    hipLaunchKernelGGL(stats_kernel, dim3(1), dim3(256), 0, h->stream, h->iters, h->status, h->ls_trials, h->cost, h->B, h->d_stats);
+    hipLaunchKernelGGL(stats_kernel, dim3(1), dim3(256), 0, h->stream, h->iters_ring, h->status_ring, h->ls_ring, h->cost_ring,
+                       h->B, h->d_ring, h->cur_slot, (int)mi_ilqr::kStatsRing);
     HIPCHK(hipGetLastError());
   }
   if (target_step) {          // keep the handle's x_nom in step with what the kernel accumulated
@@ -1080,8 +1132,16 @@ int mi_ilqr_device_ptr(mi_ilqr_t* h, int which, void** ptr, size_t* bytes) {
   return MI_ILQR_OK;
 }
 
+int mi_ilqr_set_timing(mi_ilqr_t* h, int32_t every) {
+  if (!h || every < 0) return MI_ILQR_E_BAD_ARG;
+  h->time_every = every;
+  h->seq_timed = 0;
+  return MI_ILQR_OK;
+}
+
 int mi_ilqr_last_kernel_ms(mi_ilqr_t* h, float* ms) {
   if (!h || !ms) return MI_ILQR_E_BAD_ARG;
+  if (!h->last_timed) { *ms = 0.0f; return MI_ILQR_OK; }
   HIPCHK(hipSetDevice(h->d.device_id));
   HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipEventElapsedTime(ms, h->ev0, h->ev1));

@@ -184,6 +184,10 @@ class BatchedIterativeLQR:
         _capi.check(self._lib.mi_ilqr_last_kernel_ms(self._h, C.byref(ms)), "mi_ilqr_last_kernel_ms")
         return float(ms.value)
 
+    def set_timing(self, every=1):
+        """HIP events on one pipelined solve in `every` (1 = all, the default; 0 = none): see mi_ilqr_set_timing."""
+        _capi.check(self._lib.mi_ilqr_set_timing(self._h, int(every)), "mi_ilqr_set_timing")
+
     def Reset(self):
         """Forget warm-start state: equivalent to constructing a new solver (ilqr.py:70-83)."""
         _capi.check(self._lib.mi_ilqr_reset(self._h), "mi_ilqr_reset")

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MI_ILQR_ABI_VERSION 3
+#define MI_ILQR_ABI_VERSION 4
 #define MI_ILQR_MAX_PARAMS 16
 
 /* Error codes (0 = OK).  The Python wrapper maps them onto the exception types
@@ -134,7 +134,8 @@ typedef struct {
   int32_t max_iters_seen;
   double best_cost;           /* min_b L_b over converged problems */
   int32_t best_index;
-  float kernel_ms;            /* HIP-event time of the solve kernel(s) on the handle's stream */
+  float kernel_ms;            /* HIP-event time of the solve kernel(s) on the handle's stream; 0 for a launch
+                                 * that mi_ilqr_set_timing left without events */
   double algorithmic_bytes;   /* sum_b sum_i bytes_iter(ls_{b,i}) — SURVEY.md §8d formula */
 } mi_ilqr_stats;
 
@@ -171,7 +172,10 @@ int mi_ilqr_rearm_initial_guess(mi_ilqr_t* h);
 
 /* Solve (ilqr.py:669-710) for every problem of the batch, on the device, to convergence.
  * Blocking, like the reference call; `stats` may be NULL.  _solve_async only enqueues the
- * kernel on the handle's stream; _collect_stats synchronizes and aggregates. */
+ * kernel on the handle's stream - ONE dispatch: every solve leaves its per-problem cost / iterations / status /
+ * line-search trials in its own slot of a 32-deep ring, and _collect_stats(_n) reduces all slots still owed
+ * their batch statistics in one launch, synchronizes and returns them (more than 32 uncollected solves:
+ * the oldest are overwritten). */
 int mi_ilqr_solve(mi_ilqr_t* h, mi_ilqr_stats* stats);
 int mi_ilqr_solve_async(mi_ilqr_t* h);
 int mi_ilqr_collect_stats(mi_ilqr_t* h, mi_ilqr_stats* stats);
@@ -216,7 +220,9 @@ int mi_ilqr_get_int(mi_ilqr_t* h, int which, int32_t* dst, size_t bytes);
 int mi_ilqr_set(mi_ilqr_t* h, int which, const double* src, size_t bytes);
 
 /* Raw device pointer of a double field (for zero-copy consumers, e.g. a torch tensor
- * view feeding the RCCL best-cost reduction), and the handle's stream. */
+ * view feeding the RCCL best-cost reduction), and the handle's stream.  The per-problem result scalars
+ * (MI_F_COST, MI_I_ITERS, MI_I_STATUS, MI_I_LS_TRIALS) rotate through a ring, one slot per
+ * mi_ilqr_solve / mi_ilqr_solve_async: ask for their pointer again after each solve. */
 int mi_ilqr_device_ptr(mi_ilqr_t* h, int which, void** ptr, size_t* bytes);
 int mi_ilqr_get_stream(mi_ilqr_t* h, void** hip_stream);
 int mi_ilqr_synchronize(mi_ilqr_t* h);
@@ -248,8 +254,14 @@ int mi_ilqr_allreduce_min_wait(mi_ilqr_comm_t* c, double* values, int32_t count)
  * of the reference's time_fp / time_getDerivs / time_backwardsPass (ilqr.py:364-372,696-699). */
 int mi_ilqr_get_cycles(mi_ilqr_t* h, int64_t* dst, size_t bytes);
 
-/* HIP-event duration of the most recent kernel launch on the handle's stream. */
+/* HIP-event duration of the most recent kernel launch on the handle's stream (0 if that launch was not timed). */
 int mi_ilqr_last_kernel_ms(mi_ilqr_t* h, float* ms);
+
+/* Which launches carry their start/stop events: every one (every = 1, the default), the first of every `every`
+ * solves, or none (every = 0).  The events ride on the solve kernel's own dispatch packet, but a profiled dispatch
+ * still serializes a pipelined stream by ~5 us; a caller that enqueues solves back to back (mi_ilqr_solve_async)
+ * and wants kernel_ms only as a sample asks for one in k.  Untimed launches report kernel_ms = 0. */
+int mi_ilqr_set_timing(mi_ilqr_t* h, int32_t every);
 
 /* Algorithmic bytes of one iteration of one problem with `ls` line-search trials. */
 double mi_ilqr_bytes_per_iteration(int32_t n, int32_t m, int32_t N, int32_t ls);

@@ -591,3 +591,51 @@ np.savez(sys.argv[1], x=x, u=u, L=L, fx0=fx0, it0=it0, log=s.mpc_log, xm=s.x_bar
     assert (outs[0]["st"] == 0).all()
     for k in outs[0].files:
         assert np.array_equal(outs[0][k], outs[1][k]), k
+
+
+@pytest.mark.gpu
+def test_pipelined_solves_defer_their_statistics_and_sample_their_events():
+    """mi_ilqr_solve_async is ONE dispatch: each solve leaves its per-problem results in its own ring slot and the
+    batch statistics are reduced when somebody collects (one launch over every slot still owed); the start/stop
+    events ride on one launch in k (mi_ilqr_set_timing).  A cold / warm / warm / cold sequence must come back with
+    each solve's own numbers, also when a stage call or an MPC run reuses the current slot before the collect."""
+    from test_gpu_properties import c2_setup
+    from drake_ddp_amd._capi import MiIlqrError
+    prob, x0, s = c2_setup(256)                                   # B > 64: the separate statistics kernel
+    s.Solve()                                                     # (pushes the problem to the device)
+    ref = []
+    for cold in (True, False, False, True):                       # blocking reference, one collect per solve
+        if cold:
+            s.rearm(cold=True)
+        s.solve_resident_async()
+        st = s.collect(1)[0]
+        ref.append((st.total_iters, st.total_ls_trials, st.n_converged, st.best_cost, st.best_index, s.iterations.copy(), s.cost.copy()))
+    assert ref[0][0] == ref[3][0] and ref[1][0] < ref[0][0]       # warm re-solves take fewer iterations
+    s.set_timing(2)
+    for cold in (True, False, False, True):
+        if cold:
+            s.rearm(cold=True)
+        s.solve_resident_async()
+    got = s.collect(4)
+    for g, r in zip(got, ref):
+        assert (g.total_iters, g.total_ls_trials, g.n_converged, g.best_cost, g.best_index) == r[:5]
+    assert [g.kernel_ms > 0 for g in got] == [True, False, True, False]
+    assert np.array_equal(s.iterations, ref[3][5]) and np.array_equal(s.cost, ref[3][6])    # fields: the latest slot
+    s.set_timing(1)
+    # a launch that reuses the current slot settles what is owed first
+    s.rearm(cold=True); s.solve_resident_async()                  # cold
+    s.solve_resident_async()                                      # warm
+    s.stage_backward()
+    got = s.collect(2)
+    assert (got[0].total_iters, got[0].best_cost) == (ref[0][0], ref[0][3])
+    assert (got[1].total_iters, got[1].best_cost) == (ref[1][0], ref[1][3])
+    assert all(g.kernel_ms > 0 for g in got)
+    # more than the ring holds without collecting: the newest 32 are still right
+    for i in range(40):
+        if i % 2 == 0:
+            s.rearm(cold=True)
+        s.solve_resident_async()
+    got = s.collect(32)
+    assert [g.total_iters for g in got] == [ref[0][0] if i % 2 == 0 else ref[1][0] for i in range(8, 40)]
+    with pytest.raises(MiIlqrError):
+        s.set_timing(-1)
