@@ -26,11 +26,11 @@ I_ITERS, I_STATUS, I_LS_TRIALS, I_KP_COUNT, I_KP_LIST = 100, 101, 102, 103, 104
 
 EXPORTS = [
     "mi_ilqr_abi_version", "mi_ilqr_strerror", "mi_ilqr_model_info", "mi_ilqr_create", "mi_ilqr_destroy",
-    "mi_ilqr_set_cost", "mi_ilqr_set_initial", "mi_ilqr_reset", "mi_ilqr_rearm_initial_guess",
+    "mi_ilqr_set_cost", "mi_ilqr_set_initial", "mi_ilqr_set_initial_shared", "mi_ilqr_host_alloc", "mi_ilqr_host_free", "mi_ilqr_reset", "mi_ilqr_rearm_initial_guess",
     "mi_ilqr_solve", "mi_ilqr_solve_async", "mi_ilqr_collect_stats", "mi_ilqr_collect_stats_n",
     "mi_ilqr_rollout", "mi_ilqr_forward", "mi_ilqr_linearize", "mi_ilqr_backward", "mi_ilqr_mpc_shift",
     "mi_ilqr_mpc_run", "mi_ilqr_get_mpc_log",
-    "mi_ilqr_get", "mi_ilqr_get_int", "mi_ilqr_set", "mi_ilqr_device_ptr", "mi_ilqr_get_stream",
+    "mi_ilqr_get", "mi_ilqr_get_int", "mi_ilqr_get_async", "mi_ilqr_set", "mi_ilqr_device_ptr", "mi_ilqr_get_stream",
     "mi_ilqr_synchronize", "mi_ilqr_last_kernel_ms", "mi_ilqr_set_timing", "mi_ilqr_get_cycles", "mi_ilqr_bytes_per_iteration", "mi_ilqr_lds_bytes",
     "mi_ilqr_comm_unique_id", "mi_ilqr_comm_create", "mi_ilqr_comm_destroy", "mi_ilqr_allreduce_min",
     "mi_ilqr_allreduce_min_start", "mi_ilqr_allreduce_min_wait",
@@ -92,11 +92,15 @@ def load():
     lib.mi_ilqr_collect_stats_n.argtypes = [H, C.c_int32, C.POINTER(Stats)]
     lib.mi_ilqr_rollout.argtypes = [H, C.c_void_p]
     lib.mi_ilqr_forward.argtypes = [H, C.c_void_p]
+    lib.mi_ilqr_set_initial_shared.argtypes = [H, C.c_void_p, C.c_void_p]
+    lib.mi_ilqr_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
+    lib.mi_ilqr_host_free.argtypes = [C.c_void_p]
     lib.mi_ilqr_mpc_shift.argtypes = [H, C.c_int32]
     lib.mi_ilqr_mpc_run.argtypes = [H, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(Stats)]
     lib.mi_ilqr_get_mpc_log.argtypes = [H, C.c_void_p, C.c_size_t]
     lib.mi_ilqr_get.argtypes = [H, C.c_int, C.c_void_p, C.c_size_t]
     lib.mi_ilqr_get_int.argtypes = [H, C.c_int, C.c_void_p, C.c_size_t]
+    lib.mi_ilqr_get_async.argtypes = [H, C.c_int, C.c_void_p, C.c_size_t]
     lib.mi_ilqr_set.argtypes = [H, C.c_int, C.c_void_p, C.c_size_t]
     lib.mi_ilqr_device_ptr.argtypes = [H, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     lib.mi_ilqr_get_stream.argtypes = [H, C.POINTER(C.c_void_p)]

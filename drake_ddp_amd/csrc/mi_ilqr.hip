@@ -10,6 +10,7 @@
 
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -57,6 +58,10 @@ struct mi_ilqr {
   int32_t *iters_ring = nullptr, *status_ring = nullptr, *ls_ring = nullptr;
   long long stats_done = 0;      // solves with sequence number < stats_done have their DevStats record
   bool in_async_solve = false;
+  double* u_one = nullptr;         // device copy of a shared (m, N-1) initial guess
+  char* pin_in = nullptr;          // page-locked staging ring of small host -> device inputs (stage_h2d)
+  size_t pin_off = 0;
+  hipEvent_t pin_ev = nullptr;
   long long* prof = nullptr;
   int32_t* done_counter = nullptr;   // wave-per-problem kernels: tickets of the in-kernel statistics epilogue
   DevStats* h_stats = nullptr;   // pinned host memory, device-mapped
@@ -484,6 +489,20 @@ int relayout(mi_ilqr* h, const double* src, double* dst, int rows, int len, bool
   return MI_ILQR_OK;
 }
 
+// One control sequence (m, len), time last, written for every problem in the handle's layout:
+// layout 0 = [b][k][t] (wave-per-problem), 1 = [b][t][k] (workgroup-per-problem), 2 = [t][k][b] (lane-per-problem).
+__global__ void __launch_bounds__(256) broadcast_u_kernel(const double* __restrict__ src, double* __restrict__ dst,
+                                                            int B, int m, int len, int layout) {
+  const size_t total = (size_t)B * m * len;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    int k, t;
+    if (layout == 0) { const size_t r = e % ((size_t)m * len); k = (int)(r / len); t = (int)(r - (size_t)k * len); }
+    else if (layout == 1) { const size_t r = e % ((size_t)m * len); t = (int)(r / m); k = (int)(r - (size_t)t * m); }
+    else { const size_t r = e / B; t = (int)(r / m); k = (int)(r - (size_t)t * m); }
+    dst[e] = src[(size_t)k * len + t];
+  }
+}
+
 // rows of the (rows,len) time-last view of a double field; 0 = not a trajectory array
 int traj_rows(const mi_ilqr* h, int which, int* len) {
   const int n = h->n, m = h->m, N = h->N;
@@ -550,6 +569,34 @@ int reduce_pending_stats(mi_ilqr* h) {
     HIPCHK(hipGetLastError());
   }
   h->stats_done = h->seq;
+  return MI_ILQR_OK;
+}
+
+// Host -> device copy of a caller's (pageable) buffer, ordered on the handle's stream.  Small inputs go through
+// the handle's page-locked staging block and an ASYNCHRONOUS copy: the call returns after a host memcpy, the
+// kernels that follow on the stream see the data (a blocking hipMemcpy costs ~15-20 us each whatever its size).
+// Large ones keep the runtime's own pipelined staging.
+int stage_h2d(mi_ilqr* h, void* dst, const void* src, size_t bytes) {
+  constexpr size_t kSmall = 256 * 1024;
+  if (bytes > kSmall) {
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return MI_ILQR_OK;
+  }
+  if (!h->pin_in) {
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h->pin_in), 4 * kSmall, hipHostMallocDefault));
+    HIPCHK(hipEventCreateWithFlags(&h->pin_ev, hipEventDisableTiming));
+    h->pin_off = 0;
+  }
+  if (h->pin_off + bytes > 4 * kSmall) {          // the block is used as a ring; wrap once the copies in flight are done
+    HIPCHK(hipEventSynchronize(h->pin_ev));
+    h->pin_off = 0;
+  }
+  char* stage = h->pin_in + h->pin_off;
+  std::memcpy(stage, src, bytes);
+  HIPCHK(hipMemcpyAsync(dst, stage, bytes, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipEventRecord(h->pin_ev, h->stream));
+  h->pin_off += (bytes + 255) & ~(size_t)255;
   return MI_ILQR_OK;
 }
 
@@ -773,6 +820,9 @@ void mi_ilqr_destroy(mi_ilqr_t* h) {
     if (h->ring_ev0[i]) (void)hipEventDestroy(h->ring_ev0[i]);
     if (h->ring_ev1[i]) (void)hipEventDestroy(h->ring_ev1[i]);
   }
+  if (h->u_one) (void)hipFree(h->u_one);
+  if (h->pin_in) (void)hipHostFree(h->pin_in);
+  if (h->pin_ev) (void)hipEventDestroy(h->pin_ev);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -819,35 +869,66 @@ int mi_ilqr_set_cost(mi_ilqr_t* h, const double* Q, const double* R, const doubl
                          is_sym_psd(cm.data() + n * n, (int)m, true);
     if (!regular && h->large) return MI_ILQR_E_UNSUPPORTED;
     h->exact_backward = regular ? 0 : 1;
+    // the device copy mirrors h_costmat: nothing to send when the caller repeats the matrices it set before
+    // (Solve() pushes them on every call, like the reference reads its attributes on every call)
+    if (std::memcmp(cm.data(), h->h_costmat.data(), cm.size() * 8) == 0) return MI_ILQR_OK;
     h->h_costmat.swap(cm);
   }
-  HIPCHK(hipStreamSynchronize(h->stream));
-  if (Q) HIPCHK(hipMemcpy(h->costmat, Q, n * n * 8, hipMemcpyHostToDevice));
-  if (R) HIPCHK(hipMemcpy(h->costmat + n * n, R, m * m * 8, hipMemcpyHostToDevice));
-  if (Qf) HIPCHK(hipMemcpy(h->costmat + n * n + m * m, Qf, n * n * 8, hipMemcpyHostToDevice));
-  if (x_nom) HIPCHK(hipMemcpy(h->costmat + 2 * n * n + m * m, x_nom, n * 8, hipMemcpyHostToDevice));
-  return MI_ILQR_OK;
+  return stage_h2d(h, h->costmat, h->h_costmat.data(), h->h_costmat.size() * 8);    // Q | R | Qf | x_nom: one copy
 }
 
 int mi_ilqr_set_initial(mi_ilqr_t* h, const double* x0, const double* u_guess) {
   if (!h) return MI_ILQR_E_BAD_ARG;
   HIPCHK(hipSetDevice(h->d.device_id));
-  HIPCHK(hipStreamSynchronize(h->stream));
-  if (x0) HIPCHK(hipMemcpy(h->x0, x0, (size_t)h->B * h->n * 8, hipMemcpyHostToDevice));
+  if (x0) { const int rc = stage_h2d(h, h->x0, x0, (size_t)h->B * h->n * 8); if (rc != MI_ILQR_OK) return rc; }
   if (u_guess) {
     const size_t cnt = (size_t)h->B * h->m * (h->N - 1);
     if ((h->large || h->batch_minor) && (h->m > 1 || h->batch_minor)) {
       int rc = ensure_scratch(h, cnt * 8);
       if (rc != MI_ILQR_OK) return rc;
+      HIPCHK(hipStreamSynchronize(h->stream));
       HIPCHK(hipMemcpy(h->scratch, u_guess, cnt * 8, hipMemcpyHostToDevice));
       if ((rc = relayout(h, h->scratch, h->u_guess, h->m, h->N - 1, true)) != MI_ILQR_OK) return rc;
       HIPCHK(hipStreamSynchronize(h->stream));
     } else {
-      HIPCHK(hipMemcpy(h->u_guess, u_guess, cnt * 8, hipMemcpyHostToDevice));
+      const int rc = stage_h2d(h, h->u_guess, u_guess, cnt * 8);
+      if (rc != MI_ILQR_OK) return rc;
     }
     h->u_pending = true;
     h->u_zero = false;
   }
+  return MI_ILQR_OK;
+}
+
+int mi_ilqr_set_initial_shared(mi_ilqr_t* h, const double* x0, const double* u_guess_one) {
+  if (!h) return MI_ILQR_E_BAD_ARG;
+  HIPCHK(hipSetDevice(h->d.device_id));
+  if (x0) { const int rc = stage_h2d(h, h->x0, x0, (size_t)h->B * h->n * 8); if (rc != MI_ILQR_OK) return rc; }
+  if (u_guess_one) {
+    const size_t one = (size_t)h->m * (h->N - 1);
+    if (!h->u_one) HIPCHK(hipMalloc(reinterpret_cast<void**>(&h->u_one), one * 8));
+    int rc = stage_h2d(h, h->u_one, u_guess_one, one * 8);
+    if (rc != MI_ILQR_OK) return rc;
+    const int layout = h->batch_minor ? 2 : (h->large ? 1 : 0);
+    const size_t total = one * h->B;
+    const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(broadcast_u_kernel, dim3(blocks), dim3(256), 0, h->stream, h->u_one, h->u_guess, h->B, h->m, h->N - 1, layout);
+    HIPCHK(hipGetLastError());
+    h->u_pending = true;
+    h->u_zero = false;
+  }
+  return MI_ILQR_OK;
+}
+
+int mi_ilqr_host_alloc(size_t bytes, void** out) {
+  if (!out || bytes == 0) return MI_ILQR_E_BAD_ARG;
+  *out = nullptr;
+  HIPCHK(hipHostMalloc(out, bytes, hipHostMallocDefault));
+  return MI_ILQR_OK;
+}
+
+int mi_ilqr_host_free(void* p) {
+  if (p) HIPCHK(hipHostFree(p));
   return MI_ILQR_OK;
 }
 
@@ -1051,6 +1132,7 @@ int mi_ilqr_mpc_run(mi_ilqr_t* h, int32_t num_resolves, int32_t replan_steps, co
     HIPCHK(hipMemcpy(xn.data(), h->costmat + 2 * (size_t)h->n * h->n + (size_t)h->m * h->m, h->n * 8, hipMemcpyDeviceToHost));
     for (int i = 0; i < h->n; ++i) xn[i] += num_resolves * target_step[i];
     HIPCHK(hipMemcpy(h->costmat + 2 * (size_t)h->n * h->n + (size_t)h->m * h->m, xn.data(), h->n * 8, hipMemcpyHostToDevice));
+    std::memcpy(h->h_costmat.data() + 2 * (size_t)h->n * h->n + (size_t)h->m * h->m, xn.data(), h->n * 8);   // (the host mirror too)
   }
   if (stats) return mi_ilqr_collect_stats(h, stats);
   return mi_ilqr_synchronize(h);
@@ -1086,6 +1168,25 @@ int mi_ilqr_get(mi_ilqr_t* h, int which, double* dst, size_t bytes) {
     return MI_ILQR_OK;
   }
   HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+  return MI_ILQR_OK;
+}
+
+int mi_ilqr_get_async(mi_ilqr_t* h, int which, void* dst, size_t bytes) {
+  if (!h || !dst) return MI_ILQR_E_BAD_ARG;
+  Field f = field_of(h, which);
+  if (!f.ptr) return MI_ILQR_E_BAD_ARG;
+  if (bytes != f.bytes) return MI_ILQR_E_BAD_SHAPE;
+  HIPCHK(hipSetDevice(h->d.device_id));
+  if (!f.is_int) {
+    int len = 0;
+    const int rows = (h->large || h->batch_minor) ? traj_rows(h, which, &len) : 0;
+    // fields that need a layout conversion (or are known-zero) take the blocking path
+    if (rows > 1 || (h->batch_minor && rows == 1) || (h->cold && is_state_field(which)) ||
+        (which == MI_F_U_BAR && h->u_zero && !h->u_pending))
+      return mi_ilqr_get(h, which, static_cast<double*>(dst), bytes);
+  }
+  const void* src = (!f.is_int && h->u_pending && which == MI_F_U_BAR) ? h->u_guess : f.ptr;
+  HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
   return MI_ILQR_OK;
 }
 

@@ -10,6 +10,7 @@ boundary.  ``BatchedIterativeLQR`` is the same surface with a leading batch axis
 """
 import ctypes as C
 import time
+import weakref
 
 import numpy as np
 
@@ -36,7 +37,7 @@ class BatchedIterativeLQR:
 
     def __init__(self, system, num_timesteps, batch, input_port_index=0, delta=1e-2, beta=0.95, gamma=0.0,
                  derivs_keypoint_method=None, jacobian_mode="fd", fd_step=1e-5, device=0,
-                 max_iters=1000, hist_cap=64, kernel_mode="auto"):
+                 max_iters=1000, hist_cap=64, kernel_mode="auto", pinned_results=False):
         assert isinstance(system, ModelSystem), \
             "system must be a drake_ddp_amd.models.ModelSystem (Drake systems cannot run on the GPU)"
         assert system.IsDifferenceEquationSystem()[0], "must be a discrete-time system"   # ilqr.py:37
@@ -74,6 +75,10 @@ class BatchedIterativeLQR:
         h = C.c_void_p()
         _capi.check(self._lib.mi_ilqr_create(C.byref(d), C.byref(h)), "mi_ilqr_create")
         self._h = h
+        # pinned_results=True: the arrays the state attributes / Solve() return are views of page-locked
+        # buffers the solver owns (direct DMA, no page faults of freshly allocated arrays) - one buffer per
+        # attribute, REUSED by the next read of that attribute; copy what must outlive it.  Default: fresh arrays.
+        self._pinned = {} if pinned_results else None
         # reference defaults (ilqr.py:61-67); NOTE x_nom is undefined until SetTargetState (F12)
         self.x0 = np.zeros((self.B, self.n))
         self.Q, self.R, self.Qf = np.eye(self.n), np.eye(self.m), np.eye(self.n)
@@ -121,19 +126,47 @@ class BatchedIterativeLQR:
         x0 = np.broadcast_to(np.asarray(self.x0, dtype=np.float64).reshape(-1, self.n), (self.B, self.n))
         x0 = np.ascontiguousarray(x0)
         ug = None
+        shared = False
         if self._u_guess is not None:
-            ug = np.ascontiguousarray(np.broadcast_to(np.asarray(self._u_guess, dtype=np.float64),
-                                                      (self.B, self.m, self.N - 1)))
+            ug = np.asarray(self._u_guess, dtype=np.float64)
+            # one sequence for the whole batch - (m,N-1) or (1,m,N-1), the reference's own argument - crosses the
+            # bus once; the device writes the batch's copies
+            shared = ug.size == self.m * (self.N - 1)
+            if shared:
+                ug = np.ascontiguousarray(ug.reshape(self.m, self.N - 1))
+            else:
+                ug = np.ascontiguousarray(np.broadcast_to(ug, (self.B, self.m, self.N - 1)))
             self._u_guess = None       # u_bar is rebound by the forward pass (ilqr.py:375)
-        _capi.check(self._lib.mi_ilqr_set_initial(self._h, _capi.ptr(x0), _capi.ptr(ug)), "mi_ilqr_set_initial")
+        if shared:
+            _capi.check(self._lib.mi_ilqr_set_initial_shared(self._h, _capi.ptr(x0), _capi.ptr(ug)), "mi_ilqr_set_initial_shared")
+        else:
+            _capi.check(self._lib.mi_ilqr_set_initial(self._h, _capi.ptr(x0), _capi.ptr(ug)), "mi_ilqr_set_initial")
+
+    def _out(self, which, shape, dtype):
+        """Destination of a field read: a fresh array, or (pinned_results) the solver's page-locked buffer for it."""
+        if self._pinned is None:
+            return np.empty(shape, dtype=dtype)
+        key = (which, tuple(shape))
+        arr = self._pinned.get(key)
+        if arr is None:
+            nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+            raw = C.c_void_p()
+            _capi.check(self._lib.mi_ilqr_host_alloc(max(nbytes, 8), C.byref(raw)), "mi_ilqr_host_alloc")
+            buf = (C.c_char * max(nbytes, 8)).from_address(raw.value)
+            root = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape)))
+            # the block lives as long as any view of it does (the solver's own, or one a caller kept)
+            weakref.finalize(root, self._lib.mi_ilqr_host_free, raw).atexit = False
+            arr = root.reshape(shape)
+            self._pinned[key] = arr
+        return arr
 
     def _get(self, which, shape):
-        out = np.empty(shape, dtype=np.float64)
+        out = self._out(which, shape, np.float64)
         _capi.check(self._lib.mi_ilqr_get(self._h, which, _capi.ptr(out), out.nbytes), "mi_ilqr_get")
         return out
 
     def _get_int(self, which, shape):
-        out = np.empty(shape, dtype=np.int32)
+        out = self._out(which, shape, np.int32)
         _capi.check(self._lib.mi_ilqr_get_int(self._h, which, _capi.ptr(out), out.nbytes), "mi_ilqr_get_int")
         return out
 
@@ -196,6 +229,19 @@ class BatchedIterativeLQR:
     def Solve(self):
         st = time.time()
         self._push_problem()
+        if self._pinned is not None:
+            # page-locked result buffers: the solve and the three copy-outs are enqueued on the handle's stream,
+            # ONE synchronization (in collect) covers them all
+            _capi.check(self._lib.mi_ilqr_solve_async(self._h), "mi_ilqr_solve_async")
+            res = []
+            for which, shape in ((_capi.F_X_BAR, (self.B, self.n, self.N)), (_capi.F_U_BAR, (self.B, self.m, self.N - 1)),
+                                 (_capi.F_COST, (self.B,))):
+                out = self._out(which, shape, np.float64)
+                _capi.check(self._lib.mi_ilqr_get_async(self._h, which, _capi.ptr(out), out.nbytes), "mi_ilqr_get_async")
+                res.append(out)
+            self.collect(1)
+            self.solve_wall_s = time.time() - st
+            return res[0], res[1], self.solve_wall_s, res[2]
         stats = _capi.Stats()
         _capi.check(self._lib.mi_ilqr_solve(self._h, C.byref(stats)), "mi_ilqr_solve")
         self.stats = stats

@@ -161,6 +161,17 @@ int mi_ilqr_set_cost(mi_ilqr_t* h, const double* Q, const double* R, const doubl
  * u_guess becomes u_bar (the reference aliases it, ilqr.py:156).  NULL = keep. */
 int mi_ilqr_set_initial(mi_ilqr_t* h, const double* x0, const double* u_guess);
 
+/* The same with ONE control sequence u_guess_one (m,N-1) for every problem of the batch - the argument the
+ * reference's SetInitialGuess takes (ilqr.py:148-156): m(N-1) doubles cross the bus instead of B*m*(N-1), the
+ * device writes the batch's copies. */
+int mi_ilqr_set_initial_shared(mi_ilqr_t* h, const double* x0, const double* u_guess_one);
+
+/* Page-locked host memory for the buffers a caller hands to mi_ilqr_set / _get / _set_initial: the copies then
+ * run as direct DMA (~55 GB/s over PCIe 5 x16) instead of through the runtime's staging of pageable memory.
+ * Needs a usable device; independent of any handle. */
+int mi_ilqr_host_alloc(size_t bytes, void** out);
+int mi_ilqr_host_free(void* p);
+
 /* Zero the persistent solver state (x_bar,u_bar,K,kappa,dV,fx,fu) = a freshly constructed
  * reference object (ilqr.py:70-83): a solve after it without mi_ilqr_set_initial(u_guess) /
  * mi_ilqr_rearm_initial_guess starts from u_bar = 0.  Without it the state persists across solves (F10). */
@@ -218,6 +229,12 @@ int mi_ilqr_get_mpc_log(mi_ilqr_t* h, double* dst, size_t bytes);
 int mi_ilqr_get(mi_ilqr_t* h, int which, double* dst, size_t bytes);
 int mi_ilqr_get_int(mi_ilqr_t* h, int which, int32_t* dst, size_t bytes);
 int mi_ilqr_set(mi_ilqr_t* h, int which, const double* src, size_t bytes);
+
+/* Enqueue the copy-out of a field (double or int32) on the handle's stream and return: `dst` is defined after
+ * the next mi_ilqr_synchronize / _collect_stats.  Meant for page-locked destinations (mi_ilqr_host_alloc): several
+ * results of a solve then cost one synchronization instead of one each.  Fields that need a layout conversion
+ * (the n = 36 and lane-per-problem kernels' trajectory arrays) are copied before the call returns, like mi_ilqr_get. */
+int mi_ilqr_get_async(mi_ilqr_t* h, int which, void* dst, size_t bytes);
 
 /* Raw device pointer of a double field (for zero-copy consumers, e.g. a torch tensor
  * view feeding the RCCL best-cost reduction), and the handle's stream.  The per-problem result scalars

