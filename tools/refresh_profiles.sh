@@ -33,6 +33,8 @@ json.dump({"FETCH_SIZE_KB_per_launch": out["FETCH_SIZE"], "WRITE_SIZE_KB_per_lau
            "hbm_bytes_per_launch_corrected": (2 * out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024,
            "hbm_bytes_per_launch_uncorrected": (out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024}, open("$OUT/${TAG}_pmc_raw.json", "w"), indent=1)
 PY
+python tools/pmc_issue.py ${TAG} > $OUT/${TAG}_pmc_issue.log 2>&1
+python tools/warm_sweep.py 2>/dev/null | grep events > $OUT/${TAG}_c2_clock_ramp.txt
 tail -1 $OUT/${TAG}_bench_c2.json | cut -c1-200
 head -3 $OUT/${TAG}_bench_c2_kernel_stats.csv
 cat $OUT/${TAG}_pmc_raw.json
