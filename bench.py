@@ -333,6 +333,39 @@ def boundary_inclusive(prob, x0, dev_index, reps=5):
     return out
 
 
+def concurrent_batches(prob, x0, dev_index, handles=(2, 4), groups=12, per_group=20):
+    """Independent C2 batches in flight at once: `h` solver handles (each with its own stream and its own
+    1024 problems), every one pipelining cold-start solves like the headline does.  A single batch of 1024 leaves
+    half of the SIMD-time idle (its launch lasts as long as its slowest problem); a second, independent batch
+    fills it - what a server with several clients sees.  Reported beside the headline, never `value`: the
+    headline's step is ONE batch at a time."""
+    B, N = len(x0), prob["N"]
+    out = []
+    for h in handles:
+        ss = []
+        for _ in range(h):
+            s = make_solver(prob, B, dev_index)
+            s.SetInitialState(x0)
+            s.SetInitialGuess(np.zeros((1, N - 1)))
+            s._push_problem()
+            s.set_timing(0)
+            ss.append(s)
+        best = None
+        for g in range(groups):
+            t0 = time.perf_counter()
+            for _ in range(per_group):
+                for s in ss:
+                    s.rearm(cold=True)
+                    s.solve_resident_async()
+            it = sum(st.total_iters for s in ss for st in s.collect(per_group))
+            dt = time.perf_counter() - t0
+            if g >= groups // 2:                 # the first groups bring the clock up
+                best = max(best or 0.0, it / dt)
+        out.append({"handles": h, "batch_per_handle": B, "iterations_per_s": best})
+        del ss
+    return {"workload": "C2, independent batches of 1024 on their own streams, pipelined cold-start solves", "runs": out}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -385,11 +418,13 @@ def main():
     cpu_base = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_base = cpu_baseline(prob, x0_all, min(args.cpu_sample, B))
-    configs = boundary = None
+    configs = boundary = concurrent = None
     if not args.no_configs and not os.environ.get("MI_BENCH_NESTED"):
         configs = all_configs(rk, dev_index)
         if rank == 0:
             boundary = boundary_inclusive(prob, x0, dev_index)
+            if world == 1:
+                concurrent = concurrent_batches(prob, x0, dev_index)
         rk.fence()
 
     s = make_solver(prob, B, dev_index)
@@ -507,6 +542,7 @@ def main():
                         "reaches its sustained level), the W warm-up steps, the K timed steps")
         out["configs"] = configs
         out["boundary_inclusive"] = boundary
+        out["concurrent_batches"] = concurrent
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

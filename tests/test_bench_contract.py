@@ -72,3 +72,7 @@ def test_bench_line_carries_every_config_and_the_boundary():
     assert d["configs"][3]["backward_fp64_TFLOPs_per_gpu"] > 0
     b = d["boundary_inclusive"]
     assert b["ms_per_solve"] > d["ms_per_step"] and b["bytes_out"] > b["bytes_in"]
+    assert b["pinned_results_shared_guess"]["ms_per_solve"] > d["ms_per_step"] and b["pinned_results_shared_guess"]["bytes_in"] < b["bytes_in"]
+    assert d["clock_ramp_steps"] >= 0 and "order" in d and "kernel_ms_source" in rf
+    cb = d["concurrent_batches"]["runs"]
+    assert [r_["handles"] for r_ in cb] == [2, 4] and all(r_["iterations_per_s"] > 0.8 * d["value"] for r_ in cb)
