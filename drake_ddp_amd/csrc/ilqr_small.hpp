@@ -717,27 +717,62 @@ __device__ inline int rollout_newton_impl(const WS& w, const Consts<M>& c, const
 #ifdef MI_PROF_NEWTON
   const long long pn0 = clock64(); int nsw = 0;
 #endif
+  // The sweeps work on the CORRECTION d_t = x_t(new) - X_t:  d_{t+1} = G_t d_t + r_t,  r_t = g_t(X_t) - X_{t+1},
+  // d_0 = 0 - the same linearized recurrence as x_{t+1} = g_t(X_t) + G_t (x_t - X_t), with the defect r_t of the
+  // current guess as its offset.  In this form a sweep can REUSE the Jacobians of the sweep before it (a chord
+  // step): once a full sweep has moved the guess by less than kFrozenTol, the next one evaluates the plain fp64
+  // step instead of the Dual2 one - the guess is already so close that G at the previous guess is G at the
+  // solution to ~1e-4, and the correction it computes (the defect ~c u^2 of the last full sweep, u its update)
+  // is left with an error ~2c u * c u^2: 6e-14 at the u = 3.5e-4 typical of C2's third sweep, where a full sweep
+  // leaves 3e-19 - both far below the 1e-11 the chunk-edge guard accepts, and the final pass re-steps every
+  // chunk exactly either way.  A chord sweep that does not converge is followed by a full one.
+  constexpr double kFrozenTol = 5e-4;
+  double Gs[CH][n][n];                                       // closed-loop Jacobians of the last full sweep
+  double prev_upd = __builtin_inf();
+  bool have_g = false, last_frozen = false;
   for (int sweep = 0; sweep < kMaxSweeps && !converged; ++sweep) {
 #ifdef MI_PROF_NEWTON
     ++nsw;
 #endif
+    const bool frozen = have_g && !last_frozen && prev_upd < kFrozenTol;      // wave-uniform
+    // X_{t+1} of this lane's last step = the next lane's first guess
+    const double nx0 = dpp_f64_or_zero<0x130, 0xF>(X[0][0]), nx1 = dpp_f64_or_zero<0x130, 0xF>(X[0][1]);   // wave_shl:1
     Aff2 loc[CH], agg;
     agg.G[0][0] = 1.0; agg.G[0][1] = 0.0; agg.G[1][0] = 0.0; agg.G[1][1] = 1.0; agg.c[0] = 0.0; agg.c[1] = 0.0;
+    if (!frozen) {
+#pragma unroll
+      for (int k = 0; k < CH; ++k) {
+        // g_t and G_t at the current guess: one Dual2 evaluation of the closed-loop step
+        Dual2 xd[n] = {Dual2(X[k][0], 1.0, 0.0), Dual2(X[k][1], 0.0, 1.0)};
+        Dual2 ud[m] = {dd[k] - (Kk[k][0] * (xd[0] - xb[k][0]) + Kk[k][1] * (xd[1] - xb[k][1]))};
+        Dual2 xn[n];
+        M::template step<Dual2>(xd, ud, xn, a.params, a.dt);
+#pragma unroll
+        for (int i = 0; i < n; ++i) {
+          // (steps past the horizon evaluate record 0's data: their maps only enter the prefixes of later
+          // lanes, which hold no valid step - nothing forces them to the identity)
+          Gs[k][i][0] = xn[i].d0; Gs[k][i][1] = xn[i].d1;
+          const double nxt = (k + 1 < CH) ? X[(k + 1 < CH) ? k + 1 : k][i] : (i == 0 ? nx0 : nx1);
+          loc[k].c[i] = xn[i].v - nxt;                           // the defect of the guess at this step
+        }
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < CH; ++k) {
+        double u[m] = {dd[k] - (Kk[k][0] * (X[k][0] - xb[k][0]) + Kk[k][1] * (X[k][1] - xb[k][1]))};
+        double xn[n];
+        M::template step<double>(X[k], u, xn, a.params, a.dt);
+#pragma unroll
+        for (int i = 0; i < n; ++i) {
+          const double nxt = (k + 1 < CH) ? X[(k + 1 < CH) ? k + 1 : k][i] : (i == 0 ? nx0 : nx1);
+          loc[k].c[i] = xn[i] - nxt;
+        }
+      }
+    }
 #pragma unroll
     for (int k = 0; k < CH; ++k) {
-      // g_t and G_t at the current guess: one Dual2 evaluation of the closed-loop step
-      Dual2 xd[n] = {Dual2(X[k][0], 1.0, 0.0), Dual2(X[k][1], 0.0, 1.0)};
-      Dual2 ud[m] = {dd[k] - (Kk[k][0] * (xd[0] - xb[k][0]) + Kk[k][1] * (xd[1] - xb[k][1]))};
-      Dual2 xn[n];
-      M::template step<Dual2>(xd, ud, xn, a.params, a.dt);
 #pragma unroll
-      for (int i = 0; i < n; ++i) {
-        // (steps past the horizon evaluate record 0's data: their maps only enter the prefixes of later
-        // lanes, which hold no valid step - nothing forces them to the identity)
-        const double g0 = xn[i].d0, g1 = xn[i].d1;
-        loc[k].G[i][0] = g0; loc[k].G[i][1] = g1;
-        loc[k].c[i] = xn[i].v - (g0 * X[k][0] + g1 * X[k][1]);
-      }
+      for (int i = 0; i < n; ++i) { loc[k].G[i][0] = Gs[k][i][0]; loc[k].G[i][1] = Gs[k][i][1]; }
       Aff2 t_;
       aff2_compose(t_, loc[k], agg);
       agg = t_;
@@ -746,26 +781,21 @@ __device__ inline int rollout_newton_impl(const WS& w, const Consts<M>& c, const
     Aff2 P = agg;
     P.G[0][0] -= 1.0; P.G[1][1] -= 1.0;
     aff2_prefix_dpp(P);
-    // this lane's first state = the END state of the previous lane's prefix: P_{l-1}(x0)
-    double xs[n];
-    {
-      double ye[n];
+    // this lane's first correction = the END value of the previous lane's prefix applied to d_0 = 0: its offset
+    double ds[n];
 #pragma unroll
-      for (int i = 0; i < n; ++i) ye[i] = fma(P.G[i][0], x0r[0], fma(P.G[i][1], x0r[1], P.c[i] + x0r[i]));
-#pragma unroll
-      for (int i = 0; i < n; ++i) { const double yp = dpp_f64_or_zero<0x138, 0xF>(ye[i]); xs[i] = (lane == 0) ? x0r[i] : yp; }   // wave_shr:1
-    }
+    for (int i = 0; i < n; ++i) { const double yp = dpp_f64_or_zero<0x138, 0xF>(P.c[i]); ds[i] = (lane == 0) ? 0.0 : yp; }   // wave_shr:1
     double upd = 0.0;
 #pragma unroll
     for (int k = 0; k < CH; ++k) {
       if (valid[k]) {
-        upd = fmax(upd, fmax(fabs(xs[0] - X[k][0]), fabs(xs[1] - X[k][1])));
-        upd = (xs[0] == xs[0] && xs[1] == xs[1]) ? upd : __builtin_inf();      // NaN -> not converged
+        upd = fmax(upd, fmax(fabs(ds[0]), fabs(ds[1])));
+        upd = (ds[0] == ds[0] && ds[1] == ds[1]) ? upd : __builtin_inf();      // NaN -> not converged
       }
-      X[k][0] = xs[0]; X[k][1] = xs[1];
-      const double n0 = fma(loc[k].G[0][0], xs[0], fma(loc[k].G[0][1], xs[1], loc[k].c[0]));
-      const double n1 = fma(loc[k].G[1][0], xs[0], fma(loc[k].G[1][1], xs[1], loc[k].c[1]));
-      xs[0] = n0; xs[1] = n1;
+      X[k][0] += ds[0]; X[k][1] += ds[1];
+      const double n0 = fma(loc[k].G[0][0], ds[0], fma(loc[k].G[0][1], ds[1], loc[k].c[0]));
+      const double n1 = fma(loc[k].G[1][0], ds[0], fma(loc[k].G[1][1], ds[1], loc[k].c[1]));
+      ds[0] = n0; ds[1] = n1;
     }
     // wave-wide max of the update: DPP row rotations, then the four row maxima through v_readlane
     upd = fmax(upd, row_ror_f64<8>(upd));
@@ -773,7 +803,11 @@ __device__ inline int rollout_newton_impl(const WS& w, const Consts<M>& c, const
     upd = fmax(upd, row_ror_f64<2>(upd));
     upd = fmax(upd, row_ror_f64<1>(upd));
     upd = fmax(fmax(readlane_f64(upd, 0), readlane_f64(upd, 16)), fmax(readlane_f64(upd, 32), readlane_f64(upd, 48)));
+    have_g = true; last_frozen = frozen; prev_upd = upd;
     converged = upd < kTol;
+#ifdef MI_PROF_NEWTON
+    if (lane == 0 && sweep < 4) mi_dbg_vals[3 + sweep] = upd;
+#endif
   }
 #ifdef MI_PROF_NEWTON
   const long long pn1 = clock64();
@@ -2182,6 +2216,8 @@ __global__ void __launch_bounds__(256) ilqr_small_kernel(const KArgs a) {
         ic[2] = (double)(c3 - c2); ic[3] = (double)(c3 - c0);
 #ifdef MI_PROF_NEWTON
         hist[4 * it_this + 0] = (double)(c1 - c0); hist[4 * it_this + 1] = mi_dbg_vals[0]; hist[4 * it_this + 2] = mi_dbg_vals[1]; hist[4 * it_this + 3] = mi_dbg_vals[2];
+        ic[0] = mi_dbg_vals[3]; ic[1] = mi_dbg_vals[4]; ic[2] = mi_dbg_vals[5]; ic[3] = mi_dbg_vals[6];   // the sweeps' updates
+        mi_dbg_vals[3] = mi_dbg_vals[4] = mi_dbg_vals[5] = mi_dbg_vals[6] = 0.0;
 #endif
       }
       improvement = L - L_new;                                    // :706

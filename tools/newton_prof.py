@@ -16,4 +16,5 @@ s.Solve()
 h = s.history; it = s.iterations
 for b in sorted(set([0, B // 2, int(np.argmax(it))])):
     print("problem", b, "iters", it[b], "stage cycles", s.stage_cycles[b].tolist())
-    for i in range(it[b]): print("   it %d: linesearch %6.0f  newton sweeps %6.0f (n=%d)  final pass %5.0f" % (i, *h[b, i]), " ls trials so far", s.ls_trials[b])
+    ic = s.iteration_cycles
+    for i in range(it[b]): print("   it %d: linesearch %6.0f  newton sweeps %6.0f (n=%d)  final pass %5.0f" % (i, *h[b, i]), " sweep updates", " ".join("%.1e" % v for v in ic[b, i]))
