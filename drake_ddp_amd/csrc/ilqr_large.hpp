@@ -158,6 +158,14 @@ __device__ inline double large_rollout(const LView<M::n, M::m>& v, double* lds, 
   // is still being read: two workgroup barriers per step instead of three
   double* xs2 = lds + Ly::oXb;
   static_assert(Ly::oQc - Ly::oXb >= n, "second state buffer");
+  // x_t - x_nom is formed ONCE per step - by the fourth wave, idle while the other three form the control law -
+  // and published in the backward pass's idle T1 area: the 36 cost-row lanes used to form it themselves, 2 x 36
+  // LDS reads + 36 subtractions per step each, and their wave was the step's critical path (1981 of the synthetic
+  // chain's 2685 cycles per step, against 1065 for the dynamics wave); same operands, same bits.
+  double* dxc = lds + Ly::oT1;
+  static_assert(n <= 64 && n * Ly::TS >= 64, "an n-vector inside T1");
+  const bool drole = tid >= 192 && tid < 192 + n;
+  const double xnr = drole ? xnom[tid - 192] : 0.0;
   if (tid < n) { xs[tid] = x0g[tid]; v.Xn[tid] = x0g[tid]; }
   double acc = 0.0;                    // per-thread cost partial over all time steps
   bool bad = false;                    // this thread saw an infeasible step (models that can fail)
@@ -194,6 +202,7 @@ __device__ inline double large_rollout(const LView<M::n, M::m>& v, double* lds, 
       p = row16_sum(p);
       if (ul == 0) us[uk] = (f.ubk - eps * f.kpk) - p;
     }
+    if (drole) dxc[tid - 192] = xc[tid - 192] - xnr;
     if (t + 2 < N - 1) prefetch(f, t + 2);       // this set is free again
     lds_barrier();
     // dynamics (ilqr.py:316); cost rows on the other waves (:325)
@@ -256,8 +265,8 @@ __device__ inline double large_rollout(const LView<M::n, M::m>& v, double* lds, 
       const int i = tid - 64;
       double r = 0.0;
 #pragma unroll
-      for (int j = 0; j < n; ++j) r += qrow[j] * (xc[j] - xnom[j]);
-      acc += (xc[i] - xnom[i]) * r;
+      for (int j = 0; j < n; ++j) r += qrow[j] * dxc[j];
+      acc += dxc[i] * r;
     } else if (rrole) {
       const int k = tid - 128;
       double r = 0.0;
