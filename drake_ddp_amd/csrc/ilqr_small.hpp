@@ -788,15 +788,15 @@ __device__ inline int rollout_newton_impl(const WS& w, const Consts<M>& c, const
     double upd = 0.0;
 #pragma unroll
     for (int k = 0; k < CH; ++k) {
-      if (valid[k]) {
-        upd = fmax(upd, fmax(fabs(ds[0]), fabs(ds[1])));
-        upd = (ds[0] == ds[0] && ds[1] == ds[1]) ? upd : __builtin_inf();      // NaN -> not converged
-      }
+      if (valid[k]) upd = fmax(upd, fmax(fabs(ds[0]), fabs(ds[1])));
       X[k][0] += ds[0]; X[k][1] += ds[1];
       const double n0 = fma(loc[k].G[0][0], ds[0], fma(loc[k].G[0][1], ds[1], loc[k].c[0]));
       const double n1 = fma(loc[k].G[1][0], ds[0], fma(loc[k].G[1][1], ds[1], loc[k].c[1]));
       ds[0] = n0; ds[1] = n1;
     }
+    // NaN -> not converged: a NaN anywhere in this lane's corrections has travelled down the chain into the
+    // last one (v_max_f64 above drops NaN operands, so it is tested here, once)
+    if (valid[0]) upd = (ds[0] == ds[0] && ds[1] == ds[1]) ? upd : __builtin_inf();
     // wave-wide max of the update: DPP row rotations, then the four row maxima through v_readlane
     upd = fmax(upd, row_ror_f64<8>(upd));
     upd = fmax(upd, row_ror_f64<4>(upd));
@@ -1759,10 +1759,30 @@ __device__ inline bool backward_scan(const WS& w, const Consts<M>& c) {
     }
     r.u = g[Ly::UB];
   };
-  // branch-free: a step element, the terminal element (0, 0, 0, -lf_x, lf_xx; ilqr.py:203-204) or,
-  // past the horizon, the identity - selected field by field
+  // A step element, the terminal element (0, 0, 0, -lf_x, lf_xx; ilqr.py:203-204) or, past the horizon, the
+  // identity.  Wave-uniform fast path: when no lane that holds real elements is at (or past) the terminal one,
+  // every lane builds a plain step element - no selects (they were 28 v_cndmask per build, 4 builds per pass).
+  // Lanes whose whole chunk lies past the horizon build garbage there; their aggregate is reset to the identity
+  // after the local compositions (`pad_fix`).  Otherwise: field-by-field selects.
+  const bool all_pad = e0 >= N;
   auto element = [&](RicElem<n>& r, const Raw& q, int t) __attribute__((always_inline)) {
     const bool is_step = t < N - 1, is_term = t == N - 1;
+    if (!__any(!is_step && !all_pad)) {
+#pragma unroll
+      for (int i = 0; i < n; ++i) {
+        double s = -c.qn[i];
+#pragma unroll
+        for (int j = 0; j < n; ++j) {
+          s += Q2[i][j] * q.x[j];
+          r.A[i][j] = q.fx[i][j];
+          r.J[i][j] = Q2[i][j];
+          r.C[i][j] = (q.fu[i] * R2i) * q.fu[j];
+        }
+        r.e[i] = -s;
+        r.b[i] = -q.fu[i] * q.u;
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < n; ++i) {
       double s = -c.qn[i], sf = -c.qfn[i];
@@ -1777,6 +1797,18 @@ __device__ inline bool backward_scan(const WS& w, const Consts<M>& c) {
       }
       r.e[i] = is_step ? -s : (is_term ? -sf : 0.0);         // -lx_t | -lf_x
       r.b[i] = is_step ? -q.fu[i] * q.u : 0.0;               // -fu luu^{-1} lu = -fu u_bar
+    }
+  };
+  auto pad_fix = [&](RicElem<n>& r) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < n; ++i) {
+      r.b[i] = all_pad ? 0.0 : r.b[i]; r.e[i] = all_pad ? 0.0 : r.e[i];
+#pragma unroll
+      for (int j = 0; j < n; ++j) {
+        r.A[i][j] = all_pad ? ((i == j) ? 1.0 : 0.0) : r.A[i][j];
+        r.C[i][j] = all_pad ? 0.0 : r.C[i][j];
+        r.J[i][j] = all_pad ? 0.0 : r.J[i][j];
+      }
     }
   };
   RicElem<n> S, T, U;
@@ -1800,6 +1832,7 @@ __device__ inline bool backward_scan(const WS& w, const Consts<M>& c) {
       S = U;
     }
   }
+  pad_fix(S);
   // ---- (2) inclusive scan: S_l <- g_l (x) g_{l-1} (x) ... (x) g_0  (lane l-1 holds the LATER chunk).
   // Combining with the identity reproduces the left operand exactly, so lanes without a partner need
   // no select.  Four levels inside the 16-lane rows, then the row totals into the following rows.
