@@ -1767,7 +1767,9 @@ __device__ inline bool backward_scan(const WS& w, const Consts<M>& c) {
   const bool all_pad = e0 >= N;
   auto element = [&](RicElem<n>& r, const Raw& q, int t) __attribute__((always_inline)) {
     const bool is_step = t < N - 1, is_term = t == N - 1;
-    if (!__any(!is_step && !all_pad)) {
+    // (n = 2 only: the n = 3..4 scan lives at the edge of its 512 registers, where the extra branch costs more
+    // than the selects it saves - C4's pass 47 -> 66 k cycles when it was tried there)
+    if (n == 2 && !__any(!is_step && !all_pad)) {
 #pragma unroll
       for (int i = 0; i < n; ++i) {
         double s = -c.qn[i];
@@ -1832,7 +1834,7 @@ __device__ inline bool backward_scan(const WS& w, const Consts<M>& c) {
       S = U;
     }
   }
-  pad_fix(S);
+  if constexpr (n == 2) pad_fix(S);
   // ---- (2) inclusive scan: S_l <- g_l (x) g_{l-1} (x) ... (x) g_0  (lane l-1 holds the LATER chunk).
   // Combining with the identity reproduces the left operand exactly, so lanes without a partner need
   // no select.  Four levels inside the 16-lane rows, then the row totals into the following rows.
