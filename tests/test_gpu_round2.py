@@ -676,3 +676,35 @@ def test_shared_initial_guess_and_pinned_results(cfg):
     for r in res[1:]:
         for a, b in zip(res[0], r):
             assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
+def test_c_host_drives_the_library_through_the_header_alone(tmp_path):
+    """examples/c_host.c - C99, nothing but include/mi_ilqr.h - compiled with gcc against libmi_ilqr.so: the numbers
+    it prints (iterations, trials, status, cost, final angle of four pendulum swing-ups) are those of the Python
+    mirror on the same inputs, bit for bit (it prints 12 / 9 digits; compared at that precision)."""
+    import re, shutil, subprocess
+    from drake_ddp_amd import workloads as W
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc on this box")
+    exe = str(tmp_path / "c_host")
+    libdir = os.path.join(root, "drake_ddp_amd", "lib")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-O2", "-I" + os.path.join(root, "include"),
+                    os.path.join(root, "examples", "c_host.c"), "-L" + libdir, "-lmi_ilqr", "-Wl,-rpath," + libdir, "-lm", "-o", exe],
+                   check=True, capture_output=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rows = re.findall(r"problem (\d+): iterations (\d+) trials (\d+) status (\d+) cost (\S+) theta_N (\S+)", r.stdout)
+    assert len(rows) == 4
+    prob = W.pendulum_problem()
+    x0 = np.array([[0.3 * b - 0.4, 0.1 * b] for b in range(4)])
+    s = make_solver(prob, B=4, jac="fd", hist_cap=16)
+    s.SetInitialState(x0)
+    s.SetInitialGuess(np.zeros((1, prob["N"] - 1)))
+    x, u, _, L = s.Solve()
+    for b, (pb, it, tr, stt, cost, th) in enumerate(rows):
+        assert (int(pb), int(it), int(tr), int(stt)) == (b, int(s.iterations[b]), int(s.ls_trials[b]), int(s.status[b]))
+        assert cost == "%.12g" % L[b] and th == "%.9f" % x[b, 0, -1]
+    best = re.search(r"batch: (\d+) iterations, 4 converged, best cost (\S+) \(problem (\d+)\)", r.stdout)
+    assert int(best.group(1)) == int(s.iterations.sum()) and int(best.group(3)) == int(np.argmin(L))
