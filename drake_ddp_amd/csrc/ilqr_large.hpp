@@ -142,13 +142,16 @@ __device__ inline double large_rollout(const LView<M::n, M::m>& v, double* lds, 
   const double* xnom = lds + Ly::oXnom;
   const bool urole = tid < m * 16;
   const int uk = tid >> 4, ul = tid & 15;
-  const bool qrole = tid >= 64 && tid < 64 + n;      // cost row i = tid-64
+  const bool qrole = tid >= 64 && tid < 64 + n;      // cost row i = tid-64, first half of its dot product
+  const bool q2role = tid >= 192 && tid < 192 + n;   // cost row i = tid-192, second half (the fourth wave)
+  constexpr int nh = n / 2;
   const bool rrole = tid >= 128 && tid < 128 + m;    // control-cost row k = tid-128
   // cost rows -> registers (one-off)
   double qrow[n], rrow[m];
-  if (qrole) {
+  if (qrole || q2role) {
+    const int i = qrole ? tid - 64 : tid - 192;
 #pragma unroll
-    for (int j = 0; j < n; ++j) qrow[j] = lds[Ly::oQ + (tid - 64) * n + j];
+    for (int j = 0; j < n; ++j) qrow[j] = lds[Ly::oQ + i * n + j];
   }
   if (rrole) {
 #pragma unroll
@@ -261,11 +264,17 @@ __device__ inline double large_rollout(const LView<M::n, M::m>& v, double* lds, 
       }
     }
     if (dyn_done) {
-    } else if (qrole) {
+    } else if (qrole) {                                  // (x - x_nom)^T Q (x - x_nom): row i, columns 0..n/2-1
       const int i = tid - 64;
       double r = 0.0;
 #pragma unroll
-      for (int j = 0; j < n; ++j) r += qrow[j] * dxc[j];
+      for (int j = 0; j < nh; ++j) r += qrow[j] * dxc[j];
+      acc += dxc[i] * r;
+    } else if (q2role) {                                 // ... and columns n/2..n-1, on the wave that has nothing else to do here
+      const int i = tid - 192;
+      double r = 0.0;
+#pragma unroll
+      for (int j = nh; j < n; ++j) r += qrow[j] * dxc[j];
       acc += dxc[i] * r;
     } else if (rrole) {
       const int k = tid - 128;
