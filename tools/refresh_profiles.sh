@@ -35,6 +35,9 @@ json.dump({"FETCH_SIZE_KB_per_launch": out["FETCH_SIZE"], "WRITE_SIZE_KB_per_lau
 PY
 python tools/pmc_issue.py ${TAG} > $OUT/${TAG}_pmc_issue.log 2>&1
 python tools/warm_sweep.py 2>/dev/null | grep events > $OUT/${TAG}_c2_clock_ramp.txt
+( echo "# python tools/bsweep_modes.py on one MI355X ($TAG): C2 pendulum N=200 fp64 FD, cold-start solve, kernel time from HIP events of one"
+  echo "# blocking solve.  latency = wave-per-problem (time-parallel passes), throughput = lane-per-problem."
+  python tools/bsweep_modes.py 2>/dev/null | grep "B=" ) > $OUT/${TAG}_c2_modes_batch_sweep.txt
 tail -1 $OUT/${TAG}_bench_c2.json | cut -c1-200
 head -3 $OUT/${TAG}_bench_c2_kernel_stats.csv
 cat $OUT/${TAG}_pmc_raw.json
