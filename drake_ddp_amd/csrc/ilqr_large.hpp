@@ -115,6 +115,10 @@ struct CanFail { static constexpr bool value = false; };
 template <class M>
 struct CanFail<M, decltype((void)M::kCanFail)> { static constexpr bool value = M::kCanFail; };
 
+// Models whose rollout leaves lx_t, lu_t of the accepted trial in the backward pass's cost-gradient area.
+template <class M>
+constexpr bool kLxFromRollout = !IsChainModel<M>::value;
+
 __device__ __forceinline__ double block_sum(double v, double* red) {
   // deterministic fixed-order tree: 64-lane butterfly, then 4 wave partials
 #pragma unroll
@@ -169,6 +173,16 @@ __device__ inline double large_rollout(const LView<M::n, M::m>& v, double* lds, 
   static_assert(n <= 64 && n * Ly::TS >= 64, "an n-vector inside T1");
   const bool drole = tid >= 192 && tid < 192 + n;
   const double xnr = drole ? xnom[tid - 192] : 0.0;
+  // The cost rows have (Q (x_t - x_nom))_i and (R u_t)_k in hand: twice that IS lx_t / lu_t of the trial (symmetric
+  // Q, the only kind this kernel accepts), and the last trial rolled out is the accepted one - so the rows go
+  // straight to the backward pass's cost-gradient area and its prologue need not stage x_bar, u_bar and form the
+  // (N-1) x n x n product again (14 k cycles per pass).  The two halves of a row meet through a parity-indexed
+  // scratch pair one step later.  (Not for chain models: their linearization uses that area as a cache.)
+  constexpr bool kLx = kLxFromRollout<M>;
+  double* Lxu = lds + Ly::doubles;
+  double* r2buf = lds + Ly::oT1 + 64;                                  // [2][64]
+  static_assert(n * Ly::TS >= 192, "dx + two half-row scratch vectors inside T1");
+  double r1_prev = 0.0;
   if (tid < n) { xs[tid] = x0g[tid]; v.Xn[tid] = x0g[tid]; }
   double acc = 0.0;                    // per-thread cost partial over all time steps
   bool bad = false;                    // this thread saw an infeasible step (models that can fail)
@@ -270,18 +284,24 @@ __device__ inline double large_rollout(const LView<M::n, M::m>& v, double* lds, 
 #pragma unroll
       for (int j = 0; j < nh; ++j) r += qrow[j] * dxc[j];
       acc += dxc[i] * r;
+      if constexpr (kLx) {
+        if (t > 0) Lxu[(t - 1) * (n + m) + i] = 2.0 * (r1_prev + r2buf[((t - 1) & 1) * 64 + i]);
+        r1_prev = r;
+      }
     } else if (q2role) {                                 // ... and columns n/2..n-1, on the wave that has nothing else to do here
       const int i = tid - 192;
       double r = 0.0;
 #pragma unroll
       for (int j = nh; j < n; ++j) r += qrow[j] * dxc[j];
       acc += dxc[i] * r;
+      if constexpr (kLx) r2buf[(t & 1) * 64 + i] = r;
     } else if (rrole) {
       const int k = tid - 128;
       double r = 0.0;
 #pragma unroll
       for (int j = 0; j < m; ++j) r += rrow[j] * us[j];
       acc += us[k] * r;
+      if constexpr (kLx) Lxu[t * (n + m) + n + k] = 2.0 * r;
       v.Un[(size_t)t * m + k] = us[k];
     }
     lds_barrier();
@@ -295,6 +315,9 @@ __device__ inline double large_rollout(const LView<M::n, M::m>& v, double* lds, 
     if (t + 1 < N - 1) one_step(pfB, t + 1);
   }
   xs = xc;                             // final state x_{N-1}
+  if constexpr (kLx) {
+    if (qrole && N >= 2) Lxu[(N - 2) * (n + m) + (tid - 64)] = 2.0 * (r1_prev + r2buf[((N - 2) & 1) * 64 + (tid - 64)]);
+  }
   if (qrole) {                         // terminal cost (ilqr.py:327)
     const int i = tid - 64;
     const double* Qf = lds + Ly::oQf;
@@ -721,7 +744,7 @@ struct BackSubst {
 // read per 1-2 FMAs and is LDS-issue-bound at one wave per SIMD (tools/ubench/t1.hip: 4.5-10.7k
 // cycles for T1 alone vs ~2.1k here).
 template <class M>
-__device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, long long* bp_acc = nullptr) {
+__device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, long long* bp_acc = nullptr, bool lx_ready = false) {
   constexpr int n = M::n, m = M::m, nm = n + m;
   using Ly = LLay<n, m>;
   constexpr int TS = Ly::TS, VS = Ly::VS, FS = Ly::NMP, NP = Ly::NP;
@@ -774,7 +797,9 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
     double* Us_ = F;
     // the last row tile reads up to 15 rows past step N-2: they must stay inside the staging area
     const bool staged = (size_t)n * (N + 15) <= (size_t)(n + Ly::NMP) * TS && (size_t)m * (N - 1) <= (size_t)n * FS;
-    if (staged) {
+    if (lx_ready) {
+      // the rollout of the accepted trial left lx_t, lu_t here (large_rollout)
+    } else if (staged) {
       for (int e = tid; e < n * (N - 1); e += kLargeThreads) Xs_[e] = v.X[e];
       for (int e = tid; e < m * (N - 1); e += kLargeThreads) Us_[e] = v.U[e];
       __syncthreads();
@@ -1360,13 +1385,13 @@ __global__ void __launch_bounds__(kLargeThreads) ilqr_large_kernel(const KArgs a
       // profiling build only: 16 phase accumulators of thread 0 (a matrix-core wave) and of thread
       // 192 (the spare wave) land in the last 8 rows of the history buffer (tools/bp_prof.py)
       long long bpa[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-      if (MODE != MODE_FORWARD) { large_backward<M>(v, lds, bpa); __syncthreads(); }
+      if (MODE != MODE_FORWARD) { large_backward<M>(v, lds, bpa, kLxFromRollout<M>); __syncthreads(); }
       if ((tid == 0 || tid == 192) && iters == 0 && it_this == 0) {
         double* hp = a.hist + (size_t)b * a.hist_cap * 4 + 4 * (a.hist_cap - (tid == 0 ? 4 : 8));
         for (int q_ = 0; q_ < 16; ++q_) hp[q_] = (double)bpa[q_];
       }
 #else
-      if (MODE != MODE_FORWARD) { large_backward<M>(v, lds); __syncthreads(); }      // :697
+      if (MODE != MODE_FORWARD) { large_backward<M>(v, lds, nullptr, kLxFromRollout<M>); __syncthreads(); }      // :697
 #endif
       const long long c3 = clock64();
       c_ls += c1 - c0; c_lin += c2 - c1; c_bp += c3 - c2;
