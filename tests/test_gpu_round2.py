@@ -708,3 +708,72 @@ def test_c_host_drives_the_library_through_the_header_alone(tmp_path):
         assert cost == "%.12g" % L[b] and th == "%.9f" % x[b, 0, -1]
     best = re.search(r"batch: (\d+) iterations, 4 converged, best cost (\S+) \(problem (\d+)\)", r.stdout)
     assert int(best.group(1)) == int(s.iterations.sum()) and int(best.group(3)) == int(np.argmin(L))
+
+
+@pytest.mark.gpu
+def test_cost_matrices_are_resent_when_and_only_when_they_change():
+    """mi_ilqr_set_cost keeps a host mirror and skips the upload when the caller repeats its matrices (Solve() pushes
+    them on every call): changing Q, R, Qf or x_nom between solves must still take effect, bit for bit what a
+    fresh solver with the new matrices computes - also after an MPCRun whose moving target advanced x_nom on the
+    device."""
+    from drake_ddp_amd import workloads as W
+    prob = W.pendulum_problem()
+    x0 = W.pendulum_batch_x0(16)
+    ug = np.zeros((1, prob["N"] - 1))
+
+    def fresh(p):
+        s_ = make_solver(p, B=16, jac="fd")
+        s_.SetInitialState(x0); s_.SetInitialGuess(ug)
+        return s_.Solve()
+
+    s = make_solver(prob, B=16, jac="fd")
+    s.SetInitialState(x0); s.SetInitialGuess(ug)
+    a = s.Solve()
+    ref = fresh(prob)
+    assert np.array_equal(a[0], ref[0]) and np.array_equal(a[3], ref[3])
+    p2 = dict(prob, Q=prob["Q"] * 3.0 + np.diag([1e-3, 0.0]), R=prob["R"] * 0.5, Qf=prob["Qf"] * 2.0,
+              x_nom=np.array([np.pi - 0.1, 0.0]))
+    s.SetRunningCost(p2["Q"], p2["R"]); s.SetTerminalCost(p2["Qf"]); s.SetTargetState(p2["x_nom"])
+    s.Reset(); s.SetInitialGuess(ug)
+    b = s.Solve()
+    ref2 = fresh(p2)
+    assert np.array_equal(b[0], ref2[0]) and np.array_equal(b[3], ref2[3]) and not np.array_equal(b[3], a[3])
+    s.Reset(); s.SetInitialGuess(ug)                      # the same matrices again: nothing is sent, same answer
+    c = s.Solve()
+    assert np.array_equal(c[0], b[0]) and np.array_equal(c[3], b[3])
+    # a moving target advances x_nom on the device and in the mirror: setting the OLD target again must be noticed
+    q = W.synth36_problem()
+    s36 = make_solver(q, B=2, jac="fd")
+    s36.SetInitialState(W.synth36_batch_x0(2)); s36.SetInitialGuess(W.synth36_u_guess(q["N"]))
+    s36.Solve()
+    step = np.zeros(36); step[0] = 0.004
+    s36.MPCRun(3, 4, step)
+    s36.SetTargetState(q["x_nom"])                         # back to the original target
+    s36.Reset(); s36.SetInitialState(W.synth36_batch_x0(2)); s36.SetInitialGuess(W.synth36_u_guess(q["N"]))
+    d = s36.Solve()
+    t36 = make_solver(q, B=2, jac="fd")
+    t36.SetInitialState(W.synth36_batch_x0(2)); t36.SetInitialGuess(W.synth36_u_guess(q["N"]))
+    e = t36.Solve()
+    assert np.array_equal(d[0], e[0]) and np.array_equal(d[3], e[3])
+
+
+@pytest.mark.gpu
+def test_async_reads_equal_blocking_reads_and_host_alloc_argument_checks():
+    """mi_ilqr_get_async (double and int fields, plain and layout-converted) returns what mi_ilqr_get returns."""
+    import ctypes as C
+    from drake_ddp_amd import workloads as W, _capi
+    lib = _capi.load()
+    raw = C.c_void_p()
+    assert lib.mi_ilqr_host_alloc(0, C.byref(raw)) != 0 and lib.mi_ilqr_host_alloc(64, None) != 0
+    for prob, B, x0, ug in ((W.pendulum_problem(), 9, W.pendulum_batch_x0(9), np.zeros((1, 199))),
+                            (W.synth36_problem(), 3, W.synth36_batch_x0(3), W.synth36_u_guess(40))):
+        s = make_solver(prob, B=B, jac="fd")
+        s.SetInitialState(x0); s.SetInitialGuess(ug)
+        x, u, _, L = s.Solve()
+        for which, ref in ((_capi.F_X_BAR, x), (_capi.F_U_BAR, u), (_capi.F_COST, L), (_capi.I_ITERS, s.iterations), (_capi.I_STATUS, s.status)):
+            out = np.full(ref.shape, -7, dtype=ref.dtype)
+            _capi.check(lib.mi_ilqr_get_async(s._h, which, _capi.ptr(out), out.nbytes), "mi_ilqr_get_async")
+            _capi.check(lib.mi_ilqr_synchronize(s._h), "mi_ilqr_synchronize")
+            assert np.array_equal(out, ref), which
+        bad = np.zeros(3)
+        assert lib.mi_ilqr_get_async(s._h, _capi.F_X_BAR, _capi.ptr(bad), bad.nbytes) != 0      # wrong size
