@@ -777,3 +777,35 @@ def test_async_reads_equal_blocking_reads_and_host_alloc_argument_checks():
             assert np.array_equal(out, ref), which
         bad = np.zeros(3)
         assert lib.mi_ilqr_get_async(s._h, _capi.F_X_BAR, _capi.ptr(bad), bad.nbytes) != 0      # wrong size
+
+
+@pytest.mark.gpu
+def test_staged_inputs_survive_the_ring_wrapping_and_back_to_back_setters():
+    """Small inputs travel through a 1 MB page-locked ring with asynchronous copies: 70 Solve() calls with a new x0
+    each (the ring wraps after ~50 at this size) return what a fresh solver returns for the same x0, and setters
+    issued back to back without a solve in between leave the LAST values on the device."""
+    from drake_ddp_amd import workloads as W
+    prob = W.pendulum_problem()
+    B = 1024
+    base = W.pendulum_batch_x0(B)
+    ug = np.zeros((1, prob["N"] - 1))
+    s = make_solver(prob, B=B, jac="fd", hist_cap=2)
+    picks = {}
+    for k in range(70):
+        x0 = base + 1e-3 * k
+        s.Reset(); s.SetInitialState(x0); s.SetInitialGuess(ug)
+        x, u, _, L = s.Solve()
+        if k in (0, 48, 49, 50, 51, 69):
+            picks[k] = (x0, x.copy(), L.copy())
+    t = make_solver(prob, B=B, jac="fd", hist_cap=2)
+    for k, (x0, x, L) in picks.items():
+        t.Reset(); t.SetInitialState(x0); t.SetInitialGuess(ug)
+        xr, _, _, Lr = t.Solve()
+        assert np.array_equal(x, xr) and np.array_equal(L, Lr), k
+    for k in range(5):                                        # five pushes, one solve
+        s.Reset(); s.SetInitialState(base + 0.01 * k); s.SetInitialGuess(ug + 0.001 * k)
+        s._push_problem()
+    x, u, _, L = s.Solve()
+    t.Reset(); t.SetInitialState(base + 0.04); t.SetInitialGuess(ug + 0.004)
+    xr, ur, _, Lr = t.Solve()
+    assert np.array_equal(x, xr) and np.array_equal(u, ur) and np.array_equal(L, Lr)
