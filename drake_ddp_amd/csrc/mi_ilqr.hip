@@ -75,6 +75,7 @@ struct mi_ilqr {
   bool u_zero = false;     // u_bar is to read as all zero (after reset, until a guess is set or re-armed): ilqr.py:71
   int exact_backward = 0;  // cost matrices the fast backward forms do not cover (asymmetric / indefinite): reference recursion
   std::vector<double> h_costmat;   // host mirror of costmat (Q | R | Qf | x_nom)
+  bool costmat_synced = false;     // the device copy equals the mirror
   unsigned long long* cluster_sync = nullptr;   // workgroup-per-problem kernels: 4 handshake words per problem
   int n_cus = 0;                   // compute units of the device
   double* scratch = nullptr;       // device staging area of the boundary's layout conversions (grow-only)
@@ -781,6 +782,7 @@ int mi_ilqr_create(const mi_ilqr_desc* desc, mi_ilqr_t** out) {
     for (size_t i = 0; i < m; ++i) cm[n * n + i * m + i] = 1.0;
     if (hipMemcpy(h->costmat, cm.data(), cm.size() * 8, hipMemcpyHostToDevice) != hipSuccess) { mi_ilqr_destroy(h); return MI_ILQR_E_HIP; }
     h->h_costmat = cm;
+    h->costmat_synced = true;
   }
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
     mi_ilqr_destroy(h);
@@ -871,10 +873,13 @@ int mi_ilqr_set_cost(mi_ilqr_t* h, const double* Q, const double* R, const doubl
     h->exact_backward = regular ? 0 : 1;
     // the device copy mirrors h_costmat: nothing to send when the caller repeats the matrices it set before
     // (Solve() pushes them on every call, like the reference reads its attributes on every call)
-    if (std::memcmp(cm.data(), h->h_costmat.data(), cm.size() * 8) == 0) return MI_ILQR_OK;
+    if (h->costmat_synced && std::memcmp(cm.data(), h->h_costmat.data(), cm.size() * 8) == 0) return MI_ILQR_OK;
     h->h_costmat.swap(cm);
   }
-  return stage_h2d(h, h->costmat, h->h_costmat.data(), h->h_costmat.size() * 8);    // Q | R | Qf | x_nom: one copy
+  h->costmat_synced = false;                                  // (a failed copy must not leave the mirror believed)
+  const int rc = stage_h2d(h, h->costmat, h->h_costmat.data(), h->h_costmat.size() * 8);    // Q | R | Qf | x_nom: one copy
+  h->costmat_synced = rc == MI_ILQR_OK;
+  return rc;
 }
 
 int mi_ilqr_set_initial(mi_ilqr_t* h, const double* x0, const double* u_guess) {
