@@ -5,7 +5,7 @@ import csv, glob, json, os, shutil, sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 tag = sys.argv[1]
 out, prof = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
-for name in ("bench_c2.json", "bench_c2_kernel_stats.csv", "all_configs.jsonl", "pmc_issue.json", "c2_clock_ramp.txt", "c2_modes_batch_sweep.txt"):
+for name in ("bench_c2.json", "bench_c2_kernel_stats.csv", "all_configs.jsonl", "all_configs_kernel_stats.csv", "pmc_issue.json", "c2_clock_ramp.txt", "c2_modes_batch_sweep.txt"):
     if os.path.exists(os.path.join(out, f"{tag}_{name}")):
         shutil.copy(os.path.join(out, f"{tag}_{name}"), os.path.join(prof, f"{tag}_{name}"))
 raw = json.load(open(os.path.join(out, f"{tag}_pmc_raw.json")))

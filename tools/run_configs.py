@@ -1,8 +1,8 @@
 """Run the five BASELINE.json configs on one GPU and print one JSON line each
 (iterations/s, ms/solve, algorithmic GB/s).  Not the bench contract (bench.py is)."""
-import json, sys, time
+import json, os, sys, time
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from drake_ddp_amd import workloads as W
 from drake_ddp_amd.ilqr import BatchedIterativeLQR
 from drake_ddp_amd.models import ModelSystem
