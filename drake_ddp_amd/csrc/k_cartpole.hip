@@ -1,0 +1,4 @@
+// Wave-per-problem kernels of the CartPole model: every (Jacobian mode, kernel mode) instantiation.
+#include "launch_small.hpp"
+
+MI_INTERNAL int launch_cartpole(mi_ilqr* h, int mode, const mi::KArgs& a) { return mi_host::launch_jac<mi::CartPole>(h, mode, a); }

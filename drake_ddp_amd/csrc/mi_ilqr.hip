@@ -26,97 +26,12 @@
 using namespace mi;
 
 
-struct mi_ilqr {
-  mi_ilqr_desc d;
-  int n, m, N, B;
-  hipStream_t stream = nullptr;
-  // Per-launch records (kernel start/stop events + aggregate statistics) live in a ring, so that up to
-  // kStatsRing solves can be enqueued back to back (mi_ilqr_solve_async) before anything is collected;
-  // ev0/ev1/h_stats/d_stats alias the slot of the most recent launch.
-  static constexpr int kStatsRing = 32;
-  hipEvent_t ring_ev0[kStatsRing] = {}, ring_ev1[kStatsRing] = {};
-  DevStats* h_ring = nullptr;    // pinned host memory, device-mapped
-  DevStats* d_ring = nullptr;    // its device alias
-  long long seq = 0;             // solves enqueued so far
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  unsigned long long seq_timed = 0;
-  int time_every = 1;              // mi_ilqr_set_timing: events on one solve in `time_every` (0 = never)
-  bool timed_launch = true;        // this launch carries the events
-  bool last_timed = true;          // ... and so did the most recent launch
-  int cur_slot = 0;
-  bool ring_timed[kStatsRing] = {};
-  // double fields
-  double *x_bar = nullptr, *u_bar = nullptr, *K = nullptr, *kappa = nullptr, *dV = nullptr, *fx = nullptr, *fu = nullptr;
-  double *x0 = nullptr, *u_guess = nullptr, *cost = nullptr, *hist = nullptr, *iter_cyc = nullptr;
-  double *x_trial = nullptr, *u_trial = nullptr, *trial_cost = nullptr, *stage_in = nullptr, *costmat = nullptr;
-  int32_t *iters = nullptr, *status = nullptr, *ls_trials = nullptr, *kp_count = nullptr, *kp_list = nullptr;
-  // cost / iters / status / ls_trials above alias the CURRENT slot of these rings (kStatsRing x B each): every
-  // pipelined solve leaves its per-problem results in its own slot, so their reduction to a DevStats record can
-  // wait until somebody collects - one stats_kernel launch over all pending slots - instead of one dispatch
-  // (6 us + its gap) behind every solve.
-  double* cost_ring = nullptr;
-  int32_t *iters_ring = nullptr, *status_ring = nullptr, *ls_ring = nullptr;
-  long long stats_done = 0;      // solves with sequence number < stats_done have their DevStats record
-  bool in_async_solve = false;
-  double* u_one = nullptr;         // device copy of a shared (m, N-1) initial guess
-  char* pin_in = nullptr;          // page-locked staging ring of small host -> device inputs (stage_h2d)
-  size_t pin_off = 0;
-  hipEvent_t pin_ev = nullptr;
-  long long* prof = nullptr;
-  int32_t* done_counter = nullptr;   // wave-per-problem kernels: tickets of the in-kernel statistics epilogue
-  DevStats* h_stats = nullptr;   // pinned host memory, device-mapped
-  DevStats* d_stats = nullptr;   // its device alias
-  double* mpc_log = nullptr;     // (B, mpc_log_resolves, n+2)
-  int mpc_log_resolves = 0;
-  int mpc_resolves = 0, mpc_replan = 0;
-  double mpc_target_step[mi::kMaxStateDim] = {};
-  bool cold = true;        // persistent state is known to be all zero (fresh object / after reset)
-  bool u_pending = false;  // SetInitialGuess input waiting in u_guess
-  bool u_zero = false;     // u_bar is to read as all zero (after reset, until a guess is set or re-armed): ilqr.py:71
-  int exact_backward = 0;  // cost matrices the fast backward forms do not cover (asymmetric / indefinite): reference recursion
-  std::vector<double> h_costmat;   // host mirror of costmat (Q | R | Qf | x_nom)
-  bool costmat_synced = false;     // the device copy equals the mirror
-  unsigned long long* cluster_sync = nullptr;   // workgroup-per-problem kernels: 4 handshake words per problem
-  int n_cus = 0;                   // compute units of the device
-  double* scratch = nullptr;       // device staging area of the boundary's layout conversions (grow-only)
-  size_t scratch_bytes = 0;
-  size_t lds = 0;
-  bool large = false;      // workgroup-per-problem path: state arrays are TIME-MAJOR in HBM
-  int n_store = 1;         // line-search candidate trajectories kept in LDS
-  bool batch_minor = false; // lane-per-problem path: state arrays are [t][row][b] in HBM
-};
+#include "host.hpp"
 
-// Small batches of the wave-per-problem kernels aggregate the batch statistics in the solve kernel
-// itself (last workgroup to finish): a blocking single-problem solve saves a kernel launch, 5 us of
-// 98.  Large batches keep the separate stats_kernel: with pipelined solves the two cost the same per
-// step (measured at B = 1024: 0.166 ms either way), and the solve kernel stays 3.6 us shorter.
-// MI_ILQR_STATS_KERNEL=1 / =0 forces the separate kernel / the in-kernel epilogue (A/B runs).
-static inline bool stats_in_kernel(const mi_ilqr* h) {
-  static const int forced = [] { const char* e = std::getenv("MI_ILQR_STATS_KERNEL"); return !e ? -1 : (e[0] == '1' ? 1 : 0); }();
-  if (h->large || h->batch_minor) return false;
-  if (forced >= 0) return forced == 0;
-  return h->B <= 64;
-}
-static inline void select_stats_slot(mi_ilqr* h, int slot) {
-  h->ev0 = h->ring_ev0[slot]; h->ev1 = h->ring_ev1[slot];
-  h->h_stats = h->h_ring + slot; h->d_stats = h->d_ring + slot;
-  h->cur_slot = slot;
-  const size_t o = (size_t)slot * h->B;
-  h->cost = h->cost_ring + o; h->iters = h->iters_ring + o; h->status = h->status_ring + o; h->ls_trials = h->ls_ring + o;
-}
+using namespace mi_host;
 
 namespace {
 
-#define HIPCHK(expr)                                                                      \
-  do {                                                                                    \
-    hipError_t e_ = (expr);                                                               \
-    if (e_ != hipSuccess) {                                                               \
-      std::fprintf(stderr, "mi_ilqr: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
-      return MI_ILQR_E_HIP;                                                               \
-    }                                                                                     \
-  } while (0)
-
-constexpr size_t kMaxLds = 160 * 1024;
 
 struct ModelInfo { int n, m, n_params; double defaults[MI_ILQR_MAX_PARAMS]; };
 
@@ -207,125 +122,6 @@ KArgs make_args(const mi_ilqr* h) {
   return a;
 }
 
-// The dynamic-LDS ceiling of a kernel is raised once per (kernel, device), to the hardware maximum - not
-// on every launch.
-constexpr int kMaxDevices = 64;
-template <class Kern>
-int allow_max_lds(Kern kern, bool (&done)[kMaxDevices], int device) {
-  if (device >= 0 && device < kMaxDevices && done[device]) return MI_ILQR_OK;
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds));
-  if (device >= 0 && device < kMaxDevices) done[device] = true;
-  return MI_ILQR_OK;
-}
-
-// One dispatch packet per solve: the launch carries the handle's start/stop events itself (the kernel's own
-// begin/end timestamps, what rocprofv3 reports for it) instead of two hipEventRecord marker packets around it.
-// A profiled dispatch still costs the stream ~5 us of serialization in a pipelined sequence
-// (tools/ubench/gap.hip), so mi_ilqr_set_timing can restrict the events to one launch in k.
-template <class Kern>
-int launch_timed(mi_ilqr* h, Kern kern, dim3 grid, dim3 block, size_t lds, const KArgs& a) {
-  KArgs args = a;
-  void* argv[] = {&args};
-  h->ring_timed[h->cur_slot] = h->last_timed = h->timed_launch;
-  if (!h->timed_launch) { HIPCHK(hipLaunchKernel(reinterpret_cast<const void*>(kern), grid, block, argv, lds, h->stream)); return MI_ILQR_OK; }
-  HIPCHK(hipExtLaunchKernel(reinterpret_cast<const void*>(kern), grid, block, argv, lds, h->stream, h->ev0, h->ev1, 0));
-  return MI_ILQR_OK;
-}
-
-template <class M, int JAC, int MODE>
-int launch_one(mi_ilqr* h, const KArgs& a) {
-  auto kern = ilqr_small_kernel<M, JAC, MODE>;
-  static bool lds_ok[kMaxDevices] = {};
-  { const int rc = allow_max_lds(kern, lds_ok, h->d.device_id); if (rc != MI_ILQR_OK) return rc; }
-  const int waves = (a.helpers > 0 && (MODE == MODE_SOLVE || MODE == MODE_MPC)) ? 1 + a.helpers : 1;
-  return launch_timed(h, kern, dim3(h->B), dim3(64 * waves), h->lds, a);
-  return MI_ILQR_OK;
-}
-
-template <class M, int JAC>
-int launch_mode(mi_ilqr* h, int mode, const KArgs& a) {
-  switch (mode) {
-    case MODE_SOLVE: return launch_one<M, JAC, MODE_SOLVE>(h, a);
-    case MODE_ROLLOUT: return launch_one<M, JAC, MODE_ROLLOUT>(h, a);
-    case MODE_FORWARD: return launch_one<M, JAC, MODE_FORWARD>(h, a);
-    case MODE_LINEARIZE: return launch_one<M, JAC, MODE_LINEARIZE>(h, a);
-    case MODE_BACKWARD: return launch_one<M, JAC, MODE_BACKWARD>(h, a);
-    case MODE_MPC: return launch_one<M, JAC, MODE_MPC>(h, a);
-  }
-  return MI_ILQR_E_BAD_ARG;
-}
-
-template <class M, int JAC, int MODE>
-int launch_one_large(mi_ilqr* h, const KArgs& a) {
-  auto kern = ilqr_large_kernel<M, JAC, MODE>;
-  static bool lds_ok[kMaxDevices] = {};
-  { const int rc = allow_max_lds(kern, lds_ok, h->d.device_id); if (rc != MI_ILQR_OK) return rc; }
-  const int cluster = (MODE == MODE_SOLVE || MODE == MODE_MPC) ? a.cluster : 1;
-  if (cluster > 1) HIPCHK(hipMemsetAsync(h->cluster_sync, 0, (size_t)h->B * 4 * sizeof(unsigned long long), h->stream));
-  return launch_timed(h, kern, dim3(h->B * cluster), dim3(kLargeThreads), h->lds, a);
-}
-
-template <class M, int JAC>
-int launch_mode_large(mi_ilqr* h, int mode, const KArgs& a) {
-  switch (mode) {
-    case MODE_SOLVE: return launch_one_large<M, JAC, MODE_SOLVE>(h, a);
-    case MODE_ROLLOUT: return launch_one_large<M, JAC, MODE_ROLLOUT>(h, a);
-    case MODE_FORWARD: return launch_one_large<M, JAC, MODE_FORWARD>(h, a);
-    case MODE_LINEARIZE: return launch_one_large<M, JAC, MODE_LINEARIZE>(h, a);
-    case MODE_BACKWARD: return launch_one_large<M, JAC, MODE_BACKWARD>(h, a);
-    case MODE_MPC: return launch_one_large<M, JAC, MODE_MPC>(h, a);
-  }
-  return MI_ILQR_E_BAD_ARG;
-}
-
-template <class M>
-int launch_jac_large(mi_ilqr* h, int mode, const KArgs& a) {
-  if (h->d.jacobian_mode == MI_JAC_AUTODIFF) return launch_mode_large<M, MI_JAC_AUTODIFF>(h, mode, a);
-  return launch_mode_large<M, MI_JAC_FD_CENTRAL>(h, mode, a);
-}
-
-template <class M, int JAC>
-int launch_batch_one(mi_ilqr* h, const KArgs& a) {
-  auto kern = ilqr_batch_kernel<M, JAC>;
-  return launch_timed(h, kern, dim3((h->B + 63) / 64), dim3(64), 0, a);
-}
-
-template <class M>
-int launch_batch(mi_ilqr* h, int mode, const KArgs& a) {
-  if (mode != MODE_SOLVE) return MI_ILQR_E_UNSUPPORTED;    // stage-level entries: latency kernels only
-  if (h->d.jacobian_mode == MI_JAC_AUTODIFF) return launch_batch_one<M, MI_JAC_AUTODIFF>(h, a);
-  return launch_batch_one<M, MI_JAC_FD_CENTRAL>(h, a);
-}
-
-template <class M>
-int launch_jac(mi_ilqr* h, int mode, const KArgs& a) {
-  if constexpr (M::n >= 3 && M::n <= 4 && M::m == 1) {
-    // cost matrices outside the symmetric-PSD class: the kernels whose backward pass is the reference's recursion
-    if (h->exact_backward && (mode == MODE_SOLVE || mode == MODE_MPC || mode == MODE_BACKWARD)) {
-      using E = ExactCost<M>;
-      const bool ad = h->d.jacobian_mode == MI_JAC_AUTODIFF;
-      switch (mode) {
-        case MODE_SOLVE: return ad ? launch_one<E, MI_JAC_AUTODIFF, MODE_SOLVE>(h, a) : launch_one<E, MI_JAC_FD_CENTRAL, MODE_SOLVE>(h, a);
-        case MODE_MPC: return ad ? launch_one<E, MI_JAC_AUTODIFF, MODE_MPC>(h, a) : launch_one<E, MI_JAC_FD_CENTRAL, MODE_MPC>(h, a);
-        default: return launch_one<E, MI_JAC_FD_CENTRAL, MODE_BACKWARD>(h, a);
-      }
-    }
-    // two or more steps per lane: the kernels whose backward pass is the time-parallel scan (ilqr_small.hpp:
-    // LongHorizon) - only the modes that run a backward pass have such an instantiation
-    if (h->N > 128 && (mode == MODE_SOLVE || mode == MODE_MPC || mode == MODE_BACKWARD)) {
-      using L = LongHorizon<M>;
-      const bool ad = h->d.jacobian_mode == MI_JAC_AUTODIFF;
-      switch (mode) {
-        case MODE_SOLVE: return ad ? launch_one<L, MI_JAC_AUTODIFF, MODE_SOLVE>(h, a) : launch_one<L, MI_JAC_FD_CENTRAL, MODE_SOLVE>(h, a);
-        case MODE_MPC: return ad ? launch_one<L, MI_JAC_AUTODIFF, MODE_MPC>(h, a) : launch_one<L, MI_JAC_FD_CENTRAL, MODE_MPC>(h, a);
-        default: return launch_one<L, MI_JAC_FD_CENTRAL, MODE_BACKWARD>(h, a);
-      }
-    }
-  }
-  if (h->d.jacobian_mode == MI_JAC_AUTODIFF) return launch_mode<M, MI_JAC_AUTODIFF>(h, mode, a);
-  return launch_mode<M, MI_JAC_FD_CENTRAL>(h, mode, a);
-}
-
 // Launch `mode` for the handle's model; afterwards the persistent state is no
 // longer known-zero for the fields the mode writes, and u_bar is materialized.
 int reduce_pending_stats(mi_ilqr* h);
@@ -338,22 +134,14 @@ int launch(mi_ilqr* h, int mode) {
   h->u_zero = false;
   const KArgs a = make_args(h);
   int rc;
-  if (h->batch_minor) {
-    switch (h->d.model_id) {
-      case MI_MODEL_PENDULUM: return launch_batch<Pendulum>(h, mode, a);
-      case MI_MODEL_ACROBOT: return launch_batch<Acrobot>(h, mode, a);
-      case MI_MODEL_CARTPOLE: return launch_batch<CartPole>(h, mode, a);
-      case MI_MODEL_CARTPOLE_WALL: return launch_batch<CartPoleWall>(h, mode, a);
-      default: return MI_ILQR_E_UNSUPPORTED;
-    }
-  }
+  if (h->batch_minor) return launch_batch_minor(h, mode, a);
   switch (h->d.model_id) {
-    case MI_MODEL_PENDULUM: rc = launch_jac<Pendulum>(h, mode, a); break;
-    case MI_MODEL_ACROBOT: rc = launch_jac<Acrobot>(h, mode, a); break;
-    case MI_MODEL_CARTPOLE: rc = launch_jac<CartPole>(h, mode, a); break;
-    case MI_MODEL_CARTPOLE_WALL: rc = launch_jac<CartPoleWall>(h, mode, a); break;
-    case MI_MODEL_SYNTH36: rc = launch_jac_large<Synth36>(h, mode, a); break;
-    case MI_MODEL_PLANAR_QUAD: rc = launch_jac_large<PlanarQuad>(h, mode, a); break;
+    case MI_MODEL_PENDULUM: rc = launch_pendulum(h, mode, a); break;
+    case MI_MODEL_ACROBOT: rc = launch_acrobot(h, mode, a); break;
+    case MI_MODEL_CARTPOLE: rc = launch_cartpole(h, mode, a); break;
+    case MI_MODEL_CARTPOLE_WALL: rc = launch_cartpole_wall(h, mode, a); break;
+    case MI_MODEL_SYNTH36: rc = launch_synth36(h, mode, a); break;
+    case MI_MODEL_PLANAR_QUAD: rc = launch_planar_quad(h, mode, a); break;
     default: return MI_ILQR_E_UNSUPPORTED;
   }
   return rc;
@@ -867,9 +655,26 @@ int mi_ilqr_set_cost(mi_ilqr_t* h, const double* Q, const double* R, const doubl
     if (R) std::memcpy(cm.data() + n * n, R, m * m * 8);
     if (Qf) std::memcpy(cm.data() + n * n + m * m, Qf, n * n * 8);
     if (x_nom) std::memcpy(cm.data() + 2 * n * n + m * m, x_nom, n * 8);
+    if (h->large) {
+      // The workgroup-per-problem kernels have no verbatim-recursion form, and matrices built as A^T A or by float
+      // arithmetic are often symmetric only to round-off: asymmetries up to a few ulps of the largest entry are
+      // averaged away here (|A - A^T| <= 8 eps max|A|); anything larger is refused below with E_UNSUPPORTED.
+      auto symmetrize = [](double* A, size_t k) {
+        double scale = 0.0;
+        for (size_t i = 0; i < k * k; ++i) scale = std::fmax(scale, std::fabs(A[i]));
+        for (size_t i = 0; i < k; ++i)
+          for (size_t j = 0; j < i; ++j) if (std::fabs(A[i * k + j] - A[j * k + i]) > 8 * 2.220446049250313e-16 * scale) return;
+        for (size_t i = 0; i < k; ++i)
+          for (size_t j = 0; j < i; ++j) A[i * k + j] = A[j * k + i] = 0.5 * (A[i * k + j] + A[j * k + i]);
+      };
+      symmetrize(cm.data(), n); symmetrize(cm.data() + n * n, m); symmetrize(cm.data() + n * n + m * m, n);
+    }
     const bool regular = is_sym_psd(cm.data(), (int)n, false) && is_sym_psd(cm.data() + n * n + m * m, (int)n, false) &&
                          is_sym_psd(cm.data() + n * n, (int)m, true);
-    if (!regular && h->large) return MI_ILQR_E_UNSUPPORTED;
+    if (!regular && h->large) {
+      std::fprintf(stderr, "mi_ilqr_set_cost: the n = %d kernels need symmetric (to 8 ulp) positive semi-definite Q, Qf and positive definite R\n", (int)n);
+      return MI_ILQR_E_UNSUPPORTED;
+    }
     h->exact_backward = regular ? 0 : 1;
     // the device copy mirrors h_costmat: nothing to send when the caller repeats the matrices it set before
     // (Solve() pushes them on every call, like the reference reads its attributes on every call)
@@ -1094,7 +899,9 @@ int mi_ilqr_mpc_run(mi_ilqr_t* h, int32_t num_resolves, int32_t replan_steps, co
   if ((h->large && !large_on_device) || h->batch_minor || (!h->large && (h->N > 512 || h->n > 8))) {
     // lane-per-problem path (and horizons the in-kernel shift does not cover): loop shift + solve on the host
     std::vector<double> xn(h->n);
-    if (target_step) HIPCHK(hipMemcpy(xn.data(), h->costmat + 2 * (size_t)h->n * h->n + (size_t)h->m * h->m, h->n * 8, hipMemcpyDeviceToHost));
+    // x_nom from the host mirror: mi_ilqr_set_cost uploads asynchronously on the handle's stream, so a blocking
+    // null-stream read of the device copy could still see the previous target
+    if (target_step) std::memcpy(xn.data(), h->h_costmat.data() + 2 * (size_t)h->n * h->n + (size_t)h->m * h->m, h->n * 8);
     mi_ilqr_stats acc; std::memset(&acc, 0, sizeof(acc)); acc.best_cost = INFINITY; acc.best_index = -1;
     for (int r = 0; r < num_resolves; ++r) {
       if ((rc = mi_ilqr_mpc_shift(h, replan_steps)) != MI_ILQR_OK) return rc;
@@ -1279,7 +1086,7 @@ int mi_ilqr_get_stream(mi_ilqr_t* h, void** hip_stream) {
 namespace {
 struct RcclApi {
   // the few entry points used, with the types of rccl.h (ncclResult_t = int, ncclComm_t = opaque pointer,
-  // ncclUniqueId = 128 bytes by value, ncclDataType_t / ncclRedOp_t = int enums: ncclFloat64 = 8, ncclMin = 4)
+  // ncclUniqueId = 128 bytes by value, ncclDataType_t / ncclRedOp_t = int enums: ncclFloat64 = 8, ncclMin = 3 - rccl.h: ncclSum 0, ncclProd 1, ncclMax 2, ncclMin 3, ncclAvg 4)
   struct UniqueId { char internal[MI_ILQR_COMM_ID_BYTES]; };
   int (*GetUniqueId)(UniqueId*) = nullptr;
   int (*CommInitRank)(void**, int, UniqueId, int) = nullptr;
@@ -1288,7 +1095,7 @@ struct RcclApi {
   const char* (*GetErrorString)(int) = nullptr;
   bool ok = false;
 };
-constexpr int kNcclFloat64 = 8, kNcclMin = 4;
+constexpr int kNcclFloat64 = 8, kNcclMin = 3;
 
 const RcclApi& rccl() {
   static const RcclApi api = [] {

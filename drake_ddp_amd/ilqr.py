@@ -131,7 +131,9 @@ class BatchedIterativeLQR:
             ug = np.asarray(self._u_guess, dtype=np.float64)
             # one sequence for the whole batch - (m,N-1) or (1,m,N-1), the reference's own argument - crosses the
             # bus once; the device writes the batch's copies
-            shared = ug.size == self.m * (self.N - 1)
+            if ug.shape not in ((self.m, self.N - 1), (1, self.m, self.N - 1), (self.B, self.m, self.N - 1)):
+                raise AssertionError(f"initial guess must be (m,N-1) or (B,m,N-1), got {ug.shape}")
+            shared = ug.ndim == 2 or (ug.shape[0] == 1 and self.B > 1)
             if shared:
                 ug = np.ascontiguousarray(ug.reshape(self.m, self.N - 1))
             else:
@@ -405,7 +407,15 @@ class IterativeLinearQuadraticRegulator(BatchedIterativeLQR):
                 print(f"{i + 1:^14}{L_new:11.4f}  {eps:^12.4f}{int(ls):^11}   {t_derivs:1.5f}         {pct:.1f}       "
                       f"{t_bp:1.5f}    {t_fp:1.5f}      {t_it:1.5f}          {elapsed:4.2f}")
         if status == _capi.STATUS_LINESEARCH_FAILED:
-            raise RuntimeError("linesearch failed after %s iterations" % int(self.ls_trials[0]))   # ilqr.py:337
+            # ilqr.py:337 reports the trials of the FAILING line search (not the solve's running total): every step
+            # size eps = beta^k >= 1e-8 was tried, counted with the reference's own float recurrence (ilqr.py:299-335)
+            n_trials, eps = 0, 1.0
+            while eps >= 1e-8:
+                n_trials += 1
+                eps *= self.beta
+            raise RuntimeError("linesearch failed after %s iterations" % n_trials)
+        if status == _capi.STATUS_INTERNAL:
+            raise RuntimeError("solve aborted inside the device kernel (cluster hand-shake lost); results are not a solution")
         return self.x_bar, self.u_bar, total_time, float(self.cost[0])
 
     def SaveSolution(self, fname):

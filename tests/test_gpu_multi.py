@@ -1,0 +1,75 @@
+"""Multi-GPU readiness: runs the day a node with >= 2 GPUs is there, skips on one-GPU boxes.
+
+* the library's own RCCL communicator with world = 2..N ranks contributing different values (min, not avg);
+* the shard partitioning: all-reduce(min) over the shards' best costs == min over the whole batch on one GPU;
+* `bench.py --gpus N` on the nccl (= RCCL) backend: n_gpus, weak-scaling batch, rank-summed iterations."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _n_gpus():
+    try:
+        import torch
+        return torch.cuda.device_count() if torch.cuda.is_available() else 0
+    except Exception:  # pragma: no cover
+        return 0
+
+
+needs_two = pytest.mark.skipif(_n_gpus() < 2, reason="needs >= 2 GPUs on this node")
+
+
+def _worlds():
+    n = _n_gpus()
+    return sorted({w for w in (2, 4, 8, n) if 2 <= w <= n}) or [2]
+
+
+@pytest.mark.gpu
+@needs_two
+@pytest.mark.parametrize("world", _worlds())
+def test_native_rccl_min_and_sharded_solve(world, tmp_path):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_multi_worker.py"), str(r), str(world), str(tmp_path)],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=600)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n{o[-3000:]}"
+    res = [json.load(open(tmp_path / f"ok.{r}")) for r in range(world)]
+    assert len({x["best"] for x in res}) == 1                       # every rank holds the same global best cost
+    assert sum(x["iters"] for x in res) == res[0]["whole_iters"]    # shards do exactly the whole batch's iterations
+    assert res[0]["lo"] == 0 and res[-1]["hi"] == 64 and all(a["hi"] == b["lo"] for a, b in zip(res, res[1:]))
+
+
+@pytest.mark.gpu
+@needs_two
+def test_bench_on_rccl_all_gpus():
+    n = _n_gpus()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    tail = ["--steps", "8", "--warmup", "2", "--no-cpu-baseline", "--no-configs"]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + tail,
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-2000:]
+    many = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)] + tail,
+                          env=env, capture_output=True, text=True, timeout=900)
+    assert many.returncode == 0, many.stdout[-2000:] + many.stderr[-2000:]
+    j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    jn = json.loads([l for l in many.stdout.splitlines() if l.startswith("{")][-1])
+    assert jn["n_gpus"] == n and jn["scaling"] == "weak"
+    assert jn["config"]["global_batch"] == n * j1["config"]["global_batch"]
+    # weak scaling of independent shards: the ranks' summed iterations per step = N x one rank's (different seeds
+    # of the same distribution: within 5 %)
+    per_step = lambda j: j["value"] * j["ms_per_step"] * 1e-3          # iterations of all ranks in one step
+    assert abs(per_step(jn) - n * per_step(j1)) <= 0.05 * n * per_step(j1)
+    assert "all_reduce" in jn["config"]["collective"] or "all-reduce" in jn["config"]["collective"]
