@@ -46,11 +46,19 @@ def pmc_traffic_committed(batch):
     return d.get("hbm_bytes_per_launch_corrected"), "committed " + os.path.basename(files[-1])
 
 
-def pmc_traffic_live(batch):
-    """HBM bytes per launch of the solve kernel, measured now: two separate rocprofv3 --pmc passes
-    (FETCH_SIZE, WRITE_SIZE; they do not fit one pass) over a short nested run of this script.
-    Units are KB; FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 tallies wide coalesced
-    reads at half their bytes — an upper bound for our 8 B/lane loads).  None on any failure."""
+PMC_GROUPS = {
+    # separate passes: FETCH_SIZE and WRITE_SIZE do not fit one pass (MI355X_MICROARCH.md, rocprofv3 PMC slots)
+    "fetch": ["FETCH_SIZE"],
+    "write": ["WRITE_SIZE"],
+    "fp64": ["SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_TRANS_F64"],
+    "waves": ["GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU"],
+}
+
+
+def pmc_live(batch, groups=("fetch", "write", "fp64", "waves")):
+    """Hardware counters of the solve kernel, measured now: one rocprofv3 --pmc pass per counter group (kernel
+    trace only) over a short nested run of this script; per counter the average over the kernel's launches after
+    the first.  {} on any failure."""
     import csv
     import glob
     import shutil
@@ -58,39 +66,67 @@ def pmc_traffic_live(batch):
     import tempfile
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
-        return None
+        return {}
     vals = {}
     env = dict(os.environ, TMPDIR="/tmp", MI_BENCH_NESTED="1")
-    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+    for grp in groups:
         out = tempfile.mkdtemp(prefix="mi_pmc_", dir="/tmp")
         try:
-            cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", out, "--",
+            cmd = [exe, "--pmc"] + PMC_GROUPS[grp] + ["--kernel-trace", "--output-format", "csv", "-d", out, "--",
                    sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1",
                    "--batch", str(batch), "--no-cpu-baseline", "--no-configs"]
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
                            timeout=180, check=True)
-            rows = []
+            rows = {}
             for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
                 with open(f) as fh:
-                    rows += [float(r["Counter_Value"]) for r in csv.DictReader(fh)
-                             if "ilqr_small_kernel" in r["Kernel_Name"] and r["Counter_Name"] == ctr]
-            if len(rows) < 2:
-                return None
-            vals[ctr] = sum(rows[1:]) / len(rows[1:])          # skip the first (cold) launch
+                    for r in csv.DictReader(fh):
+                        if "ilqr_small_kernel" in r["Kernel_Name"]:
+                            rows.setdefault(r["Counter_Name"], []).append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
+            for ctr, v in rows.items():
+                v.sort()
+                if len(v) >= 2:
+                    vals[ctr] = sum(x for _, x in v[1:]) / len(v[1:])          # skip the first (cold) launch
         except Exception:
-            return None
+            pass
         finally:
             shutil.rmtree(out, ignore_errors=True)
+    return vals
+
+
+def pmc_traffic_live(batch, vals=None):
+    """HBM bytes per launch of the solve kernel from FETCH_SIZE / WRITE_SIZE (KB; FETCH_SIZE is doubled per
+    MI355X_MICROARCH.md: gfx950 tallies wide coalesced reads at half their bytes - an upper bound for our
+    8 B/lane loads).  None on any failure."""
+    vals = pmc_live(batch, ("fetch", "write")) if vals is None else vals
+    if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
+        return None
     return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
 
 
-def pmc_traffic(batch):
+def pmc_traffic(batch, vals=None):
     if os.environ.get("MI_BENCH_NESTED"):
         return None, None
-    live = pmc_traffic_live(batch)
+    live = pmc_traffic_live(batch, vals)
     if live is not None:
         return live, "live rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH x2 gfx950 correction"
     return pmc_traffic_committed(batch)
+
+
+def committed_issue_counters():
+    """profiles/rNN_pmc_issue.json of the latest round (tools/pmc_issue.py on an MI355X): per BASELINE config the fp64
+    flops per iLQR iteration counted by the SQ instruction counters, and the wave-slot occupancy of its launches."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_issue.json")))
+    for f in reversed(files):
+        try:
+            with open(f) as fh:
+                d = json.load(fh)
+            if d.get("configs"):
+                return d["configs"], os.path.basename(f)
+        except Exception:
+            pass
+    return {}, None
 
 
 def cpu_baseline(prob, x0, sample, budget_s=8.0):
@@ -104,23 +140,28 @@ def cpu_baseline(prob, x0, sample, budget_s=8.0):
     N = prob["N"]
     model = M.Model(prob["model_id"], prob["dt"])
     cores = len(os.sched_getaffinity(0))
-    c_oracle.solve_batch(model, prob, x0[:8], None, want_arrays=False)         # build + warm
+    native = True
+    try:
+        c_oracle.solve_batch(model, prob, x0[:8], None, want_arrays=False, native=True)     # build for this host + warm
+    except Exception:
+        native = False                                                                      # (no compiler here: the checker build)
+        c_oracle.solve_batch(model, prob, x0[:8], None, want_arrays=False)
     # pick the thread count that serves this box best (1024 sub-millisecond tasks do not always
     # scale to every hardware thread); the count actually used is what `cores` reports
     best_nt, best_rate = 1, 0.0
     for nt in sorted({1, 8, 16, 32, 64, 128, cores}):
         if nt > cores:
             continue
-        c_oracle.solve_batch(model, prob, x0, None, nthreads=nt, want_arrays=False)
+        c_oracle.solve_batch(model, prob, x0, None, nthreads=nt, want_arrays=False, native=native)
         t_ = time.perf_counter()
-        r_ = c_oracle.solve_batch(model, prob, x0, None, nthreads=nt, want_arrays=False)
+        r_ = c_oracle.solve_batch(model, prob, x0, None, nthreads=nt, want_arrays=False, native=native)
         rate = r_["iters"].sum() / (time.perf_counter() - t_)
         if rate > best_rate:
             best_nt, best_rate = nt, rate
     cores = best_nt
     reps, iters, t0 = 0, 0, time.perf_counter()
     while True:
-        r = c_oracle.solve_batch(model, prob, x0, None, nthreads=cores, want_arrays=False)
+        r = c_oracle.solve_batch(model, prob, x0, None, nthreads=cores, want_arrays=False, native=native)
         iters += int(r["iters"].sum())
         reps += 1
         if time.perf_counter() - t0 > budget_s:
@@ -129,7 +170,9 @@ def cpu_baseline(prob, x0, sample, budget_s=8.0):
     out = {"value": iters / dt, "unit": "iterations/s", "cores": int(r["threads"]), "kind": "port",
            "sample": f"{reps} repetitions of the full {len(x0)}-problem C2 batch ({iters} iterations, {dt:.1f} s), "
                      f"oracle/ilqr_oracle.c, OpenMP {int(r['threads'])} threads",
-           "ms_per_solve": 1e3 * dt / reps}
+           "ms_per_solve": 1e3 * dt / reps,
+           "build": ("gcc " + " ".join(c_oracle.NATIVE_FLAGS) + " (compiled on this host)") if native
+                    else "oracle/Makefile: gcc -O2 -fopenmp -ffp-contract=off (prebuilt checker library)"}
     # NumPy restatement, single thread, a few problems
     it2, done, t1 = 0, 0, time.perf_counter()
     for b in range(min(sample, len(x0))):
@@ -266,6 +309,16 @@ def run_config(rk, dev_index, name, prob, x0_all, u_guess, reps, mpc=None):
            "ms_per_solve": 1e3 * wall / solves, "kernel_ms_per_solve": kms_max / solves,
            "max_iterations_per_problem": int(mx), "converged": int(conv),
            "algorithmic_GBps_per_gpu": gbps, "hbm_frac": gbps / HBM_PEAK_GBS}
+    cc, src = committed_issue_counters()
+    key = name.split()[0]
+    if key in cc and kms_max > 0:
+        # the binding roofline of these kernels: fp64 arithmetic issued / fp64 vector+matrix peak.  Flops per iteration
+        # are the SQ counters' (profiles/, same kernels, same workload); iterations and kernel time are this run's.
+        tf = cc[key]["fp64_flops_per_iteration"] * it / (kms_max * 1e-3) / 1e12 / max(rk.world, 1)
+        out["roofline_compute"] = {"bound": "fp64", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS,
+                                   "fp64_flops_per_iteration": cc[key]["fp64_flops_per_iteration"],
+                                   "wave_slots_occupied": None if "shard" in name else cc[key]["wave_slots_occupied"],
+                                   "counters": "committed " + src}
     if n >= 16:                                      # C5: the backward pass is matrix-core work
         tf = backward_flops_per_iteration(n, m, N) * it / (kms_max * 1e-3) / 1e12 / max(rk.world, 1)
         out["backward_fp64_TFLOPs_per_gpu"] = tf
@@ -479,6 +532,17 @@ def main():
     # 20-step group after an idle spell runs 4-5 % slower than the fourth); W warm-up steps of 0.16 ms do not get
     # there, so CLOCK_RAMP_STEPS more untimed steps precede them.  Reported in the line as `clock_ramp_steps`.
     CLOCK_RAMP_STEPS = 96
+    # The same K steps from an IDLE clock first (no ramp, no warm-up beyond the module load above): `value_cold_clock`,
+    # what a caller who solves one batch now and then sees.  The device idles for half a second before it.
+    rk.fence()
+    time.sleep(0.5)
+    rk.fence()
+    tc0 = time.perf_counter()
+    cold_steps = run_steps(args.steps)
+    drain()
+    rk.fence()
+    cold_elapsed = rk.reduce([time.perf_counter() - tc0], "max")[0]
+    cold_iters = rk.reduce([sum(st.total_iters for st in cold_steps)], "sum")[0]
     run_steps(CLOCK_RAMP_STEPS)
     run_steps(args.warmup)
     drain()
@@ -503,7 +567,33 @@ def main():
         k_ms = kernel_ms / n_timed                          # avg launch duration of the dominant kernel (HIP events)
         bytes_per_launch = alg_bytes / args.steps
         achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic(B) if world == 1 else pmc_traffic_committed(B)
+        ctr = pmc_live(B) if (world == 1 and not os.environ.get("MI_BENCH_NESTED")) else {}
+        traffic, traffic_src = pmc_traffic(B, ctr) if world == 1 else pmc_traffic_committed(B)
+        # the BINDING roofline: fp64 arithmetic issued (SQ instruction counters of this kernel, live when one GPU runs
+        # the bench, else the committed pass) against the fp64 vector peak
+        cc, cc_src = committed_issue_counters()
+        if all(k in ctr for k in PMC_GROUPS["fp64"]):
+            flops = 64.0 * (2 * ctr["SQ_INSTS_VALU_FMA_F64"] + ctr["SQ_INSTS_VALU_ADD_F64"] + ctr["SQ_INSTS_VALU_MUL_F64"] + ctr["SQ_INSTS_VALU_TRANS_F64"])
+            flops_src = "live rocprofv3 --pmc SQ_INSTS_VALU_{FMA,ADD,MUL,TRANS}_F64 x 64 lanes (FMA = 2)"
+        elif "C2" in cc and B == 1024:
+            flops = cc["C2"]["fp64_flops_per_iteration"] * iters / args.steps
+            flops_src = "committed " + cc_src + " (flops per iteration) x this run's iterations"
+        else:
+            flops, flops_src = None, None
+        slots = slots_src = None
+        if "GRBM_GUI_ACTIVE" in ctr and "SQ_WAVE_CYCLES" in ctr and ctr["GRBM_GUI_ACTIVE"] > 0:
+            slots = 4.0 * ctr["SQ_WAVE_CYCLES"] / ((ctr["GRBM_GUI_ACTIVE"] / 8.0) * 1024.0)
+            slots_src = "live: 4 x SQ_WAVE_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)"
+        elif "C2" in cc and B == 1024:
+            slots, slots_src = cc["C2"]["wave_slots_occupied"], "committed " + cc_src
+        compute = None
+        if flops is not None:
+            tf = flops / (k_ms * 1e-3) / 1e12
+            compute = {"bound": "fp64", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS,
+                       "fp64_flops_per_launch": flops, "source": flops_src, "wave_slots_occupied": slots, "wave_slots_source": slots_src,
+                       "valu_busy_of_resident_wave_time": (ctr["SQ_ACTIVE_INST_VALU"] / ctr["SQ_WAVE_CYCLES"]) if ("SQ_ACTIVE_INST_VALU" in ctr and ctr.get("SQ_WAVE_CYCLES")) else None,
+                       "note": "what binds this kernel: one wave per SIMD issues an fp64 instruction every ~5.3 cycles, and the launch lasts as long "
+                               "as its slowest problem (12 iterations against a mean of 6), so about half of the wave slots idle"}
         out = {
             "metric": "iLQR iterations/sec (batch, whole node)",
             "value": iters_all / elapsed,
@@ -526,6 +616,8 @@ def main():
                        "parallelism": f"batch-shard x{world}",
                        "collective": None if world == 1 else ("librccl all-reduce(min) via mi_ilqr_allreduce_min_start" if native is not None
                                                               else f"torch.distributed all_reduce(MIN), backend {backend}")},
+            "value_cold_clock": cold_iters / cold_elapsed,
+            "ms_per_step_cold_clock": 1e3 * cold_elapsed / args.steps,
             "iterations_per_step_rank0": iters / args.steps,
             "max_iterations_per_problem": int(last.max_iters_seen),
             "converged_rank0": int(last.n_converged),
@@ -535,11 +627,14 @@ def main():
                          "kernel": "ilqr_small_kernel<Pendulum,FD,SOLVE>", "kernel_ms": k_ms,
                          "kernel_ms_source": f"HIP events carried by {n_timed} of the {args.steps} timed launches (one in {TIME_EVERY})",
                          "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "hbm_traffic_frac": (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                          "note": "issue-latency-bound: one wave per problem, rollout and Riccati sweep as time-parallel scans; state is LDS-resident, the launch lasts as long as its slowest problem"},
         }
+        out["roofline_compute"] = compute
         out["cpu_baseline"] = cpu_base
-        out["order"] = ("cpu_baseline, configs, boundary_inclusive, then the headline: clock_ramp_steps untimed steps (the shader clock "
-                        "reaches its sustained level), the W warm-up steps, the K timed steps")
+        out["order"] = ("cpu_baseline, configs, boundary_inclusive, then the headline: 0.5 s idle, K steps from the idle clock "
+                        "(value_cold_clock), clock_ramp_steps untimed steps (the shader clock reaches its sustained level), the W "
+                        "warm-up steps, the K timed steps (value)")
         out["configs"] = configs
         out["boundary_inclusive"] = boundary
         out["concurrent_batches"] = concurrent

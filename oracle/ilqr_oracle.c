@@ -20,7 +20,7 @@
 #include <omp.h>
 #endif
 
-#define MAXN 36
+#define MAXN 40
 #define MAXM 12
 
 typedef struct {
@@ -30,6 +30,9 @@ typedef struct {
   int minN;          /* setInterval spacing (ilqr.py:417-432) */
   double fd_h;
   int max_iters;
+  /* key-point method (ilqr.py:393-404): 0 setInterval, 1 adaptiveJerk, 2 iterativeError; zero-initialized = setInterval */
+  int kp_method, maxN;
+  double jerk_thr, err_thr;
 } oracle_cfg;
 
 /* ---- models: same formulas / operation order as oracle/models_np.py ---- */
@@ -219,6 +222,9 @@ static void step(const oracle_cfg* c, const double* x, const double* u, double* 
 
 typedef struct {
   double *x_bar, *u_bar, *K, *kappa, *dV, *fx, *fu, *x, *u;
+  int* kp;          /* key-points of the last linearization (N entries) */
+  int nk;
+  unsigned char* done;   /* iterativeError: derivative evaluated at this index */
 } work;
 
 /* one line-search trial: ilqr.py:306-327 */
@@ -269,32 +275,103 @@ static void invert(int m, const double* A, double* Ai) {
   for (int i = 0; i < m; ++i) for (int j = 0; j < m; ++j) Ai[i * m + j] = a[i][m + j];
 }
 
-/* _get_derivatives with setInterval key-points + interpolation: ilqr.py:380-432, 596-621 */
-static void linearize(const oracle_cfg* c, const work* w) {
-  const int n = c->n, m = c->m, N = c->N, minN = c->minN;
+/* _calc_dynamics_partials at step t of the trial (central differences stand in for AutoDiff): ilqr.py:233-272 */
+static void partials_at(const oracle_cfg* c, const work* w, int t) {
+  const int n = c->n, m = c->m, N = c->N;
   const double h = c->fd_h, inv2h = 1.0 / (2.0 * h);
-  int nk = (N - 2) / minN + 1;
-  int* kp = (int*)calloc((size_t)nk + 1, sizeof(int));
-  for (int i = 0; i < nk; ++i) kp[i] = i * minN;
-  if (kp[nk - 1] != N - 2) kp[nk - 1] = N - 2;                        /* overwrite, not append (:428-430) */
   double xt[MAXN], ut[MAXM], xp[MAXN], up[MAXM], fp[MAXN], fm[MAXN];
-  for (int q = 0; q < nk; ++q) {
-    const int t = kp[q];
-    for (int i = 0; i < n; ++i) xt[i] = X(w->x, i, t);
-    for (int k = 0; k < m; ++k) ut[k] = U(w->u, k, t);
-    for (int col = 0; col < n + m; ++col) {
-      memcpy(xp, xt, sizeof(double) * n); memcpy(up, ut, sizeof(double) * m);
-      if (col < n) xp[col] = xt[col] + h; else up[col - n] = ut[col - n] + h;
-      step(c, xp, up, fp);
-      if (col < n) xp[col] = xt[col] - h; else up[col - n] = ut[col - n] - h;
-      step(c, xp, up, fm);
-      for (int i = 0; i < n; ++i) {
-        const double d = (fp[i] - fm[i]) * inv2h;
-        if (col < n) FX(w->fx, i, col, t) = d; else FU(w->fu, i, col - n, t) = d;
-      }
+  for (int i = 0; i < n; ++i) xt[i] = X(w->x, i, t);
+  for (int k = 0; k < m; ++k) ut[k] = U(w->u, k, t);
+  for (int col = 0; col < n + m; ++col) {
+    memcpy(xp, xt, sizeof(double) * n); memcpy(up, ut, sizeof(double) * m);
+    if (col < n) xp[col] = xt[col] + h; else up[col - n] = ut[col - n] + h;
+    step(c, xp, up, fp);
+    if (col < n) xp[col] = xt[col] - h; else up[col - n] = ut[col - n] - h;
+    step(c, xp, up, fm);
+    for (int i = 0; i < n; ++i) {
+      const double d = (fp[i] - fm[i]) * inv2h;
+      if (col < n) FX(w->fx, i, col, t) = d; else FU(w->fu, i, col - n, t) = d;
     }
   }
-  if (minN != 1) {                                                    /* :414 */
+}
+
+/* get_keypoints_set_interval: ilqr.py:417-432 (the LAST entry is overwritten, not appended) */
+static int keypoints_set_interval(const oracle_cfg* c, int* kp) {
+  const int N = c->N, minN = c->minN;
+  const int nk = (N - 2) / minN + 1;
+  for (int i = 0; i < nk; ++i) kp[i] = i * minN;
+  if (kp[nk - 1] != N - 2) kp[nk - 1] = N - 2;
+  return nk;
+}
+
+/* get_keypoints_adaptive_jerk + calc_jerk_profile: ilqr.py:434-486 (signed second difference of the velocity rows,
+ * dof = int(n/2); the last entry is overwritten with N-2) */
+static int keypoints_adaptive_jerk(const oracle_cfg* c, const work* w, int* kp) {
+  const int n = c->n, N = c->N, dof = n / 2;
+  int nk = 0, counter = 0;
+  kp[nk++] = 0;
+  for (int t = 0; t < N - 3; ++t) {
+    counter += 1;
+    if (counter >= c->minN) {
+      for (int i = 0; i < dof; ++i) {
+        const double a1 = X(w->x, i + dof, t + 2) - X(w->x, i + dof, t + 1);
+        const double a2 = X(w->x, i + dof, t + 1) - X(w->x, i + dof, t);
+        if (a1 - a2 > c->jerk_thr) { kp[nk++] = t; counter = 0; break; }
+      }
+    }
+    if (counter >= c->maxN) { kp[nk++] = t; counter = 0; }
+  }
+  if (kp[nk - 1] != N - 2) kp[nk - 1] = N - 2;
+  return nk;
+}
+
+/* get_keypoints_iterative_error + check_one_matrix_error: ilqr.py:488-593.  Level-synchronous bisection; a bin is
+ * split when sum_ij ((fx[s]+fx[e])/2 - fx[mid])^2 / (2n) > threshold; bins with e - s <= minN pass untested.  The
+ * Jacobians it evaluates are written into fx/fu as it goes, like the reference. */
+static int keypoints_iterative_error(const oracle_cfg* c, const work* w, int* kp) {
+  const int n = c->n, N = c->N;
+  memset(w->done, 0, (size_t)N);
+  int* bins = (int*)malloc(sizeof(int) * 4 * (size_t)N);
+  int* next = (int*)malloc(sizeof(int) * 4 * (size_t)N);
+  int nb = 1;
+  bins[0] = 0; bins[1] = N - 2;
+  while (nb > 0) {
+    int nn = 0;
+    for (int q = 0; q < nb; ++q) {
+      const int s = bins[2 * q], e = bins[2 * q + 1];
+      if (e - s <= c->minN) continue;
+      const int mid = (s + e) / 2;
+      if (!w->done[s]) { partials_at(c, w, s); w->done[s] = 1; }
+      if (!w->done[mid]) { partials_at(c, w, mid); w->done[mid] = 1; }
+      if (!w->done[e]) { partials_at(c, w, e); w->done[e] = 1; }
+      double sum = 0.0;
+      for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) {
+        const double lin = (FX(w->fx, i, j, e) + FX(w->fx, i, j, s)) / 2;
+        const double d = lin - FX(w->fx, i, j, mid);
+        sum += d * d;
+      }
+      if (sum / (2 * n) > c->err_thr) { next[2 * nn] = s; next[2 * nn + 1] = mid; nn++; next[2 * nn] = mid; next[2 * nn + 1] = e; nn++; }
+    }
+    int* tmp = bins; bins = next; next = tmp;
+    nb = nn;
+  }
+  free(bins); free(next);
+  int nk = 0;
+  for (int t = 0; t < N - 1; ++t) if (w->done[t]) kp[nk++] = t;
+  return nk;
+}
+
+/* _get_derivatives: key-points, partials at them, interpolation in between - ilqr.py:380-415, 596-621 */
+static void linearize(const oracle_cfg* c, work* w) {
+  const int n = c->n, m = c->m, N = c->N;
+  int* kp = w->kp;
+  int nk;
+  if (c->kp_method == 1) nk = keypoints_adaptive_jerk(c, w, kp);
+  else if (c->kp_method == 2) nk = keypoints_iterative_error(c, w, kp);
+  else nk = keypoints_set_interval(c, kp);
+  w->nk = nk;
+  if (c->kp_method != 2) for (int q = 0; q < nk; ++q) partials_at(c, w, kp[q]);      /* :409-411 */
+  if (!(c->kp_method == 0 && c->minN == 1)) {                        /* :414 */
     for (int q = 0; q + 1 < nk; ++q) {
       const int s = kp[q], e = kp[q + 1];
       for (int j = s + 1; j < e; ++j) {
@@ -303,7 +380,6 @@ static void linearize(const oracle_cfg* c, const work* w) {
       }
     }
   }
-  free(kp);
 }
 
 /* _backward_pass with the cost partials folded in: ilqr.py:161-206, 623-667 */
@@ -369,23 +445,26 @@ static void fresh_state(const oracle_cfg* c, work* w) {
  * calls exactly as the attributes of the reference object do - SURVEY F10: the first rollout of a re-solve
  * applies the previous solve's gains about the previous x_bar and is accepted unconditionally, L_last = inf).
  * status: 0 ok, 1 max_iters, 2 linesearch failed */
-static int solve_one(const oracle_cfg* c, const double* Q, const double* R, const double* Qf, const double* xnom,
-                     const double* x0, work* w, double* cost, int* iters, int* ls_trials) {
+/* hist (optional): hist_cap rows of (cost, eps, line-search trials, key-point count) per iteration, like the rows of
+ * the reference's console table (ilqr.py:704) */
+static int solve_one_h(const oracle_cfg* c, const double* Q, const double* R, const double* Qf, const double* xnom,
+                       const double* x0, work* w, double* cost, int* iters, int* ls_trials, double* hist, int hist_cap) {
   const int n = c->n, m = c->m, N = c->N;
   double L = INFINITY, improvement = INFINITY;
   int it = 0, ls = 0, status = 0;
   while (improvement > c->delta) {
     if (it >= c->max_iters) { status = 1; break; }
     double eps = 1.0, Lnew = 0.0, ex;
-    int accepted = 0;
+    int accepted = 0, ls_it = 0;
     while (eps >= 1e-8) {                                             /* :302 */
-      ls++;
+      ls++; ls_it++;
       Lnew = rollout(c, Q, R, Qf, xnom, x0, w, eps, &ex);
       if (L - Lnew > c->gamma * ex) { accepted = 1; break; }          /* :330-331 */
       eps *= c->beta;                                                 /* :335 */
     }
     if (!accepted) { status = 2; break; }
     linearize(c, w);                                                  /* :370 */
+    if (hist && it < hist_cap) { hist[4 * it] = Lnew; hist[4 * it + 1] = eps; hist[4 * it + 2] = (double)ls_it; hist[4 * it + 3] = (double)w->nk; }
     memcpy(w->x_bar, w->x, sizeof(double) * n * N);                   /* :375-376 */
     memcpy(w->u_bar, w->u, sizeof(double) * m * (N - 1));
     backward(c, Q, R, Qf, xnom, w);                                   /* :697 */
@@ -396,6 +475,10 @@ static int solve_one(const oracle_cfg* c, const double* Q, const double* R, cons
   *cost = L; *iters = it; *ls_trials = ls;
   return status;
 }
+static int solve_one(const oracle_cfg* c, const double* Q, const double* R, const double* Qf, const double* xnom,
+                     const double* x0, work* w, double* cost, int* iters, int* ls_trials) {
+  return solve_one_h(c, Q, R, Qf, xnom, x0, w, cost, iters, ls_trials, NULL, 0);
+}
 
 static void work_alloc(work* w, int n, int m, int N) {
   w->x_bar = (double*)malloc(sizeof(double) * n * N); w->x = (double*)malloc(sizeof(double) * n * N);
@@ -403,13 +486,29 @@ static void work_alloc(work* w, int n, int m, int N) {
   w->K = (double*)malloc(sizeof(double) * m * n * (N - 1)); w->kappa = (double*)malloc(sizeof(double) * m * (N - 1));
   w->dV = (double*)malloc(sizeof(double) * (N - 1));
   w->fx = (double*)malloc(sizeof(double) * n * n * (N - 1)); w->fu = (double*)malloc(sizeof(double) * n * m * (N - 1));
+  w->kp = (int*)calloc((size_t)N + 1, sizeof(int)); w->nk = 0;
+  w->done = (unsigned char*)calloc((size_t)N + 1, 1);
 }
-static void work_free(work* w) { free(w->x_bar); free(w->x); free(w->u_bar); free(w->u); free(w->K); free(w->kappa); free(w->dV); free(w->fx); free(w->fu); }
+static void work_free(work* w) { free(w->x_bar); free(w->x); free(w->u_bar); free(w->u); free(w->K); free(w->kappa); free(w->dV); free(w->fx); free(w->fu); free(w->kp); free(w->done); }
 
 /* Batched cold-start solve; outputs may be NULL.  Returns the number of threads used. */
+int oracle_solve_batch_ex(const oracle_cfg* c, int B, const double* Q, const double* R, const double* Qf, const double* xnom,
+                          const double* x0, const double* u_guess, double* x_bar, double* u_bar, double* K, double* kappa,
+                          double* cost, int* iters, int* ls_trials, int* status, int nthreads,
+                          double* hist, int hist_cap, int* kp_count, int* kp_list);
 int oracle_solve_batch(const oracle_cfg* c, int B, const double* Q, const double* R, const double* Qf, const double* xnom,
                        const double* x0, const double* u_guess, double* x_bar, double* u_bar, double* K, double* kappa,
                        double* cost, int* iters, int* ls_trials, int* status, int nthreads) {
+  return oracle_solve_batch_ex(c, B, Q, R, Qf, xnom, x0, u_guess, x_bar, u_bar, K, kappa, cost, iters, ls_trials, status, nthreads,
+                               NULL, 0, NULL, NULL);
+}
+
+/* ... with the per-iteration history (B, hist_cap, 4) and the key-points of the LAST linearization (counts (B,), lists
+ * (B, N-1)); any of them may be NULL. */
+int oracle_solve_batch_ex(const oracle_cfg* c, int B, const double* Q, const double* R, const double* Qf, const double* xnom,
+                          const double* x0, const double* u_guess, double* x_bar, double* u_bar, double* K, double* kappa,
+                          double* cost, int* iters, int* ls_trials, int* status, int nthreads,
+                          double* hist, int hist_cap, int* kp_count, int* kp_list) {
   const int n = c->n, m = c->m, N = c->N;
   if (n > MAXN || m > MAXM) return -1;
   int used = 1;
@@ -429,7 +528,10 @@ int oracle_solve_batch(const oracle_cfg* c, int B, const double* Q, const double
       double L; int it, ls;
       fresh_state(c, &w);
       if (u_guess) memcpy(w.u_bar, u_guess + (size_t)b * m * (N - 1), sizeof(double) * m * (N - 1));   /* SetInitialGuess (:148-156) */
-      const int st = solve_one(c, Q, R, Qf, xnom, x0 + (size_t)b * n, &w, &L, &it, &ls);
+      const int st = solve_one_h(c, Q, R, Qf, xnom, x0 + (size_t)b * n, &w, &L, &it, &ls,
+                                 hist ? hist + (size_t)b * hist_cap * 4 : NULL, hist_cap);
+      if (kp_count) kp_count[b] = w.nk;
+      if (kp_list) memcpy(kp_list + (size_t)b * (N - 1), w.kp, sizeof(int) * (size_t)(w.nk < N - 1 ? w.nk : N - 1));
       if (cost) cost[b] = L;
       if (iters) iters[b] = it;
       if (ls_trials) ls_trials[b] = ls;

@@ -36,3 +36,23 @@ def make_oracle(prob, keypoint=None, jacobian="ad", fd_step=1e-5):
 def rel_err(a, b):
     a, b = np.asarray(a, float), np.asarray(b, float)
     return float(np.max(np.abs(a - b)) / max(1e-300, np.max(np.abs(b))))
+
+
+# Problems of a batch whose line-search decisions (iteration / trial counts) differ from the checker's.  An
+# ill-conditioned solve can flip one decision at round-off level; the budget of every test is the count OBSERVED on
+# its committed seeds (MI355X, round 3) - a regression that makes more problems deviate fails loudly, and a test
+# that spends budget says so in its own entry here.
+FLIP_BUDGET = {
+    "c3_mpc_full": 0, "c5_mpc_full": 0, "quad_mpc_full": 0,
+    "randomized_0": 0, "randomized_1": 0, "randomized_2": 0, "randomized_3": 0,
+    "short_horizons": 0, "pendulum_mpc_par_vs_seq": 0, "scan_vs_seq_backward": 0,
+    "quad_batch_free": 0, "quad_batch_tight": 0, "quad_batch_free_unconverged": 0, "quad_batch_tight_unconverged": 0,
+    "c4_full_leading5": 0,
+}
+
+
+def assert_flip_budget(name, same, detail=None):
+    """`same`: boolean per problem (counts identical to the checker's).  At most FLIP_BUDGET[name] may be False."""
+    import numpy as _np
+    flipped = int((~_np.asarray(same, bool)).sum())
+    assert flipped <= FLIP_BUDGET[name], (name, f"{flipped} problems deviate, budget {FLIP_BUDGET[name]}", detail)

@@ -83,3 +83,30 @@ def test_c_oracle_planar_quadruped_vs_reference_golden(name):
     assert r["status"][0] == 0 and r["iters"][0] == len(g["hist"]) and r["ls"][0] == int(g["hist"][:, 2].sum())
     assert abs(r["cost"][0] - g["L"]) < 1e-7 * abs(g["L"])
     assert np.max(np.abs(r["x_bar"][0] - g["x_bar"])) < 1e-5 and rel_err(r["K"][0], g["K"]) < 1e-4
+
+
+@pytest.mark.parametrize("name", ["pendulum_kp_setinterval5", "pendulum_kp_adaptivejerk", "pendulum_kp_iterativeerror",
+                                  "acrobot_kp_adaptivejerk", "acrobot_kp_iterativeerror"])
+def test_c_oracle_keypoint_methods_vs_numpy_oracle_and_golden(name):
+    """setInterval / adaptiveJerk / iterativeError (ilqr.py:417-593) in the C restatement: against the NumPy oracle with
+    the same central differences (per-iteration trials, step sizes and key-point counts exact, the last key-point
+    list exact), and against the list the unmodified reference recorded (exact Jacobians there)."""
+    from common import golden_keypoint
+    from oracle import c_oracle, models_np as M
+    g, prob = load_golden(name)
+    kp = golden_keypoint(g)
+    o = make_oracle(prob, keypoint=kp, jacobian="fd", fd_step=1e-5)
+    o.set_problem(g["x0"], prob["x_nom"], prob["Q"], prob["R"], prob["Qf"], g["u_guess"])
+    x, u, L, hist = o.solve()
+    hist = np.array(hist)
+    r = c_oracle.solve_batch(M.Model(prob["model_id"], prob["dt"]), prob, g["x0"][None], g["u_guess"], keypoint=kp, hist_cap=64)
+    it = int(r["iters"][0])
+    assert it == len(hist) and r["status"][0] == 0
+    h = r["hist"][0][:it]
+    assert np.array_equal(h[:, 1:3], hist[:, 1:3])                                        # eps and trials of every iteration
+    assert np.array_equal(h[:, 3], np.round(hist[:, 3] * (prob["N"] - 1) / 100.0))        # key-point count of every iteration
+    assert rel_err(h[:, 0], hist[:, 0]) < 1e-8          # (central differences of the acrobot: round-off level 1e-9)
+    nk = int(r["kp_count"][0])
+    assert np.array_equal(r["kp_list"][0][:nk], o.keypoints)
+    assert np.array_equal(r["kp_list"][0][:nk], g["kp_last"]) and it == len(g["hist"])
+    assert rel_err(r["x_bar"][0], x) < 1e-6 and abs(r["cost"][0] - L) < 1e-8 * abs(L)

@@ -6,6 +6,8 @@ import os
 import numpy as np
 import pytest
 
+from common import assert_flip_budget
+
 from test_gpu_parity import make_solver
 
 pytestmark = pytest.mark.gpu
@@ -240,7 +242,7 @@ def test_randomized_configs_vs_c_oracle(seed):
     same = (it == r["iters"]) & (ls == r["ls"])
     # a long or ill-conditioned solve may flip one line-search decision at round-off level: rare (none on these
     # seeds today), and such a problem must still land on the oracle's optimum
-    assert same.mean() >= 0.97, (same.mean(), it[~same][:10], r["iters"][~same][:10])
+    assert_flip_budget(f"randomized_{seed}", same, (it[~same][:10], r["iters"][~same][:10]))
     rel = np.abs(L - r["cost"]) / np.abs(r["cost"])
     assert np.max(rel[same]) < 1e-7
     assert np.all(rel[~same] < 1e-3)
@@ -334,7 +336,7 @@ def test_pendulum_horizons_around_the_lane_chunk_edges(N):
     r = c_oracle.solve_batch(M.Model(0, dt), prob, x0, ug)
     assert np.array_equal(s.status, r["status"]) and (s.status == 0).all()
     same = (s.iterations == r["iters"]) & (s.ls_trials == r["ls"])
-    assert same.mean() >= 0.97, (same.mean(), s.iterations[~same][:8], r["iters"][~same][:8])
+    assert_flip_budget("short_horizons", same, (s.iterations[~same][:8], r["iters"][~same][:8]))
     rel = np.abs(L - r["cost"]) / np.abs(r["cost"])
     assert np.max(rel[same]) < 1e-7 and np.all(rel[~same] < 1e-3)          # a flipped decision still reaches the same optimum
     # (the shortest horizons need controls ~1e3 to reach the target in 3 steps: relative to the largest entry)
@@ -366,7 +368,7 @@ np.savez(sys.argv[1], log=s.mpc_log, x=s.x_bar, u=s.u_bar, K=s.K, it=s.iteration
     par = _run_variant(script, {}, str(tmp_path / "par.npz"), tmp_path)
     seq = _run_variant(script, {"MI_ILQR_SEQ_BACKWARD": "1", "MI_ILQR_SEQ_ROLLOUT": "1"}, str(tmp_path / "seq.npz"), tmp_path)
     same = (par["it"] == seq["it"]) & (par["ls"] == seq["ls"])
-    assert same.mean() >= 0.95
+    assert_flip_budget("pendulum_mpc_par_vs_seq", same)
     # (a problem whose counts differ flipped one decision in one of 12 re-solves: its final costs still agree)
     assert np.allclose(par["log"][~same][:, -1, -2], seq["log"][~same][:, -1, -2], rtol=1e-3)
     assert np.allclose(par["log"][same], seq["log"][same], rtol=1e-7, atol=1e-9)
@@ -482,6 +484,6 @@ np.savez(sys.argv[1], K1=K1, k1=k1, dV1=dV1, L=L, it=s.iterations, ls=s.ls_trial
     for f in ("K1", "k1", "dV1"):
         assert np.max(np.abs(par[f] - seq[f])) < 1e-9 * max(1.0, np.max(np.abs(seq[f]))), f
     same = (par["it"] == seq["it"]) & (par["ls"] == seq["ls"])
-    assert same.mean() >= 0.9, (par["ls"], seq["ls"])
+    assert_flip_budget("scan_vs_seq_backward", same, (par["ls"], seq["ls"]))
     # (the stiff contact model amplifies faster: 1e-5 there)
     assert np.max(np.abs(par["L"][same] - seq["L"][same]) / np.abs(seq["L"][same])) < (1e-5 if model_id == 3 else 1e-6)

@@ -11,7 +11,7 @@ import os
 import numpy as np
 import pytest
 
-from common import load_golden, make_oracle, rel_err
+from common import load_golden, make_oracle, rel_err, assert_flip_budget
 from test_gpu_parity import make_solver
 
 pytestmark = pytest.mark.gpu
@@ -20,15 +20,15 @@ pytestmark = pytest.mark.gpu
 # ----------------------------------------------------------------------------------
 # the benchmarked MPC paths at BASELINE.json's sizes
 # ----------------------------------------------------------------------------------
-def _check_mpc_against_oracle(s, r, first_it, first_L, n, tol_L, tol_x):
+def _check_mpc_against_oracle(s, r, first_it, first_L, n, tol_L, tol_x, budget="c3_mpc_full"):
     log = s.mpc_log
     assert np.array_equal(first_it, r["first"][:, 1].astype(int))
     assert np.max(np.abs(first_L - r["first"][:, 0]) / np.abs(r["first"][:, 0])) < tol_L
     assert (s.status == 0).all() and (r["status"] == 0).all()
     same = log[:, :, -1] == r["log"][:, :, -1]                        # iterations of every re-solve of every problem
     full = same.all(axis=1)
-    # a flipped line-search decision at round-off level is tolerated in at most 2 % of the problems (none today) ...
-    assert full.mean() >= 0.98, full.mean()
+    # a flipped line-search decision at round-off level: as many problems as were observed to have one (common.FLIP_BUDGET) ...
+    assert_flip_budget(budget, full)
     relL = np.abs(log[:, :, -2] - r["log"][:, :, -2]) / np.abs(r["log"][:, :, -2])
     assert np.max(relL[full]) < tol_L
     # ... and such a problem must still track the oracle's closed loop: cost of every re-solve within 1e-3
@@ -80,7 +80,7 @@ def test_c5_full_size_mpc_run_vs_oracle():
     st = s.MPCRun(100, 4, target_step=step)
     r = c_oracle.mpc_batch(M.Model(q["model_id"], q["dt"]), q, x0, ug, 100, 4, target_step=step)
     r["ls"] = r["ls"] - ls0
-    log = _check_mpc_against_oracle(s, r, first_it, first_L, 36, tol_L=5e-8, tol_x=1e-6)
+    log = _check_mpc_against_oracle(s, r, first_it, first_L, 36, tol_L=5e-8, tol_x=1e-6, budget="c5_mpc_full")
     assert st.total_iters == int(log[:, :, -1].sum()) and st.n_converged == B
     assert np.allclose(s.x_nom, q["x_nom"] + 100 * step)              # the handle's target followed the loop
 
@@ -464,7 +464,8 @@ def test_quad_batch_fd_vs_c_oracle_with_infeasible_trials():
         assert np.array_equal(s.status, r["status"])
         ok = s.status == 0
         same = ok & (s.iterations == r["iters"]) & (s.ls_trials == r["ls"])
-        assert ok.mean() > 0.9 and same[ok].mean() >= 0.95, (tag, ok.mean(), same.mean())
+        assert_flip_budget(f"quad_batch_{tag}_unconverged", ok)
+        assert_flip_budget(f"quad_batch_{tag}", same[ok])
         rel = np.abs(L - r["cost"]) / np.abs(r["cost"])
         assert np.max(rel[same]) < 1e-6 and np.all(rel[ok & ~same] < 1e-2)
         assert np.max(np.abs(x[same] - r["x_bar"][same])) < 1e-4
@@ -517,7 +518,7 @@ def test_quad_full_size_mpc_run_vs_oracle():
     st = s.MPCRun(100, 4, target_step=step)
     r = c_oracle.mpc_batch(M.Model(q["model_id"], q["dt"]), q, x0, ug, 100, 4, target_step=step)
     r["ls"] = r["ls"] - ls0
-    log = _check_mpc_against_oracle(s, r, first_it, first_L, 36, tol_L=1e-6, tol_x=1e-5)
+    log = _check_mpc_against_oracle(s, r, first_it, first_L, 36, tol_L=1e-6, tol_x=1e-5, budget="quad_mpc_full")
     assert st.n_converged == B and np.all(log[:, -1, 0] > 0.3)        # the trunk moved forward by 0.3 m or more
 
 

@@ -56,10 +56,36 @@ for k, c in acc.items():
             "lds_bank_conflict_fraction (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE)": c.get("SQ_LDS_BANK_CONFLICT", 0) / max(1.0, c.get("SQ_LDS_IDX_ACTIVE", 0)),
             "mfma_busy_fraction_of_chip: SQ_VALU_MFMA_BUSY_CYCLES / (kernel_cycles * 1024 SIMDs)": c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (g * N_SIMD),
         }
+# fp64 work per launch from the instruction counters (wave-instructions x 64 lanes, i.e. an upper bound where exec
+# masks are partial; an FMA = 2 flops, one v_mfma_f64_16x16x4 = 2048) and, per BASELINE config, per iLQR iteration:
+# the iteration counts come from one un-profiled run of the same script (the solves are deterministic).
+for k, c in acc.items():
+    c["fp64_flops_per_launch"] = 64.0 * (2 * c.get("SQ_INSTS_VALU_FMA_F64", 0) + c.get("SQ_INSTS_VALU_ADD_F64", 0) + c.get("SQ_INSTS_VALU_MUL_F64", 0)
+                                         + c.get("SQ_INSTS_VALU_TRANS_F64", 0)) + 2048.0 * c.get("SQ_INSTS_MFMA", 0)
+r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "run_configs.py")], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600)
+lines = [json.loads(l) for l in r.stdout.decode().splitlines() if l.startswith("{")]
+iters = {l["config"].split()[0] + ("/8" if "shard" in l["config"] else ""): l.get("iters_total", l.get("iters_per_solve")) for l in lines}
+KERNELS = {   # config -> (model substring, workgroups of the launch); every kernel mode of that model and grid is the config's
+    "C1": ("Pendulum", 1), "C2": ("Pendulum", 1024), "C3": ("Acrobot", 512), "C4": ("CartPoleT<true>", 256),
+    "C5": ("Synth36", 64), "C5q": ("PlanarQuad", None)}
+per_config = {}
+for cfg, (model, grid) in KERNELS.items():
+    ks = [k for k in acc if model in k and (grid is None or ("grid=%d x" % grid) in k)]
+    key = cfg
+    if not ks or key not in iters:
+        continue
+    fl = sum(acc[k]["fp64_flops_per_launch"] for k in ks)
+    wc = sum(acc[k].get("SQ_WAVE_CYCLES", 0) for k in ks)
+    kc = sum(acc[k].get("kernel_cycles (GRBM_GUI_ACTIVE / 8 XCDs)", 0) for k in ks)
+    per_config[cfg] = {
+        "kernels": ks, "iterations_per_run": iters[key], "fp64_flops_per_run": fl, "fp64_flops_per_iteration": fl / max(1.0, iters[key]),
+        "wave_slots_occupied": 4 * wc / max(1.0, kc * N_SIMD)}
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 path = os.path.join(ROOT, "gpurun_out", tag + "_pmc_issue.json")
 json.dump({"command": "rocprofv3 --pmc <group> --kernel-trace --output-format csv -- python tools/run_configs.py (one pass per group)",
-           "groups": GROUPS, "kernels": acc}, open(path, "w"), indent=1)
+           "groups": GROUPS, "kernels": acc, "configs": per_config}, open(path, "w"), indent=1)
+for k, c in per_config.items():
+    print("%-10s fp64 flops/iteration %.4g   wave slots %.3f" % (k, c["fp64_flops_per_iteration"], c["wave_slots_occupied"]))
 for k, c in acc.items():
     print(k)
     for name, v in c.get("derived", {}).items():
