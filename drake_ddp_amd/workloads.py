@@ -8,7 +8,7 @@ Pure NumPy, importable without a GPU.
 """
 import numpy as np
 
-PENDULUM, ACROBOT, CARTPOLE, CARTPOLE_WALL, SYNTH36, PLANAR_QUAD = 0, 1, 2, 3, 4, 5
+PENDULUM, ACROBOT, CARTPOLE, CARTPOLE_WALL, SYNTH36, PLANAR_QUAD, QUAD3D = 0, 1, 2, 3, 4, 5, 6
 SYNTH_TARGET_VEL = 1.0
 
 
@@ -147,6 +147,58 @@ def planar_quad_batch_x0(B, seed=4):
 def planar_quad_u_guess(N):
     """Constant standing torques (the 'u_stand' of mini_cheetah.py:47-49,177)."""
     return np.repeat(_QUAD_U_STAND[:, None], N - 1, axis=1)
+
+
+# ---- 3-D quadruped: floating base with a quaternion attitude + four 3-joint legs + feet contact (csrc/models.hpp: Quad3D), n=37 m=12
+QUAD3D_TARGET_VEL = 1.0                             # mini_cheetah.py:25
+_Q3_LEG = np.array([0.0, -0.8, 1.6])                # ab/ad, hip, knee (mini_cheetah.py:41-46)
+_Q3_STAND_Z = 0.27711117215837355                   # feet 4.4 mm into the compliant ground: 4 f_n = m g
+_Q3_U_STAND = np.array([1.368495, 0.221674, -3.087599, -1.368495, 0.221674, -3.087599,
+                        1.368495, 0.221674, -3.087599, -1.368495, 0.221674, -3.087599])
+
+
+def quad3d_stand():
+    """Standing state (mini_cheetah.py:41-52: q0 = [1,0,0,0 | 0,0,z | 4 x (0,-0.8,1.6)], zero velocity)."""
+    x = np.zeros(37)
+    x[0] = 1.0
+    x[6] = _Q3_STAND_Z
+    x[7:19] = np.tile(_Q3_LEG, 4)
+    return x
+
+
+def quad3d_problem(N=40):
+    """mini_cheetah.py:54-69,168-173 on the build's 3-D quadruped: Q = diag([3,3,3,3,1,1,1 | 0 x 12 | 0.01 x 6 | 0.01 x 12]),
+    R = 0.01 I, Qf = diag([5 x base | 0.1 x 12 | 1 x 6 | 0.01 x 12]), passed as dt*Q, dt*R, Qf; the target is the standing
+    state moved forward by target_vel * T with base x velocity target_vel; dt = 4e-3, beta = 0.5, delta = 1e-2."""
+    dt = 4e-3
+    qb = np.ones(7)
+    qb[0:4] += 2.0
+    vb = np.ones(6)
+    ql, vl = np.zeros(12), 0.01 * np.ones(12)
+    Q = np.diag(np.hstack([qb, ql, 0.01 * vb, vl]))
+    R = 0.01 * np.eye(12)
+    Qf = np.diag(np.hstack([5 * qb, 0.1 + ql, vb, vl]))
+    x_nom = quad3d_stand()
+    x_nom[4] += QUAD3D_TARGET_VEL * N * dt          # base x position (mini_cheetah.py:56)
+    x_nom[22] += QUAD3D_TARGET_VEL                  # base x velocity (:57)
+    return dict(name="quadruped_3d", model_id=QUAD3D, dt=dt, N=N, x_nom=x_nom,
+                Q=dt * Q, R=dt * R, Qf=Qf, delta=1e-2, beta=0.5, gamma=0.0)
+
+
+def quad3d_batch_x0(B, seed=5):
+    """Standing states with the attitude, height and joints perturbed (unit quaternions)."""
+    rng = np.random.default_rng(seed)
+    x0 = np.tile(quad3d_stand(), (B, 1))
+    x0[:, 1:4] += rng.uniform(-0.02, 0.02, (B, 3))
+    x0[:, 0:4] /= np.linalg.norm(x0[:, 0:4], axis=1, keepdims=True)
+    x0[:, 6] += rng.uniform(0.0, 0.01, B)
+    x0[:, 7:19] += rng.uniform(-0.05, 0.05, (B, 12))
+    return x0
+
+
+def quad3d_u_guess(N):
+    """Constant standing torques (the u_stand of mini_cheetah.py:47-49,177)."""
+    return np.repeat(_Q3_U_STAND[:, None], N - 1, axis=1)
 
 
 def mpc_shift(x, u, replan):

@@ -234,6 +234,19 @@ def main():
     for k, i in enumerate((6, 7)):
         single_solve(f"quad_infeasible_{k}", cqt, qx0[i], qug)
 
+    # (f)4: the 3-D quadruped (quaternion floating base, n = 37, feet contact): mini_cheetah.py's own state layout,
+    # cost weights, moving target (x_nom[4] += target_vel * dt * replan, :151-156) and MPC loop (:186-201).
+    c3d = P.quad3d_problem()
+    x3 = P.quad3d_batch_x0(8)
+    u3 = P.quad3d_u_guess(c3d["N"])
+    stage_level("quad3d_stage", c3d, x3[0], u3, n_iters=2)
+    single_solve("quad3d_solve_0", c3d, x3[0], u3)
+    single_solve("quad3d_solve_1", c3d, x3[1], u3)
+    mpc("quad3d_mpc_0", c3d, x3[2], u3, resolves=3, replan=4, move_target=(4, P.QUAD3D_TARGET_VEL * c3d["dt"] * 4))
+    tight3 = np.array(M.DEFAULT_PARAMS[M.QUAD3D], float)
+    tight3[6] = 2.5
+    single_solve("quad3d_infeasible_0", dict(c3d, params=tight3), x3[3], u3)
+
 
 if __name__ == "__main__":
     main()

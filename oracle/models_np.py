@@ -19,6 +19,8 @@ Model ids / parameter vectors (must match include/mi_ilqr.h and models.hpp):
   3 CARTPOLE_WALL  n=4  m=1   [mc, mp, l, g, wall_face_x, ball_radius, k, sigma]
   4 SYNTH36        n=36 m=12  [ks, c, kc, bu]
   5 PLANAR_QUAD    n=36 m=12  [g, k, sigma, dn, mu, b_leg, b_tail, k_tail, v_max]   (articulated, contact, can FAIL)
+  6 QUAD3D         n=37 m=12  [g, k, sigma, dn, mu, b_joint, v_max, m_trunk, Ixx, Iyy, Izz, I_abad, I_hip, I_knee]
+                              (3-D floating base with a unit-quaternion attitude, contact at four feet, can FAIL)
 
 A model may declare a step INFEASIBLE (the analogue of Drake's discrete update throwing): ``Model.step``
 then raises RuntimeError, which the reference's line search catches (ilqr.py:315-323).
@@ -27,13 +29,14 @@ import numpy as np
 
 from . import dual as D
 
-PENDULUM, ACROBOT, CARTPOLE, CARTPOLE_WALL, SYNTH36, PLANAR_QUAD = 0, 1, 2, 3, 4, 5
+PENDULUM, ACROBOT, CARTPOLE, CARTPOLE_WALL, SYNTH36, PLANAR_QUAD, QUAD3D = 0, 1, 2, 3, 4, 5, 6
 
 MODEL_DIMS = {PENDULUM: (2, 1), ACROBOT: (4, 1), CARTPOLE: (4, 1),
-              CARTPOLE_WALL: (4, 1), SYNTH36: (36, 12), PLANAR_QUAD: (36, 12)}
+              CARTPOLE_WALL: (4, 1), SYNTH36: (36, 12), PLANAR_QUAD: (36, 12), QUAD3D: (37, 12)}
 
 MODEL_NAMES = {PENDULUM: "pendulum", ACROBOT: "acrobot", CARTPOLE: "cart_pole",
-               CARTPOLE_WALL: "cart_pole_with_wall", SYNTH36: "synth36", PLANAR_QUAD: "planar_quadruped"}
+               CARTPOLE_WALL: "cart_pole_with_wall", SYNTH36: "synth36", PLANAR_QUAD: "planar_quadruped",
+               QUAD3D: "quadruped_3d"}
 
 DEFAULT_PARAMS = {
     # m=1, l=0.5, b=0.1, g=9.81 (the shape of pendulum.py's plant; SURVEY.md §8c anchor)
@@ -49,6 +52,10 @@ DEFAULT_PARAMS = {
     # gravity; ground penalty k*sigma*softplus(-z/sigma) with normal damping dn and load-proportional viscous
     # friction mu; joint damping of the legs / tail, tail spring; |v| bound beyond which a step is infeasible
     PLANAR_QUAD: [9.81, 4000.0, 0.004, 0.3, 0.15, 0.05, 0.02, 2.0, 60.0],
+    # gravity; ground penalty k*sigma*softplus(-z/sigma), normal damping dn, load-proportional viscous friction mu;
+    # joint damping; |v| bound beyond which a step is infeasible; trunk mass and principal inertias (mini-cheetah
+    # sized: 9 kg); reflected actuator inertias of the ab/ad, hip and knee joints
+    QUAD3D: [9.81, 4000.0, 0.004, 0.3, 0.15, 0.3, 60.0, 9.0, 0.07, 0.26, 0.28, 0.06, 0.06, 0.04],
 }
 
 
@@ -324,9 +331,102 @@ def planar_quad_infeasible(xn, p):
     return False
 
 
+# ----------------------------------------------------------------------------------------------------
+# QUAD3D: a 3-D floating-base quadruped with the state layout of mini_cheetah.py:41-52 - 19 positions
+# (unit quaternion w,x,y,z | base position | 4 x (ab/ad, hip, knee)) + 18 velocities (angular | linear | joint
+# rates), 12 actuators: n = 37, m = 12.  Build-owned like every model here (Drake is absent): the trunk is a 3-D
+# rigid body (Euler's equations, body-frame angular velocity, the attitude quaternion integrated as
+# q+ = q + dt/2 q (x) (0, w+) and - like the reference's plain-vector iLQR - never renormalized inside a step);
+# the legs carry 3-D kinematics (ab/ad about the body x axis, hip and knee about the rotated y axis; link lengths
+# of the mini cheetah) and their links are massless: each joint has its actuator's reflected inertia, a foot's
+# contact force reaches the trunk as a wrench and the joints through J^T f.  Compliant ground contact at the four
+# feet (mini_cheetah.py:92-101 uses hydroelastics; here the smooth penalty of the other contact models).
+# The legs' contributions are summed in the order (leg0 + leg2) + (leg1 + leg3): the order a 16-lane DPP row sum
+# produces on the device, where one lane per leg evaluates them.
+# ----------------------------------------------------------------------------------------------------
+Q3_NQ, Q3_NV = 19, 18
+Q3_L0, Q3_L1, Q3_L2 = 0.062, 0.209, 0.195
+Q3_HIPX, Q3_HIPY = 0.19, 0.049
+
+
+def quad3d_leg(k, quat_R, om, vlin, pz, q, jd, u, p):
+    """Leg k: foot kinematics, contact force, joint accelerations; returns (f_world[3], torque_body[3], jacc[3])."""
+    kc, sig, dn, mu, b_j = p[1], p[2], p[3], p[4], p[5]
+    Ij = (p[11], p[12], p[13])
+    sx = 1.0 if k < 2 else -1.0
+    sy = -1.0 if (k % 2) == 0 else 1.0
+    a, b, c = q[0], q[1], q[2]
+    sa, ca = D.sin(a), D.cos(a)
+    sb, cb = D.sin(b), D.cos(b)
+    sbc, cbc = D.sin(b + c), D.cos(b + c)
+    X = -(Q3_L1 * sb + Q3_L2 * sbc)
+    Z = -(Q3_L1 * cb + Q3_L2 * cbc)
+    Y = sy * Q3_L0
+    fb = [sx * Q3_HIPX + X, sy * Q3_HIPY + (Y * ca - Z * sa), Y * sa + Z * ca]      # foot in the body frame
+    Ja = [0.0, -(Y * sa) - Z * ca, Y * ca - Z * sa]
+    Jb = [Z, X * sa, -(X * ca)]
+    dXc, dZc = -(Q3_L2 * cbc), Q3_L2 * sbc
+    Jc = [dXc, -(dZc * sa), dZc * ca]
+    R = quat_R
+    # foot height and velocity in the world frame
+    zf = pz + (R[2][0] * fb[0] + R[2][1] * fb[1] + R[2][2] * fb[2])
+    vb = [om[1] * fb[2] - om[2] * fb[1] + (Ja[0] * jd[0] + Jb[0] * jd[1] + Jc[0] * jd[2]),
+          om[2] * fb[0] - om[0] * fb[2] + (Ja[1] * jd[0] + Jb[1] * jd[1] + Jc[1] * jd[2]),
+          om[0] * fb[1] - om[1] * fb[0] + (Ja[2] * jd[0] + Jb[2] * jd[1] + Jc[2] * jd[2])]
+    vf = [vlin[i] + (R[i][0] * vb[0] + R[i][1] * vb[1] + R[i][2] * vb[2]) for i in range(3)]
+    fn0 = kc * sig * D.softplus(-zf / sig)
+    fw = [-(mu * fn0) * vf[0], -(mu * fn0) * vf[1], fn0 * (1.0 - dn * vf[2])]
+    fbd = [R[0][i] * fw[0] + R[1][i] * fw[1] + R[2][i] * fw[2] for i in range(3)]  # R^T f: the force in the body frame
+    tq = [fb[1] * fbd[2] - fb[2] * fbd[1], fb[2] * fbd[0] - fb[0] * fbd[2], fb[0] * fbd[1] - fb[1] * fbd[0]]
+    jacc = [(u[0] - b_j * jd[0] + (Ja[0] * fbd[0] + Ja[1] * fbd[1] + Ja[2] * fbd[2])) / Ij[0],
+            (u[1] - b_j * jd[1] + (Jb[0] * fbd[0] + Jb[1] * fbd[1] + Jb[2] * fbd[2])) / Ij[1],
+            (u[2] - b_j * jd[2] + (Jc[0] * fbd[0] + Jc[1] * fbd[1] + Jc[2] * fbd[2])) / Ij[2]]
+    return fw, tq, jacc
+
+
+def quad3d_step(x, u, p, dt):
+    g, mt, Ix, Iy, Iz = p[0], p[7], p[8], p[9], p[10]
+    qw, qx, qy, qz = x[0], x[1], x[2], x[3]
+    pos = x[4:7]
+    jq = x[7:19]
+    om = x[19:22]
+    vl = x[22:25]
+    jd = x[25:37]
+    s2 = 2.0 / (qw * qw + qx * qx + qy * qy + qz * qz)
+    R = [[1.0 - s2 * (qy * qy + qz * qz), s2 * (qx * qy - qw * qz), s2 * (qx * qz + qw * qy)],
+         [s2 * (qx * qy + qw * qz), 1.0 - s2 * (qx * qx + qz * qz), s2 * (qy * qz - qw * qx)],
+         [s2 * (qx * qz - qw * qy), s2 * (qy * qz + qw * qx), 1.0 - s2 * (qx * qx + qy * qy)]]
+    legs = [quad3d_leg(k, R, om, vl, pos[2], jq[3 * k:3 * k + 3], jd[3 * k:3 * k + 3], u[3 * k:3 * k + 3], p) for k in range(4)]
+    F = [(legs[0][0][i] + legs[2][0][i]) + (legs[1][0][i] + legs[3][0][i]) for i in range(3)]
+    T = [(legs[0][1][i] + legs[2][1][i]) + (legs[1][1][i] + legs[3][1][i]) for i in range(3)]
+    al = [F[0] / mt, F[1] / mt, F[2] / mt - g]
+    aw = [(T[0] - (Iz - Iy) * om[1] * om[2]) / Ix, (T[1] - (Ix - Iz) * om[2] * om[0]) / Iy, (T[2] - (Iy - Ix) * om[0] * om[1]) / Iz]
+    omn = [om[i] + dt * aw[i] for i in range(3)]
+    vln = [vl[i] + dt * al[i] for i in range(3)]
+    jdn = [jd[3 * k + i] + dt * legs[k][2][i] for k in range(4) for i in range(3)]
+    hd = 0.5 * dt
+    qn = [qw + hd * (-(qx * omn[0]) - qy * omn[1] - qz * omn[2]),
+          qx + hd * (qw * omn[0] + qy * omn[2] - qz * omn[1]),
+          qy + hd * (qw * omn[1] + qz * omn[0] - qx * omn[2]),
+          qz + hd * (qw * omn[2] + qx * omn[1] - qy * omn[0])]
+    pn = [pos[i] + dt * vln[i] for i in range(3)]
+    jn = [jq[i] + dt * jdn[i] for i in range(12)]
+    return qn + pn + jn + omn + vln + jdn
+
+
+def quad3d_infeasible(xn, p):
+    """Like planar_quad_infeasible: a velocity outside [-v_max, v_max] (or not finite) makes the step infeasible."""
+    vmax = p[6]
+    for i in range(Q3_NQ, Q3_NQ + Q3_NV):
+        val = xn[i].v if isinstance(xn[i], D.Dual) else xn[i]
+        if not (abs(val) <= vmax):
+            return True
+    return False
+
+
 STEP_FUNCS = {PENDULUM: pendulum_step, ACROBOT: acrobot_step, CARTPOLE: cartpole_step,
-              CARTPOLE_WALL: cartpole_wall_step, SYNTH36: synth36_step, PLANAR_QUAD: planar_quad_step}
-INFEASIBLE_FUNCS = {PLANAR_QUAD: planar_quad_infeasible}
+              CARTPOLE_WALL: cartpole_wall_step, SYNTH36: synth36_step, PLANAR_QUAD: planar_quad_step, QUAD3D: quad3d_step}
+INFEASIBLE_FUNCS = {PLANAR_QUAD: planar_quad_infeasible, QUAD3D: quad3d_infeasible}
 
 
 class Model:

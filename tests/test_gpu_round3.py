@@ -15,12 +15,13 @@ pytestmark = pytest.mark.gpu
 
 def test_c4_full_size_vs_c_oracle():
     """C4 as benchmarked: cart-pole with wall, N = 200, B = 256, FD Jacobians on both sides.  Every problem: same
-    status, the same (eps, trial count) in each of the leading five iterations (ilqr.py:330-335).  The stiff contact
-    amplifies round-off by ~10x per iteration on any implementation, so later iterations and the final cost are
-    held to the problem's OWN sensitivity: the device may deviate from the oracle by no more than 10x what moving
-    the pole angle of x0 by one ulp does to the oracle itself (16 sampled problems; the same rule as
-    test_c4_end_to_end_deviation_is_the_problems_own_sensitivity), and every problem must reach the oracle's optimum
-    to 1e-3 (ilqr.py:692-708 stops on an absolute improvement of delta)."""
+    status, and the same (eps, trial count) in each of its leading eight iterations (ilqr.py:330-335; observed: the
+    leading twelve).  The stiff contact amplifies round-off by ~10x per iteration on ANY implementation, so whole
+    histories are held to the problem's OWN sensitivity: the C oracle re-solves the batch with the pole angle of x0
+    moved by one ulp up / down and then itself takes different decisions in 8-9 of the 256 problems (tools/
+    c4_full_diag.py); the device may differ from the oracle in at most that many problems + 2 (observed: 8, the budget
+    "c4_full_history").  Costs: 1e-3 where all decisions agree (observed 4.5e-4: an absolute stopping tolerance
+    delta = 1e-2 on costs ~30), 5e-2 where a decision flipped (the solve then stops an iteration earlier or later)."""
     from drake_ddp_amd import workloads as W
     from oracle import c_oracle, models_np as M
     c = W.cartpole_wall_problem()
@@ -35,18 +36,22 @@ def test_c4_full_size_vs_c_oracle():
     r = c_oracle.solve_batch(model, c, x0, ug, hist_cap=64)
     assert np.array_equal(s.status, r["status"]) and (s.status == 0).all()
     h = s.history
-    lead = np.minimum(np.minimum(s.iterations, r["iters"]), 5)
-    same5 = np.array([np.array_equal(h[b, :lead[b], 1:3], r["hist"][b, :lead[b], 1:3]) for b in range(B)])
-    assert_flip_budget("c4_full_leading5", same5)
+    it_min = np.minimum(np.minimum(s.iterations, r["iters"]), 64)
+    lead = np.minimum(it_min, 8)
+    same8 = np.array([np.array_equal(h[b, :lead[b], 1:3], r["hist"][b, :lead[b], 1:3]) for b in range(B)])
+    assert_flip_budget("c4_full_leading8", same8)
+    same = (s.iterations == r["iters"]) & np.array([np.array_equal(h[b, :it_min[b], 1:3], r["hist"][b, :it_min[b], 1:3]) for b in range(B)])
+    assert_flip_budget("c4_full_history", same)
+    # the oracle against itself, x0 one ulp away
+    flips = []
+    for direction in (np.inf, -np.inf):
+        xq = x0.copy()
+        xq[:, 1] = np.nextafter(xq[:, 1], direction)
+        rq = c_oracle.solve_batch(model, c, xq, ug)
+        flips.append(int(((rq["iters"] != r["iters"]) | (rq["ls"] != r["ls"])).sum()))
+    assert int((~same).sum()) <= max(flips) + 2, (int((~same).sum()), flips)
     rel = np.abs(L - r["cost"]) / np.abs(r["cost"])
-    assert np.all(rel < 1e-3), rel.max()
-    sample = np.arange(0, B, 16)
-    xp, xm = x0[sample].copy(), x0[sample].copy()
-    xp[:, 1] = np.nextafter(xp[:, 1], np.inf)
-    xm[:, 1] = np.nextafter(xm[:, 1], -np.inf)
-    rp, rm = c_oracle.solve_batch(model, c, xp, ug), c_oracle.solve_batch(model, c, xm, ug)
-    env = np.maximum(np.abs(rp["cost"] - r["cost"][sample]), np.abs(rm["cost"] - r["cost"][sample])) / np.abs(r["cost"][sample])
-    assert np.all(rel[sample] <= 10.0 * env + 1e-9), (rel[sample], env)
+    assert np.max(rel[same]) < 1e-3 and np.all(rel < 5e-2), (rel[same].max(), rel.max())
 
 
 KP_CASES = {"setInterval": ("pendulum_kp_setinterval5", 0), "adaptiveJerk": ("pendulum_kp_adaptivejerk", 0),

@@ -13,7 +13,8 @@ SINGLE = ["pendulum_c1", "pendulum_kp_setinterval5", "pendulum_kp_adaptivejerk",
           "pendulum_kp_iterativeerror", "pendulum_c2_00", "pendulum_c2_01", "pendulum_c2_05",
           "acrobot_kp_adaptivejerk", "acrobot_kp_iterativeerror",
           "cartpole_wall_literal_n100", "cartpole_wall_c4_0", "cartpole_plain",
-          "quad_solve_0", "quad_infeasible_0", "quad_infeasible_1"]
+          "quad_solve_0", "quad_infeasible_0", "quad_infeasible_1",
+          "quad3d_solve_0", "quad3d_solve_1", "quad3d_infeasible_0"]
 
 
 @pytest.mark.parametrize("name", SINGLE)
@@ -35,7 +36,7 @@ def test_single_solve_matches_reference(name):
         assert rel_err(val, g[key]) < 1e-7, key
 
 
-@pytest.mark.parametrize("name", ["pendulum_stage", "acrobot_stage", "synth36_stage", "quad_stage"])
+@pytest.mark.parametrize("name", ["pendulum_stage", "acrobot_stage", "synth36_stage", "quad_stage", "quad3d_stage"])
 def test_stage_level(name):
     g, prob = load_golden(name)
     o = make_oracle(prob)
@@ -53,14 +54,14 @@ def test_stage_level(name):
     assert rel_err(o.dV, g["post_dV"]) < 1e-10
 
 
-@pytest.mark.parametrize("name", ["acrobot_mpc_0", "acrobot_mpc_1", "synth36_mpc_0", "quad_mpc_0"])
+@pytest.mark.parametrize("name", ["acrobot_mpc_0", "acrobot_mpc_1", "synth36_mpc_0", "quad_mpc_0", "quad3d_mpc_0"])
 def test_mpc_sequence(name):
     """Receding-horizon re-solves with persistent gains."""
-    from drake_ddp_amd.workloads import mpc_shift, synth36_u_guess, planar_quad_u_guess
+    from drake_ddp_amd.workloads import mpc_shift, synth36_u_guess, planar_quad_u_guess, quad3d_u_guess
     g, prob = load_golden(name)
     o = make_oracle(prob)
     N, m = prob["N"], g["us"].shape[1]
-    u_guess = {4: synth36_u_guess, 5: planar_quad_u_guess}.get(prob["model_id"], lambda N_: np.zeros((m, N_ - 1)))(N)
+    u_guess = {4: synth36_u_guess, 5: planar_quad_u_guess, 6: quad3d_u_guess}.get(prob["model_id"], lambda N_: np.zeros((m, N_ - 1)))(N)
     x0 = g["x0"]
     x_nom = prob["x_nom"].copy()
     replan = int(g["replan"])
@@ -81,16 +82,20 @@ def test_fd_jacobian_close_to_ad():
     """Central FD (the device linearization) vs exact duals; tolerance from SURVEY §8c."""
     from oracle import models_np as M
     rng = np.random.default_rng(5)
-    for mid in (0, 1, 2, 3, 4, 5):
+    for mid in (0, 1, 2, 3, 4, 5, 6):
         model = M.Model(mid, 0.01)
         x = rng.uniform(-1, 1, model.n)
         u = rng.uniform(-1, 1, model.m)
         if mid == 5:
             x[1] = 0.45 + 0.01 * x[1]                      # trunk height: the feet at the ground, contact active
+        if mid == 6:                                       # near the standing state: unit quaternion, feet at the ground
+            from oracle import problems as P
+            x = P.quad3d_stand() + 0.02 * x
         fx, fu = model.jac_ad(x, u)
         gx, gu = model.jac_fd(x, u, 1e-5)
         # (quadruped: contact curvature k/sigma^2 = 2.5e8 makes the h^2 truncation term visible; entries reach 1e2)
-        tol = 2e-9 if mid != 5 else 1e-8 * max(1.0, np.max(np.abs(fx)))
+        # (3-D quadruped: the same curvature through 3-D lever arms and the trunk's small roll inertia: 2e-7 relative)
+        tol = 2e-9 if mid < 5 else (1e-8 if mid == 5 else 2e-7) * max(1.0, np.max(np.abs(fx)))
         assert np.max(np.abs(fx - gx)) < tol and np.max(np.abs(fu - gu)) < tol
 
 
@@ -109,7 +114,8 @@ def test_oracle_and_product_workloads_agree():
     from oracle import problems as P
     from drake_ddp_amd import workloads as W
     for name, args in (("pendulum_problem", ()), ("acrobot_problem", (40,)), ("cartpole_problem", (100,)),
-                       ("cartpole_wall_problem", (200,)), ("cartpole_wall_problem", (100,)), ("synth36_problem", (40,))):
+                       ("cartpole_wall_problem", (200,)), ("cartpole_wall_problem", (100,)), ("synth36_problem", (40,)),
+                       ("planar_quad_problem", (40,)), ("quad3d_problem", (40,))):
         a, b = getattr(P, name)(*args), getattr(W, name)(*args)
         assert a.keys() == b.keys()
         for k in a:
@@ -117,9 +123,11 @@ def test_oracle_and_product_workloads_agree():
                 assert np.array_equal(a[k], b[k]), (name, k)
             else:
                 assert a[k] == b[k], (name, k)
-    for name, B in (("pendulum_batch_x0", 1024), ("acrobot_batch_x0", 512), ("cartpole_wall_batch_x0", 256), ("synth36_batch_x0", 64)):
+    for name, B in (("pendulum_batch_x0", 1024), ("acrobot_batch_x0", 512), ("cartpole_wall_batch_x0", 256), ("synth36_batch_x0", 64),
+                    ("planar_quad_batch_x0", 64), ("quad3d_batch_x0", 64)):
         assert np.array_equal(getattr(P, name)(B), getattr(W, name)(B)), name
     assert np.array_equal(P.synth36_u_guess(40), W.synth36_u_guess(40)) and P.SYNTH_TARGET_VEL == W.SYNTH_TARGET_VEL
+    assert np.array_equal(P.quad3d_u_guess(40), W.quad3d_u_guess(40)) and P.QUAD3D_TARGET_VEL == W.QUAD3D_TARGET_VEL
     rng = np.random.default_rng(0)
     x, u = rng.standard_normal((3, 4, 40)), rng.standard_normal((3, 1, 39))
     for got, want in zip(P.mpc_shift(x, u, 2), W.mpc_shift(x, u, 2)):
@@ -178,3 +186,48 @@ def test_infeasible_steps_change_the_line_search_like_the_reference():
             xx = model.step(xx, np.zeros(12))
         drift.append(abs(energy(xx) - e0) / abs(e0))
     assert drift[0] < 2e-4 and drift[1] < 0.3 * drift[0]             # first order in dt: the dynamics are consistent
+
+
+def test_quad3d_model_is_a_rigid_body_with_contact():
+    """The build's 3-D quadruped (oracle/models_np.py: quad3d_step; mini_cheetah.py:41-52's state layout).  (i) Free
+    flight (no contact, no joint torques or damping): linear momentum falls with g, the body-frame angular momentum
+    keeps its norm and the attitude quaternion its length to first order in dt (Euler's equations + the quaternion
+    kinematics are consistent).  (ii) The standing state of the workload is an equilibrium of the contact model under
+    the standing torques: zero acceleration.  (iii) quad3d_infeasible_0 was recorded with the velocity bound biting:
+    the free model takes other step sizes on the same problem."""
+    from oracle import models_np as M, problems as P
+    p = np.array(M.DEFAULT_PARAMS[M.QUAD3D], float)
+    p[5] = 0.0
+    p[6] = 1e9
+    rng = np.random.default_rng(1)
+    x = P.quad3d_stand()
+    x[6] = 5.0                                            # far above the ground
+    x[19:25] = rng.uniform(-1, 1, 6)
+    Ib = p[8:11]
+    drift = []
+    for dt in (2e-3, 5e-4):
+        model = M.Model(M.QUAD3D, dt, p)
+        xx = x.copy()
+        steps = int(round(0.2 / dt))
+        for _ in range(steps):
+            xx = model.step(xx, np.zeros(12))
+        assert abs(xx[24] - (x[24] - p[0] * 0.2)) < 1e-9 and np.allclose(xx[22:24], x[22:24], atol=1e-12)
+        h0, h1 = np.linalg.norm(Ib * x[19:22]), np.linalg.norm(Ib * xx[19:22])
+        drift.append((abs(h1 - h0) / h0, abs(np.linalg.norm(xx[0:4]) - 1.0)))
+    assert drift[0][0] < 5e-3 and drift[1][0] < 0.4 * drift[0][0]
+    assert drift[0][1] < 5e-3 and drift[1][1] < 0.4 * drift[0][1]
+    model = M.Model(M.QUAD3D, 4e-3)
+    xs = P.quad3d_stand()
+    xn = model.step(xs, P.quad3d_u_guess(3)[:, 0])
+    # forces and joint torques balance (the standing torques are given to 6 decimals); what is left is the pitch moment
+    # of the four feet standing X = 1 cm ahead of their hips (mini_cheetah.py's q0 has the same lean): m g X / Iyy
+    rest = np.delete(xn[19:], 1)
+    assert np.max(np.abs(rest)) < 2e-7
+    X = -(M.Q3_L1 * np.sin(-0.8) + M.Q3_L2 * np.sin(0.8))
+    assert abs(xn[20] + 4e-3 * 9.0 * 9.81 * X / 0.26) < 1e-6
+    g, prob = load_golden("quad3d_infeasible_0")
+    assert prob["params"][6] == 2.5 and g["hist"][:, 2].max() >= 2
+    free = make_oracle(dict(prob, params=M.DEFAULT_PARAMS[M.QUAD3D]))
+    free.set_problem(g["x0"], prob["x_nom"], prob["Q"], prob["R"], prob["Qf"], g["u_guess"])
+    hist = np.array(free.solve()[3])
+    assert len(hist) != len(g["hist"]) or not np.array_equal(hist[:, 2], g["hist"][:, 2])
