@@ -349,6 +349,11 @@ def all_configs(rk, dev_index):
                           "1 + 100 re-solves x batch 64, moving target, device loop", pq,
                           W.planar_quad_batch_x0(64), W.planar_quad_u_guess(pq["N"]), reps=2,
                           mpc=(100, 4, (0, W.QUAD_TARGET_VEL * pq["dt"] * 4))))
+    q3 = W.quad3d_problem()
+    out.append(run_config(rk, dev_index, "C5q3d 3-D quadruped (quaternion floating base, feet contact) n=37 m=12 N=40 MPC: "
+                          "1 + 100 re-solves x batch 64, moving target, device loop", q3,
+                          W.quad3d_batch_x0(64), W.quad3d_u_guess(q3["N"]), reps=2,
+                          mpc=(100, 4, (4, W.QUAD3D_TARGET_VEL * q3["dt"] * 4))))
     if rk.world == 1:
         out.append(run_config(rk, dev_index, "C5 shard of an 8-GPU run: batch 8 on this GPU", q,
                               W.synth36_batch_x0(64)[:8], W.synth36_u_guess(q["N"]), reps=2,

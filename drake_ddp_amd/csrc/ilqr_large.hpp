@@ -37,18 +37,26 @@ constexpr int kLargeThreads = 256;
 template <int n, int m>
 struct LLay {
   static constexpr int nm = n + m;
-  static constexpr int TS = ((n + m + 15) / 16) * 16 + 4;  // row stride of T1 / H: whole tiles + the Vx/first-order column
   // doubles
   static constexpr int QC = m * (m + 1) / 2;               // packed lower triangle of Quu
   static constexpr int T16 = 16;                           // MFMA tile edge
   static constexpr int NP = ((n + 15) / 16) * 16;          // n padded to whole tiles (rows of Vxx)
-  static constexpr int NMP = ((nm + 15) / 16) * 16;
-  static constexpr int VS = n + 1;                         // odd row stride of Vxx: conflict-free column-of-tile reads
+  static constexpr int KN = (n + 3) / 4, NK = 4 * KN;      // MFMA k-steps over a contraction of length n, n padded to them
+  // Columns of the augmented matrices F = [fx | fu], T1, H.  COMPACT: u follows x directly and the last column tile
+  // holds the tail of x together with all of u (n = 36, m = 12: three tiles).  SPLIT (that tile would not start inside
+  // x, or n is not a multiple of 4: n = 37): x is padded to whole tiles and u gets a tile of its own - the pad
+  // rows / columns are zero and never stored, so Quu still sits at the corner of the last diagonal tile.
+  static constexpr int NMPc = ((nm + 15) / 16) * 16;
+  static constexpr bool kSplit = !(NMPc - 16 <= n && n % 4 == 0);
+  static constexpr int UC = kSplit ? NP : n;               // column of u_0
+  static constexpr int NMP = kSplit ? NP + ((m + 15) / 16) * 16 : NMPc;
+  static constexpr int TS = NMP + 4;                       // row stride of T1 / H: whole tiles + the Vx/first-order column
+  static constexpr int VS = NK | 1;                        // odd row stride of Vxx: conflict-free column-of-tile reads
   static constexpr int oQ = 0, oQf = oQ + n * n, oR = oQf + n * n, oXnom = oR + m * m, oQn = oXnom + n,
-                       oQfn = oQn + n, oVxx = oQfn + n, oVx = oVxx + NP * VS, oF = oVx + n,
-                       oT1 = oF + n * NMP, oH = oT1 + n * TS, oXs = oH + NMP * TS, oUs = oXs + n,
+                       oQfn = oQn + n, oVxx = oQfn + n, oVx = oVxx + NP * VS, oF = oVx + NK + (NK & 1),
+                       oT1 = oF + NK * NMP, oH = oT1 + NK * TS, oXs = oH + NMP * TS, oUs = oXs + n,
                        oRed = oUs + m, oXb = oRed + kLargeThreads, oQc = oXb + n + m + ((n + m) & 1),
-                       oQT = oQc + m * m + m + (m & 1), oS = oQT + n * n + ((n * n) & 1),
+                       oQT = oQc + m * m + m + (m & 1), oS = oQT + (kSplit ? 0 : n * n + ((n * n) & 1)),
                        oEnd = oS + 16 * 17 + 1;                // 16x16 tile, odd row stride
   static constexpr size_t doubles = oEnd + 8;
 };
@@ -109,6 +117,12 @@ template <class M, class = void>
 struct IsChainModel { static constexpr bool value = false; };
 template <class M>
 struct IsChainModel<M, decltype((void)M::kChainCooperative)> { static constexpr bool value = M::kChainCooperative; };
+// Models whose step is cut per LEG of a floating-base body (models.hpp: Quad3D): one lane per leg in the rollout, the
+// legs' wrenches summed over the 16-lane row; whole-step evaluation per (key-point, column) item in the linearization.
+template <class M, class = void>
+struct IsLegModel { static constexpr bool value = false; };
+template <class M>
+struct IsLegModel<M, decltype((void)M::kLegCooperative)> { static constexpr bool value = M::kLegCooperative; };
 // Models that can declare a step infeasible (Drake's update throwing -> L = inf, ilqr.py:315-323).
 template <class M, class = void>
 struct CanFail { static constexpr bool value = false; };
@@ -264,6 +278,43 @@ __device__ inline double large_rollout(const LView<M::n, M::m>& v, double* lds, 
           xn_[tid] = qn_; xn_[M::nq + tid] = vn_;
           v.Xn[(size_t)(t + 1) * n + tid] = qn_; v.Xn[(size_t)(t + 1) * n + M::nq + tid] = vn_;
           bad = bad || M::infeasible_velocity(vn_, a.params);
+        }
+        dyn_done = true;
+      }
+    } else if constexpr (IsLegModel<M>::value) {
+      // floating base + legs: ONE LANE PER LEG (lanes 0..kLegs-1 of wave 0; the rest of the first 16-lane row shadows
+      // the last leg and contributes zeros).  Foot kinematics, contact force and joint accelerations per leg, the legs'
+      // wrenches summed over the row with DPP rotations - (0 + 2) + (1 + 3), the order M::step uses - and the trunk
+      // advanced redundantly by every lane.  No LDS traffic, no barrier inside the step.
+      if (tid < 16) {
+        const int k = tid < M::kLegs ? tid : M::kLegs - 1;
+        double Rm[3][3];
+        M::template rotation<double>(xc, Rm);
+        typename M::template LegOut<double> lo;
+        M::template leg<double>(k, Rm, xc, us, a.params, lo);
+        const double keep = tid < M::kLegs ? 1.0 : 0.0;
+        double Fw[3], Tq[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { Fw[i] = row16_sum(keep * lo.fw[i]); Tq[i] = row16_sum(keep * lo.tq[i]); }
+        double xt[n];
+        M::template trunk<double>(xc, Fw, Tq, xt, a.params, a.dt);
+        double* Xo = v.Xn + (size_t)(t + 1) * n;
+        if (tid < M::kLegs) {
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            const int j = 3 * k + i;
+            const double jdn = xc[25 + j] + a.dt * lo.ja[i];
+            const double jn = xc[7 + j] + a.dt * jdn;
+            xn_[25 + j] = jdn; xn_[7 + j] = jn;
+            Xo[25 + j] = jdn; Xo[7 + j] = jn;
+            bad = bad || M::infeasible_velocity(jdn, a.params);
+          }
+        }
+        if (tid == 0) {
+#pragma unroll
+          for (int i = 0; i < 7; ++i) { xn_[i] = xt[i]; Xo[i] = xt[i]; }
+#pragma unroll
+          for (int i = 19; i < 25; ++i) { xn_[i] = xt[i]; Xo[i] = xt[i]; bad = bad || M::infeasible_velocity(xt[i], a.params); }
         }
         dyn_done = true;
       }
@@ -749,7 +800,10 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
   using Ly = LLay<n, m>;
   constexpr int TS = Ly::TS, VS = Ly::VS, FS = Ly::NMP, NP = Ly::NP;
   constexpr int RT = NP / 16, CT = Ly::NMP / 16;       // row tiles of an n-row matrix, col tiles of an nm-col one
-  static_assert(n % 4 == 0 && m % 4 == 0, "k-steps of 4");
+  constexpr bool SPLIT = Ly::kSplit;                   // u in a column tile of its own (LLay)
+  constexpr int UC = Ly::UC, KN = Ly::KN, NK = Ly::NK;
+  constexpr int CX = SPLIT ? RT : CT;                  // column tiles the three matrix-core waves own
+  static_assert(m % 4 == 0, "k-steps of 4 over m");
   const int tid = threadIdx.x, N = v.N, wave = tid >> 6, lane = tid & 63;
   const int lr = lane & 15, lk = lane >> 4;
   const double* Q = lds + Ly::oQ;
@@ -762,7 +816,7 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
   double* F = lds + Ly::oF;          // [n][FS]  = [fx | fu | 0-pad]
   double* T1 = lds + Ly::oT1;        // [n][TS]  = [Vxx F | . | Vx at column FS]; later rows 0..m-1 hold [K | kappa]
   double* H = lds + Ly::oH;          // [NMP][TS] = F^T T1, first-order terms in column FS
-  double* QT = lds + Ly::oQT;        // Q^T
+  double* QT = lds + Ly::oQT;        // Q^T (compact layout only: the horizon's cost-gradient product)
   constexpr int CV = FS;             // column index of Vx / first-order terms
 #ifdef MI_PROF_BACKWARD
   long long bp_last = clock64();
@@ -773,7 +827,8 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
     const int i = e / VS, j = e - i * VS;
     Vxx[e] = (i < n && j < n) ? 2.0 * Qf[i * n + j] : 0.0;
   }
-  for (int e = tid; e < n * n; e += kLargeThreads) { const int i = e / n, j = e - i * n; QT[j * n + i] = Q[e]; }
+  if constexpr (!SPLIT) { for (int e = tid; e < n * n; e += kLargeThreads) { const int i = e / n, j = e - i * n; QT[j * n + i] = Q[e]; } }
+  if (tid >= n && tid < NK) Vx[tid] = 0.0;                           // pad of the k-steps
   if (tid < n) {
     const double* xT = v.X + (size_t)(N - 1) * n;
     double xr[n];
@@ -796,10 +851,11 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
     double* Xs_ = T1;                                        // T1 and H are contiguous
     double* Us_ = F;
     // the last row tile reads up to 15 rows past step N-2: they must stay inside the staging area
-    const bool staged = (size_t)n * (N + 15) <= (size_t)(n + Ly::NMP) * TS && (size_t)m * (N - 1) <= (size_t)n * FS;
+    const bool staged = !SPLIT && (size_t)n * (N + 15) <= (size_t)(n + Ly::NMP) * TS && (size_t)m * (N - 1) <= (size_t)n * FS;
     if (lx_ready) {
       // the rollout of the accepted trial left lx_t, lu_t here (large_rollout)
     } else if (staged) {
+     if constexpr (!SPLIT) {
       for (int e = tid; e < n * (N - 1); e += kLargeThreads) Xs_[e] = v.X[e];
       for (int e = tid; e < m * (N - 1); e += kLargeThreads) Us_[e] = v.U[e];
       __syncthreads();
@@ -829,14 +885,15 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
         for (int j = 0; j < m; ++j) s_ += (2.0 * R[a_ * m + j]) * Us_[tt * m + j];
         Lxu[tt * nm + n + a_] = s_;
       }
+     }
     } else {
-      for (int idx = tid; idx < (N - 1) * nm; idx += kLargeThreads) {   // long horizons: straight from L2
+      for (int idx = tid; idx < (N - 1) * nm; idx += kLargeThreads) {   // long horizons (and the split layout): straight from L2
         const int tt = idx / nm, pp = idx - tt * nm;
         double s_;
         if (pp < n) {
           const double* xg = v.X + (size_t)tt * n;
           s_ = -qn[pp];
-          for (int j = 0; j < n; ++j) s_ += (2.0 * QT[j * n + pp]) * xg[j];
+          for (int j = 0; j < n; ++j) s_ += (2.0 * Q[pp * n + j]) * xg[j];
         } else {
           const double* ug = v.U + (size_t)tt * m;
           s_ = 0.0;
@@ -849,27 +906,30 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
     __syncthreads();
     if (wave == 0) BP_TICK(7);
     // the zero padding the tiles rely on (F's pad columns; H for tidiness)
-    for (int e = tid; e < n * FS; e += kLargeThreads) F[e] = 0.0;
+    for (int e = tid; e < NK * FS; e += kLargeThreads) F[e] = 0.0;
     for (int e = tid; e < Ly::NMP * TS; e += kLargeThreads) H[e] = 0.0;
+    for (int e = n * TS + tid; e < NK * TS; e += kLargeThreads) T1[e] = 0.0;     // rows of the k-step pad: read, never stored
   }
   __syncthreads();
   BP_TICK(14);
   // The spare wave (wave 3) prefetches the WHOLE next F = [fx_t | fu_t] (contiguous n*n and n*m
   // blocks in HBM) as 16-byte pairs into registers during the T1 phase and publishes it to LDS
   // during the last phase: the three matrix-core waves never touch global memory in the loop.
-  static_assert(n % 2 == 0 && m % 2 == 0 && FS % 2 == 0 && Ly::oF % 2 == 0, "16-byte pairs of F stay inside a row");
-  constexpr int PFX = n * n / 2, PFU = n * m / 2;                       // pairs
+  // (16-byte pairs where the rows allow it - n, m even; single doubles otherwise, e.g. n = 37)
+  constexpr int W = (n % 2 == 0 && m % 2 == 0 && FS % 2 == 0 && Ly::oF % 2 == 0) ? 2 : 1;
+  constexpr int PFX = n * n / W, PFU = n * m / W;                       // pairs (or single doubles)
   constexpr int NFX = (PFX + 63) / 64, NFU = (PFU + 63) / 64;
   typedef double d2_t __attribute__((ext_vector_type(2)));
-  d2_t frx[NFX], fru[NFU];
+  using fw_t = std::conditional_t<W == 2, d2_t, double>;
+  fw_t frx[NFX], fru[NFU];
   int fx_off[NFX], fu_off[NFU];                                          // LDS offsets (doubles) of this lane's pairs
 #pragma unroll
-  for (int r = 0; r < NFX; ++r) { int e = 2 * (lane + 64 * r); e = e < n * n ? e : n * n - 2; fx_off[r] = (e / n) * FS + (e % n); }
+  for (int r = 0; r < NFX; ++r) { int e = W * (lane + 64 * r); e = e < n * n ? e : n * n - W; fx_off[r] = (e / n) * FS + (e % n); }
 #pragma unroll
-  for (int r = 0; r < NFU; ++r) { int e = 2 * (lane + 64 * r); e = e < n * m ? e : n * m - 2; fu_off[r] = (e / m) * FS + n + (e % m); }
+  for (int r = 0; r < NFU; ++r) { int e = W * (lane + 64 * r); e = e < n * m ? e : n * m - W; fu_off[r] = (e / m) * FS + UC + (e % m); }
   auto fetch = [&](int t) __attribute__((always_inline)) {
-    const d2_t* fxg = reinterpret_cast<const d2_t*>(v.Fx + (size_t)t * n * n);
-    const d2_t* fug = reinterpret_cast<const d2_t*>(v.Fu + (size_t)t * n * m);
+    const fw_t* fxg = reinterpret_cast<const fw_t*>(v.Fx + (size_t)t * n * n);
+    const fw_t* fug = reinterpret_cast<const fw_t*>(v.Fu + (size_t)t * n * m);
 #pragma unroll
     for (int r = 0; r < NFX; ++r) { const int pi = lane + 64 * r; frx[r] = fxg[pi < PFX ? pi : PFX - 1]; }
 #pragma unroll
@@ -877,18 +937,18 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
   };
   auto publish = [&]() __attribute__((always_inline)) {       // clamped duplicates rewrite the last pair with itself
 #pragma unroll
-    for (int r = 0; r < NFX; ++r) *reinterpret_cast<d2_t*>(F + fx_off[r]) = frx[r];
+    for (int r = 0; r < NFX; ++r) *reinterpret_cast<fw_t*>(F + fx_off[r]) = frx[r];
 #pragma unroll
-    for (int r = 0; r < NFU; ++r) *reinterpret_cast<d2_t*>(F + fu_off[r]) = fru[r];
+    for (int r = 0; r < NFU; ++r) *reinterpret_cast<fw_t*>(F + fu_off[r]) = fru[r];
   };
   if (wave == 3) { fetch(N - 2); publish(); }
   __syncthreads();
   BP_TICK(15);
   double* Sq = lds + Ly::oS;         // wave 3's private copy of the H tile that holds Quu - luu
   constexpr int SS = 17;
-  static_assert(RT == 3 && CT == 3 && 2 * m <= n && m <= 16, "wave roles below: three matrix-core waves + one spare");
-  static_assert(16 * (CT - 1) <= n && n + m <= 16 * CT, "Quu lies inside the last diagonal tile of H");
-  constexpr int QO = n - 16 * (CT - 1);                       // Quu's offset inside that tile
+  static_assert(RT == 3 && CX == 3 && CT - CX <= 1 && 2 * m <= n && m <= 16, "wave roles below: three matrix-core waves + one spare");
+  static_assert(16 * (CT - 1) <= UC && UC + m <= 16 * CT, "Quu lies inside the last diagonal tile of H");
+  constexpr int QO = UC - 16 * (CT - 1);                      // Quu's offset inside that tile
   // Solver-wave state, alive across phases and steps: row i of L (lane i), 1/D, and this lane's
   // column of D^{-1} Y whose back-substitution is deferred into the next step's phase A.
   double arow[m], dinv[m], zcol[m];
@@ -927,11 +987,11 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
     //      k-step.  Wave w < CT owns column tile w and sweeps the RT row tiles, so every tile
     //      offset is a compile-time immediate on top of one per-lane base address.
     //      Spare wave: next step's F into registers; first-order column H[:, CV] = l_{x,u} + F^T Vx.
-    if (wave < CT) {
+    if (wave < CX) {
       const double* a_base = Vxx + lr * VS + lk;
       const double* b_base = F + lk * FS + 16 * wave + lr;
       double* d_base = T1 + lk * TS + 16 * wave + lr;
-      TileOps<n / 4> ops[RT];
+      TileOps<KN> ops[RT];
       d4_t accs[RT];
       ops[0].load(a_base, 4, b_base, 4 * FS);
 #pragma unroll
@@ -955,22 +1015,36 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
           else if (ib < n) { if (ib + lk < n) d_base[ib * TS] = accs[q][reg]; }
         }
       }
+      if constexpr (SPLIT) {
+        // u's own column tile of T1 (= Vxx fu): its RT row tiles are dealt one to each matrix-core wave
+        TileOps<KN> ou;
+        ou.load(a_base + 16 * wave * VS, 4, F + lk * FS + 16 * (CT - 1) + lr, 4 * FS);
+        const d4_t zero = {0.0, 0.0, 0.0, 0.0};
+        const d4_t au = ou.run(zero);
+        double* du = T1 + lk * TS + 16 * (CT - 1) + lr;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int ib = 16 * wave + 4 * reg;
+          if (ib + lk < n) du[ib * TS] = au[reg];
+        }
+      }
     } else {
       if (t > 0) fetch(t - 1);
       BP_TICK(5);
       if (lane < nm) {                                     // (:651-652) lx_t / lu_t precomputed for all t
         double s = Lxu[t * nm + lane];
-        constexpr int CH = (n % 12 == 0) ? 12 : (n % 4 == 0 ? 4 : 1);   // a chunk's LDS reads are in flight together
+        const int hp = lane < n ? lane : UC + (lane - n);  // this entry's column of F / row of H
+        constexpr int CH = (NK % 12 == 0) ? 12 : 4;        // a chunk's LDS reads are in flight together (rows >= n: zeros)
 #pragma unroll
-        for (int k0 = 0; k0 < n; k0 += CH) {
+        for (int k0 = 0; k0 < NK; k0 += CH) {
           double fv[CH], vv[CH];
 #pragma unroll
-          for (int k = 0; k < CH; ++k) { fv[k] = F[(k0 + k) * FS + lane]; vv[k] = Vx[k0 + k]; }
+          for (int k = 0; k < CH; ++k) { fv[k] = F[(k0 + k) * FS + hp]; vv[k] = Vx[k0 + k]; }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int k = 0; k < CH; ++k) s += fv[k] * vv[k];
         }
-        H[lane * TS + CV] = s;
+        H[hp * TS + CV] = s;
       }
       BP_TICK(6);
       if (t < N - 2) back_substitute(t + 1);               // previous step's gains, off the recursion
@@ -982,11 +1056,11 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
     //      one tile that contains Quu - luu (bitwise the tile wave CT-1 stores), turns it into one
     //      row per lane through a private LDS scratch and factorizes Quu = 2R + fu^T Vxx fu (:654)
     //      = L D L^T (DPP row broadcasts, no barriers): the factorization is off the critical path.
-    if (wave < CT) {
+    if (wave < CX) {
       const double* a_base = F + lk * FS + lr;                       // A = F^T: A[p][k] = F[k][p]
       const double* b_base = T1 + lk * TS + 16 * wave + lr;
       double* d_base = H + lk * TS + 16 * wave + lr;
-      TileOps<n / 4> ops[CT];
+      TileOps<KN> ops[CT];
       d4_t accs[CT];
       ops[0].load(a_base, 4 * FS, b_base, 4 * TS);
 #pragma unroll
@@ -1002,7 +1076,7 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) d_base[(16 * q + 4 * reg) * TS] = accs[q][reg];
     } else {
-      TileOps<n / 4> op;
+      TileOps<KN> op;
       op.load(F + lk * FS + 16 * (CT - 1) + lr, 4 * FS, T1 + lk * TS + 16 * (CT - 1) + lr, 4 * TS);
       d4_t acc = {0.0, 0.0, 0.0, 0.0};
       acc = op.run(acc);
@@ -1027,7 +1101,7 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
       double y[m];
       const int rhs = lane < n ? lane : CV;                 // lanes > n shadow the Qu column, store nothing
 #pragma unroll
-      for (int i = 0; i < m; ++i) y[i] = H[(n + i) * TS + rhs];
+      for (int i = 0; i < m; ++i) y[i] = H[(UC + i) * TS + rhs];
       FwdSubst<m, 1>::run(arow, y);
       double dv = 0.0;
 #pragma unroll

@@ -43,8 +43,9 @@ const ModelInfo* model_info(int id) {
       {4, 1, 8, {10.0, 1.0, 0.5, 9.81, -0.45, 0.05, 2000.0, 0.01}},
       {36, 12, 4, {4.0, 0.5, 6.0, 0.1}},
       {36, 12, 9, {9.81, 4000.0, 0.004, 0.3, 0.15, 0.05, 0.02, 2.0, 60.0}},
+      {37, 12, 14, {9.81, 4000.0, 0.004, 0.3, 0.15, 0.3, 60.0, 9.0, 0.07, 0.26, 0.28, 0.06, 0.06, 0.04}},
   };
-  if (id < 0 || id > 5) return nullptr;
+  if (id < 0 || id > 6) return nullptr;
   return &table[id];
 }
 
@@ -62,6 +63,7 @@ size_t large_lds(int model_id, int N) {
   switch (model_id) {
     case MI_MODEL_SYNTH36: return large_lds_bytes<Synth36::n, Synth36::m>(N);
     case MI_MODEL_PLANAR_QUAD: return large_lds_bytes<PlanarQuad::n, PlanarQuad::m>(N);
+    case MI_MODEL_QUAD3D: return large_lds_bytes<Quad3D::n, Quad3D::m>(N);
     default: return 0;
   }
 }
@@ -142,6 +144,7 @@ int launch(mi_ilqr* h, int mode) {
     case MI_MODEL_CARTPOLE_WALL: rc = launch_cartpole_wall(h, mode, a); break;
     case MI_MODEL_SYNTH36: rc = launch_synth36(h, mode, a); break;
     case MI_MODEL_PLANAR_QUAD: rc = launch_planar_quad(h, mode, a); break;
+    case MI_MODEL_QUAD3D: rc = launch_quad3d(h, mode, a); break;
     default: return MI_ILQR_E_UNSUPPORTED;
   }
   return rc;

@@ -343,4 +343,115 @@ struct PlanarQuad {
   __device__ static inline bool infeasible_velocity(double vn, const double* p) { return !(fabs(vn) <= p[8]); }
 };
 
+// 3-D floating-base quadruped with the state layout of mini_cheetah.py:41-52: 19 positions (unit quaternion w,x,y,z |
+// base position | 4 x (ab/ad, hip, knee)) + 18 velocities (body-frame angular | world-frame linear | joint rates),
+// 12 joint torques: n = 37, m = 12.  The same formulas, in the same operation order, as oracle/models_np.py:quad3d_leg /
+// quad3d_step and oracle/ilqr_oracle.c.  params [g, k, sigma, dn, mu, b_joint, v_max, m_trunk, Ixx, Iyy, Izz, I_abad,
+// I_hip, I_knee].  The trunk is a 3-D rigid body (Euler's equations; the attitude quaternion is integrated as
+// q+ = q + dt/2 q (x) (0, w+) and never renormalized inside a step, like the reference's plain-vector iLQR); legs have
+// 3-D kinematics and massless links, every joint carries its actuator's reflected inertia; a foot's contact force
+// (smooth penalty, normal damping, viscous friction) reaches the trunk as a wrench and the joints through J^T f.
+// The work is cut per LEG: leg() yields the foot's force (world frame), its moment about the trunk origin (body frame) and
+// the leg's three joint accelerations; the four legs are summed as (0 + 2) + (1 + 3) - the order a DPP row sum of one
+// lane per leg produces in the rollout, and the order step() uses, so both give the same bits.
+// The model can FAIL like PlanarQuad: a velocity outside [-v_max, v_max] makes the step infeasible (ilqr.py:315-323).
+struct Quad3D {
+  static constexpr int n = 37, m = 12, n_params = 14, nq = 19, nv = 18, kLegs = 4;
+  static constexpr bool kLegCooperative = true;
+  static constexpr bool kCanFail = true;
+  static constexpr double kL0 = 0.062, kL1 = 0.209, kL2 = 0.195, kHipX = 0.19, kHipY = 0.049;
+  template <class T> struct LegOut { T fw[3], tq[3], ja[3]; };
+
+  template <class T, class XA>
+  __device__ static inline void rotation(const XA& x, T (&R)[3][3]) {
+    const T qw = x[0], qx = x[1], qy = x[2], qz = x[3];
+    const T s2 = 2.0 * mi_rcp(qw * qw + qx * qx + qy * qy + qz * qz);
+    R[0][0] = 1.0 - s2 * (qy * qy + qz * qz); R[0][1] = s2 * (qx * qy - qw * qz); R[0][2] = s2 * (qx * qz + qw * qy);
+    R[1][0] = s2 * (qx * qy + qw * qz); R[1][1] = 1.0 - s2 * (qx * qx + qz * qz); R[1][2] = s2 * (qy * qz - qw * qx);
+    R[2][0] = s2 * (qx * qz - qw * qy); R[2][1] = s2 * (qy * qz + qw * qx); R[2][2] = 1.0 - s2 * (qx * qx + qy * qy);
+  }
+  template <class T, class XA, class UA>
+  __device__ static inline void leg(int k, const T (&R)[3][3], const XA& x, const UA& u, const double* p, LegOut<T>& o) {
+    const double kc = p[1], sig = p[2], dn = p[3], mu = p[4], b_j = p[5];
+    const double sx = k < 2 ? 1.0 : -1.0, sy = (k & 1) == 0 ? -1.0 : 1.0;
+    const T a = x[7 + 3 * k], b = x[8 + 3 * k], c = x[9 + 3 * k];
+    const T jd0 = x[25 + 3 * k], jd1 = x[26 + 3 * k], jd2 = x[27 + 3 * k];
+    const T om0 = x[19], om1 = x[20], om2 = x[21];
+    const T sa = mi_sin(a), ca = mi_cos(a), sb = mi_sin(b), cb = mi_cos(b), sbc = mi_sin(b + c), cbc = mi_cos(b + c);
+    const T X = -(kL1 * sb + kL2 * sbc), Z = -(kL1 * cb + kL2 * cbc);
+    const double Y = sy * kL0;
+    const T fb0 = sx * kHipX + X, fb1 = sy * kHipY + (Y * ca - Z * sa), fb2 = Y * sa + Z * ca;
+    const T Ja1 = -(Y * sa) - Z * ca, Ja2 = Y * ca - Z * sa;                     // Ja0 = 0
+    const T Jb0 = Z, Jb1 = X * sa, Jb2 = -(X * ca);
+    const T dXc = -(kL2 * cbc), dZc = kL2 * sbc;
+    const T Jc0 = dXc, Jc1 = -(dZc * sa), Jc2 = dZc * ca;
+    const T zf = x[6] + (R[2][0] * fb0 + R[2][1] * fb1 + R[2][2] * fb2);
+    const T vb0 = om1 * fb2 - om2 * fb1 + (0.0 * jd0 + Jb0 * jd1 + Jc0 * jd2);
+    const T vb1 = om2 * fb0 - om0 * fb2 + (Ja1 * jd0 + Jb1 * jd1 + Jc1 * jd2);
+    const T vb2 = om0 * fb1 - om1 * fb0 + (Ja2 * jd0 + Jb2 * jd1 + Jc2 * jd2);
+    const T vf0 = x[22] + (R[0][0] * vb0 + R[0][1] * vb1 + R[0][2] * vb2);
+    const T vf1 = x[23] + (R[1][0] * vb0 + R[1][1] * vb1 + R[1][2] * vb2);
+    const T vf2 = x[24] + (R[2][0] * vb0 + R[2][1] * vb1 + R[2][2] * vb2);
+    const T fn0 = (kc * sig) * mi_softplus(-zf * (1.0 / sig));
+    o.fw[0] = -(mu * fn0) * vf0; o.fw[1] = -(mu * fn0) * vf1; o.fw[2] = fn0 * (1.0 - dn * vf2);
+    const T f0 = R[0][0] * o.fw[0] + R[1][0] * o.fw[1] + R[2][0] * o.fw[2];        // R^T f: the force in the body frame
+    const T f1 = R[0][1] * o.fw[0] + R[1][1] * o.fw[1] + R[2][1] * o.fw[2];
+    const T f2 = R[0][2] * o.fw[0] + R[1][2] * o.fw[1] + R[2][2] * o.fw[2];
+    o.tq[0] = fb1 * f2 - fb2 * f1; o.tq[1] = fb2 * f0 - fb0 * f2; o.tq[2] = fb0 * f1 - fb1 * f0;
+    o.ja[0] = (u[3 * k + 0] - b_j * jd0 + (0.0 * f0 + Ja1 * f1 + Ja2 * f2)) * (1.0 / p[11]);
+    o.ja[1] = (u[3 * k + 1] - b_j * jd1 + (Jb0 * f0 + Jb1 * f1 + Jb2 * f2)) * (1.0 / p[12]);
+    o.ja[2] = (u[3 * k + 2] - b_j * jd2 + (Jc0 * f0 + Jc1 * f1 + Jc2 * f2)) * (1.0 / p[13]);
+  }
+  // trunk update from the summed wrench F (world), Tq (body): writes quaternion, position, angular and linear velocity
+  template <class T, class XA>
+  __device__ static inline void trunk(const XA& x, const T (&F)[3], const T (&Tq)[3], T* xn, const double* p, double dt) {
+    const double g = p[0], imt = 1.0 / p[7], Ix = p[8], Iy = p[9], Iz = p[10];
+    const T qw = x[0], qx = x[1], qy = x[2], qz = x[3];
+    const T om0 = x[19], om1 = x[20], om2 = x[21];
+    const T al0 = F[0] * imt, al1 = F[1] * imt, al2 = F[2] * imt - g;
+    const T aw0 = (Tq[0] - (Iz - Iy) * om1 * om2) * (1.0 / Ix), aw1 = (Tq[1] - (Ix - Iz) * om2 * om0) * (1.0 / Iy),
+            aw2 = (Tq[2] - (Iy - Ix) * om0 * om1) * (1.0 / Iz);
+    const T w0 = om0 + dt * aw0, w1 = om1 + dt * aw1, w2 = om2 + dt * aw2;
+    const T v0 = x[22] + dt * al0, v1 = x[23] + dt * al1, v2 = x[24] + dt * al2;
+    const double hd = 0.5 * dt;
+    xn[0] = qw + hd * (-(qx * w0) - qy * w1 - qz * w2);
+    xn[1] = qx + hd * (qw * w0 + qy * w2 - qz * w1);
+    xn[2] = qy + hd * (qw * w1 + qz * w0 - qx * w2);
+    xn[3] = qz + hd * (qw * w2 + qx * w1 - qy * w0);
+    xn[4] = x[4] + dt * v0; xn[5] = x[5] + dt * v1; xn[6] = x[6] + dt * v2;
+    xn[19] = w0; xn[20] = w1; xn[21] = w2; xn[22] = v0; xn[23] = v1; xn[24] = v2;
+  }
+  template <class T, class XA>
+  __device__ static inline void joints(int k, const XA& x, const LegOut<T>& o, T* xn, double dt) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const T jdn = x[25 + 3 * k + i] + dt * o.ja[i];
+      xn[25 + 3 * k + i] = jdn;
+      xn[7 + 3 * k + i] = x[7 + 3 * k + i] + dt * jdn;
+    }
+  }
+  template <class T>
+  __device__ static inline void step(const T* x, const T* u, T* xn, const double* p, double dt) {
+    T R[3][3];
+    rotation<T>(x, R);
+    T F[3], Tq[3];
+    {
+      LegOut<T> l0, l2;
+      leg<T>(0, R, x, u, p, l0); joints<T>(0, x, l0, xn, dt);
+      leg<T>(2, R, x, u, p, l2); joints<T>(2, x, l2, xn, dt);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { F[i] = l0.fw[i] + l2.fw[i]; Tq[i] = l0.tq[i] + l2.tq[i]; }
+    }
+    {
+      LegOut<T> l1, l3;
+      leg<T>(1, R, x, u, p, l1); joints<T>(1, x, l1, xn, dt);
+      leg<T>(3, R, x, u, p, l3); joints<T>(3, x, l3, xn, dt);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { F[i] = F[i] + (l1.fw[i] + l3.fw[i]); Tq[i] = Tq[i] + (l1.tq[i] + l3.tq[i]); }
+    }
+    trunk<T>(x, F, Tq, xn, p, dt);
+  }
+  __device__ static inline bool infeasible_velocity(double vn, const double* p) { return !(fabs(vn) <= p[6]); }
+};
+
 }  // namespace mi

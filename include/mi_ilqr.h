@@ -58,9 +58,12 @@ enum {
   MI_MODEL_CARTPOLE = 2,       /* n=4  m=1  */
   MI_MODEL_CARTPOLE_WALL = 3,  /* n=4  m=1  */
   MI_MODEL_SYNTH36 = 4,        /* n=36 m=12 */
-  MI_MODEL_PLANAR_QUAD = 5     /* n=36 m=12: planar floating-base quadruped (articulated-body algorithm, ground
-                                  contact); the one model that can declare a step INFEASIBLE - such a line-search
-                                  trial costs +inf, as when Drake's update throws (ilqr.py:315-323) */
+  MI_MODEL_PLANAR_QUAD = 5,    /* n=36 m=12: planar floating-base quadruped (articulated-body algorithm, ground
+                                  contact); can declare a step INFEASIBLE - such a line-search trial costs +inf, as
+                                  when Drake's update throws (ilqr.py:315-323) */
+  MI_MODEL_QUAD3D = 6          /* n=37 m=12: 3-D floating-base quadruped with mini_cheetah.py:41-52's state layout
+                                  (unit quaternion | position | 12 joints | 18 velocities), feet contact; can declare a
+                                  step infeasible like the planar one */
 };
 
 /* utils_derivs_interpolation.derivs_interpolation.keypoint_method

@@ -143,10 +143,70 @@ static void quad_accel(const double* x, const double* u, const double* p, double
   }
 }
 
+/* ---- 3-D quadruped (model 6): the formulas and operation order of oracle/models_np.py:quad3d_leg / quad3d_step ---- */
+#define Q3_L0 0.062
+#define Q3_L1 0.209
+#define Q3_L2 0.195
+#define Q3_HIPX 0.19
+#define Q3_HIPY 0.049
+/* leg k: contact force in the world frame fw[3], its moment about the trunk's origin in the body frame tq[3], joint accelerations */
+static void quad3d_leg(int k, const double R[3][3], const double* om, const double* vlin, double pz, const double* q, const double* jd,
+                       const double* u, const double* p, double* fw, double* tq, double* jacc) {
+  const double kc = p[1], sig = p[2], dn = p[3], mu = p[4], b_j = p[5];
+  const double sx = k < 2 ? 1.0 : -1.0, sy = (k % 2) == 0 ? -1.0 : 1.0;
+  const double a = q[0], b = q[1], c = q[2];
+  const double sa = sin(a), ca = cos(a), sb = sin(b), cb = cos(b), sbc = sin(b + c), cbc = cos(b + c);
+  const double X = -(Q3_L1 * sb + Q3_L2 * sbc), Z = -(Q3_L1 * cb + Q3_L2 * cbc), Y = sy * Q3_L0;
+  const double fb[3] = {sx * Q3_HIPX + X, sy * Q3_HIPY + (Y * ca - Z * sa), Y * sa + Z * ca};
+  const double Ja[3] = {0.0, -(Y * sa) - Z * ca, Y * ca - Z * sa};
+  const double Jb[3] = {Z, X * sa, -(X * ca)};
+  const double dXc = -(Q3_L2 * cbc), dZc = Q3_L2 * sbc;
+  const double Jc[3] = {dXc, -(dZc * sa), dZc * ca};
+  const double zf = pz + (R[2][0] * fb[0] + R[2][1] * fb[1] + R[2][2] * fb[2]);
+  const double vb[3] = {om[1] * fb[2] - om[2] * fb[1] + (Ja[0] * jd[0] + Jb[0] * jd[1] + Jc[0] * jd[2]),
+                        om[2] * fb[0] - om[0] * fb[2] + (Ja[1] * jd[0] + Jb[1] * jd[1] + Jc[1] * jd[2]),
+                        om[0] * fb[1] - om[1] * fb[0] + (Ja[2] * jd[0] + Jb[2] * jd[1] + Jc[2] * jd[2])};
+  double vf[3], fbd[3];
+  for (int i = 0; i < 3; ++i) vf[i] = vlin[i] + (R[i][0] * vb[0] + R[i][1] * vb[1] + R[i][2] * vb[2]);
+  const double fn0 = kc * sig * softplus(-zf / sig);
+  fw[0] = -(mu * fn0) * vf[0]; fw[1] = -(mu * fn0) * vf[1]; fw[2] = fn0 * (1.0 - dn * vf[2]);
+  for (int i = 0; i < 3; ++i) fbd[i] = R[0][i] * fw[0] + R[1][i] * fw[1] + R[2][i] * fw[2];
+  tq[0] = fb[1] * fbd[2] - fb[2] * fbd[1]; tq[1] = fb[2] * fbd[0] - fb[0] * fbd[2]; tq[2] = fb[0] * fbd[1] - fb[1] * fbd[0];
+  jacc[0] = (u[0] - b_j * jd[0] + (Ja[0] * fbd[0] + Ja[1] * fbd[1] + Ja[2] * fbd[2])) / p[11];
+  jacc[1] = (u[1] - b_j * jd[1] + (Jb[0] * fbd[0] + Jb[1] * fbd[1] + Jb[2] * fbd[2])) / p[12];
+  jacc[2] = (u[2] - b_j * jd[2] + (Jc[0] * fbd[0] + Jc[1] * fbd[1] + Jc[2] * fbd[2])) / p[13];
+}
+static void quad3d_step(const double* x, const double* u, const double* p, double dt, double* xn) {
+  const double g = p[0], mt = p[7], Ix = p[8], Iy = p[9], Iz = p[10];
+  const double qw = x[0], qx = x[1], qy = x[2], qz = x[3];
+  const double *pos = x + 4, *jq = x + 7, *om = x + 19, *vl = x + 22, *jd = x + 25;
+  const double s2 = 2.0 / (qw * qw + qx * qx + qy * qy + qz * qz);
+  const double R[3][3] = {{1.0 - s2 * (qy * qy + qz * qz), s2 * (qx * qy - qw * qz), s2 * (qx * qz + qw * qy)},
+                          {s2 * (qx * qy + qw * qz), 1.0 - s2 * (qx * qx + qz * qz), s2 * (qy * qz - qw * qx)},
+                          {s2 * (qx * qz - qw * qy), s2 * (qy * qz + qw * qx), 1.0 - s2 * (qx * qx + qy * qy)}};
+  double fw[4][3], tq[4][3], ja[4][3], F[3], T[3];
+  for (int k = 0; k < 4; ++k) quad3d_leg(k, R, om, vl, pos[2], jq + 3 * k, jd + 3 * k, u + 3 * k, p, fw[k], tq[k], ja[k]);
+  for (int i = 0; i < 3; ++i) { F[i] = (fw[0][i] + fw[2][i]) + (fw[1][i] + fw[3][i]); T[i] = (tq[0][i] + tq[2][i]) + (tq[1][i] + tq[3][i]); }
+  const double al[3] = {F[0] / mt, F[1] / mt, F[2] / mt - g};
+  const double aw[3] = {(T[0] - (Iz - Iy) * om[1] * om[2]) / Ix, (T[1] - (Ix - Iz) * om[2] * om[0]) / Iy, (T[2] - (Iy - Ix) * om[0] * om[1]) / Iz};
+  double omn[3], vln[3];
+  for (int i = 0; i < 3; ++i) { omn[i] = om[i] + dt * aw[i]; vln[i] = vl[i] + dt * al[i]; }
+  const double hd = 0.5 * dt;
+  xn[0] = qw + hd * (-(qx * omn[0]) - qy * omn[1] - qz * omn[2]);
+  xn[1] = qx + hd * (qw * omn[0] + qy * omn[2] - qz * omn[1]);
+  xn[2] = qy + hd * (qw * omn[1] + qz * omn[0] - qx * omn[2]);
+  xn[3] = qz + hd * (qw * omn[2] + qx * omn[1] - qy * omn[0]);
+  for (int i = 0; i < 3; ++i) { xn[4 + i] = pos[i] + dt * vln[i]; xn[19 + i] = omn[i]; xn[22 + i] = vln[i]; }
+  for (int k = 0; k < 4; ++k) for (int i = 0; i < 3; ++i) {
+    const double jdn = jd[3 * k + i] + dt * ja[k][i];
+    xn[25 + 3 * k + i] = jdn; xn[7 + 3 * k + i] = jq[3 * k + i] + dt * jdn;
+  }
+}
+
 /* A model may declare a step infeasible (Drake's discrete update throwing, caught at ilqr.py:315-323). */
 static int step_infeasible(const oracle_cfg* c, const double* xn) {
-  if (c->model_id != 5) return 0;
-  for (int i = 18; i < 36; ++i) if (!(fabs(xn[i]) <= c->params[8])) return 1;
+  if (c->model_id == 5) { for (int i = 18; i < 36; ++i) if (!(fabs(xn[i]) <= c->params[8])) return 1; }
+  if (c->model_id == 6) { for (int i = 19; i < 37; ++i) if (!(fabs(xn[i]) <= c->params[6])) return 1; }
   return 0;
 }
 
@@ -198,6 +258,7 @@ static void step(const oracle_cfg* c, const double* x, const double* u, double* 
       for (int i = 0; i < 18; ++i) { const double vn = x[18 + i] + dt * qdd[i]; xn[18 + i] = vn; xn[i] = x[i] + dt * vn; }
       break;
     }
+    case 6: quad3d_step(x, u, p, dt, xn); break;    /* 3-D quadruped */
     default: { /* synth36 */
       const double ks = p[0], cd = p[1], kc = p[2], bu = p[3];
       const int nq = 18;

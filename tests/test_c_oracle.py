@@ -44,7 +44,7 @@ def test_c_oracle_vs_reference_golden_and_threads():
         assert rel_err(r1["K"][b], g["K"]) < 1e-5
 
 
-@pytest.mark.parametrize("name", ["acrobot_mpc_0", "acrobot_mpc_1", "synth36_mpc_0", "quad_mpc_0"])
+@pytest.mark.parametrize("name", ["acrobot_mpc_0", "acrobot_mpc_1", "synth36_mpc_0", "quad_mpc_0", "quad3d_mpc_0"])
 def test_c_oracle_mpc_loop_vs_reference_golden(name):
     """oracle_mpc_batch (shift warm start, moving target, gains persisting across solves - SURVEY F10)
     against MPC sequences recorded from the unmodified reference (exact Jacobians there, central FD here:
@@ -59,7 +59,7 @@ def test_c_oracle_mpc_loop_vs_reference_golden(name):
     if "move_target" in g:
         step = np.zeros(n)
         step[int(g["move_target"][0])] = g["move_target"][1]
-        ug = P.synth36_u_guess(N) if prob["model_id"] == 4 else P.planar_quad_u_guess(N)
+        ug = {4: P.synth36_u_guess, 5: P.planar_quad_u_guess, 6: P.quad3d_u_guess}[prob["model_id"]](N)
     r = c_oracle.mpc_batch(M.Model(prob["model_id"], prob["dt"]), prob, g["x0"][None], ug, R, replan, target_step=step)
     assert r["status"][0] == 0
     assert int(r["first"][0, 1]) == g["iters"][0] and abs(r["first"][0, 0] - g["Ls"][0]) < 1e-8 * abs(g["Ls"][0])
@@ -73,10 +73,11 @@ def test_c_oracle_mpc_loop_vs_reference_golden(name):
     assert rel_err(r["K"][0], g["Ks"][-1]) < 1e-5
 
 
-@pytest.mark.parametrize("name", ["quad_solve_0", "quad_infeasible_0", "quad_infeasible_1"])
+@pytest.mark.parametrize("name", ["quad_solve_0", "quad_infeasible_0", "quad_infeasible_1",
+                                  "quad3d_solve_0", "quad3d_solve_1", "quad3d_infeasible_0"])
 def test_c_oracle_planar_quadruped_vs_reference_golden(name):
-    """The C restatement of the articulated-body model and of the infeasible-step rule (L = inf, ilqr.py:315-323)
-    against solves recorded from the reference (exact Jacobians there, central FD here)."""
+    """The C restatement of the articulated-body model, of the 3-D quadruped and of the infeasible-step rule
+    (L = inf, ilqr.py:315-323) against solves recorded from the reference (exact Jacobians there, central FD here)."""
     from oracle import c_oracle, models_np as M
     g, prob = load_golden(name)
     r = c_oracle.solve_batch(M.Model(prob["model_id"], prob["dt"], prob.get("params")), prob, g["x0"][None], g["u_guess"])

@@ -129,3 +129,128 @@ def test_wide_random_sweep_vs_c_oracle():
             loose_bad.append((case, model_id, N, B, int(ok.sum()), int(same.sum()), relc))
     assert not strict_bad, strict_bad
     assert not loose_bad, loose_bad
+
+
+# ----------------------------------------------------------------------------------
+# (f)4: the 3-D quadruped - quaternion floating base, n = 37, m = 12 - on the workgroup-per-problem (MFMA) kernels in
+# their split tile layout (ilqr_large.hpp: u in a column tile of its own)
+# ----------------------------------------------------------------------------------
+@pytest.mark.parametrize("jac", ["ad", "fd"])
+def test_quad3d_stage_level_vs_reference_golden(jac):
+    """One iteration's stages against the snapshot of the unmodified reference (quad3d_stage): the rollout (one lane
+    per leg, DPP row sums for the trunk's wrench), the Jacobians (whole-step evaluation per (step, column) item) and
+    the backward pass on the matrix core with n = 37 padded to k-steps of 4 and u in its own tile."""
+    g, prob = load_golden("quad3d_stage")
+    s = make_solver(prob, jac=jac)
+    s.SetInitialState(g["x0"][None])
+    s.SetInitialGuess(g["pre_u_bar"])
+    s.set_state(x_bar=g["pre_x_bar"][None], K=g["pre_K"][None], kappa=g["pre_kappa"][None], dV_coeff=g["pre_dV"][None])
+    x, u, L, ex = s.stage_rollout(1.0)
+    assert rel_err(x[0], g["roll_x"]) < 1e-10 and rel_err(u[0], g["roll_u"]) < 1e-10
+    assert abs(L[0] - g["roll_L"]) < 1e-10 * abs(g["roll_L"])
+    s.set_state(x_bar=x, u_bar=u)
+    s.stage_linearize()
+    tolj = 1e-10 if jac == "ad" else 2e-6                    # (contact curvature k/sigma^2 = 2.5e8: FD truncation ~2e-7 relative)
+    assert rel_err(s.fx[0], g["fx"]) < tolj and rel_err(s.fu[0], g["fu"]) < tolj
+    s.stage_backward()
+    tolk = 1e-7 if jac == "ad" else 1e-4
+    assert rel_err(s.K[0], g["post_K"]) < tolk
+    assert rel_err(s.kappa[0], g["post_kappa"]) < (1e-7 if jac == "ad" else 1e-3)
+    assert rel_err(s.dV_coeff[0], g["post_dV"]) < (1e-7 if jac == "ad" else 1e-3)
+
+
+@pytest.mark.parametrize("name", ["quad3d_solve_0", "quad3d_solve_1", "quad3d_infeasible_0"])
+def test_quad3d_solve_vs_reference_golden(name):
+    """Whole solves recorded from the unmodified reference (exact Jacobians on both sides).  quad3d_infeasible_0: the
+    model declares line-search trials infeasible (|v| bound 2.5) and the device backs off exactly like ilqr.py:315-335."""
+    g, prob = load_golden(name)
+    s = make_solver(prob, jac="ad", single=True, hist_cap=32)
+    s.SetInitialState(g["x0"])
+    s.SetInitialGuess(g["u_guess"])
+    x, u, _, L = s.Solve()
+    iters = int(s.iterations[0])
+    assert iters == len(g["hist"])
+    h = s.history[0][:iters]
+    assert np.array_equal(h[:, 1:3], g["hist"][:, 1:3])              # eps and trial count of every iteration
+    assert rel_err(h[:, 0], g["hist"][:, 0]) < 1e-8 and abs(L - g["L"]) < 1e-8 * abs(g["L"])
+    assert np.max(np.abs(x - g["x_bar"])) < 1e-7 and np.max(np.abs(u - g["u_bar"])) < 1e-6
+    assert rel_err(s.K, g["K"]) < 1e-5 and rel_err(s.fx, g["fx"]) < 1e-6
+
+
+@pytest.mark.parametrize("device_loop", [False, True])
+def test_quad3d_mpc_vs_reference_golden(device_loop):
+    """mini_cheetah.py:186-201's loop with its moving target (x_nom[4] += target_vel * dt * replan), recorded from the
+    reference: host loop of Solve() calls, and the whole loop in one launch (mi_ilqr_mpc_run)."""
+    from drake_ddp_amd.workloads import mpc_shift, quad3d_u_guess
+    g, prob = load_golden("quad3d_mpc_0")
+    s = make_solver(prob, jac="ad")
+    N, replan, R = prob["N"], int(g["replan"]), len(g["Ls"]) - 1
+    s.SetInitialState(g["x0"][None])
+    s.SetInitialGuess(quad3d_u_guess(N))
+    x, u, _, L = s.Solve()
+    assert s.iterations[0] == g["iters"][0] and abs(L[0] - g["Ls"][0]) < 1e-8 * abs(g["Ls"][0])
+    step = np.zeros(37)
+    step[int(g["move_target"][0])] = g["move_target"][1]
+    if device_loop:
+        s.MPCRun(R, replan, target_step=step)
+        log = s.mpc_log[0]
+        assert np.array_equal(log[:, -1].astype(int), g["iters"][1:]) and rel_err(log[:, -2], g["Ls"][1:]) < 1e-8
+    else:
+        x_nom = prob["x_nom"].copy()
+        for r in range(1, R + 1):
+            x_nom = x_nom + step
+            x0, ug = mpc_shift(x, u, replan)
+            s.SetInitialState(x0); s.SetInitialGuess(ug); s.SetTargetState(x_nom)
+            x, u, _, L = s.Solve()
+            assert s.iterations[0] == g["iters"][r] and abs(L[0] - g["Ls"][r]) < 1e-8 * abs(g["Ls"][r])
+    assert rel_err(s.x_bar[0], g["xs"][-1]) < 1e-7 and rel_err(s.K[0], g["Ks"][-1]) < 1e-5
+
+
+def test_quad3d_batch_fd_vs_c_oracle():
+    """64 seeded 3-D quadruped problems, central differences on both sides, default and tightened velocity bound,
+    against the C oracle (pinned to the quad3d goldens): iteration / trial counts of every problem, costs, trajectories."""
+    from drake_ddp_amd import workloads as W
+    from oracle import c_oracle, models_np as M
+    prob = W.quad3d_problem()
+    B = 64
+    x0, ug = W.quad3d_batch_x0(B), W.quad3d_u_guess(prob["N"])
+    counts = {}
+    for tag, vmax in (("free", 60.0), ("tight", 3.0)):                  # (3.0: 28 of the 64 problems take other steps, none fails)
+        par = np.array(M.DEFAULT_PARAMS[M.QUAD3D], float)
+        par[6] = vmax
+        p = dict(prob, params=par)
+        s = make_solver(p, B=B, jac="fd")
+        s.SetInitialState(x0)
+        s.SetInitialGuess(ug)
+        x, u, _, L = s.Solve()
+        r = c_oracle.solve_batch(M.Model(p["model_id"], p["dt"], par), p, x0, ug)
+        assert np.array_equal(s.status, r["status"]) and (s.status == 0).all()
+        same = (s.iterations == r["iters"]) & (s.ls_trials == r["ls"])
+        assert_flip_budget(f"quad3d_batch_{tag}", same, (s.iterations[~same], r["iters"][~same]))
+        rel = np.abs(L - r["cost"]) / np.abs(r["cost"])
+        assert np.max(rel[same]) < 1e-7 and np.max(np.abs(x[same] - r["x_bar"][same])) < 1e-5
+        counts[tag] = s.ls_trials.copy()
+    assert not np.array_equal(counts["free"], counts["tight"])         # the bound really changes line searches on the device
+
+
+def test_quad3d_full_size_mpc_run_vs_oracle():
+    """The benchmarked 3-D quadruped config (C5q3d): B = 64, cold solve + MPCRun(100, 4, moving target) in one launch,
+    every problem and re-solve against the C oracle's receding-horizon loop (mini_cheetah.py:186-213)."""
+    from drake_ddp_amd import workloads as W
+    from oracle import c_oracle, models_np as M
+    from test_gpu_round2 import _check_mpc_against_oracle
+    q = W.quad3d_problem()
+    B = 64
+    x0, ug = W.quad3d_batch_x0(B), W.quad3d_u_guess(q["N"])
+    step = np.zeros(37)
+    step[4] = W.QUAD3D_TARGET_VEL * q["dt"] * 4
+    s = make_solver(q, B=B, jac="fd")
+    s.SetInitialState(x0)
+    s.SetInitialGuess(ug)
+    s.Solve()
+    first_it, first_L, ls0 = s.iterations.copy(), s.cost.copy(), s.ls_trials.copy()
+    st = s.MPCRun(100, 4, target_step=step)
+    r = c_oracle.mpc_batch(M.Model(q["model_id"], q["dt"]), q, x0, ug, 100, 4, target_step=step)
+    r["ls"] = r["ls"] - ls0
+    log = _check_mpc_against_oracle(s, r, first_it, first_L, 37, tol_L=1e-6, tol_x=1e-5, budget="quad3d_mpc_full")
+    assert st.n_converged == B and np.all(log[:, -1, 4] > 0.1)        # the trunk moved forward

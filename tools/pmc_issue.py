@@ -67,7 +67,7 @@ lines = [json.loads(l) for l in r.stdout.decode().splitlines() if l.startswith("
 iters = {l["config"].split()[0] + ("/8" if "shard" in l["config"] else ""): l.get("iters_total", l.get("iters_per_solve")) for l in lines}
 KERNELS = {   # config -> (model substring, workgroups of the launch); every kernel mode of that model and grid is the config's
     "C1": ("Pendulum", 1), "C2": ("Pendulum", 1024), "C3": ("Acrobot", 512), "C4": ("CartPoleT<true>", 256),
-    "C5": ("Synth36", 64), "C5q": ("PlanarQuad", None)}
+    "C5": ("Synth36", 64), "C5q": ("PlanarQuad", None), "C5q3d": ("Quad3D", None)}
 per_config = {}
 for cfg, (model, grid) in KERNELS.items():
     ks = [k for k in acc if model in k and (grid is None or ("grid=%d x" % grid) in k)]

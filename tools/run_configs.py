@@ -65,6 +65,9 @@ mpc("C5 synth36 MPC B=64 x 101 solves", q, W.synth36_batch_x0(64), W.synth36_u_g
 pq = W.planar_quad_problem()
 mpc("C5q planar quadruped MPC B=64 x 101 solves", pq, W.planar_quad_batch_x0(64), W.planar_quad_u_guess(pq["N"]), 100, 4,
     move=(0, W.QUAD_TARGET_VEL * pq["dt"] * 4))
+q3 = W.quad3d_problem()
+mpc("C5q3d 3-D quadruped MPC B=64 x 101 solves", q3, W.quad3d_batch_x0(64), W.quad3d_u_guess(q3["N"]), 100, 4,
+    move=(4, W.QUAD3D_TARGET_VEL * q3["dt"] * 4))
 if os.environ.get("MI_RUN_SHARD") == "1":     # (same grid as C5 - 8 problems x 8 workgroups: kept out of the counter passes)
     mpc("C5/8GPU shard: synth36 MPC B=8 x 101 solves", q, W.synth36_batch_x0(64)[:8], W.synth36_u_guess(q["N"]), 100, 4,
         move=(0, W.SYNTH_TARGET_VEL * q["dt"] * 4))
