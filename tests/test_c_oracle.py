@@ -44,7 +44,7 @@ def test_c_oracle_vs_reference_golden_and_threads():
         assert rel_err(r1["K"][b], g["K"]) < 1e-5
 
 
-@pytest.mark.parametrize("name", ["acrobot_mpc_0", "acrobot_mpc_1", "synth36_mpc_0", "quad_mpc_0", "quad3d_mpc_0"])
+@pytest.mark.parametrize("name", ["acrobot_mpc_0", "acrobot_mpc_1", "synth36_mpc_0", "quad_mpc_0", "quad3d_mpc_0", "quad3d_mpc_1"])
 def test_c_oracle_mpc_loop_vs_reference_golden(name):
     """oracle_mpc_batch (shift warm start, moving target, gains persisting across solves - SURVEY F10)
     against MPC sequences recorded from the unmodified reference (exact Jacobians there, central FD here:

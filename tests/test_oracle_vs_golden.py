@@ -54,7 +54,7 @@ def test_stage_level(name):
     assert rel_err(o.dV, g["post_dV"]) < 1e-10
 
 
-@pytest.mark.parametrize("name", ["acrobot_mpc_0", "acrobot_mpc_1", "synth36_mpc_0", "quad_mpc_0", "quad3d_mpc_0"])
+@pytest.mark.parametrize("name", ["acrobot_mpc_0", "acrobot_mpc_1", "synth36_mpc_0", "quad_mpc_0", "quad3d_mpc_0", "quad3d_mpc_1"])
 def test_mpc_sequence(name):
     """Receding-horizon re-solves with persistent gains."""
     from drake_ddp_amd.workloads import mpc_shift, synth36_u_guess, planar_quad_u_guess, quad3d_u_guess
