@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmi_ilqr.so")
 
 MAX_PARAMS = 16
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # enums (include/mi_ilqr.h)
 OK, E_BAD_SHAPE, E_BAD_METHOD, E_LINESEARCH, E_HIP, E_NO_DEVICE, E_BAD_ARG, E_UNSUPPORTED, E_RCCL = 0, -1, -2, -3, -4, -5, -6, -7, -8
@@ -26,7 +26,7 @@ I_ITERS, I_STATUS, I_LS_TRIALS, I_KP_COUNT, I_KP_LIST = 100, 101, 102, 103, 104
 
 EXPORTS = [
     "mi_ilqr_abi_version", "mi_ilqr_strerror", "mi_ilqr_model_info", "mi_ilqr_create", "mi_ilqr_destroy",
-    "mi_ilqr_set_cost", "mi_ilqr_set_initial", "mi_ilqr_set_initial_shared", "mi_ilqr_host_alloc", "mi_ilqr_host_free", "mi_ilqr_reset", "mi_ilqr_rearm_initial_guess",
+    "mi_ilqr_set_cost", "mi_ilqr_set_initial", "mi_ilqr_set_initial_shared", "mi_ilqr_host_alloc", "mi_ilqr_host_free", "mi_ilqr_set_result_sink", "mi_ilqr_reset", "mi_ilqr_rearm_initial_guess",
     "mi_ilqr_solve", "mi_ilqr_solve_async", "mi_ilqr_collect_stats", "mi_ilqr_collect_stats_n",
     "mi_ilqr_rollout", "mi_ilqr_forward", "mi_ilqr_linearize", "mi_ilqr_backward", "mi_ilqr_mpc_shift",
     "mi_ilqr_mpc_run", "mi_ilqr_get_mpc_log",
@@ -95,6 +95,7 @@ def load():
     lib.mi_ilqr_set_initial_shared.argtypes = [H, C.c_void_p, C.c_void_p]
     lib.mi_ilqr_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
     lib.mi_ilqr_host_free.argtypes = [C.c_void_p]
+    lib.mi_ilqr_set_result_sink.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.mi_ilqr_mpc_shift.argtypes = [H, C.c_int32]
     lib.mi_ilqr_mpc_run.argtypes = [H, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(Stats)]
     lib.mi_ilqr_get_mpc_log.argtypes = [H, C.c_void_p, C.c_size_t]

@@ -72,6 +72,7 @@ struct mi_ilqr {
   bool large = false;      // workgroup-per-problem path: state arrays are TIME-MAJOR in HBM
   int n_store = 1;         // line-search candidate trajectories kept in LDS
   bool batch_minor = false; // lane-per-problem path: state arrays are [t][row][b] in HBM
+  double *sink_x = nullptr, *sink_u = nullptr, *sink_cost = nullptr;   // result sink (device aliases of host arrays), optional
 };
 
 // Small batches of the wave-per-problem kernels aggregate the batch statistics in the solve kernel

@@ -602,6 +602,43 @@ __device__ __forceinline__ void large_jac_at_tree(const LView<M::n, M::m>& v, co
   }
 }
 
+// Leg models (Quad3D): whole-step evaluation per (key-point, column) item through accessors that perturb / seed one
+// entry of the LDS copy of the nominal trajectory on the fly - no per-thread copies of x and u.
+template <class M, int JAC>
+__device__ __forceinline__ void large_jac_at_legs(const LView<M::n, M::m>& v, const KArgs& a, const int* list, int count,
+                                                  const double* Xsrc, const double* Usrc, int xstride, int ustride) {
+  constexpr int n = M::n, m = M::m, nc = n + m;
+  const double h = a.fd_h, inv2h = 1.0 / (2.0 * h);
+  for (int it = threadIdx.x; it < count * nc; it += kLargeThreads) {
+    const int ki = it / nc, col = it - ki * nc;
+    const int t = list[ki];
+    const double* xg = Xsrc + (size_t)t * xstride;
+    const double* ug = Usrc + (size_t)t * ustride;
+    double d[n];
+    if (JAC == MI_JAC_FD_CENTRAL) {
+      double f[n];
+      M::template step_acc<double>(PertAcc{xg, col, h}, PertAcc{ug, col - n, h}, d, a.params, a.dt);
+      M::template step_acc<double>(PertAcc{xg, col, -h}, PertAcc{ug, col - n, -h}, f, a.params, a.dt);
+#pragma unroll
+      for (int i = 0; i < n; ++i) d[i] = (d[i] - f[i]) * inv2h;
+    } else {
+      Dual1 fd[n];
+      M::template step_acc<Dual1>(SeedAcc{xg, col}, SeedAcc{ug, col - n}, fd, a.params, a.dt);
+#pragma unroll
+      for (int i = 0; i < n; ++i) d[i] = fd[i].d;
+    }
+    if (col < n) {
+      double* o = v.Fx + (size_t)t * n * n + col;
+#pragma unroll
+      for (int i = 0; i < n; ++i) o[i * n] = d[i];
+    } else {
+      double* o = v.Fu + (size_t)t * n * m + (col - n);
+#pragma unroll
+      for (int i = 0; i < n; ++i) o[i * m] = d[i];
+    }
+  }
+}
+
 template <class M, int JAC>
 __device__ __forceinline__ void large_jac_at(const LView<M::n, M::m>& v, const KArgs& a, const int* list, int count) {
   constexpr int n = M::n, m = M::m, nc = n + m;
@@ -1235,8 +1272,8 @@ __global__ void __launch_bounds__(kLargeThreads) ilqr_large_kernel(const KArgs a
   // The sparse Jacobian code reads a handful of x/u entries per evaluation: it takes them from an
   // LDS copy of the nominal trajectory (the backward pass's T1|H and F areas are idle during the
   // linearization) instead of paying an L2 round trip per dependent access.
-  const bool lin_staged = (HasSparsity<M>::value || IsChainModel<M>::value) && (size_t)(n + 1) * N <= (size_t)(n + Ly::NMP) * Ly::TS &&
-                          (size_t)(m + 1) * (N - 1) <= (size_t)n * Ly::NMP;
+  const bool lin_staged = (HasSparsity<M>::value || IsChainModel<M>::value || IsLegModel<M>::value) &&
+                          (size_t)(n + 1) * N <= (size_t)(Ly::NK + Ly::NMP) * Ly::TS && (size_t)(m + 1) * (N - 1) <= (size_t)Ly::NK * Ly::NMP;
   const double* lin_X = lin_staged ? lds + Ly::oT1 : v.X;
   const double* lin_U = lin_staged ? lds + Ly::oF : v.U;
   // Row strides of the LDS copy.  Chain models deal their items key-point fastest: the lanes of a wave read the
@@ -1247,6 +1284,7 @@ __global__ void __launch_bounds__(kLargeThreads) ilqr_large_kernel(const KArgs a
   auto jac = [&](const int* list, int count) __attribute__((always_inline)) {
     if constexpr (HasSparsity<M>::value) large_jac_at_sparse<M, JAC>(v, a, list, count, lin_X, lin_U);
     else if constexpr (IsChainModel<M>::value) large_jac_at_tree<M, JAC>(v, a, list, count, lin_X, lin_U, lin_xs, lin_us, lds + Ly::doubles);   // (the cost-gradient area of the backward pass is idle here)
+    else if constexpr (IsLegModel<M>::value) large_jac_at_legs<M, JAC>(v, a, list, count, lin_X, lin_U, lin_xs, lin_us);
     else large_jac_at<M, JAC>(v, a, list, count);
   };
   // ---- cluster handshake (G > 1; every step a key-point, models with an LDS-staged linearization) -------------

@@ -84,6 +84,10 @@ struct KArgs {
   // (ilqr_large.hpp: cluster handshake).  cluster_sync: 4 x 64-bit words per problem, zero at launch.
   int32_t cluster;
   unsigned long long* cluster_sync;
+  // wave-per-problem kernels: optional RESULT SINK (mi_ilqr_set_result_sink) - device-visible, page-locked HOST arrays
+  // that receive x_bar (B,n,N), u_bar (B,m,N-1) and the costs (B,) straight from the kernel's write-back, problem by
+  // problem as each one finishes: the copy-out of a batch overlaps the launch's stragglers instead of following it.
+  double *sink_x, *sink_u, *sink_cost;
 };
 
 __device__ __forceinline__ double bcast_lane0(double v) {
@@ -2314,6 +2318,14 @@ __global__ void __launch_bounds__(256) ilqr_small_kernel(const KArgs a) {
         for (int k = 0; k < n * m; ++k) fur[k] = jr[Ly::FU + k];
   #pragma unroll
         for (int i = 0; i < n; ++i) wt_store(&a.x_bar[oX + (size_t)i * N + t], xb[i]);
+        if (a.sink_x != nullptr) {                                   // result sink in host memory (optional)
+  #pragma unroll
+          for (int i = 0; i < n; ++i) a.sink_x[oX + (size_t)i * N + t] = xb[i];
+          if (t < N - 1) {
+  #pragma unroll
+            for (int k = 0; k < m; ++k) a.sink_u[oU + (size_t)k * (N - 1) + t] = ub[k];
+          }
+        }
         if (t < N - 1) {
   #pragma unroll
           for (int k = 0; k < m; ++k) wt_store(&a.u_bar[oU + (size_t)k * (N - 1) + t], ub[k]);
@@ -2334,6 +2346,10 @@ __global__ void __launch_bounds__(256) ilqr_small_kernel(const KArgs a) {
   } else {
     stage_out(a.x_bar + oX, w.G, Ly::GS, Ly::XB, n, N);
     stage_out(a.u_bar + oU, w.G, Ly::GS, Ly::UB, m, N - 1);
+    if (a.sink_x != nullptr) {                                       // result sink in host memory (optional)
+      stage_out(a.sink_x + oX, w.G, Ly::GS, Ly::XB, n, N);
+      stage_out(a.sink_u + oU, w.G, Ly::GS, Ly::UB, m, N - 1);
+    }
     stage_out(a.fx + oFx, w.J, Ly::JS, Ly::FX, n * n, N - 1);
     stage_out(a.fu + oFu, w.J, Ly::JS, Ly::FU, n * m, N - 1);
     if (MODE == MODE_SOLVE || MODE == MODE_MPC) {
@@ -2345,6 +2361,7 @@ __global__ void __launch_bounds__(256) ilqr_small_kernel(const KArgs a) {
   for (int i = lane; i < nk; i += 64) a.kp_list[(size_t)b * (N - 1) + i] = w.kp[i];
   if (lane == 0) {
     a.cost[b] = L; a.iters[b] = iters; a.status[b] = status; a.ls_trials[b] = ls_total; a.kp_count[b] = nk;
+    if (a.sink_cost != nullptr) a.sink_cost[b] = L;
     a.prof[4 * b + 0] = c_ls; a.prof[4 * b + 1] = c_lin; a.prof[4 * b + 2] = c_bp; a.prof[4 * b + 3] = clock64() - c_begin;
 #ifdef MI_PROF_NEWTON
     // debug build: launch phases instead of the stage stopwatches

@@ -108,6 +108,7 @@ KArgs make_args(const mi_ilqr* h) {
   // workgroup-per-problem kernels: with few problems per GPU most CUs idle - up to 8 workgroups per problem share the
   // linearization (ilqr_large.hpp: cluster handshake), as many as keep every workgroup of the launch on its own CU.
   // MI_ILQR_CLUSTER=k forces k (1 = off) for A/B runs.
+  a.sink_x = h->sink_x; a.sink_u = h->sink_u; a.sink_cost = h->sink_cost;
   a.cluster = 1;
   a.cluster_sync = h->cluster_sync;
   if (h->large && h->cluster_sync && h->d.keypoint_method == MI_KP_SET_INTERVAL && h->d.minN == 1) {
@@ -736,7 +737,25 @@ int mi_ilqr_set_initial_shared(mi_ilqr_t* h, const double* x0, const double* u_g
 int mi_ilqr_host_alloc(size_t bytes, void** out) {
   if (!out || bytes == 0) return MI_ILQR_E_BAD_ARG;
   *out = nullptr;
-  HIPCHK(hipHostMalloc(out, bytes, hipHostMallocDefault));
+  HIPCHK(hipHostMalloc(out, bytes, hipHostMallocMapped));            // page-locked AND device-visible (result sinks)
+  return MI_ILQR_OK;
+}
+
+int mi_ilqr_set_result_sink(mi_ilqr_t* h, double* x_bar_host, double* u_bar_host, double* cost_host) {
+  if (!h) return MI_ILQR_E_BAD_ARG;
+  if (h->large || h->batch_minor) return MI_ILQR_E_UNSUPPORTED;     // (their kernel layouts are not the boundary's)
+  HIPCHK(hipSetDevice(h->d.device_id));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->sink_x = h->sink_u = h->sink_cost = nullptr;
+  if (!x_bar_host && !u_bar_host && !cost_host) return MI_ILQR_OK;
+  if (!x_bar_host || !u_bar_host || !cost_host) return MI_ILQR_E_BAD_ARG;
+  void *dx = nullptr, *du = nullptr, *dc = nullptr;
+  if (hipHostGetDevicePointer(&dx, x_bar_host, 0) != hipSuccess || hipHostGetDevicePointer(&du, u_bar_host, 0) != hipSuccess ||
+      hipHostGetDevicePointer(&dc, cost_host, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    return MI_ILQR_E_BAD_ARG;                                        // not page-locked, device-visible host memory
+  }
+  h->sink_x = static_cast<double*>(dx); h->sink_u = static_cast<double*>(du); h->sink_cost = static_cast<double*>(dc);
   return MI_ILQR_OK;
 }
 

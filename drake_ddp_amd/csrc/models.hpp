@@ -431,7 +431,10 @@ struct Quad3D {
     }
   }
   template <class T>
-  __device__ static inline void step(const T* x, const T* u, T* xn, const double* p, double dt) {
+  __device__ static inline void step(const T* x, const T* u, T* xn, const double* p, double dt) { step_acc<T>(x, u, xn, p, dt); }
+  // x, u: anything indexable (pointers, or accessors that perturb / seed one entry on the fly)
+  template <class T, class XA, class UA>
+  __device__ static inline void step_acc(const XA& x, const UA& u, T* xn, const double* p, double dt) {
     T R[3][3];
     rotation<T>(x, R);
     T F[3], Tq[3];

@@ -79,6 +79,7 @@ class BatchedIterativeLQR:
         # buffers the solver owns (direct DMA, no page faults of freshly allocated arrays) - one buffer per
         # attribute, REUSED by the next read of that attribute; copy what must outlive it.  Default: fresh arrays.
         self._pinned = {} if pinned_results else None
+        self._sink = None              # pinned_results: True once the kernels write the results into the pinned buffers themselves
         # reference defaults (ilqr.py:61-67); NOTE x_nom is undefined until SetTargetState (F12)
         self.x0 = np.zeros((self.B, self.n))
         self.Q, self.R, self.Qf = np.eye(self.n), np.eye(self.m), np.eye(self.n)
@@ -90,7 +91,7 @@ class BatchedIterativeLQR:
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
         if h:
-            self._lib.mi_ilqr_destroy(h)
+            self._lib.mi_ilqr_destroy(h)           # (synchronizes the stream: no kernel writes a result sink afterwards)
 
     # ------------------------------------------------------------- setters (ilqr.py:102-159)
     def SetInitialState(self, x0):
@@ -232,15 +233,20 @@ class BatchedIterativeLQR:
         st = time.time()
         self._push_problem()
         if self._pinned is not None:
-            # page-locked result buffers: the solve and the three copy-outs are enqueued on the handle's stream,
-            # ONE synchronization (in collect) covers them all
+            # page-locked result buffers.  Wave-per-problem kernels write x_bar / u_bar / cost straight into them as
+            # each problem finishes (mi_ilqr_set_result_sink: the copy-out overlaps the launch's stragglers); the
+            # other kernel families enqueue three copy-outs behind the solve.  ONE synchronization (in collect).
+            res = [self._out(which, shape, np.float64) for which, shape in
+                   ((_capi.F_X_BAR, (self.B, self.n, self.N)), (_capi.F_U_BAR, (self.B, self.m, self.N - 1)), (_capi.F_COST, (self.B,)))]
+            if self._sink is None:
+                rc = self._lib.mi_ilqr_set_result_sink(self._h, _capi.ptr(res[0]), _capi.ptr(res[1]), _capi.ptr(res[2]))
+                if rc not in (_capi.OK, _capi.E_UNSUPPORTED):
+                    _capi.check(rc, "mi_ilqr_set_result_sink")
+                self._sink = rc == _capi.OK
             _capi.check(self._lib.mi_ilqr_solve_async(self._h), "mi_ilqr_solve_async")
-            res = []
-            for which, shape in ((_capi.F_X_BAR, (self.B, self.n, self.N)), (_capi.F_U_BAR, (self.B, self.m, self.N - 1)),
-                                 (_capi.F_COST, (self.B,))):
-                out = self._out(which, shape, np.float64)
-                _capi.check(self._lib.mi_ilqr_get_async(self._h, which, _capi.ptr(out), out.nbytes), "mi_ilqr_get_async")
-                res.append(out)
+            if not self._sink:
+                for out, which in zip(res, (_capi.F_X_BAR, _capi.F_U_BAR, _capi.F_COST)):
+                    _capi.check(self._lib.mi_ilqr_get_async(self._h, which, _capi.ptr(out), out.nbytes), "mi_ilqr_get_async")
             self.collect(1)
             self.solve_wall_s = time.time() - st
             return res[0], res[1], self.solve_wall_s, res[2]

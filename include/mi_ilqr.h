@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MI_ILQR_ABI_VERSION 4
+#define MI_ILQR_ABI_VERSION 5
 #define MI_ILQR_MAX_PARAMS 16
 
 /* Error codes (0 = OK).  The Python wrapper maps them onto the exception types
@@ -238,6 +238,15 @@ int mi_ilqr_set(mi_ilqr_t* h, int which, const double* src, size_t bytes);
  * results of a solve then cost one synchronization instead of one each.  Fields that need a layout conversion
  * (the n = 36 and lane-per-problem kernels' trajectory arrays) are copied before the call returns, like mi_ilqr_get. */
 int mi_ilqr_get_async(mi_ilqr_t* h, int which, void* dst, size_t bytes);
+
+/* Result sink (wave-per-problem kernels; MI_ILQR_E_UNSUPPORTED for the n = 36/37 and lane-per-problem layouts): three
+ * host arrays from mi_ilqr_host_alloc - x_bar (B,n,N), u_bar (B,m,N-1), cost (B,), the boundary's layouts - that every
+ * later solve / mpc_run kernel ALSO writes its results into, problem by problem as each finishes, over the host link:
+ * after mi_ilqr_collect_stats / mi_ilqr_synchronize they hold what mi_ilqr_get would return, and the copy-out of the
+ * batch has overlapped the launch's slowest problems instead of following it (Solve() through the class surface:
+ * 0.32 -> 0.2x ms at B = 1024).  The arrays must stay allocated while the sink is set; three NULLs clear it.
+ * The persistent state in HBM is written as always (warm starts, mi_ilqr_get). */
+int mi_ilqr_set_result_sink(mi_ilqr_t* h, double* x_bar_host, double* u_bar_host, double* cost_host);
 
 /* Raw device pointer of a double field (for zero-copy consumers, e.g. a torch tensor
  * view feeding the RCCL best-cost reduction), and the handle's stream.  The per-problem result scalars

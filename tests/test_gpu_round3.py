@@ -259,3 +259,38 @@ def test_quad3d_full_size_mpc_run_vs_oracle():
     r["ls"] = r["ls"] - ls0
     log = _check_mpc_against_oracle(s, r, first_it, first_L, 37, tol_L=1e-6, tol_x=1e-5, budget="quad3d_mpc_full")
     assert st.n_converged == B and np.all(log[:, -1, 4] > 0.05)       # the trunk moved forward (0.08 .. 0.11 m in 1.6 s)
+
+
+def test_result_sink_streams_what_get_returns():
+    """mi_ilqr_set_result_sink: with page-locked result buffers the wave-per-problem kernels write x_bar / u_bar / cost
+    into them themselves (problem by problem, overlapping the launch's stragglers).  Bitwise what the copy-out path
+    returns, solve after solve; the n = 36 layouts refuse the sink and keep the copy-out path."""
+    from drake_ddp_amd import workloads as W, _capi
+    prob = W.pendulum_problem()
+    B = 300
+    x0 = W.pendulum_batch_x0(1024)[:B]
+    ref = make_solver(prob, B=B, jac="fd")
+    pin = make_solver(prob, B=B, jac="fd", pinned_results=True)
+    for k in range(3):
+        for s in (ref, pin):
+            s.Reset()
+            s.SetInitialState(x0 + 0.01 * k)
+            s.SetInitialGuess(np.zeros((1, prob["N"] - 1)))
+        xr, ur, _, Lr = ref.Solve()
+        xp, up, _, Lp = pin.Solve()
+        assert pin._sink is True
+        assert np.array_equal(xp, xr) and np.array_equal(up, ur) and np.array_equal(Lp, Lr), k
+        assert np.array_equal(pin.x_bar, xr)                       # and the HBM state is the same as ever
+    a = W.acrobot_problem()
+    pa = make_solver(a, B=64, jac="fd", pinned_results=True)
+    ra = make_solver(a, B=64, jac="fd")
+    for s in (pa, ra):
+        s.SetInitialState(W.acrobot_batch_x0(512)[:64]); s.SetInitialGuess(np.zeros((1, a["N"] - 1)))
+    xa, ua, _, La = pa.Solve()
+    xb, ub, _, Lb = ra.Solve()
+    assert pa._sink is True and np.array_equal(xa, xb) and np.array_equal(ua, ub) and np.array_equal(La, Lb)
+    q = W.synth36_problem()
+    pq = make_solver(q, B=8, jac="fd", pinned_results=True)
+    pq.SetInitialState(W.synth36_batch_x0(8)); pq.SetInitialGuess(W.synth36_u_guess(q["N"]))
+    x, u, _, L = pq.Solve()
+    assert pq._sink is False and np.array_equal(x, pq.x_bar)

@@ -33,7 +33,7 @@ json.dump({"FETCH_SIZE_KB_per_launch": out["FETCH_SIZE"], "WRITE_SIZE_KB_per_lau
            "hbm_bytes_per_launch_corrected": (2 * out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024,
            "hbm_bytes_per_launch_uncorrected": (out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024}, open("$OUT/${TAG}_pmc_raw.json", "w"), indent=1)
 PY
-( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_all -- python $REPO/tools/run_configs.py > $OUT/${TAG}_run_configs.log 2>&1 )
+( cd /tmp && MI_RUN_SHARD=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_all -- python $REPO/tools/run_configs.py > $OUT/${TAG}_run_configs.log 2>&1 )
 find $OUT/${TAG}_prof_all -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/${TAG}_all_configs_kernel_stats.csv
 python tools/pmc_issue.py ${TAG} > $OUT/${TAG}_pmc_issue.log 2>&1
 python tools/warm_sweep.py 2>/dev/null | grep events > $OUT/${TAG}_c2_clock_ramp.txt
