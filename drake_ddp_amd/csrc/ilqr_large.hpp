@@ -602,39 +602,106 @@ __device__ __forceinline__ void large_jac_at_tree(const LView<M::n, M::m>& v, co
   }
 }
 
-// Leg models (Quad3D): whole-step evaluation per (key-point, column) item through accessors that perturb / seed one
-// entry of the LDS copy of the nominal trajectory on the fly - no per-thread copies of x and u.
-template <class M, int JAC>
+// Leg models (Quad3D): one (key-point, column) item per thread, the step evaluated LEG BY LEG through accessors that
+// perturb / seed one entry of the LDS copy of the nominal trajectory on the fly, every leg's six Jacobian entries stored
+// as soon as they exist (two whole next-state vectors per thread never do - they cost the kernel its register
+// allocation).  A perturbed input belongs to the trunk (quaternion, position, angular / linear velocity: every leg
+// changes) or to ONE leg (a joint angle, rate or torque): the other legs then see identical inputs on both sides of the
+// difference - evaluated once, their wrench enters both trunk sums and their six entries are the exact zeros the
+// two-sided evaluation produces.  Same arithmetic, same summation order (0 + 2) + (1 + 3) as M::step: bitwise the
+// Jacobians of the whole-step form.  Items are dealt key-point fastest with the columns ordered by owner, so the
+// owner test is (nearly) wave-uniform.
+template <class M, int JAC, bool COH = false>
 __device__ __forceinline__ void large_jac_at_legs(const LView<M::n, M::m>& v, const KArgs& a, const int* list, int count,
-                                                  const double* Xsrc, const double* Usrc, int xstride, int ustride) {
+                                                  const double* Xsrc, const double* Usrc, int xstride, int ustride,
+                                                  int first = 0, int cstride = 1) {
   constexpr int n = M::n, m = M::m, nc = n + m;
-  const double h = a.fd_h, inv2h = 1.0 / (2.0 * h);
-  for (int it = threadIdx.x; it < count * nc; it += kLargeThreads) {
-    const int ki = it / nc, col = it - ki * nc;
+  const double h = a.fd_h, inv2h = 1.0 / (2.0 * h), dt = a.dt;
+  for (int it = first * kLargeThreads + threadIdx.x; it < count * nc; it += cstride * kLargeThreads) {
+    const int rank = it / count, ki = it - rank * count;
+    const int col = M::input_by_owner(rank);
+    const int owner = M::leg_of_input(col);                    // -1: the trunk's own coordinates
     const int t = list[ki];
     const double* xg = Xsrc + (size_t)t * xstride;
     const double* ug = Usrc + (size_t)t * ustride;
-    double d[n];
+    double* o;
+    int stride;
+    if (col < n) { o = v.Fx + (size_t)t * n * n + col; stride = n; }
+    else { o = v.Fu + (size_t)t * n * m + (col - n); stride = m; }
     if (JAC == MI_JAC_FD_CENTRAL) {
-      double f[n];
-      M::template step_acc<double>(PertAcc{xg, col, h}, PertAcc{ug, col - n, h}, d, a.params, a.dt);
-      M::template step_acc<double>(PertAcc{xg, col, -h}, PertAcc{ug, col - n, -h}, f, a.params, a.dt);
+      const PertAcc xp{xg, col, h}, up{ug, col - n, h}, xm{xg, col, -h}, um{ug, col - n, -h};
+      double Rp[3][3], Rm[3][3];
+      M::template rotation<double>(xp, Rp);
+      M::template rotation<double>(xm, Rm);
+      double Fp[3], Tp[3], Fm[3], Tm[3];
 #pragma unroll
-      for (int i = 0; i < n; ++i) d[i] = (d[i] - f[i]) * inv2h;
+      for (int half = 0; half < 2; ++half) {
+        double hFp[3], hTp[3], hFm[3], hTm[3];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int k = half + 2 * j;                           // legs 0, 2 | 1, 3
+          typename M::template LegOut<double> lp, lm;
+          M::template leg<double>(k, Rp, xp, up, a.params, lp);
+          if (owner < 0 || owner == k) M::template leg<double>(k, Rm, xm, um, a.params, lm);
+          else lm = lp;                                         // identical inputs: identical outputs
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            const int q = 3 * k + i;
+            const double jdp = xp[25 + q] + dt * lp.ja[i], jdm = xm[25 + q] + dt * lm.ja[i];
+            const double jqp = xp[7 + q] + dt * jdp, jqm = xm[7 + q] + dt * jdm;
+            st_shared<COH>(o + (25 + q) * stride, (jdp - jdm) * inv2h);
+            st_shared<COH>(o + (7 + q) * stride, (jqp - jqm) * inv2h);
+            if (j == 0) { hFp[i] = lp.fw[i]; hTp[i] = lp.tq[i]; hFm[i] = lm.fw[i]; hTm[i] = lm.tq[i]; }
+            else { hFp[i] = hFp[i] + lp.fw[i]; hTp[i] = hTp[i] + lp.tq[i]; hFm[i] = hFm[i] + lm.fw[i]; hTm[i] = hTm[i] + lm.tq[i]; }
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          if (half == 0) { Fp[i] = hFp[i]; Tp[i] = hTp[i]; Fm[i] = hFm[i]; Tm[i] = hTm[i]; }
+          else { Fp[i] = Fp[i] + hFp[i]; Tp[i] = Tp[i] + hTp[i]; Fm[i] = Fm[i] + hFm[i]; Tm[i] = Tm[i] + hTm[i]; }
+        }
+      }
+      double tp[n], tm[n];                                      // (only the trunk's 13 entries are ever touched)
+      M::template trunk<double>(xp, Fp, Tp, tp, a.params, dt);
+      M::template trunk<double>(xm, Fm, Tm, tm, a.params, dt);
+#pragma unroll
+      for (int i = 0; i < 7; ++i) st_shared<COH>(o + i * stride, (tp[i] - tm[i]) * inv2h);
+#pragma unroll
+      for (int i = 19; i < 25; ++i) st_shared<COH>(o + i * stride, (tp[i] - tm[i]) * inv2h);
     } else {
-      Dual1 fd[n];
-      M::template step_acc<Dual1>(SeedAcc{xg, col}, SeedAcc{ug, col - n}, fd, a.params, a.dt);
+      const SeedAcc xs{xg, col}, us{ug, col - n};
+      Dual1 R[3][3];
+      M::template rotation<Dual1>(xs, R);
+      Dual1 F[3], Tq[3];
 #pragma unroll
-      for (int i = 0; i < n; ++i) d[i] = fd[i].d;
-    }
-    if (col < n) {
-      double* o = v.Fx + (size_t)t * n * n + col;
+      for (int half = 0; half < 2; ++half) {
+        Dual1 hF[3], hT[3];
 #pragma unroll
-      for (int i = 0; i < n; ++i) o[i * n] = d[i];
-    } else {
-      double* o = v.Fu + (size_t)t * n * m + (col - n);
+        for (int j = 0; j < 2; ++j) {
+          const int k = half + 2 * j;
+          typename M::template LegOut<Dual1> lo;
+          M::template leg<Dual1>(k, R, xs, us, a.params, lo);
 #pragma unroll
-      for (int i = 0; i < n; ++i) o[i * m] = d[i];
+          for (int i = 0; i < 3; ++i) {
+            const int q = 3 * k + i;
+            const Dual1 jd = xs[25 + q] + dt * lo.ja[i];
+            const Dual1 jq = xs[7 + q] + dt * jd;
+            st_shared<COH>(o + (25 + q) * stride, jd.d);
+            st_shared<COH>(o + (7 + q) * stride, jq.d);
+            if (j == 0) { hF[i] = lo.fw[i]; hT[i] = lo.tq[i]; } else { hF[i] = hF[i] + lo.fw[i]; hT[i] = hT[i] + lo.tq[i]; }
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          if (half == 0) { F[i] = hF[i]; Tq[i] = hT[i]; } else { F[i] = F[i] + hF[i]; Tq[i] = Tq[i] + hT[i]; }
+        }
+      }
+      Dual1 tn[n];
+      M::template trunk<Dual1>(xs, F, Tq, tn, a.params, dt);
+#pragma unroll
+      for (int i = 0; i < 7; ++i) st_shared<COH>(o + i * stride, tn[i].d);
+#pragma unroll
+      for (int i = 19; i < 25; ++i) st_shared<COH>(o + i * stride, tn[i].d);
     }
   }
 }
@@ -1299,7 +1366,7 @@ __global__ void __launch_bounds__(kLargeThreads) ilqr_large_kernel(const KArgs a
   // single-workgroup path - bitwise the same fx, fu).  Trajectory and Jacobians cross workgroups through global
   // memory under device-scope release / acquire fences.
   unsigned long long* csync = a.cluster_sync + (size_t)4 * b;
-  constexpr bool kClusterable = HasSparsity<M>::value || IsChainModel<M>::value;
+  constexpr bool kClusterable = HasSparsity<M>::value || IsChainModel<M>::value || IsLegModel<M>::value;
   const bool clustered = kClusterable && G > 1 && lin_staged && a.kp_method == MI_KP_SET_INTERVAL && a.minN == 1;
   auto stage_trajectory = [&]() __attribute__((always_inline)) {          // helper: the leader's x_bar / u_bar -> LDS
     double* xs_ = lds + Ly::oT1;
@@ -1313,6 +1380,7 @@ __global__ void __launch_bounds__(kLargeThreads) ilqr_large_kernel(const KArgs a
     constexpr bool COH = decltype(coherent)::value;
     if constexpr (HasSparsity<M>::value) large_jac_at_sparse<M, JAC, COH>(v, a, acc.kp, N - 1, lin_X, lin_U, first, stride);
     else if constexpr (IsChainModel<M>::value) large_jac_at_tree<M, JAC, COH>(v, a, acc.kp, N - 1, lin_X, lin_U, lin_xs, lin_us, lds + Ly::doubles, first, stride);
+    else if constexpr (IsLegModel<M>::value) large_jac_at_legs<M, JAC, COH>(v, a, acc.kp, N - 1, lin_X, lin_U, lin_xs, lin_us, first, stride);
   };
   constexpr long long kSpinCap = 1ll << 22;                 // x s_sleep(4) ~ 1 s: a lost partner ends the wait, not the device
   if (role > 0) {

@@ -117,7 +117,7 @@ KArgs make_args(const mi_ilqr* h) {
     // a handshake costs ~40 k cycles when a few hundred workgroups fence at once: worth it for the articulated
     // model at any batch (its linearization is 450 k cycles), for the sparse chain model (75 k) only while the
     // launch stays small
-    if (forced <= 0 && h->d.model_id != MI_MODEL_PLANAR_QUAD && h->B > 16) g = 1;
+    if (forced <= 0 && h->d.model_id != MI_MODEL_PLANAR_QUAD && h->d.model_id != MI_MODEL_QUAD3D && h->B > 16) g = 1;
     if (g > 8) g = 8;
     if (g < 1) g = 1;
     a.cluster = g;

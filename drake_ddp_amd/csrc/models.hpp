@@ -361,6 +361,16 @@ struct Quad3D {
   static constexpr bool kCanFail = true;
   static constexpr double kL0 = 0.062, kL1 = 0.209, kL2 = 0.195, kHipX = 0.19, kHipY = 0.049;
   template <class T> struct LegOut { T fw[3], tq[3], ja[3]; };
+  // which leg an input column of [x | u] belongs to (-1: the trunk's own coordinates - every leg reads them)
+  __device__ static constexpr int leg_of_input(int col) {
+    return col < 7 ? -1 : (col < nq ? (col - 7) / 3 : (col < 25 ? -1 : (col < n ? (col - 25) / 3 : (col - n) / 3)));
+  }
+  // the n + m input columns ordered by owner: legs 0..3 (3 angles, 3 rates, 3 torques each), then the trunk's 13
+  __device__ static constexpr int input_by_owner(int rank) {
+    if (rank < 36) { const int k = rank / 9, r = rank - 9 * k; return r < 3 ? 7 + 3 * k + r : (r < 6 ? 25 + 3 * k + (r - 3) : n + 3 * k + (r - 6)); }
+    const int r = rank - 36;
+    return r < 7 ? r : 19 + (r - 7);
+  }
 
   template <class T, class XA>
   __device__ static inline void rotation(const XA& x, T (&R)[3][3]) {

@@ -555,7 +555,8 @@ def test_per_iteration_stopwatches_and_console_table(capsys):
         assert s.time_backwardsPass > 0 and s.time_fp > 0
 
 
-@pytest.mark.parametrize("cfg,B,forced", [("quad", 8, None), ("synth36", 8, None), ("quad", 64, "8"), ("quad", 3, "5")])
+@pytest.mark.parametrize("cfg,B,forced", [("quad", 8, None), ("synth36", 8, None), ("quad", 64, "8"), ("quad", 3, "5"),
+                                          ("quad3d", 8, None), ("quad3d", 64, None), ("quad3d", 5, "3")])
 def test_cluster_linearization_is_bitwise_the_single_workgroup_one(cfg, B, forced, tmp_path):
     """With few problems per GPU the linearization of ONE problem is shared by a cluster of workgroups (leader +
     helpers, handshake through global memory, ilqr_large.hpp).  Every Jacobian entry is still computed by the
@@ -573,6 +574,9 @@ from test_gpu_parity import make_solver
 if {cfg!r} == 'quad':
     prob, x0, ug = W.planar_quad_problem(), W.planar_quad_batch_x0(64)[:{B}], W.planar_quad_u_guess(40)
     step = np.zeros(36); step[0] = W.QUAD_TARGET_VEL * prob['dt'] * 4
+elif {cfg!r} == 'quad3d':
+    prob, x0, ug = W.quad3d_problem(target_vel=1.0), W.quad3d_batch_x0(64)[:{B}], W.quad3d_u_guess(40)
+    step = np.zeros(37); step[4] = 1.0 * prob['dt'] * 4
 else:
     prob, x0, ug = W.synth36_problem(), W.synth36_batch_x0(64)[:{B}], W.synth36_u_guess(40)
     step = np.zeros(36); step[0] = W.SYNTH_TARGET_VEL * prob['dt'] * 4
