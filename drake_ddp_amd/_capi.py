@@ -56,7 +56,7 @@ class Stats(C.Structure):
         ("n_converged", C.c_int32), ("n_max_iters", C.c_int32), ("n_ls_failed", C.c_int32),
         ("max_iters_seen", C.c_int32),
         ("best_cost", C.c_double), ("best_index", C.c_int32), ("kernel_ms", C.c_float),
-        ("algorithmic_bytes", C.c_double),
+        ("algorithmic_bytes", C.c_double), ("n_internal", C.c_int32), ("reserved_", C.c_int32),
     ]
 
 

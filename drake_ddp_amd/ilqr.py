@@ -228,6 +228,13 @@ class BatchedIterativeLQR:
         """Forget warm-start state: equivalent to constructing a new solver (ilqr.py:70-83)."""
         _capi.check(self._lib.mi_ilqr_reset(self._h), "mi_ilqr_reset")
 
+    def _check_internal(self, stats):
+        """A solve aborted inside the kernel (MI_STATUS_INTERNAL: a cluster helper stopped answering) left x_bar / u_bar
+        that are not a solution: never hand them out as one."""
+        if stats is not None and stats.n_internal > 0:
+            raise RuntimeError(f"{stats.n_internal} problem(s) aborted inside the device kernel (status {_capi.STATUS_INTERNAL}); "
+                               "their results are not a solution")
+
     # ------------------------------------------------------------- Solve (ilqr.py:669-710)
     def Solve(self):
         st = time.time()
@@ -248,11 +255,13 @@ class BatchedIterativeLQR:
                 for out, which in zip(res, (_capi.F_X_BAR, _capi.F_U_BAR, _capi.F_COST)):
                     _capi.check(self._lib.mi_ilqr_get_async(self._h, which, _capi.ptr(out), out.nbytes), "mi_ilqr_get_async")
             self.collect(1)
+            self._check_internal(self.stats)
             self.solve_wall_s = time.time() - st
             return res[0], res[1], self.solve_wall_s, res[2]
         stats = _capi.Stats()
         _capi.check(self._lib.mi_ilqr_solve(self._h, C.byref(stats)), "mi_ilqr_solve")
         self.stats = stats
+        self._check_internal(stats)
         self.solve_wall_s = time.time() - st
         return self.x_bar, self.u_bar, self.solve_wall_s, self.cost
 
@@ -299,6 +308,7 @@ class BatchedIterativeLQR:
                     "mi_ilqr_mpc_run")
         self.stats = stats
         self._mpc_resolves = int(num_resolves)
+        self._check_internal(stats)
         return stats
 
     @property

@@ -140,6 +140,9 @@ typedef struct {
   float kernel_ms;            /* HIP-event time of the solve kernel(s) on the handle's stream; 0 for a launch
                                  * that mi_ilqr_set_timing left without events */
   double algorithmic_bytes;   /* sum_b sum_i bytes_iter(ls_{b,i}) — SURVEY.md §8d formula */
+  int32_t n_internal;         /* problems aborted with MI_STATUS_INTERNAL (a lost cluster helper; counted apart from
+                               * n_ls_failed since ABI 5: their x_bar / u_bar are NOT a solution) */
+  int32_t reserved_;
 } mi_ilqr_stats;
 
 int mi_ilqr_abi_version(void);

@@ -294,3 +294,41 @@ def test_result_sink_streams_what_get_returns():
     pq.SetInitialState(W.synth36_batch_x0(8)); pq.SetInitialGuess(W.synth36_u_guess(q["N"]))
     x, u, _, L = pq.Solve()
     assert pq._sink is False and np.array_equal(x, pq.x_bar)
+
+
+@pytest.mark.parametrize("name", ["cartpole_plain", "cartpole_wall_literal_n100"])
+def test_sensitive_goldens_deviate_no_more_than_their_own_sensitivity(name):
+    """The two remaining SENSITIVE goldens of tests/test_gpu_parity.py (long cart-pole swing-ups, R ~ 1e-5).  They are
+    chaotic in the literal sense: the ORACLE itself, given x0 with the pole angle moved by one ulp, takes a different
+    number of iterations (cartpole_plain: 108 against 13).  So the device is held to what the problem allows: it follows
+    the oracle's (eps, trial count) sequence for at least as many leading iterations as the one-ulp runs do (minus two),
+    and its final cost lies within the spread of the three oracle runs' optima widened by 2 % (they stop at different local
+    plateaus of a flat landscape; central differences on both sides)."""
+    g, prob = load_golden(name)
+    s = make_solver(prob, jac="fd", single=True, hist_cap=256)
+    s.SetInitialState(g["x0"])
+    s.SetInitialGuess(g["u_guess"])
+    x, u, _, L = s.Solve()
+    h = s.history[0][:min(int(s.iterations[0]), 256)]
+    from common import make_oracle
+    runs = []
+    for k in range(3):
+        o = make_oracle(prob, jacobian="fd", fd_step=1e-5)
+        x0 = np.array(g["x0"], float)
+        if k:
+            x0[1] = np.nextafter(x0[1], np.inf if k == 1 else -np.inf)
+        o.set_problem(x0, prob["x_nom"], prob["Q"], prob["R"], prob["Qf"], g["u_guess"])
+        _, _, Lo, hist = o.solve()
+        runs.append((np.array(hist), Lo))
+
+    def lead(a, b):
+        k = 0
+        while k < min(len(a), len(b)) and np.array_equal(a[k, 1:3], b[k, 1:3]):
+            k += 1
+        return k
+    A = runs[0][0]
+    own = min(lead(runs[1][0], A), lead(runs[2][0], A))
+    assert lead(h, A) >= own - 2, (lead(h, A), own)
+    assert lead(h, A) >= 5                                     # (and never fewer than the leading five)
+    Ls = [r[1] for r in runs]
+    assert 0.98 * min(Ls) <= L <= 1.02 * max(Ls), (L, Ls)
