@@ -25,7 +25,7 @@ F_X_BAR, F_U_BAR, F_K, F_KAPPA, F_DV, F_FX, F_FU, F_COST, F_X0, F_HIST, F_X_TRIA
 I_ITERS, I_STATUS, I_LS_TRIALS, I_KP_COUNT, I_KP_LIST = 100, 101, 102, 103, 104
 
 EXPORTS = [
-    "mi_ilqr_abi_version", "mi_ilqr_strerror", "mi_ilqr_model_info", "mi_ilqr_create", "mi_ilqr_destroy",
+    "mi_ilqr_abi_version", "mi_ilqr_strerror", "mi_ilqr_model_info", "mi_ilqr_register_model", "mi_ilqr_create", "mi_ilqr_destroy",
     "mi_ilqr_set_cost", "mi_ilqr_set_initial", "mi_ilqr_set_initial_shared", "mi_ilqr_host_alloc", "mi_ilqr_host_free", "mi_ilqr_set_result_sink", "mi_ilqr_reset", "mi_ilqr_rearm_initial_guess",
     "mi_ilqr_solve", "mi_ilqr_solve_async", "mi_ilqr_collect_stats", "mi_ilqr_collect_stats_n",
     "mi_ilqr_rollout", "mi_ilqr_forward", "mi_ilqr_linearize", "mi_ilqr_backward", "mi_ilqr_mpc_shift",
@@ -79,6 +79,7 @@ def load():
     lib.mi_ilqr_strerror.restype = C.c_char_p
     lib.mi_ilqr_strerror.argtypes = [C.c_int]
     lib.mi_ilqr_model_info.argtypes = [C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), dp]
+    lib.mi_ilqr_register_model.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
     lib.mi_ilqr_create.argtypes = [C.POINTER(Desc), C.POINTER(H)]
     lib.mi_ilqr_destroy.argtypes = [H]
     lib.mi_ilqr_destroy.restype = None

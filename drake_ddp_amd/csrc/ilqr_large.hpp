@@ -123,6 +123,12 @@ template <class M, class = void>
 struct IsLegModel { static constexpr bool value = false; };
 template <class M>
 struct IsLegModel<M, decltype((void)M::kLegCooperative)> { static constexpr bool value = M::kLegCooperative; };
+// Models that only provide the whole step (plugins, include/mi_ilqr.h: open model interface): one lane advances the
+// dynamics in the rollout, whole-step evaluation per (key-point, column) item in the linearization.
+template <class M, class = void>
+struct IsWholeStepModel { static constexpr bool value = false; };
+template <class M>
+struct IsWholeStepModel<M, decltype((void)M::kWholeStep)> { static constexpr bool value = M::kWholeStep; };
 // Models that can declare a step infeasible (Drake's update throwing -> L = inf, ilqr.py:315-323).
 template <class M, class = void>
 struct CanFail { static constexpr bool value = false; };
@@ -316,6 +322,14 @@ __device__ inline double large_rollout(const LView<M::n, M::m>& v, double* lds, 
 #pragma unroll
           for (int i = 19; i < 25; ++i) { xn_[i] = xt[i]; Xo[i] = xt[i]; bad = bad || M::infeasible_velocity(xt[i], a.params); }
         }
+        dyn_done = true;
+      }
+    } else if constexpr (IsWholeStepModel<M>::value) {
+      if (tid == 0) {                                      // (plugin models without cooperative hooks)
+        double xt[n];
+        M::template step<double>(xc, us, xt, a.params, a.dt);
+#pragma unroll
+        for (int i = 0; i < n; ++i) { xn_[i] = xt[i]; v.Xn[(size_t)(t + 1) * n + i] = xt[i]; }
         dyn_done = true;
       }
     } else {

@@ -35,7 +35,16 @@ namespace {
 
 struct ModelInfo { int n, m, n_params; double defaults[MI_ILQR_MAX_PARAMS]; };
 
+// models registered at run time (mi_ilqr_register_model): id = MI_MODEL_PLUGIN_BASE + slot
+struct PluginSlot { ModelInfo info; mi_ilqr_model_plugin p; bool used = false; };
+PluginSlot g_plugins[MI_ILQR_MAX_PLUGINS];
+const PluginSlot* plugin_of(int id) {
+  const int s_ = id - MI_MODEL_PLUGIN_BASE;
+  return (s_ >= 0 && s_ < MI_ILQR_MAX_PLUGINS && g_plugins[s_].used) ? &g_plugins[s_] : nullptr;
+}
+
 const ModelInfo* model_info(int id) {
+  if (const PluginSlot* ps = plugin_of(id)) return &ps->info;
   static const ModelInfo table[] = {
       {2, 1, 3, {0.25, 0.1, 4.905}},
       {4, 1, 10, {1.0, 1.0, 1.0, 0.5, 1.0, 0.083, 0.33, 0.1, 0.1, 9.81}},
@@ -50,6 +59,7 @@ const ModelInfo* model_info(int id) {
 }
 
 size_t small_lds_bytes(int model_id, int N, int n_store = 1) {
+  if (const PluginSlot* ps = plugin_of(model_id)) return ps->p.family == 0 ? ps->p.lds_bytes(N, n_store) : 0;
   switch (model_id) {
     case MI_MODEL_PENDULUM: return ws_bytes<2, 1>(N, n_store);
     case MI_MODEL_ACROBOT:
@@ -60,6 +70,7 @@ size_t small_lds_bytes(int model_id, int N, int n_store = 1) {
 }
 
 size_t large_lds(int model_id, int N) {
+  if (const PluginSlot* ps = plugin_of(model_id)) return ps->p.family == 1 ? ps->p.lds_bytes(N, 1) : 0;
   switch (model_id) {
     case MI_MODEL_SYNTH36: return large_lds_bytes<Synth36::n, Synth36::m>(N);
     case MI_MODEL_PLANAR_QUAD: return large_lds_bytes<PlanarQuad::n, PlanarQuad::m>(N);
@@ -146,7 +157,9 @@ int launch(mi_ilqr* h, int mode) {
     case MI_MODEL_SYNTH36: rc = launch_synth36(h, mode, a); break;
     case MI_MODEL_PLANAR_QUAD: rc = launch_planar_quad(h, mode, a); break;
     case MI_MODEL_QUAD3D: rc = launch_quad3d(h, mode, a); break;
-    default: return MI_ILQR_E_UNSUPPORTED;
+    default:
+      if (const PluginSlot* ps = plugin_of(h->d.model_id)) { rc = ps->p.launch(h, mode, &a); break; }
+      return MI_ILQR_E_UNSUPPORTED;
   }
   return rc;
 }
@@ -456,6 +469,23 @@ const char* mi_ilqr_strerror(int code) {
   return "unknown error";
 }
 
+int mi_ilqr_register_model(const mi_ilqr_model_plugin* p, int32_t* model_id_out) {
+  if (!p || !model_id_out || !p->launch || !p->lds_bytes) return MI_ILQR_E_BAD_ARG;
+  if (p->n < 1 || p->m < 1 || p->n > kMaxStateDim || p->n_params < 0 || p->n_params > MI_ILQR_MAX_PARAMS) return MI_ILQR_E_BAD_SHAPE;
+  if (p->family == 0 ? p->m > 2 : (p->family != 1 || p->n <= 32 || p->n > 48 || p->m > 16 || 2 * p->m > p->n || p->m % 4 != 0)) return MI_ILQR_E_UNSUPPORTED;
+  for (int s_ = 0; s_ < MI_ILQR_MAX_PLUGINS; ++s_) {
+    if (g_plugins[s_].used) continue;
+    PluginSlot& ps = g_plugins[s_];
+    ps.p = *p;
+    ps.info.n = p->n; ps.info.m = p->m; ps.info.n_params = p->n_params;
+    for (int i = 0; i < MI_ILQR_MAX_PARAMS; ++i) ps.info.defaults[i] = p->default_params[i];
+    ps.used = true;
+    *model_id_out = MI_MODEL_PLUGIN_BASE + s_;
+    return MI_ILQR_OK;
+  }
+  return MI_ILQR_E_UNSUPPORTED;                                       // registry full
+}
+
 int mi_ilqr_model_info(int model_id, int32_t* n, int32_t* m, int32_t* n_params, double* default_params) {
   const ModelInfo* mi_ = model_info(model_id);
   if (!mi_) return MI_ILQR_E_BAD_ARG;
@@ -499,7 +529,7 @@ int mi_ilqr_create(const mi_ilqr_desc* desc, mi_ilqr_t** out) {
   bool batch_minor = false;
   if (desc->kernel_mode < MI_KERNEL_AUTO || desc->kernel_mode > MI_KERNEL_THROUGHPUT) return MI_ILQR_E_BAD_ARG;
   {
-    const bool can = !large && desc->keypoint_method == MI_KP_SET_INTERVAL && desc->minN == 1;
+    const bool can = !large && desc->keypoint_method == MI_KP_SET_INTERVAL && desc->minN == 1 && !plugin_of(desc->model_id);
     if (desc->kernel_mode == MI_KERNEL_THROUGHPUT && !can) return MI_ILQR_E_UNSUPPORTED;
     // n = 2 within the time-parallel passes' horizon: the wave-per-problem kernel is the faster one at
     // every batch size (B = 65536: 68 M vs 42 M it/s, profiles/r01n_c2_modes_batch_sweep.txt)

@@ -48,6 +48,16 @@ class ModelSystem:
         if self.params.size > _capi.MAX_PARAMS:
             raise ValueError("too many model parameters")
 
+    @classmethod
+    def registered(cls, model_id, n, m, dt, params):
+        """A model registered at run time (drake_ddp_amd/plugin.py, mi_ilqr_register_model)."""
+        s = cls.__new__(cls)
+        s.model_id, s.n, s.m, s.dt = int(model_id), int(n), int(m), float(dt)
+        s.params = np.array(params, dtype=np.float64)
+        if s.params.size > _capi.MAX_PARAMS:
+            raise ValueError("too many model parameters")
+        return s
+
     # --- the Drake calls made on the plant by the reference ctor / scripts ---
     def IsDifferenceEquationSystem(self):          # ilqr.py:37
         return (True, self.dt)

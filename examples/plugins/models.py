@@ -1,0 +1,71 @@
+"""Two models that are NOT compiled into libmi_ilqr.so, written the way a user of the open model interface writes them
+(drake_ddp_amd/plugin.py, include/mi_ilqr.h: mi_ilqr_register_model): the C++ body of the discrete update for the device
+and - for the tests - the same update as a float-or-dual Python function for the oracle.
+
+  vdp     n = 2, m = 1   controlled Van der Pol oscillator, params [mu]
+                         (an n = 2 model: served by the time-parallel rollout and Riccati scan, like the pendulum)
+  chain3  n = 6, m = 2   three coupled pendula, the outer two actuated, params [ks, c, kc]
+                         (a shape no built-in model has: served by the generic scalar passes of the wave-per-problem kernel)
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+VDP_BODY = """    // q'' = mu (1 - q^2) q' - q + u, semi-implicit Euler
+    const T q = x[0], v = x[1];
+    const T a = p[0] * (1.0 - q * q) * v - q + u[0];
+    const T vn = v + dt * a;
+    xn[1] = vn; xn[0] = q + dt * vn;"""
+VDP_DEFAULTS = [1.0]
+
+CHAIN3_BODY = """    const double ks = p[0], c = p[1], kc = p[2];
+    const T l01 = mi_sin(x[1] - x[0]), l12 = mi_sin(x[2] - x[1]);
+    const T a0 = -ks * mi_sin(x[0]) - c * x[3] + kc * l01 + u[0];
+    const T a1 = -ks * mi_sin(x[1]) - c * x[4] + kc * l12 - kc * l01;
+    const T a2 = -ks * mi_sin(x[2]) - c * x[5] - kc * l12 + u[1];
+    const T v0 = x[3] + dt * a0, v1 = x[4] + dt * a1, v2 = x[5] + dt * a2;
+    xn[3] = v0; xn[4] = v1; xn[5] = v2;
+    xn[0] = x[0] + dt * v0; xn[1] = x[1] + dt * v1; xn[2] = x[2] + dt * v2;"""
+CHAIN3_DEFAULTS = [4.0, 0.3, 3.0]
+
+
+def vdp_step(x, u, p, dt):
+    q, v = x[0], x[1]
+    a = p[0] * (1.0 - q * q) * v - q + u[0]
+    vn = v + dt * a
+    return [q + dt * vn, vn]
+
+
+def chain3_step(x, u, p, dt):
+    from oracle import dual as D
+    ks, c, kc = p[0], p[1], p[2]
+    l01, l12 = D.sin(x[1] - x[0]), D.sin(x[2] - x[1])
+    a0 = -ks * D.sin(x[0]) - c * x[3] + kc * l01 + u[0]
+    a1 = -ks * D.sin(x[1]) - c * x[4] + kc * l12 - kc * l01
+    a2 = -ks * D.sin(x[2]) - c * x[5] - kc * l12 + u[1]
+    v0, v1, v2 = x[3] + dt * a0, x[4] + dt * a1, x[5] + dt * a2
+    return [x[0] + dt * v0, x[1] + dt * v1, x[2] + dt * v2, v0, v1, v2]
+
+
+def build_all(verbose=False):
+    """Compile both plugins (hipcc, ~15-25 s each the first time) and return their ModelSystem factories."""
+    from drake_ddp_amd import plugin
+    return {"vdp": plugin.build_model("vdp", 2, 1, VDP_BODY, VDP_DEFAULTS, verbose=verbose),
+            "chain3": plugin.build_model("chain3", 6, 2, CHAIN3_BODY, CHAIN3_DEFAULTS, verbose=verbose)}
+
+
+if __name__ == "__main__":
+    import numpy as np
+    from drake_ddp_amd.ilqr import BatchedIterativeLQR
+    make = build_all(verbose=True)
+    dt, N, B = 0.02, 100, 256
+    s = BatchedIterativeLQR(make["vdp"](dt), N, B, delta=1e-3, beta=0.8)
+    s.SetTargetState(np.zeros(2)); s.SetRunningCost(dt * np.eye(2), dt * 0.1 * np.eye(1)); s.SetTerminalCost(10.0 * np.eye(2))
+    rng = np.random.default_rng(0)
+    s.SetInitialState(rng.uniform(-2, 2, (B, 2))); s.SetInitialGuess(np.zeros((1, N - 1)))
+    x, u, t, L = s.Solve()
+    print(f"Van der Pol plugin model: {B} problems, {int(s.iterations.sum())} iLQR iterations, all converged: {bool((s.status == 0).all())}, "
+          f"kernel {s.stats.kernel_ms:.3f} ms, |x_N| <= {np.abs(x[:, :, -1]).max():.3f}")

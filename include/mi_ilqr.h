@@ -151,6 +151,26 @@ const char* mi_ilqr_strerror(int code);
 /* Model registry: dimensions and default parameters of a model id. */
 int mi_ilqr_model_info(int model_id, int32_t* n, int32_t* m, int32_t* n_params, double* default_params);
 
+/* OPEN MODEL INTERFACE.  The reference takes any discrete System (ilqr.py:21,37-58); here a model is a C++ struct with
+ * `template <class T> static void step(const T* x, const T* u, T* xn, const double* params, double dt)` (T = double, or
+ * the forward-mode dual types of csrc/dual.hpp) compiled against the kernel headers of drake_ddp_amd/csrc into a PLUGIN
+ * shared library - one translation unit, ~25 s of hipcc, nothing of libmi_ilqr.so is rebuilt
+ * (drake_ddp_amd/plugin.py writes and builds that unit; INTEGRATION.md section 5 shows it by hand).  The plugin hands the
+ * library this record; the returned id (>= MI_MODEL_PLUGIN_BASE) is used as mi_ilqr_desc.model_id like a built-in one.
+ *   family 0: wave-per-problem kernels (state in LDS; any n, m <= 2 - n = 2 takes the time-parallel passes, n = 3..4 the
+ *             matrix-core backward step, other n the scalar recursion);
+ *   family 1: workgroup-per-problem kernels (32 < n <= 48, m <= 16, 2 m <= n; dynamics as `step` per Jacobian column and a
+ *             one-lane step in the rollout unless the model provides the cooperative hooks of csrc/models.hpp).
+ * Plugin models are served by these two families only (no lane-per-problem THROUGHPUT kernels). */
+enum { MI_MODEL_PLUGIN_BASE = 100, MI_ILQR_MAX_PLUGINS = 32 };
+typedef struct {
+  int32_t n, m, n_params, family;
+  double default_params[MI_ILQR_MAX_PARAMS];
+  int (*launch)(mi_ilqr_t* h, int mode, const void* kernel_args);   /* instantiates and launches the model's kernels */
+  size_t (*lds_bytes)(int32_t N, int32_t n_store);                  /* dynamic LDS of one problem */
+} mi_ilqr_model_plugin;
+int mi_ilqr_register_model(const mi_ilqr_model_plugin* plugin, int32_t* model_id_out);
+
 /* ilqr.py:21-100 — allocate the solver state on the device, zeroed (ilqr.py:70-83). */
 int mi_ilqr_create(const mi_ilqr_desc* desc, mi_ilqr_t** out);
 void mi_ilqr_destroy(mi_ilqr_t* h);

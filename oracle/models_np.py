@@ -441,6 +441,16 @@ class Model:
         self._f = STEP_FUNCS[self.model_id]
         self._bad = INFEASIBLE_FUNCS.get(self.model_id)
 
+    @classmethod
+    def custom(cls, n, m, step_fn, params, dt, model_id=-1):
+        """A model given as a float-or-Dual Python function step_fn(x, u, p, dt) -> list (the oracle side of a plugin
+        model, drake_ddp_amd/plugin.py)."""
+        s = cls.__new__(cls)
+        s.model_id, s.n, s.m, s.dt = int(model_id), int(n), int(m), float(dt)
+        s.params = np.array(params, dtype=float)
+        s._f, s._bad = step_fn, None
+        return s
+
     def step(self, x, u):
         """Next state for float inputs -> (n,) float array.  RuntimeError when the model declares the step
         infeasible (the reference's line search catches it: ilqr.py:315-323)."""

@@ -1,0 +1,90 @@
+"""The open model interface (include/mi_ilqr.h: mi_ilqr_register_model; drake_ddp_amd/plugin.py): models that are not
+compiled into libmi_ilqr.so, built as plugins from the C++ body of their discrete update (examples/plugins/models.py) and
+checked against the NumPy oracle driven by the same update written in Python (the reference takes ANY discrete System:
+ilqr.py:21,37-58)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "examples", "plugins"))
+
+
+def test_plugin_registers_without_a_gpu():
+    """Built by __graft_entry__.build(); loading and registering needs no device: ids from MI_MODEL_PLUGIN_BASE, the
+    registry answers mi_ilqr_model_info for them, bad records are refused."""
+    import ctypes as C
+    import models as PM
+    from drake_ddp_amd import _capi, plugin
+    make = PM.build_all()
+    lib = _capi.load()
+    for name, n, m, defaults in (("vdp", 2, 1, PM.VDP_DEFAULTS), ("chain3", 6, 2, PM.CHAIN3_DEFAULTS)):
+        sys_ = make[name](0.01)
+        assert sys_.model_id >= 100 and (sys_.n, sys_.m) == (n, m) and list(sys_.params) == defaults
+        nn, mm, npar = C.c_int32(), C.c_int32(), C.c_int32()
+        dp = (C.c_double * _capi.MAX_PARAMS)()
+        assert lib.mi_ilqr_model_info(sys_.model_id, C.byref(nn), C.byref(mm), C.byref(npar), dp) == 0
+        assert (nn.value, mm.value, npar.value) == (n, m, len(defaults)) and list(dp[:len(defaults)]) == defaults
+    assert make["vdp"](0.01).model_id == make["vdp"](0.02).model_id                  # registered once per process
+    bad = plugin._Plugin(n=2, m=3, n_params=0, family=0, launch=1, lds_bytes=1)
+    mid = C.c_int32()
+    assert lib.mi_ilqr_register_model(C.byref(bad), C.byref(mid)) == _capi.E_UNSUPPORTED     # m > 2 on the wave-per-problem family
+    src = plugin.source("vdp", 2, 1, PM.VDP_BODY, PM.VDP_DEFAULTS)
+    assert "launch_small.hpp" in src and "mi_plugin_describe" in src and "PluginModel" in src
+
+
+CASES = {
+    "vdp": dict(n=2, m=1, dt=0.02, N=100, x_nom=np.zeros(2), Q=np.eye(2), R=0.1 * np.eye(1), Qf=10.0 * np.eye(2), span=2.0),
+    "chain3": dict(n=6, m=2, dt=0.02, N=60, x_nom=np.array([np.pi, np.pi, np.pi, 0, 0, 0.0]), Q=np.diag([1, 1, 1, .1, .1, .1]),
+                   R=0.05 * np.eye(2), Qf=20.0 * np.eye(6), span=0.6),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("jac", ["ad", "fd"])
+@pytest.mark.parametrize("name", ["vdp", "chain3"])
+def test_plugin_model_solves_like_the_oracle(name, jac):
+    """A batch of 24 problems on a plugin model: iterations and line-search trials of every problem exactly the NumPy
+    oracle's (driven by the Python statement of the same update), costs 1e-9 (duals) / 1e-8 (central differences),
+    trajectories 1e-6; then three receding-horizon re-solves on the device (mi_ilqr_mpc_run) against the oracle's loop."""
+    import models as PM
+    from drake_ddp_amd.ilqr import BatchedIterativeLQR
+    from drake_ddp_amd.workloads import mpc_shift
+    from oracle import models_np as M
+    from oracle.ilqr_np import OracleILQR
+    c = CASES[name]
+    n, m, dt, N = c["n"], c["m"], c["dt"], c["N"]
+    sys_ = PM.build_all()[name](dt)
+    B = 24
+    rng = np.random.default_rng(11)
+    x0 = c["x_nom"] + rng.uniform(-c["span"], c["span"], (B, n))
+    ug = rng.uniform(-0.1, 0.1, (m, N - 1))
+    s = BatchedIterativeLQR(sys_, N, B, delta=1e-3, beta=0.7, gamma=0.0, jacobian_mode=jac, hist_cap=64)
+    s.SetTargetState(c["x_nom"]); s.SetRunningCost(dt * c["Q"], dt * c["R"]); s.SetTerminalCost(c["Qf"])
+    s.SetInitialState(x0); s.SetInitialGuess(ug)
+    x, u, _, L = s.Solve()
+    assert (s.status == 0).all()
+    step_fn = {"vdp": PM.vdp_step, "chain3": PM.chain3_step}[name]
+    model = M.Model.custom(n, m, step_fn, sys_.params, dt)
+    tolL = 1e-9 if jac == "ad" else 1e-8
+    oracles = []
+    for b in range(B):
+        o = OracleILQR(model, N, 1e-3, 0.7, 0.0, jacobian=jac, fd_step=1e-5)
+        o.set_problem(x0[b], c["x_nom"], dt * c["Q"], dt * c["R"], c["Qf"], ug)
+        xo, uo, Lo, hist = o.solve()
+        hist = np.array(hist)
+        assert len(hist) == s.iterations[b] and int(hist[:, 2].sum()) == s.ls_trials[b], b
+        assert np.array_equal(s.history[b][:len(hist), 1:3], hist[:, 1:3]), b
+        assert abs(L[b] - Lo) < tolL * abs(Lo) and np.max(np.abs(x[b] - xo)) < 1e-6 * max(1.0, np.abs(xo).max()), b
+        oracles.append((o, xo, uo))
+    s.MPCRun(3, 2)
+    log = s.mpc_log
+    for b in range(0, B, 6):
+        o, xo, uo = oracles[b]
+        for r in range(3):
+            x0r, ugr = mpc_shift(xo, uo, 2)
+            o.set_problem(x0r, c["x_nom"], dt * c["Q"], dt * c["R"], c["Qf"], ugr)
+            xo, uo, Lo, hist = o.solve()
+            assert log[b, r, -1] == len(hist) and abs(log[b, r, -2] - Lo) < 10 * tolL * abs(Lo), (b, r)
