@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmi_ilqr.so")
+# (MI_ILQR_LIB: another build of the same library, e.g. the AddressSanitizer one of drake_ddp_amd/build.py)
+LIB_PATH = os.environ.get("MI_ILQR_LIB") or os.path.join(_HERE, "lib", "libmi_ilqr.so")
 
 MAX_PARAMS = 16
 ABI_VERSION = 5

@@ -89,6 +89,31 @@ def build(force=False, verbose=True, extra=(), lib=LIB):
     return lib
 
 
+ASAN_LIB = os.path.join(LIBDIR, "libmi_ilqr_asan.so")
+ASAN_RT = "/opt/rocm/lib/llvm/lib/clang/22/lib/linux/libclang_rt.asan-x86_64.so"
+
+
+def build_asan(verbose=False):
+    """libmi_ilqr_asan.so: the HOST side of the C ABI (csrc/mi_ilqr.hip) instrumented with AddressSanitizer, linked
+    with the regular kernel objects (device code cannot be instrumented on gfx950).  tests/test_gpu_asan.py drives it."""
+    build(verbose=verbose)
+    host_src = os.path.join(CSRC, "mi_ilqr.hip")
+    obj = os.path.join(OBJDIR, "mi_ilqr-asan.o")
+    if _stale(obj, host_src):
+        cmd = [HIPCC] + [f for f in FLAGS if f != "-O3"] + ["-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address", "-shared-libsan",
+                                                           "-Wno-option-ignored", "-c", host_src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    if not os.path.exists(ASAN_LIB) or os.path.getmtime(ASAN_LIB) < max(os.path.getmtime(obj), os.path.getmtime(LIB)):
+        objs = [_obj(s_, "") for s_ in sources() if os.path.basename(s_) != "mi_ilqr.hip"]
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-fsanitize=address", "-shared-libsan", "-Wno-option-ignored",
+                               obj] + objs + ["-o", ASAN_LIB, "-ldl"])
+    return ASAN_LIB
+
+
 if __name__ == "__main__":
     ex = ["-Rpass-analysis=kernel-resource-usage"] if "--resource-usage" in sys.argv else []
     build(force="--force" in sys.argv, extra=ex)
+    if "--asan" in sys.argv:
+        build_asan(verbose=True)
