@@ -13,7 +13,10 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 SCRIPT = r"""
-import sys, numpy as np
+import ctypes, sys, numpy as np
+# (the HIP runtime is brought up BEFORE the instrumented library registers its code objects: under the sanitizer's
+#  interposed loader the other order ends in a null call inside libamdhip64 - nothing of ours is on that stack)
+_hip = ctypes.CDLL("libamdhip64.so"); _n = ctypes.c_int(); assert _hip.hipGetDeviceCount(ctypes.byref(_n)) == 0
 sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests"); sys.path.insert(0, %(root)r + "/examples/plugins")
 from drake_ddp_amd import workloads as W, _capi
 assert "asan" in _capi.LIB_PATH
