@@ -96,11 +96,13 @@ def test_keypoint_methods_at_batch_scale_vs_c_oracle(case):
 def test_wide_random_sweep_vs_c_oracle():
     """The sweep of tools/stress_vs_c_oracle.py as a test: 60 random models / weights / beta / gamma / horizons 8-260 /
     batches 1-700, central differences on both sides.  Pendulum and acrobot cases: every problem takes the oracle's
-    iterations and line-search trials, costs to 1e-9 / 1e-7.  Cart-pole (with and without wall) cases - the finite-difference
-    conditioning quantified by the C4 tests: both sides converge, at least 90 % of a case's problems take identical
-    decisions unless the case is one of the long stiff ones, and problems with identical decisions agree to 1e-6."""
+    iterations and line-search trials, costs to 1e-9 / 1e-7.  Cart-pole cases (with and without the wall): either the same
+    (costs to 1e-6), or - the long, stiff ones, where round-off is amplified by the iteration itself - held to the case's
+    OWN sensitivity like C4: the C oracle re-solves the case with x0 one ulp up / down; the device may disagree with the
+    oracle on no more problems than the oracle disagrees with itself (+ 2 % of the batch + 2), and where all three agree on
+    the decisions the device's largest cost deviation is at most 10x the largest one the one-ulp change produces."""
     from oracle import c_oracle, models_np as M
-    strict_bad, loose_bad = [], []
+    bad = []
     for case in range(60):
         rng = np.random.default_rng(1000 + case)
         model_id = int(rng.integers(0, 4))
@@ -121,18 +123,33 @@ def test_wide_random_sweep_vs_c_oracle():
         s.SetInitialState(x0)
         s.SetInitialGuess(ug)
         x, u, _, L = s.Solve()
-        r = c_oracle.solve_batch(M.Model(model_id, dt), prob, x0, ug)
-        ok = (r["status"] == 0) & (s.status == 0)
-        same = ok & (s.iterations == r["iters"]) & (s.ls_trials == r["ls"])
-        relc = np.max(np.abs(L[same] - r["cost"][same]) / np.abs(r["cost"][same])) if same.any() else 0.0
+        model = M.Model(model_id, dt)
+        r = c_oracle.solve_batch(model, prob, x0, ug, want_arrays=False)
+        same = (s.status == r["status"]) & (s.iterations == r["iters"]) & (s.ls_trials == r["ls"])
+        conv = same & (s.status == 0)
+        rel = np.abs(L - r["cost"]) / np.abs(r["cost"])
+        relc = float(np.max(rel[conv])) if conv.any() else 0.0
+        tol = {0: 1e-9, 1: 1e-7}.get(model_id, 1e-6)
+        if same.all() and relc < tol:
+            continue
         if model_id <= 1:
-            # (costs: pendulum 1e-9; the acrobot's central differences carry ~1e-8 of round-off into a flat optimum)
-            if not (np.array_equal(s.status, r["status"]) and same.sum() == ok.sum() and relc < (1e-9 if model_id == 0 else 1e-7)):
-                strict_bad.append((case, model_id, N, B, int(ok.sum()), int(same.sum()), relc))
-        elif relc > 1e-6 or not np.array_equal(s.status == 2, r["status"] == 2):
-            loose_bad.append((case, model_id, N, B, int(ok.sum()), int(same.sum()), relc))
-    assert not strict_bad, strict_bad
-    assert not loose_bad, loose_bad
+            bad.append((case, model_id, N, B, int(same.sum()), relc))
+            continue
+        # the case's own sensitivity
+        own_diff, own_rel = 0, np.zeros(B)
+        for direction in (np.inf, -np.inf):
+            xq = x0.copy()
+            xq[:, 1] = np.nextafter(xq[:, 1], direction)
+            rq = c_oracle.solve_batch(model, prob, xq, ug, want_arrays=False)
+            sq = (rq["status"] == r["status"]) & (rq["iters"] == r["iters"]) & (rq["ls"] == r["ls"])
+            own_diff = max(own_diff, int((~sq).sum()))
+            own_rel = np.maximum(own_rel, np.where(sq, np.abs(rq["cost"] - r["cost"]) / np.abs(r["cost"]), np.inf))
+        ok_count = int((~same).sum()) <= own_diff + int(0.02 * B) + 2
+        both = conv & np.isfinite(own_rel)
+        ok_cost = (not both.any()) or float(np.max(rel[both])) <= 10.0 * float(np.max(own_rel[both])) + 1e-8
+        if not (ok_count and ok_cost):
+            bad.append((case, model_id, N, B, int((~same).sum()), own_diff, relc, float(np.max(own_rel[both])) if both.any() else 0.0))
+    assert not bad, bad
 
 
 # ----------------------------------------------------------------------------------
