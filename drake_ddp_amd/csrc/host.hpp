@@ -73,6 +73,8 @@ struct mi_ilqr {
   int n_store = 1;         // line-search candidate trajectories kept in LDS
   bool batch_minor = false; // lane-per-problem path: state arrays are [t][row][b] in HBM
   double *sink_x = nullptr, *sink_u = nullptr, *sink_cost = nullptr;   // result sink (device aliases of host arrays), optional
+  int32_t* cont = nullptr;         // two-phase solves (ilqr_wide.hpp): [0], [1] the counters of alternate solves, [2..2+B) the list
+  long long phase_seq = 0;         // two-phase solves launched so far (parity selects the counter)
 };
 
 // Small batches of the wave-per-problem kernels aggregate the batch statistics in the solve kernel
@@ -80,9 +82,22 @@ struct mi_ilqr {
 // 98.  Large batches keep the separate stats_kernel: with pipelined solves the two cost the same per
 // step (measured at B = 1024: 0.166 ms either way), and the solve kernel stays 3.6 us shorter.
 // MI_ILQR_STATS_KERNEL=1 / =0 forces the separate kernel / the in-kernel epilogue (A/B runs).
+// Two-phase solve of the n = 2 models (ilqr_wide.hpp): the number of first-phase iterations, 0 = single-phase.  A rule on
+// the iteration index alone - the same for every batch size, so that results stay bitwise independent of batch size,
+// position and sharding.  MI_ILQR_PHASE_CAP=k overrides it (0 = off, for A/B runs).
+static inline int phase_cap_of(const mi_ilqr* h) {
+  static const int env = [] { const char* e = std::getenv("MI_ILQR_PHASE_CAP"); return e ? std::atoi(e) : -1; }();
+  static const bool seq = [] { const char* a = std::getenv("MI_ILQR_SEQ_BACKWARD"); const char* b = std::getenv("MI_ILQR_SEQ_ROLLOUT");
+                               return (a && a[0] == '1') || (b && b[0] == '1'); }();
+  if (!h->cont || h->large || h->batch_minor || h->n != 2 || h->m != 1 || h->N - 1 > 64 * 4 || seq || h->exact_backward ||
+      h->d.keypoint_method != MI_KP_SET_INTERVAL || h->d.minN != 1)
+    return 0;
+  return env >= 0 ? env : 6;
+}
 static inline bool stats_in_kernel(const mi_ilqr* h) {
   static const int forced = [] { const char* e = std::getenv("MI_ILQR_STATS_KERNEL"); return !e ? -1 : (e[0] == '1' ? 1 : 0); }();
   if (h->large || h->batch_minor) return false;
+  if (phase_cap_of(h) > 0) return false;                 // (the statistics exist after the second launch only)
   if (forced >= 0) return forced == 0;
   return h->B <= 64;
 }
@@ -122,13 +137,16 @@ int allow_max_lds(Kern kern, bool (&done)[kMaxDevices], int device) {
 // begin/end timestamps, what rocprofv3 reports for it) instead of two hipEventRecord marker packets around it.
 // A profiled dispatch still costs the stream ~5 us of serialization in a pipelined sequence
 // (tools/ubench/gap.hip), so mi_ilqr_set_timing can restrict the events to one launch in k.
+// `part`: 0 = a launch on its own (start and stop events); 1 / 2 = first / last kernel of a solve made of two launches
+// (the start event rides on the first, the stop event on the last: the elapsed time covers both and the gap).
 template <class Kern>
-int launch_timed(mi_ilqr* h, Kern kern, dim3 grid, dim3 block, size_t lds, const KArgs& a) {
+int launch_timed(mi_ilqr* h, Kern kern, dim3 grid, dim3 block, size_t lds, const KArgs& a, int part = 0) {
   KArgs args = a;
   void* argv[] = {&args};
   h->ring_timed[h->cur_slot] = h->last_timed = h->timed_launch;
   if (!h->timed_launch) { HIPCHK(hipLaunchKernel(reinterpret_cast<const void*>(kern), grid, block, argv, lds, h->stream)); return MI_ILQR_OK; }
-  HIPCHK(hipExtLaunchKernel(reinterpret_cast<const void*>(kern), grid, block, argv, lds, h->stream, h->ev0, h->ev1, 0));
+  HIPCHK(hipExtLaunchKernel(reinterpret_cast<const void*>(kern), grid, block, argv, lds, h->stream, part == 2 ? nullptr : h->ev0,
+                            part == 1 ? nullptr : h->ev1, 0));
   return MI_ILQR_OK;
 }
 

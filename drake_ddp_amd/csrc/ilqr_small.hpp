@@ -88,7 +88,14 @@ struct KArgs {
   // that receive x_bar (B,n,N), u_bar (B,m,N-1) and the costs (B,) straight from the kernel's write-back, problem by
   // problem as each one finishes: the copy-out of a batch overlaps the launch's stragglers instead of following it.
   double *sink_x, *sink_u, *sink_cost;
+  // n = 2, MODE_SOLVE: TWO-PHASE solve (ilqr_wide.hpp).  phase_cap > 0: a problem that has not converged after
+  // phase_cap iterations leaves this kernel with the internal status MI_STATUS_CONTINUE_, its state written back as
+  // usual, and appends its index to cont_list (cont_count: running count); the 4-wave continuation kernel picks it up.
+  // cont_reset: the counter of the NEXT solve, zeroed here.
+  int32_t phase_cap;
+  int32_t *cont_count, *cont_list, *cont_reset;
 };
+enum { MI_STATUS_CONTINUE_ = 4 };      // internal: never leaves the library
 
 __device__ __forceinline__ double bcast_lane0(double v) {
   union { double d; int i[2]; } u;
@@ -954,18 +961,19 @@ __device__ inline int rollout_newton(const WS& w, const Consts<M>& c, const KArg
 template <class M, int JAC>
 __device__ inline bool linesearch(const WS& w, const Consts<M>& c, const KArgs& a, const double* x0r,
                                   double L_last, bool optimistic, int fuse, double& L_out, double& eps_out, int& trials,
-                                  int& slot_out, int& fused_out, bool cold_start = false) {
+                                  int& slot_out, int& fused_out, bool cold_start = false, bool no_newton = false) {
   fused_out = 0;
   const int lane = threadIdx.x;
   int base = 0;
   double eps_base = 1.0;
   // the stored nominal trajectory is a usable first guess except at the first iteration of a solve
-  const bool newton = newton_capable<M>(w, a) && L_last < __builtin_inf();
+  // (no_newton: the caller already tried the time-parallel rollout itself - ilqr_wide.hpp)
+  const bool newton = !no_newton && newton_capable<M>(w, a) && L_last < __builtin_inf();
   if (optimistic) {
     double L, ex;
     int nr = NEWTON_FAILED;
     if (newton) nr = rollout_newton<M, JAC>(w, c, a, x0r, 1.0, fuse, L_last, L);
-    else if (cold_start && newton_capable<M>(w, a)) nr = rollout_newton<M, JAC>(w, c, a, x0r, 1.0, fuse, L_last, L, true);
+    else if (cold_start && !no_newton && newton_capable<M>(w, a)) nr = rollout_newton<M, JAC>(w, c, a, x0r, 1.0, fuse, L_last, L, true);
     if (nr == NEWTON_ACCEPTED) {
       L_out = L;
       eps_out = 1.0;
@@ -2202,6 +2210,7 @@ __global__ void __launch_bounds__(256) ilqr_small_kernel(const KArgs a) {
     long long c_prev = 0;
     while (improvement > a.delta) {
       if (it_this >= a.max_iters) { status = MI_STATUS_MAX_ITERS; break; }
+      if (MODE == MODE_SOLVE && n == 2 && a.phase_cap > 0 && it_this >= a.phase_cap) { status = MI_STATUS_CONTINUE_; break; }   // -> ilqr_wide_kernel
       double L_new, eps; int trials, slot = 0;
       // stopwatch reads cost an s_memtime round trip each: an iteration starts where the previous one
       // ended, and a rollout that linearized on the way has no separate linearization span
@@ -2362,6 +2371,13 @@ __global__ void __launch_bounds__(256) ilqr_small_kernel(const KArgs a) {
   if (lane == 0) {
     a.cost[b] = L; a.iters[b] = iters; a.status[b] = status; a.ls_trials[b] = ls_total; a.kp_count[b] = nk;
     if (a.sink_cost != nullptr) a.sink_cost[b] = L;
+    if (MODE == MODE_SOLVE && n == 2 && a.phase_cap > 0) {
+      if (b == 0) __hip_atomic_store(a.cont_reset, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (status == MI_STATUS_CONTINUE_) {
+        const int idx = __hip_atomic_fetch_add(a.cont_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a.cont_list[idx] = b;
+      }
+    }
     a.prof[4 * b + 0] = c_ls; a.prof[4 * b + 1] = c_lin; a.prof[4 * b + 2] = c_bp; a.prof[4 * b + 3] = clock64() - c_begin;
 #ifdef MI_PROF_NEWTON
     // debug build: launch phases instead of the stage stopwatches
