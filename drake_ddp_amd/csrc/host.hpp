@@ -84,7 +84,9 @@ struct mi_ilqr {
 // MI_ILQR_STATS_KERNEL=1 / =0 forces the separate kernel / the in-kernel epilogue (A/B runs).
 // Two-phase solve of the n = 2 models (ilqr_wide.hpp): the number of first-phase iterations, 0 = single-phase.  A rule on
 // the iteration index alone - the same for every batch size, so that results stay bitwise independent of batch size,
-// position and sharding.  MI_ILQR_PHASE_CAP=k overrides it (0 = off, for A/B runs).
+// position and sharding.  OFF by default: built and measured in round 3 - exact parity, but slower than the single-phase
+// solve on C2 (DESIGN.md section 8 has the numbers and the reasons); MI_ILQR_PHASE_CAP=k turns it on with k first-phase
+// iterations.
 static inline int phase_cap_of(const mi_ilqr* h) {
   static const int env = [] { const char* e = std::getenv("MI_ILQR_PHASE_CAP"); return e ? std::atoi(e) : -1; }();
   static const bool seq = [] { const char* a = std::getenv("MI_ILQR_SEQ_BACKWARD"); const char* b = std::getenv("MI_ILQR_SEQ_ROLLOUT");
@@ -92,7 +94,7 @@ static inline int phase_cap_of(const mi_ilqr* h) {
   if (!h->cont || h->large || h->batch_minor || h->n != 2 || h->m != 1 || h->N - 1 > 64 * 4 || seq || h->exact_backward ||
       h->d.keypoint_method != MI_KP_SET_INTERVAL || h->d.minN != 1)
     return 0;
-  return env >= 0 ? env : 6;
+  return env > 0 ? env : 0;
 }
 static inline bool stats_in_kernel(const mi_ilqr* h) {
   static const int forced = [] { const char* e = std::getenv("MI_ILQR_STATS_KERNEL"); return !e ? -1 : (e[0] == '1' ? 1 : 0); }();

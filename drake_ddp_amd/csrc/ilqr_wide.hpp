@@ -344,8 +344,11 @@ __global__ void __launch_bounds__(kWideThreads) ilqr_wide_kernel(const KArgs a) 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int count = __hip_atomic_load(a.cont_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if ((int)blockIdx.x >= count) return;
-  const int b = a.cont_list[blockIdx.x];
+  // one workgroup per compute unit (the launch asks for the whole LDS), each takes the listed problems blockIdx.x,
+  // blockIdx.x + gridDim.x, ...: with at most as many unfinished problems as compute units every problem has a CU -
+  // four SIMDs - to itself
+  for (int entry = blockIdx.x; entry < count; entry += gridDim.x) {
+  const int b = a.cont_list[entry];
   const int N = a.N;
   WS w = carve<n, m>(smem, N, a.n_store);
   const WideX xc = wide_xch(w);
@@ -450,6 +453,8 @@ __global__ void __launch_bounds__(kWideThreads) ilqr_wide_kernel(const KArgs a) 
     a.cost[b] = L; a.iters[b] = it_this; a.status[b] = status; a.ls_trials[b] = ls_total;
     if (a.sink_cost != nullptr) a.sink_cost[b] = L;
     a.prof[4 * b + 0] += c_ls; a.prof[4 * b + 2] += c_bp; a.prof[4 * b + 3] += clock64() - c_begin;
+  }
+  team_barrier();                                              // (the next problem reuses the LDS arrays)
   }
 }
 

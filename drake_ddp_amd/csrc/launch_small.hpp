@@ -22,7 +22,8 @@ int launch_one(mi_ilqr* h, const KArgs& a) {
       b.cont_count = h->cont + par; b.cont_reset = h->cont + (par ^ 1); b.cont_list = h->cont + 2;
       const int rc = launch_timed(h, kern, dim3(h->B), dim3(64 * waves), h->lds, b, 1);
       if (rc != MI_ILQR_OK) return rc;
-      return launch_timed(h, wide, dim3(h->B), dim3(kWideThreads), h->lds, b, 2);
+      const int wgs = h->n_cus > 0 ? (h->B < h->n_cus ? h->B : h->n_cus) : h->B;
+      return launch_timed(h, wide, dim3(wgs), dim3(kWideThreads), kMaxLds, b, 2);    // the whole LDS: one workgroup per CU
     }
   }
   return launch_timed(h, kern, dim3(h->B), dim3(64 * waves), h->lds, a);
