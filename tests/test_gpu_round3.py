@@ -392,4 +392,7 @@ np.savez(sys.argv[1], **out)
         # (different association of the scans -> 1e-15-level trajectories -> 1e-10 through the central differences)
         assert np.max(np.abs(a[tag + "_L"] - b[tag + "_L"]) / np.abs(a[tag + "_L"])) < 1e-8
         assert np.max(np.abs(a[tag + "_x"] - b[tag + "_x"])) < 1e-7 and rel_err(b[tag + "_K"], a[tag + "_K"]) < 1e-6
-    assert (a["coarse_ls"] > a["coarse_it"]).any()                                # backtracking happened
+    # C2's backtracking iterations (problems 27, 73, 95, ...: 2-14 trials in their 4th / 5th iteration) fall into the second
+    # phase with phase_cap = 3: the 4-wave kernel's single-wave line-search fallback really ran
+    bt = a["c2_h"][:, 3:, 1] > 1
+    assert bt.any() and not (a["c2_h"][:, :3, 1] > 1).any()
