@@ -6,6 +6,7 @@ and - for the tests - the same update as a float-or-dual Python function for the
                          (an n = 2 model: served by the time-parallel rollout and Riccati scan, like the pendulum)
   chain3  n = 6, m = 2   three coupled pendula, the outer two actuated, params [ks, c, kc]
                          (a shape no built-in model has: served by the generic scalar passes of the wave-per-problem kernel)
+  synth36p n = 36, m = 12 the built-in 36-state chain re-stated as a plugin (whole-step form) for the matrix-core family
 """
 import os
 import sys
@@ -32,6 +33,24 @@ CHAIN3_BODY = """    const double ks = p[0], c = p[1], kc = p[2];
 CHAIN3_DEFAULTS = [4.0, 0.3, 3.0]
 
 
+# The built-in synthetic 36-state chain (csrc/models.hpp: Synth36) written AGAIN as a plugin - whole-step form only, no
+# per-dof hooks - to exercise the open interface on the workgroup-per-problem (matrix-core) family: the plugin must solve
+# like the built-in model.
+SYNTH36P_BODY = """    const double ks = p[0], c = p[1], kc = p[2], bu = p[3];
+    constexpr int nq = 18;
+    for (int i = 0; i < nq; ++i) {
+      const T qi = x[i], vi = x[nq + i];
+      T a = -ks * mi_sin(qi) - c * vi;
+      if (i < nq - 1) a = a + kc * mi_sin(x[i + 1] - qi);
+      if (i > 0) a = a - kc * mi_sin(qi - x[i - 1]);
+      if (i >= 6) a = a + u[i - 6];
+      else a = a + bu * (u[2 * i] - u[2 * i + 1]);
+      const T vn = vi + dt * a;
+      xn[nq + i] = vn; xn[i] = qi + dt * vn;
+    }"""
+SYNTH36P_DEFAULTS = [4.0, 0.5, 6.0, 0.1]
+
+
 def vdp_step(x, u, p, dt):
     q, v = x[0], x[1]
     a = p[0] * (1.0 - q * q) * v - q + u[0]
@@ -51,10 +70,11 @@ def chain3_step(x, u, p, dt):
 
 
 def build_all(verbose=False):
-    """Compile both plugins (hipcc, ~15-25 s each the first time) and return their ModelSystem factories."""
+    """Compile the plugins (hipcc, ~15-40 s each the first time) and return their ModelSystem factories."""
     from drake_ddp_amd import plugin
     return {"vdp": plugin.build_model("vdp", 2, 1, VDP_BODY, VDP_DEFAULTS, verbose=verbose),
-            "chain3": plugin.build_model("chain3", 6, 2, CHAIN3_BODY, CHAIN3_DEFAULTS, verbose=verbose)}
+            "chain3": plugin.build_model("chain3", 6, 2, CHAIN3_BODY, CHAIN3_DEFAULTS, verbose=verbose),
+            "synth36p": plugin.build_model("synth36p", 36, 12, SYNTH36P_BODY, SYNTH36P_DEFAULTS, family="large", verbose=verbose)}
 
 
 if __name__ == "__main__":

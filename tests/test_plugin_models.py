@@ -20,7 +20,7 @@ def test_plugin_registers_without_a_gpu():
     from drake_ddp_amd import _capi, plugin
     make = PM.build_all()
     lib = _capi.load()
-    for name, n, m, defaults in (("vdp", 2, 1, PM.VDP_DEFAULTS), ("chain3", 6, 2, PM.CHAIN3_DEFAULTS)):
+    for name, n, m, defaults in (("vdp", 2, 1, PM.VDP_DEFAULTS), ("chain3", 6, 2, PM.CHAIN3_DEFAULTS), ("synth36p", 36, 12, PM.SYNTH36P_DEFAULTS)):
         sys_ = make[name](0.01)
         assert sys_.model_id >= 100 and (sys_.n, sys_.m) == (n, m) and list(sys_.params) == defaults
         nn, mm, npar = C.c_int32(), C.c_int32(), C.c_int32()
@@ -88,3 +88,34 @@ def test_plugin_model_solves_like_the_oracle(name, jac):
             o.set_problem(x0r, c["x_nom"], dt * c["Q"], dt * c["R"], c["Qf"], ugr)
             xo, uo, Lo, hist = o.solve()
             assert log[b, r, -1] == len(hist) and abs(log[b, r, -2] - Lo) < 10 * tolL * abs(Lo), (b, r)
+
+
+@pytest.mark.gpu
+def test_plugin_on_the_matrix_core_family_solves_like_the_builtin_model():
+    """Family 1 of the open interface (workgroup-per-problem kernels, 32 < n <= 48): the built-in 36-state chain written
+    again as a plugin in whole-step form - one lane advances the dynamics in the rollout, dense whole-step Jacobian columns -
+    must reproduce the built-in model's solve and MPC loop (same formulas, other evaluation order of the linearization:
+    counts exact, costs 1e-9, trajectories 1e-8)."""
+    import models as PM
+    from drake_ddp_amd import workloads as W
+    from drake_ddp_amd.ilqr import BatchedIterativeLQR
+    from drake_ddp_amd.models import Synth36
+    q = W.synth36_problem()
+    B = 6
+    x0, ug = W.synth36_batch_x0(64)[:B], W.synth36_u_guess(q["N"])
+    step = np.zeros(36)
+    step[0] = W.SYNTH_TARGET_VEL * q["dt"] * 4
+    res = []
+    for sys_ in (Synth36(q["dt"]), PM.build_all()["synth36p"](q["dt"])):
+        s = BatchedIterativeLQR(sys_, q["N"], B, delta=q["delta"], beta=q["beta"], gamma=q["gamma"], jacobian_mode="fd")
+        s.SetTargetState(q["x_nom"]); s.SetRunningCost(q["Q"], q["R"]); s.SetTerminalCost(q["Qf"])
+        s.SetInitialState(x0); s.SetInitialGuess(ug)
+        x, u, _, L = s.Solve()
+        it0 = s.iterations.copy()
+        s.MPCRun(5, 4, target_step=step)
+        res.append((x, L, it0, s.mpc_log, s.x_bar, s.status))
+    a, b = res
+    assert (a[5] == 0).all() and (b[5] == 0).all()
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[3][:, :, -1], b[3][:, :, -1])
+    assert np.max(np.abs(a[1] - b[1]) / np.abs(a[1])) < 1e-9 and np.max(np.abs(a[0] - b[0])) < 1e-8
+    assert np.max(np.abs(a[3][:, :, -2] - b[3][:, :, -2]) / np.abs(a[3][:, :, -2])) < 1e-8 and np.max(np.abs(a[4] - b[4])) < 1e-7
