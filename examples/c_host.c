@@ -47,16 +47,18 @@ int main(void) {
   memset(u_guess, 0, sizeof u_guess);
   CHECK(mi_ilqr_set_initial_shared(h, x0, u_guess));      /* one guess for the whole batch, like SetInitialGuess */
 
-  /* page-locked result buffers: the solve and the copy-outs are enqueued, one synchronization covers them */
-  void *xb = NULL, *cost = NULL, *iters = NULL, *status = NULL, *trials = NULL;
+  /* page-locked result buffers.  x_bar, u_bar and the costs are the handle's RESULT SINK: the solve kernel writes them
+   * there itself, problem by problem as each finishes; the integer results are copy-outs enqueued behind the solve.
+   * One synchronization (collect_stats) covers it all. */
+  void *xb = NULL, *ub = NULL, *cost = NULL, *iters = NULL, *status = NULL, *trials = NULL;
   CHECK(mi_ilqr_host_alloc(sizeof(double) * B * n * N, &xb));
+  CHECK(mi_ilqr_host_alloc(sizeof(double) * B * m * (N - 1), &ub));
   CHECK(mi_ilqr_host_alloc(sizeof(double) * B, &cost));
+  CHECK(mi_ilqr_set_result_sink(h, (double*)xb, (double*)ub, (double*)cost));
   CHECK(mi_ilqr_host_alloc(sizeof(int32_t) * B, &iters));
   CHECK(mi_ilqr_host_alloc(sizeof(int32_t) * B, &status));
   CHECK(mi_ilqr_host_alloc(sizeof(int32_t) * B, &trials));
   CHECK(mi_ilqr_solve_async(h));
-  CHECK(mi_ilqr_get_async(h, MI_F_X_BAR, xb, sizeof(double) * B * n * N));
-  CHECK(mi_ilqr_get_async(h, MI_F_COST, cost, sizeof(double) * B));
   CHECK(mi_ilqr_get_async(h, MI_I_ITERS, iters, sizeof(int32_t) * B));
   CHECK(mi_ilqr_get_async(h, MI_I_STATUS, status, sizeof(int32_t) * B));
   CHECK(mi_ilqr_get_async(h, MI_I_LS_TRIALS, trials, sizeof(int32_t) * B));
@@ -71,7 +73,8 @@ int main(void) {
   printf("batch: %lld iterations, %d converged, best cost %.12g (problem %d), kernel %.3f ms\n", (long long)st.total_iters,
          st.n_converged, st.best_cost, st.best_index, st.kernel_ms);
 
-  mi_ilqr_host_free(xb); mi_ilqr_host_free(cost); mi_ilqr_host_free(iters); mi_ilqr_host_free(status); mi_ilqr_host_free(trials);
+  CHECK(mi_ilqr_set_result_sink(h, NULL, NULL, NULL));
+  mi_ilqr_host_free(xb); mi_ilqr_host_free(ub); mi_ilqr_host_free(cost); mi_ilqr_host_free(iters); mi_ilqr_host_free(status); mi_ilqr_host_free(trials);
   mi_ilqr_destroy(h);
   return st.n_converged == B ? 0 : 2;
 }

@@ -396,3 +396,21 @@ np.savez(sys.argv[1], **out)
     # phase with phase_cap = 3: the 4-wave kernel's single-wave line-search fallback really ran
     bt = a["c2_h"][:, 3:, 1] > 1
     assert bt.any() and not (a["c2_h"][:, :3, 1] > 1).any()
+
+
+def test_lane_per_problem_kernels_refuse_other_keypoint_methods():
+    """ilqr_batch.hpp serves setInterval / minN = 1 only: adaptiveJerk / iterativeError (ilqr.py:434-593) with
+    kernel_mode = throughput are refused at create (MI_ILQR_E_UNSUPPORTED), and AUTO serves them on the wave-per-problem
+    kernels at any batch size."""
+    from drake_ddp_amd import workloads as W, _capi
+    from drake_ddp_amd._capi import MiIlqrError
+    a = W.acrobot_problem()
+    for kp in (("adaptiveJerk", 2, 10, 1e-5, 0.0), ("iterativeError", 2, 0, 0.0, 1e-9), ("setInterval", 3, 0, 0.0, 0.0)):
+        with pytest.raises(MiIlqrError) as e:
+            make_solver(a, B=16, keypoint=kp, jac="fd", kernel_mode="throughput")
+        assert e.value.code == _capi.E_UNSUPPORTED
+    s = make_solver(a, B=9000, keypoint=("adaptiveJerk", 2, 10, 1e-5, 0.0), jac="fd")        # AUTO at a large batch
+    s.SetInitialState(np.tile(W.acrobot_batch_x0(512), (18, 1))[:9000])
+    s.SetInitialGuess(np.zeros((1, a["N"] - 1)))
+    s.Solve()
+    assert (s.status == 0).all() and (s.keypoint_count < a["N"] - 1).all()
