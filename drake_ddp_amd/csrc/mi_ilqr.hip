@@ -472,6 +472,11 @@ const char* mi_ilqr_strerror(int code) {
 
 int mi_ilqr_register_model(const mi_ilqr_model_plugin* p, int32_t* model_id_out) {
   if (!p || !model_id_out || !p->launch || !p->lds_bytes) return MI_ILQR_E_BAD_ARG;
+  if (p->abi_version != MI_ILQR_ABI_VERSION || p->kernel_args_bytes != (int32_t)sizeof(KArgs)) {
+    std::fprintf(stderr, "mi_ilqr_register_model: plugin built against other headers (ABI %d, %d-byte kernel arguments; the library: %d, %d)\n",
+                 p->abi_version, p->kernel_args_bytes, MI_ILQR_ABI_VERSION, (int)sizeof(KArgs));
+    return MI_ILQR_E_BAD_ARG;
+  }
   if (p->n < 1 || p->m < 1 || p->n > kMaxStateDim || p->n_params < 0 || p->n_params > MI_ILQR_MAX_PARAMS) return MI_ILQR_E_BAD_SHAPE;
   if (p->family == 0 ? p->m > 2 : (p->family != 1 || p->n <= 32 || p->n > 48 || p->m > 16 || 2 * p->m > p->n || p->m % 4 != 0)) return MI_ILQR_E_UNSUPPORTED;
   for (int s_ = 0; s_ < MI_ILQR_MAX_PLUGINS; ++s_) {
