@@ -897,6 +897,77 @@ struct BackSubst {
   }
 };
 
+// In-place Gauss-Jordan inverse (no pivoting: the matrix is symmetric positive definite) of an m x m matrix held one
+// ROW PER LANE (lane i of a 16-lane row holds A[i][0..m-1]); the pivot row travels by DPP row_share, no LDS, no
+// barriers.  Row scaling is deferred: lane i keeps a factor s (1 until its own pivot, 1 / pivot after) and the true
+// row is s * a - the elimination  a_i[j] -= (a_i[k] / p) a_k[j]  of the other lanes' rows does not see their factors,
+// and the pivot lane itself only sets a[k] = 1.  On exit  A^{-1}[i][j] = s * a[j]  on lane i.
+// As in the LDL^T above the serial part is pivot -> reciprocal -> multiplier -> next pivot: each step updates the
+// column of the next pivot first, starts that pivot's reciprocal and places the other column updates between its
+// dependent instructions.  Columns are visited in the order K+1, K+2, ..., K-1 (mod m).
+template <int m, int K, int NTH>
+__device__ __forceinline__ void gj_update(double (&a)[m], double g) {
+  if constexpr (NTH < m) {
+    constexpr int J = (K + NTH) % m;
+    a[J] = fma(-g, row_share<K>(a[J]), a[J]);
+  }
+}
+template <int m, int K, int NTH>
+struct GjRest {
+  static __device__ __forceinline__ void run(double (&a)[m], double g) {
+    gj_update<m, K, NTH>(a, g);
+    GjRest<m, K, NTH + 1>::run(a, g);
+  }
+};
+template <int m, int K>
+struct GjRest<m, K, m> {
+  static __device__ __forceinline__ void run(double (&)[m], double) {}
+};
+template <int m, int K>
+struct GjOuter {
+  // `inv` = 1 / pivot K, already computed; `i` = this lane's row
+  static __device__ __forceinline__ void run(double (&a)[m], double& s, int i, double inv) {
+    const bool piv = i == K;
+    const double g = piv ? 0.0 : a[K] * inv;
+    double r = 0.0;
+    if constexpr (K + 1 < m) {
+      gj_update<m, K, 1>(a, g);                         // column K+1: the next pivot is in it
+      gj_update<m, K, 2>(a, g);                         // (also covers the DPP-after-VALU wait states of the pivot read)
+      __builtin_amdgcn_sched_barrier(0);
+      const double d = row_share<K + 1>(a[K + 1]);
+      r = __builtin_amdgcn_rcp(d);
+      gj_update<m, K, 3>(a, g);
+      gj_update<m, K, 4>(a, g);
+      __builtin_amdgcn_sched_barrier(0);
+      double e = fma(-d, r, 1.0);
+      gj_update<m, K, 5>(a, g);
+      __builtin_amdgcn_sched_barrier(0);
+      r = fma(r, e, r);
+      gj_update<m, K, 6>(a, g);
+      __builtin_amdgcn_sched_barrier(0);
+      e = fma(-d, r, 1.0);
+      gj_update<m, K, 7>(a, g);
+      __builtin_amdgcn_sched_barrier(0);
+      r = fma(r, e, r);                                 // == fast_rcp(d)
+      GjRest<m, K, (8 < m ? 8 : m)>::run(a, g);
+    } else {
+      GjRest<m, K, 1>::run(a, g);
+    }
+    a[K] = piv ? 1.0 : -g;
+    s = piv ? inv : s;
+    GjOuter<m, K + 1>::run(a, s, i, r);
+  }
+  static __device__ __forceinline__ void run(double (&a)[m], double& s, int i) {
+    static_assert(K == 0, "entry point");
+    run(a, s, i, fast_rcp(row_share<0>(a[0])));
+  }
+};
+template <int m>
+struct GjOuter<m, m> {
+  static __device__ __forceinline__ void run(double (&)[m], double&, int, double) {}
+};
+
+
 // Backward Riccati pass (ilqr.py:623-667), cost expansion (:161-206) fused.
 //
 // Per time step, with F = [fx | fu] (n x (n+m)):
@@ -935,7 +1006,6 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
   double* T1 = lds + Ly::oT1;        // [n][TS]  = [Vxx F | . | Vx at column FS]; later rows 0..m-1 hold [K | kappa]
   double* H = lds + Ly::oH;          // [NMP][TS] = F^T T1, first-order terms in column FS
   double* QT = lds + Ly::oQT;        // Q^T (compact layout only: the horizon's cost-gradient product)
-  constexpr int CV = FS;             // column index of Vx / first-order terms
 #ifdef MI_PROF_BACKWARD
   long long bp_last = clock64();
 #endif
@@ -1026,7 +1096,6 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
     // the zero padding the tiles rely on (F's pad columns; H for tidiness)
     for (int e = tid; e < NK * FS; e += kLargeThreads) F[e] = 0.0;
     for (int e = tid; e < Ly::NMP * TS; e += kLargeThreads) H[e] = 0.0;
-    for (int e = n * TS + tid; e < NK * TS; e += kLargeThreads) T1[e] = 0.0;     // rows of the k-step pad: read, never stored
   }
   __syncthreads();
   BP_TICK(14);
@@ -1034,7 +1103,7 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
   // blocks in HBM) as 16-byte pairs into registers during the T1 phase and publishes it to LDS
   // during the last phase: the three matrix-core waves never touch global memory in the loop.
   // (16-byte pairs where the rows allow it - n, m even; single doubles otherwise, e.g. n = 37)
-  constexpr int W = (n % 2 == 0 && m % 2 == 0 && FS % 2 == 0 && Ly::oF % 2 == 0) ? 2 : 1;
+  constexpr int W = (n % 2 == 0 && m % 2 == 0 && FS % 2 == 0 && Ly::oF % 2 == 0 && Ly::oT1 % 2 == 0) ? 2 : 1;
   constexpr int PFX = n * n / W, PFU = n * m / W;                       // pairs (or single doubles)
   constexpr int NFX = (PFX + 63) / 64, NFU = (PFU + 63) / 64;
   typedef double d2_t __attribute__((ext_vector_type(2)));
@@ -1053,42 +1122,121 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
 #pragma unroll
     for (int r = 0; r < NFU; ++r) { const int pi = lane + 64 * r; fru[r] = fug[pi < PFU ? pi : PFU - 1]; }
   };
-  auto publish = [&]() __attribute__((always_inline)) {       // clamped duplicates rewrite the last pair with itself
+  auto publish = [&](double* Fb) __attribute__((always_inline)) {       // clamped duplicates rewrite the last pair with itself
 #pragma unroll
-    for (int r = 0; r < NFX; ++r) *reinterpret_cast<fw_t*>(F + fx_off[r]) = frx[r];
+    for (int r = 0; r < NFX; ++r) *reinterpret_cast<fw_t*>(Fb + fx_off[r]) = frx[r];
 #pragma unroll
-    for (int r = 0; r < NFU; ++r) *reinterpret_cast<fw_t*>(F + fu_off[r]) = fru[r];
+    for (int r = 0; r < NFU; ++r) *reinterpret_cast<fw_t*>(Fb + fu_off[r]) = fru[r];
   };
-  if (wave == 3) { fetch(N - 2); publish(); }
-  __syncthreads();
-  BP_TICK(15);
-  double* Sq = lds + Ly::oS;         // wave 3's private copy of the H tile that holds Quu - luu
+  // =====================================================================================================
+  // Fused chain.  The D (result) layout of one 16x16x4 product IS the B-operand layout of the next: lane
+  // (lr, lk) receives D[4 reg + lk][lr] and supplies B[4 ks + lk][lr], so result register `reg` of row tile q is
+  // k-step 4q + reg of a product that contracts over those rows - and, the matrix being symmetric, also the A operand
+  // of a product whose ROWS are the tile's columns.  Every matrix-core wave therefore keeps ITS column tile in
+  // registers from one product to the next, T1 -> H -> K -> Vxx' -> (Vxx' fu) -> its share of Quu, and only three
+  // small things cross waves per step: the m rows of Qux (every wave needs all of Qux^T as an A operand), Vxx' (the
+  // A operand of the next step's T1) and the three partial Quu tiles (one per matrix-core wave, summed by the solver).
+  //
+  //   step t, first half                                             | second half
+  //   matrix-core wave w:  T1[:, w] = Vxx F_t[:, w]                  | K[:, w] = Quu^{-1} Qux[:, w]  (-> HBM, :660)
+  //                        H[:, w]  = F_t^T T1[:, w]                 | Vxx'[:, w] = Qxx[:, w] + 2Q - Qux^T K[:, w]  (:667) -> LDS
+  //                        Qux[:, w] -> LDS                          | T1u[w, :] = Vxx'[w, :] fu_{t-1},  P_w = fu_{t-1}[w, :]^T T1u[w, :] -> LDS
+  //   solver wave:         Quu_t = 2R + P_0 + P_1 + P_2  (:654)      | kappa = Quu^{-1} Qu (:659), dV (:663),
+  //                        Quu^{-1}: Gauss-Jordan, a row per lane    | Vx' = Qx - Qux^T kappa (:666)
+  //                        first-order column l + F_t^T Vx (:651-652)| F_{t-2} -> LDS, prefetch of F_{t-3}
+  // Two barriers per step, no T1 / H / Y round trips through LDS, no triangular solves; the solver wave's chain
+  // (Quu -> inverse) runs beside the two big products instead of between them.  F is double-buffered in LDS (the
+  // second buffer is the old T1 area): F_t is read until the middle of step t and F_{t-1} from there on.
+  // =====================================================================================================
   constexpr int SS = 17;
-  static_assert(RT == 3 && CX == 3 && CT - CX <= 1 && 2 * m <= n && m <= 16, "wave roles below: three matrix-core waves + one spare");
+  static_assert(RT == 3 && CX == 3 && CT - CX <= 1 && 2 * m <= n && m <= 16, "wave roles below: three matrix-core waves + the solver wave");
   static_assert(16 * (CT - 1) <= UC && UC + m <= 16 * CT, "Quu lies inside the last diagonal tile of H");
   constexpr int QO = UC - 16 * (CT - 1);                      // Quu's offset inside that tile
-  // Solver-wave state, alive across phases and steps: row i of L (lane i), 1/D, and this lane's
-  // column of D^{-1} Y whose back-substitution is deferred into the next step's phase A.
-  double arow[m], dinv[m], zcol[m];
+  static_assert(QO % 4 == 0, "the rows of Qux are whole result registers");
+  constexpr int R0 = QO / 4, MK = m / 4;
+  constexpr int QS = NP, WSS = 13, PS = 16 * SS;              // row strides (QS = 48: the four rows of a k-step on disjoint banks)
+  constexpr int FB1 = Ly::oT1 - Ly::oF;                       // F_t lives in buffer (N - 2 - t) & 1; the second buffer is the T1 area
+  double* QuxS = H;                                           // [m][QS]   Qux_t, exchanged between the waves
+  double* Ws = QuxS + m * QS;                                 // [16][WSS] Quu^{-1}, rows >= m zero (an A operand)
+  double* Kap = Ws + 16 * WSS;                                // [m]       kappa_t
+  double* Fo = Kap + m + (m & 1);                             // [NMP]     first-order column: Qx (rows < n), Qu (rows UC..)
+  double* Pq = Fo + Ly::NMP;                                  // [3][16][SS] the waves' shares of Quu - luu
+  static_assert(m * QS + 16 * WSS + m + 1 + Ly::NMP + 3 * PS <= Ly::NMP * TS, "the exchange buffers live in the H area");
+  static_assert(NK * FS <= NK * TS, "the second F buffer lives in the T1 area");
+  constexpr int NG = 3, GS = (KN + NG - 1) / NG;              // operand loads run a group of k-steps ahead of the MFMAs
+  const d4_t zero4 = {0.0, 0.0, 0.0, 0.0};
+  auto wave_lds_fence = [&]() __attribute__((always_inline)) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+  };
+  // first-order column of step ts: l_{x,u} + F^T Vx (:651-652); F_ts (buffer Fb) and Vx are in LDS
+  auto first_order = [&](int ts, const double* Fb) __attribute__((always_inline)) {
+    if (lane < nm) {
+      double s = Lxu[ts * nm + lane];
+      const int hp = lane < n ? lane : UC + (lane - n);      // this entry's column of F
+      constexpr int CH = (NK % 12 == 0) ? 12 : 4;            // a chunk's LDS reads are in flight together (rows >= n: zeros)
 #pragma unroll
-  for (int i = 0; i < m; ++i) { arow[i] = 0.0; dinv[i] = 0.0; zcol[i] = 0.0; }
-  // gains of step tk: K = L^{-T} (D^{-1} Y) (:659-660).  L[k][i] sits in lane k's registers and
-  // reaches every lane with one DPP64 row broadcast - no LDS traffic.
-  // All 64 lanes take part (every 16-lane DPP row holds a copy of L's rows and DPP reads from
-  // exec-masked lanes return 0); lanes beyond the n+1 right-hand sides compute on garbage and
-  // store nothing.
-  auto back_substitute = [&](int tk) __attribute__((always_inline)) {
-    BackSubst<m, m - 1>::run(arow, zcol);
-    if (lane < n) {
-      double* Kg = v.K + (size_t)tk * m * n + lane;                  // K_t[:, lane]
+      for (int k0 = 0; k0 < NK; k0 += CH) {
+        double fv[CH], vv[CH];
 #pragma unroll
-      for (int i = 0; i < m; ++i) Kg[i * n] = zcol[i];
-    } else if (lane == n) {
+        for (int k = 0; k < CH; ++k) { fv[k] = Fb[(k0 + k) * FS + hp]; vv[k] = Vx[k0 + k]; }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int i = 0; i < m; ++i) v.kap[(size_t)tk * m + i] = zcol[i];     // kappa_t
+        for (int k = 0; k < CH; ++k) s += fv[k] * vv[k];
+      }
+      Fo[hp] = s;
     }
   };
-  // 2 lxx = 2Q entries this lane adds to its Vxx tiles (phase D): constant over the sweep
+  // This wave's share of Quu_ts - luu = fu^T Vxx fu: vc = its column tile of the (symmetric) Vxx in the D layout, i.e.
+  // the A operand of  T1u[16w + r][a] = sum_k Vxx[16w + r][k] fu[k][a];  then  P_w = fu[16w.., :]^T T1u[16w.., :].
+  auto quu_share = [&](const d4_t (&vc)[RT], const double* Fb) __attribute__((always_inline)) {
+    const double* ub = Fb + lk * FS + 16 * (CT - 1) + lr;    // lane (lr, lk): F[4 ks + lk][u tile column lr]
+    double fu_[KN];
+#pragma unroll
+    for (int ks = 0; ks < KN; ++ks) fu_[ks] = ub[ks * 4 * FS];
+    __builtin_amdgcn_sched_barrier(0);
+    d4_t tu = zero4;
+#pragma unroll
+    for (int ks = 0; ks < KN; ++ks) tu = __builtin_amdgcn_mfma_f64_16x16x4f64(vc[ks >> 2][ks & 3], fu_[ks], tu, 0, 0, 0);
+    d4_t pw = zero4;
+    // rows 16w + 4 reg + lk of T1u = k-step 4w + reg; k-steps past the contraction length do not exist
+    // (wave-uniform switch: each arm is straight-line code with compile-time register indices)
+    auto arm = [&](auto wc) __attribute__((always_inline)) {
+      constexpr int w_ = decltype(wc)::value;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg)
+        if (4 * w_ + reg < KN) pw = __builtin_amdgcn_mfma_f64_16x16x4f64(fu_[4 * w_ + reg], tu[reg], pw, 0, 0, 0);
+    };
+    if (wave == 0) arm(std::integral_constant<int, 0>{});
+    else if (wave == 1) arm(std::integral_constant<int, 1>{});
+    else arm(std::integral_constant<int, 2>{});
+    double* pd = Pq + wave * PS + lk * SS + lr;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) pd[4 * reg * SS] = pw[reg];
+  };
+  for (int e = tid; e < NK * FS; e += kLargeThreads) F[FB1 + e] = 0.0;     // the second buffer's zero padding
+  for (int e = tid; e < 16 * WSS; e += kLargeThreads) Ws[e] = 0.0;
+  if (wave == 3) {
+    fetch(N - 2); publish(F);
+    if (N >= 3) { fetch(N - 3); }
+  }
+  __syncthreads();                                            // (buffer 1's padding is in place)
+  if (wave == 3) {
+    if (N >= 3) publish(F + FB1);
+    if (N >= 4) fetch(N - 4);
+  } else {
+    // the terminal Vxx, this wave's column tile in the D layout
+    d4_t vc[RT];
+#pragma unroll
+    for (int q = 0; q < RT; ++q)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) vc[q][reg] = (16 * wave + lr < n) ? Vxx[(16 * q + 4 * reg + lk) * VS + 16 * wave + lr] : 0.0;
+    quu_share(vc, F);
+  }
+  __syncthreads();
+  BP_TICK(15);
+  // 2 lxx = 2Q entries this lane adds to its Vxx tiles: constant over the sweep
   double q2[RT][4];
 #pragma unroll
   for (int q = 0; q < RT; ++q)
@@ -1097,199 +1245,177 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
       const int row = 16 * q + 4 * reg + lk, col = 16 * (wave < RT ? wave : 0) + lr;
       q2[q][reg] = (row < n && col < n) ? 2.0 * Q[row * n + col] : 0.0;
     }
+  // this lane's row of luu = 2R (solver wave; lanes >= m of each 16-lane row shadow the last row)
+  const int si = lr < m ? lr : m - 1;
+  double r2[m];
+#pragma unroll
+  for (int j = 0; j < m; ++j) r2[j] = 2.0 * R[si * m + j];
 
   for (int t = N - 2; t >= 0; --t) {
     BP_TICK(0);
-    // ---- phase A.  T1 = Vxx F : RT x CT tiles, K = n.  Operands of ALL of a wave's tiles are
-    //      loaded before the first MFMA (sched_barrier) so LDS latency is paid once, not per
-    //      k-step.  Wave w < CT owns column tile w and sweeps the RT row tiles, so every tile
-    //      offset is a compile-time immediate on top of one per-lane base address.
-    //      Spare wave: next step's F into registers; first-order column H[:, CV] = l_{x,u} + F^T Vx.
+    const double* Fc = F + ((N - 2 - t) & 1) * FB1;           // F_t
+    const double* Fn = F + ((N - 1 - t) & 1) * FB1;           // F_{t-1}, published a step ago
     if (wave < CX) {
+      // ---- T1[:, w] = Vxx F[:, w]; the A operands of the next product (F^T, all row tiles) arrive meanwhile
       const double* a_base = Vxx + lr * VS + lk;
-      const double* b_base = F + lk * FS + 16 * wave + lr;
-      double* d_base = T1 + lk * TS + 16 * wave + lr;
-      TileOps<KN> ops[RT];
-      d4_t accs[RT];
-      ops[0].load(a_base, 4, b_base, 4 * FS);
+      const double* b_base = Fc + lk * FS + 16 * wave + lr;
+      const double* ft = Fc + lk * FS + lr;                  // A = F^T: A[p][k] = F[k][p]
+      double va[RT][KN], fb[KN], fa[CT][KN];
+      auto load_group = [&](int g) __attribute__((always_inline)) {
 #pragma unroll
-      for (int q = 0; q < RT; ++q) {
-        // tile q+1's operands are requested before tile q's MFMAs are issued and land while the
-        // matrix core works; each tile has its own accumulator and all results are stored after
-        // the last MFMA, so the matrix pipe runs the wave's 27 instructions back to back
-        // (sched_barrier: the compiler may not sink loads to their use or hoist the stores)
-        if (q + 1 < RT) ops[q + 1].load(a_base + 16 * (q + 1) * VS, 4, b_base, 4 * FS);
-        __builtin_amdgcn_sched_barrier(0);
-        const d4_t zero = {0.0, 0.0, 0.0, 0.0};
-        accs[q] = ops[q].run(zero);
-      }
+        for (int ks = g * GS; ks < (g + 1) * GS && ks < KN; ++ks) {
+          fb[ks] = b_base[ks * 4 * FS];
+#pragma unroll
+          for (int q = 0; q < RT; ++q) va[q][ks] = a_base[16 * q * VS + 4 * ks];
+        }
+      };
+      auto load_fa = [&](int g) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ks = g * GS; ks < (g + 1) * GS && ks < KN; ++ks)
+#pragma unroll
+          for (int q = 0; q < CT; ++q) fa[q][ks] = ft[16 * q + ks * 4 * FS];
+      };
+      d4_t accA[RT];
+#pragma unroll
+      for (int q = 0; q < RT; ++q) accA[q] = zero4;
+      load_group(0);
+      load_group(1);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int q = 0; q < RT; ++q) {
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const int ib = 16 * q + 4 * reg;                 // rows ib + lk, lk = 0..3
-          if (ib + 3 < n) d_base[ib * TS] = accs[q][reg];
-          else if (ib < n) { if (ib + lk < n) d_base[ib * TS] = accs[q][reg]; }
-        }
-      }
-      if constexpr (SPLIT) {
-        // u's own column tile of T1 (= Vxx fu): its RT row tiles are dealt one to each matrix-core wave
-        TileOps<KN> ou;
-        ou.load(a_base + 16 * wave * VS, 4, F + lk * FS + 16 * (CT - 1) + lr, 4 * FS);
-        const d4_t zero = {0.0, 0.0, 0.0, 0.0};
-        const d4_t au = ou.run(zero);
-        double* du = T1 + lk * TS + 16 * (CT - 1) + lr;
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const int ib = 16 * wave + 4 * reg;
-          if (ib + lk < n) du[ib * TS] = au[reg];
-        }
-      }
-    } else {
-      if (t > 0) fetch(t - 1);
-      BP_TICK(5);
-      if (lane < nm) {                                     // (:651-652) lx_t / lu_t precomputed for all t
-        double s = Lxu[t * nm + lane];
-        const int hp = lane < n ? lane : UC + (lane - n);  // this entry's column of F / row of H
-        constexpr int CH = (NK % 12 == 0) ? 12 : 4;        // a chunk's LDS reads are in flight together (rows >= n: zeros)
-#pragma unroll
-        for (int k0 = 0; k0 < NK; k0 += CH) {
-          double fv[CH], vv[CH];
-#pragma unroll
-          for (int k = 0; k < CH; ++k) { fv[k] = F[(k0 + k) * FS + hp]; vv[k] = Vx[k0 + k]; }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int k = 0; k < CH; ++k) s += fv[k] * vv[k];
-        }
-        H[hp * TS + CV] = s;
-      }
-      BP_TICK(6);
-      if (t < N - 2) back_substitute(t + 1);               // previous step's gains, off the recursion
-      BP_TICK(9);
-    }
-    lds_barrier();
-    BP_TICK(1);
-    // ---- phase B.  H = F^T T1 : CT x CT tiles, K = n.  Meanwhile the spare wave recomputes the
-    //      one tile that contains Quu - luu (bitwise the tile wave CT-1 stores), turns it into one
-    //      row per lane through a private LDS scratch and factorizes Quu = 2R + fu^T Vxx fu (:654)
-    //      = L D L^T (DPP row broadcasts, no barriers): the factorization is off the critical path.
-    if (wave < CX) {
-      const double* a_base = F + lk * FS + lr;                       // A = F^T: A[p][k] = F[k][p]
-      const double* b_base = T1 + lk * TS + 16 * wave + lr;
-      double* d_base = H + lk * TS + 16 * wave + lr;
-      TileOps<KN> ops[CT];
-      d4_t accs[CT];
-      ops[0].load(a_base, 4 * FS, b_base, 4 * TS);
-#pragma unroll
-      for (int q = 0; q < CT; ++q) {
-        if (q + 1 < CT) ops[q + 1].load(a_base + 16 * (q + 1), 4 * FS, b_base, 4 * TS);
+      for (int g = 0; g < NG; ++g) {
+        if (g + 2 < NG) load_group(g + 2); else load_fa(g + 2 - NG);
         __builtin_amdgcn_sched_barrier(0);
-        const d4_t zero = {0.0, 0.0, 0.0, 0.0};
-        accs[q] = ops[q].run(zero);
+#pragma unroll
+        for (int ks = g * GS; ks < (g + 1) * GS && ks < KN; ++ks)
+#pragma unroll
+          for (int q = 0; q < RT; ++q) accA[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(va[q][ks], fb[ks], accA[q], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
+      BP_TICK(1);
+      // ---- H[:, w] = F^T T1[:, w], T1 from the accumulators
+      d4_t accB[CT];
+#pragma unroll
+      for (int q = 0; q < CT; ++q) accB[q] = zero4;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        if (g + 2 < NG) load_fa(g + 2);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = g * GS; ks < (g + 1) * GS && ks < KN; ++ks)
+#pragma unroll
+          for (int q = 0; q < CT; ++q) accB[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[q][ks], accA[ks >> 2][ks & 3], accB[q], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // the m rows of Qux this wave holds (rows UC + 4j + lk, column 16w + lr) -> every wave
+      double qux[MK];
+#pragma unroll
+      for (int j = 0; j < MK; ++j) {
+        qux[j] = accB[CT - 1][R0 + j];
+        QuxS[(4 * j + lk) * QS + 16 * wave + lr] = qux[j];
+      }
+      BP_TICK(2);
+      lds_barrier();
+      BP_TICK(3);
+      // ---- K[:, w] = Quu^{-1} Qux[:, w] (:660), Vxx'[:, w] = Qxx[:, w] + 2Q - Qux^T K[:, w] (:667)
+      double wa[MK], qa[RT][MK];
+#pragma unroll
+      for (int j = 0; j < MK; ++j) wa[j] = Ws[lr * WSS + 4 * j + lk];
+#pragma unroll
+      for (int q = 0; q < RT; ++q)
+#pragma unroll
+        for (int j = 0; j < MK; ++j) qa[q][j] = QuxS[(4 * j + lk) * QS + 16 * q + lr];
       __builtin_amdgcn_sched_barrier(0);
+      d4_t kt = zero4;
 #pragma unroll
-      for (int q = 0; q < CT; ++q)
+      for (int j = 0; j < MK; ++j) kt = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[j], qux[j], kt, 0, 0, 0);
+      d4_t accD[RT];
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) d_base[(16 * q + 4 * reg) * TS] = accs[q][reg];
-    } else {
-      TileOps<KN> op;
-      op.load(F + lk * FS + 16 * (CT - 1) + lr, 4 * FS, T1 + lk * TS + 16 * (CT - 1) + lr, 4 * TS);
-      d4_t acc = {0.0, 0.0, 0.0, 0.0};
-      acc = op.run(acc);
+      for (int q = 0; q < RT; ++q)
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) Sq[(lk + 4 * reg) * SS + lr] = acc[reg];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
-      BP_TICK(7);
-      const int i = lr < m ? lr : m - 1;                   // lanes >= m of each 16-lane row shadow the last row
+        for (int reg = 0; reg < 4; ++reg) accD[q][reg] = accB[q][reg] + q2[q][reg];
+      const int col = 16 * wave + lr;
+      const bool col_ok = col < n;
+      if (col_ok) {
+        double* Kg = v.K + (size_t)t * m * n + col;          // K_t[4 reg + lk][col]
 #pragma unroll
-      for (int j = 0; j < m; ++j) arow[j] = 2.0 * R[i * m + j] + Sq[(QO + i) * SS + QO + j];
-      LdlOuter<m, 0>::run(arow, dinv);                     // lane i < m: arow[k] = L[i][k], k < i
-      BP_TICK(8);
-    }
-    lds_barrier();
-    BP_TICK(2);
-    // ---- phase C (solver wave only).  Forward substitution Y = L^{-1} [Qux | Qu], one right-hand
-    //      side per lane, L through v_readlane.  The recursion needs just Y:
-    //      Qux^T Quu^{-1} Qux = Y^T D^{-1} Y  (:666-667).  T1 rows [0,m) <- D^{-1}Y, rows [m,2m) <- Y.
-    if (wave == 3) {
-      double y[m];
-      const int rhs = lane < n ? lane : CV;                 // lanes > n shadow the Qu column, store nothing
-#pragma unroll
-      for (int i = 0; i < m; ++i) y[i] = H[(UC + i) * TS + rhs];
-      FwdSubst<m, 1>::run(arow, y);
-      double dv = 0.0;
-#pragma unroll
-      for (int i = 0; i < m; ++i) {
-        zcol[i] = y[i] * dinv[i];
-        dv = fma(y[i], zcol[i], dv);                        // Qu^T Quu^{-1} Qu = y_u^T D^{-1} y_u (:663)
+        for (int j = 0; j < MK; ++j) Kg[(4 * j + lk) * n] = kt[j];
       }
-      if (lane <= n) {
+      double nk[MK];
 #pragma unroll
-        for (int i = 0; i < m; ++i) { T1[(m + i) * TS + rhs] = y[i]; T1[i * TS + rhs] = zcol[i]; }
-      }
-      if (lane == n) v.dV[t] = dv;
-    }
-    lds_barrier();
-    BP_TICK(3);
-    // ---- phase D.  Vxx = Qxx - Y^T (D^{-1} Y) : RT x RT tiles, K = m (:667).
-    //      Solver wave: Vx = Qx - Y^T D^{-1} y_u (:666); next step's F into LDS (F is free after B).
-    if (wave < RT) {
-      const double* a_base = T1 + (m + lk) * TS + lr;                // A = Y^T: A[i][a] = Y[a][i]
-      const double* b_base = T1 + lk * TS + 16 * wave + lr;          // B = D^{-1} Y
-      const double* c_base = H + lk * TS + 16 * wave + lr;           // C = Qxx - lxx
+      for (int j = 0; j < MK; ++j) nk[j] = -kt[j];
+#pragma unroll
+      for (int j = 0; j < MK; ++j)
+#pragma unroll
+        for (int q = 0; q < RT; ++q) accD[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[q][j], nk[j], accD[q], 0, 0, 0);
       double* d_base = Vxx + lk * VS + 16 * wave + lr;
-      const bool col_ok = 16 * wave + lr < n;
-      TileOps<m / 4> ops[RT];
-      d4_t accs[RT];
-#pragma unroll
-      for (int q = 0; q < RT; ++q) {
-        ops[q].load(a_base + 16 * q, 4 * TS, b_base, 4 * TS);
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) accs[q][reg] = c_base[(16 * q + 4 * reg) * TS];   // pad rows/cols: in-bounds, never stored
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int q = 0; q < RT; ++q) {
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) accs[q][reg] += q2[q][reg];
-#pragma unroll
-        for (int ks = 0; ks < m / 4; ++ks) ops[q].av[ks] = -ops[q].av[ks];
-        accs[q] = ops[q].run(accs[q]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int q = 0; q < RT; ++q) {
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
           const int ib = 16 * q + 4 * reg;
           const bool ok = col_ok && (ib + 3 < n || (ib < n && ib + lk < n));
-          if (ok) d_base[ib * VS] = accs[q][reg];
+          if (ok) d_base[ib * VS] = accD[q][reg];
         }
       }
+      BP_TICK(4);
+      // ---- this wave's share of the NEXT step's Quu, from the Vxx' it still holds (rows / columns past n: the
+      //      k-steps stop at the contraction length, and what lies between n and it is exact zeros - F's padding)
+      if (t > 0) quu_share(accD, Fn);
       BP_TICK(12);
     } else {
-      if (lane < n) {
-        double ya[m], za[m];
+      // ---- solver wave: Quu = 2R + the three shares (:654), inverted one row per lane; the step's first-order column
+      double arow[m];
+      {
+        const double* p0 = Pq + (QO + si) * SS + QO;
 #pragma unroll
-        for (int a_ = 0; a_ < m; ++a_) { ya[a_] = T1[(m + a_) * TS + lane]; za[a_] = T1[a_ * TS + CV]; }
-        double s = H[lane * TS + CV];
+        for (int j = 0; j < m; ++j) arow[j] = r2[j] + ((p0[j] + p0[PS + j]) + p0[2 * PS + j]);
+      }
+      BP_TICK(5);
+      double sc = 1.0;
+      GjOuter<m, 0>::run(arow, sc, si);                      // Quu^{-1}[si][j] = sc * arow[j]
+      if (lane < m) {
+#pragma unroll
+        for (int j = 0; j < m; ++j) Ws[lane * WSS + j] = sc * arow[j];
+      }
+      BP_TICK(6);
+      first_order(t, Fc);
+      BP_TICK(7);
+      lds_barrier();
+      BP_TICK(8);
+      // kappa = Quu^{-1} Qu (:659), dV = Qu^T kappa (:663), Vx' = Qx - Qux^T kappa (:666)
+      double kp = 0.0;
+      {
+        double qu[m];
+#pragma unroll
+        for (int j = 0; j < m; ++j) qu[j] = Fo[UC + j];
+#pragma unroll
+        for (int j = 0; j < m; ++j) kp = fma(arow[j], qu[j], kp);
+        kp *= sc;
+        const double dv = row16_sum(lr < m ? Fo[UC + si] * kp : 0.0);
+        if (lane < m) { Kap[lane] = kp; v.kap[(size_t)t * m + lane] = kp; }
+        if (lane == 0) v.dV[t] = dv;
+      }
+      wave_lds_fence();
+      if (lane < n) {
+        double qc[m], kc[m];
+#pragma unroll
+        for (int a_ = 0; a_ < m; ++a_) { qc[a_] = QuxS[a_ * QS + lane]; kc[a_] = Kap[a_]; }
+        double s = Fo[lane];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int a_ = 0; a_ < m; ++a_) s -= ya[a_] * za[a_];
+        for (int a_ = 0; a_ < m; ++a_) s -= qc[a_] * kc[a_];
         Vx[lane] = s;
       }
+      BP_TICK(9);
+      if (t > 1) {
+        publish(const_cast<double*>(Fc));                    // F_{t-2} replaces F_t, which nobody reads any more
+        if (t > 2) fetch(t - 3);
+      }
       BP_TICK(10);
-      if (t > 0) publish();
-      BP_TICK(11);
     }
     lds_barrier();
-    BP_TICK(4);
+    BP_TICK(11);
   }
-  if (wave == 3) back_substitute(0);
 }
 
 template <class M, int JAC, int MODE>

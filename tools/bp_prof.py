@@ -1,17 +1,38 @@
-"""Phase profile of the workgroup-per-problem backward pass (needs a -DMI_PROF_BACKWARD build): cycles per phase A/B/C/D."""
-import sys, numpy as np
+"""Phase profile of the workgroup-per-problem backward pass (csrc/ilqr_large.hpp: large_backward, fused chain).
+
+Builds its own -DMI_PROF_BACKWARD library (lib/libmi_ilqr_bpprof.so: per-wave stopwatches between the phases, thread 0 =
+a matrix-core wave, thread 192 = the solver wave) and prints cycles per step.
+
+    python tools/bp_prof.py [synth36|quad3d]
+"""
+import os, sys
 sys.path.insert(0, ".")
+from drake_ddp_amd import build as B
+lib = os.path.join(B.LIBDIR, "libmi_ilqr_bpprof.so")
+B.build(verbose=False, extra=["-DMI_PROF_BACKWARD"], lib=lib)
+os.environ["MI_ILQR_LIB"] = lib
+import numpy as np
 from drake_ddp_amd import workloads as W
 from drake_ddp_amd.ilqr import BatchedIterativeLQR
 from drake_ddp_amd.models import ModelSystem
-q = W.synth36_problem(); N = q["N"]
+
+which = sys.argv[1] if len(sys.argv) > 1 else "synth36"
+if which == "quad3d":
+    q = W.quad3d_problem(); x0 = W.quad3d_batch_x0(1); ug = W.quad3d_u_guess(q["N"])
+else:
+    q = W.synth36_problem(); x0 = W.synth36_batch_x0(64)[:1]; ug = W.synth36_u_guess(q["N"])
+N = q["N"]
 s = BatchedIterativeLQR(ModelSystem(q["model_id"], q["dt"]), N, 1, delta=q["delta"], beta=q["beta"], gamma=q["gamma"], jacobian_mode="ad")
 s.SetTargetState(q["x_nom"]); s.SetRunningCost(q["Q"], q["R"]); s.SetTerminalCost(q["Qf"])
-s.SetInitialState(W.synth36_batch_x0(64)[:1]); s.SetInitialGuess(W.synth36_u_guess(N))
+s.SetInitialState(x0); s.SetInitialGuess(ug)
 s.Solve()
 H = s.history[0]; cap = H.shape[0]
-w0 = H[cap - 4:cap].reshape(-1) / 39; w3 = H[cap - 8:cap - 4].reshape(-1) / 39
-print("matrix-core wave 0, cycles/step: top %.0f  A %.0f  B %.0f  C %.0f  D-work %.0f  D-wait %.0f   (sum %.0f)" % (w0[0], w0[1], w0[2], w0[3], w0[12], w0[4], w0[[0,1,2,3,4,12]].sum()))
-print("solver wave 3,      cycles/step: top %.0f  A: fetch %.0f  F^T Vx %.0f  back-subst(t+1) %.0f  wait %.0f | B: Quu tile %.0f  LDL %.0f  wait %.0f | C fwd-subst %.0f | D: Vx %.0f  publish %.0f  wait %.0f" % (w3[0], w3[5], w3[6], w3[9], w3[1], w3[7], w3[8], w3[2], w3[3], w3[10], w3[11], w3[4]))
-print("prologue, cycles per backward pass (wave 0): init stores + terminal Vx %.0f  cost gradients %.0f  first F fetch+publish %.0f  rest %.0f" % (39*w0[13], 39*w0[14], 39*w0[15], 39*w0[0]))
-print("  cost gradients split (wave 0): staging %.0f  dot products %.0f  barrier wait %.0f  zeroing+sync %.0f" % (39*w0[5], 39*w0[6], 39*w0[7], 39*w0[14]))
+st = N - 1
+w0 = H[cap - 4:cap].reshape(-1) / st; w3 = H[cap - 8:cap - 4].reshape(-1) / st
+print(f"{which}: n = {q['x_nom'].size}, {st} steps; cycles per step")
+print("matrix-core wave 0: T1 = Vxx F %.0f | H = F^T T1 + Qux store %.0f | wait %.0f || K, Vxx' + stores %.0f | share of the next Quu %.0f | wait %.0f   (sum %.0f)"
+      % (w0[1], w0[2], w0[3], w0[4], w0[12], w0[11], w0[[0, 1, 2, 3, 4, 11, 12]].sum()))
+print("solver wave:        gather Quu %.0f | Gauss-Jordan + store %.0f | first-order column %.0f | wait %.0f || kappa, dV, Vx' %.0f | publish F, prefetch %.0f | wait %.0f   (sum %.0f)"
+      % (w3[5], w3[6], w3[7], w3[8], w3[9], w3[10], w3[11], w3[[0, 5, 6, 7, 8, 9, 10, 11]].sum()))
+print("prologue, cycles per backward pass (wave 0): init stores + terminal Vx %.0f  cost gradients %.0f  first F fetch+publish %.0f"
+      % (st * w0[13], st * w0[14], st * w0[15]))
