@@ -1161,7 +1161,8 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
   double* Kap = Ws + 16 * WSS;                                // [m]       kappa_t
   double* Fo = Kap + m + (m & 1);                             // [NMP]     first-order column: Qx (rows < n), Qu (rows UC..)
   double* Pq = Fo + Ly::NMP;                                  // [3][16][SS] the waves' shares of Quu - luu
-  static_assert(m * QS + 16 * WSS + m + 1 + Ly::NMP + 3 * PS <= Ly::NMP * TS, "the exchange buffers live in the H area");
+  double* Xt = Pq + 3 * PS;                                   // [3][16][SS] the off-diagonal Qxx tiles, transposed for their mirror's owner
+  static_assert(m * QS + 16 * WSS + m + 1 + Ly::NMP + 6 * PS <= Ly::NMP * TS, "the exchange buffers live in the H area");
   static_assert(NK * FS <= NK * TS, "the second F buffer lives in the T1 area");
   constexpr int NG = 3, GS = (KN + NG - 1) / NG;              // operand loads run a group of k-steps ahead of the MFMAs
   const d4_t zero4 = {0.0, 0.0, 0.0, 0.0};
@@ -1170,110 +1171,88 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
   };
-  // first-order column of step ts: l_{x,u} + F^T Vx (:651-652); F_ts (buffer Fb) and Vx are in LDS
-  auto first_order = [&](int ts, const double* Fb) __attribute__((always_inline)) {
-    if (lane < nm) {
-      double s = Lxu[ts * nm + lane];
-      const int hp = lane < n ? lane : UC + (lane - n);      // this entry's column of F
-      constexpr int CH = (NK % 12 == 0) ? 12 : 4;            // a chunk's LDS reads are in flight together (rows >= n: zeros)
-#pragma unroll
-      for (int k0 = 0; k0 < NK; k0 += CH) {
-        double fv[CH], vv[CH];
-#pragma unroll
-        for (int k = 0; k < CH; ++k) { fv[k] = Fb[(k0 + k) * FS + hp]; vv[k] = Vx[k0 + k]; }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int k = 0; k < CH; ++k) s += fv[k] * vv[k];
-      }
-      Fo[hp] = s;
-    }
-  };
-  // This wave's share of Quu_ts - luu = fu^T Vxx fu: vc = its column tile of the (symmetric) Vxx in the D layout, i.e.
-  // the A operand of  T1u[16w + r][a] = sum_k Vxx[16w + r][k] fu[k][a];  then  P_w = fu[16w.., :]^T T1u[16w.., :].
-  auto quu_share = [&](const d4_t (&vc)[RT], const double* Fb) __attribute__((always_inline)) {
-    const double* ub = Fb + lk * FS + 16 * (CT - 1) + lr;    // lane (lr, lk): F[4 ks + lk][u tile column lr]
-    double fu_[KN];
-#pragma unroll
-    for (int ks = 0; ks < KN; ++ks) fu_[ks] = ub[ks * 4 * FS];
-    __builtin_amdgcn_sched_barrier(0);
-    d4_t tu = zero4;
-#pragma unroll
-    for (int ks = 0; ks < KN; ++ks) tu = __builtin_amdgcn_mfma_f64_16x16x4f64(vc[ks >> 2][ks & 3], fu_[ks], tu, 0, 0, 0);
-    d4_t pw = zero4;
-    // rows 16w + 4 reg + lk of T1u = k-step 4w + reg; k-steps past the contraction length do not exist
-    // (wave-uniform switch: each arm is straight-line code with compile-time register indices)
-    auto arm = [&](auto wc) __attribute__((always_inline)) {
-      constexpr int w_ = decltype(wc)::value;
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg)
-        if (4 * w_ + reg < KN) pw = __builtin_amdgcn_mfma_f64_16x16x4f64(fu_[4 * w_ + reg], tu[reg], pw, 0, 0, 0);
-    };
-    if (wave == 0) arm(std::integral_constant<int, 0>{});
-    else if (wave == 1) arm(std::integral_constant<int, 1>{});
-    else arm(std::integral_constant<int, 2>{});
-    double* pd = Pq + wave * PS + lk * SS + lr;
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) pd[4 * reg * SS] = pw[reg];
-  };
   for (int e = tid; e < NK * FS; e += kLargeThreads) F[FB1 + e] = 0.0;     // the second buffer's zero padding
   for (int e = tid; e < 16 * WSS; e += kLargeThreads) Ws[e] = 0.0;
   if (wave == 3) {
     fetch(N - 2); publish(F);
-    if (N >= 3) { fetch(N - 3); }
+    if (N >= 3) fetch(N - 3);
   }
   __syncthreads();                                            // (buffer 1's padding is in place)
-  if (wave == 3) {
-    if (N >= 3) publish(F + FB1);
-    if (N >= 4) fetch(N - 4);
-  } else {
-    // the terminal Vxx, this wave's column tile in the D layout
+  BP_TICK(15);
+
+  // ------------------------------------------------------------------------------------------------------------
+  // Matrix-core wave W (a compile-time role: every tile offset is an immediate and every register index static).
+  // Of the symmetric Qxx block of H it computes the diagonal tile (W, W) and the tile ((W+1)%3, W); the third tile of
+  // its column, ((W+2)%3, W), is the mirror of what wave (W+2)%3 computes and crosses through LDS transposed.
+  // ------------------------------------------------------------------------------------------------------------
+  auto matrix_role = [&](auto wc) __attribute__((always_inline)) {
+    constexpr int W_ = decltype(wc)::value;
+    constexpr int Q1 = (W_ + 1) % 3, Q2 = (W_ + 2) % 3;       // row tiles: off-diagonal computed here / received
+    constexpr bool kHasU = SPLIT;                            // u's rows of H are a tile of their own (row tile CT - 1)
+    // where this wave finds the rows of Qux among its result tiles (compact layout: inside x's last row tile)
+    constexpr bool kQuxDiag = !SPLIT && W_ == CT - 1, kQuxOff = !SPLIT && Q1 == CT - 1;
+    const int col = 16 * W_ + lr;
+    const bool col_ok = col < n;
+    // This wave's share of Quu_ts - luu = fu^T Vxx fu: vc = its column tile of the (symmetric) Vxx in the D layout,
+    // i.e. the A operand of  T1u[16W + r][a] = sum_k Vxx[16W + r][k] fu[k][a];  then  P_W = fu[16W.., :]^T T1u[16W.., :].
+    auto quu_share = [&](const d4_t (&vc)[RT], const double (&fu_)[KN]) __attribute__((always_inline)) {
+      d4_t tu = zero4;
+#pragma unroll
+      for (int ks = 0; ks < KN; ++ks) tu = __builtin_amdgcn_mfma_f64_16x16x4f64(vc[ks >> 2][ks & 3], fu_[ks], tu, 0, 0, 0);
+      d4_t pw = zero4;
+      // rows 16W + 4 reg + lk of T1u = k-step 4W + reg; k-steps past the contraction length do not exist
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg)
+        if (4 * W_ + reg < KN) pw = __builtin_amdgcn_mfma_f64_16x16x4f64(fu_[4 * W_ + reg], tu[reg], pw, 0, 0, 0);
+      double* pd = Pq + W_ * PS + lk * SS + lr;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) pd[4 * reg * SS] = pw[reg];
+    };
+    auto load_fu = [&](double (&fu_)[KN], const double* Fb) __attribute__((always_inline)) {
+      const double* ub = Fb + lk * FS + 16 * (CT - 1) + lr;  // lane (lr, lk): F[4 ks + lk][u tile column lr]
+#pragma unroll
+      for (int ks = 0; ks < KN; ++ks) fu_[ks] = ub[ks * 4 * FS];
+    };
+    // the terminal Vxx, this wave's column tile in the D layout, and its share of the first Quu
     d4_t vc[RT];
 #pragma unroll
     for (int q = 0; q < RT; ++q)
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) vc[q][reg] = (16 * wave + lr < n) ? Vxx[(16 * q + 4 * reg + lk) * VS + 16 * wave + lr] : 0.0;
-    quu_share(vc, F);
-  }
-  __syncthreads();
-  BP_TICK(15);
-  // 2 lxx = 2Q entries this lane adds to its Vxx tiles: constant over the sweep
-  double q2[RT][4];
-#pragma unroll
-  for (int q = 0; q < RT; ++q)
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int row = 16 * q + 4 * reg + lk, col = 16 * (wave < RT ? wave : 0) + lr;
-      q2[q][reg] = (row < n && col < n) ? 2.0 * Q[row * n + col] : 0.0;
+      for (int reg = 0; reg < 4; ++reg) vc[q][reg] = col_ok ? Vxx[(16 * q + 4 * reg + lk) * VS + col] : 0.0;
+    {
+      double fu_[KN];
+      load_fu(fu_, F);
+      quu_share(vc, fu_);
     }
-  // this lane's row of luu = 2R (solver wave; lanes >= m of each 16-lane row shadow the last row)
-  const int si = lr < m ? lr : m - 1;
-  double r2[m];
+    // 2 lxx = 2Q entries this lane adds to its Vxx tiles: constant over the sweep
+    double q2[RT][4];
 #pragma unroll
-  for (int j = 0; j < m; ++j) r2[j] = 2.0 * R[si * m + j];
-
-  for (int t = N - 2; t >= 0; --t) {
-    BP_TICK(0);
-    const double* Fc = F + ((N - 2 - t) & 1) * FB1;           // F_t
-    const double* Fn = F + ((N - 1 - t) & 1) * FB1;           // F_{t-1}, published a step ago
-    if (wave < CX) {
-      // ---- T1[:, w] = Vxx F[:, w]; the A operands of the next product (F^T, all row tiles) arrive meanwhile
-      const double* a_base = Vxx + lr * VS + lk;
-      const double* b_base = Fc + lk * FS + 16 * wave + lr;
-      const double* ft = Fc + lk * FS + lr;                  // A = F^T: A[p][k] = F[k][p]
-      double va[RT][KN], fb[KN], fa[CT][KN];
+    for (int q = 0; q < RT; ++q)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int row = 16 * q + 4 * reg + lk;
+        q2[q][reg] = (row < n && col_ok) ? 2.0 * Q[row * n + col] : 0.0;
+      }
+    __syncthreads();
+    for (int t = N - 2; t >= 0; --t) {
+      BP_TICK(0);
+      const double* Fc = F + ((N - 2 - t) & 1) * FB1;         // F_t
+      const double* Fn = F + ((N - 1 - t) & 1) * FB1;         // F_{t-1}, published a step ago
+      // ---- T1[:, W] = Vxx F[:, W].  Row tile W of Vxx is this wave's own column tile, mirrored: already in registers
+      //      (vc, from the previous step); the other two row tiles and F come from LDS, a group of k-steps ahead.
+      const double* a1 = Vxx + (16 * Q1 + lr) * VS + lk;
+      const double* a2 = Vxx + (16 * Q2 + lr) * VS + lk;
+      const double* b_base = Fc + lk * FS + 16 * W_ + lr;    // also A = F^T of the diagonal tile: A[p][k] = F[k][16W + p]
+      const double* f1 = Fc + lk * FS + 16 * Q1 + lr;        // A = F^T, row tile Q1
+      const double* f3 = Fc + lk * FS + 16 * (CT - 1) + lr;  // A = F^T, u's row tile (split layout)
+      double va1[KN], va2[KN], fb[KN], fo[KN], fuu[kHasU ? KN : 1];
       auto load_group = [&](int g) __attribute__((always_inline)) {
 #pragma unroll
-        for (int ks = g * GS; ks < (g + 1) * GS && ks < KN; ++ks) {
-          fb[ks] = b_base[ks * 4 * FS];
-#pragma unroll
-          for (int q = 0; q < RT; ++q) va[q][ks] = a_base[16 * q * VS + 4 * ks];
-        }
+        for (int ks = g * GS; ks < (g + 1) * GS && ks < KN; ++ks) { fb[ks] = b_base[ks * 4 * FS]; va1[ks] = a1[4 * ks]; va2[ks] = a2[4 * ks]; }
       };
       auto load_fa = [&](int g) __attribute__((always_inline)) {
 #pragma unroll
-        for (int ks = g * GS; ks < (g + 1) * GS && ks < KN; ++ks)
-#pragma unroll
-          for (int q = 0; q < CT; ++q) fa[q][ks] = ft[16 * q + ks * 4 * FS];
+        for (int ks = g * GS; ks < (g + 1) * GS && ks < KN; ++ks) { fo[ks] = f1[ks * 4 * FS]; if constexpr (kHasU) fuu[ks] = f3[ks * 4 * FS]; }
       };
       d4_t accA[RT];
 #pragma unroll
@@ -1286,84 +1265,136 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
         if (g + 2 < NG) load_group(g + 2); else load_fa(g + 2 - NG);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int ks = g * GS; ks < (g + 1) * GS && ks < KN; ++ks)
-#pragma unroll
-          for (int q = 0; q < RT; ++q) accA[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(va[q][ks], fb[ks], accA[q], 0, 0, 0);
+        for (int ks = g * GS; ks < (g + 1) * GS && ks < KN; ++ks) {
+          accA[W_] = __builtin_amdgcn_mfma_f64_16x16x4f64(vc[ks >> 2][ks & 3], fb[ks], accA[W_], 0, 0, 0);
+          accA[Q1] = __builtin_amdgcn_mfma_f64_16x16x4f64(va1[ks], fb[ks], accA[Q1], 0, 0, 0);
+          accA[Q2] = __builtin_amdgcn_mfma_f64_16x16x4f64(va2[ks], fb[ks], accA[Q2], 0, 0, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
       BP_TICK(1);
-      // ---- H[:, w] = F^T T1[:, w], T1 from the accumulators
-      d4_t accB[CT];
-#pragma unroll
-      for (int q = 0; q < CT; ++q) accB[q] = zero4;
+      // ---- H[:, W] = F^T T1[:, W], T1 from the accumulators: the diagonal tile, one off-diagonal tile, u's rows
+      d4_t bd = zero4, bo = zero4, bu = zero4;
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
         if (g + 2 < NG) load_fa(g + 2);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int ks = g * GS; ks < (g + 1) * GS && ks < KN; ++ks)
-#pragma unroll
-          for (int q = 0; q < CT; ++q) accB[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[q][ks], accA[ks >> 2][ks & 3], accB[q], 0, 0, 0);
+        for (int ks = g * GS; ks < (g + 1) * GS && ks < KN; ++ks) {
+          bd = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[ks], accA[ks >> 2][ks & 3], bd, 0, 0, 0);
+          bo = __builtin_amdgcn_mfma_f64_16x16x4f64(fo[ks], accA[ks >> 2][ks & 3], bo, 0, 0, 0);
+          if constexpr (kHasU) bu = __builtin_amdgcn_mfma_f64_16x16x4f64(fuu[ks], accA[ks >> 2][ks & 3], bu, 0, 0, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
-      // the m rows of Qux this wave holds (rows UC + 4j + lk, column 16w + lr) -> every wave
-      double qux[MK];
+      // the off-diagonal tile, transposed, for the owner of its mirror; the rows of Qux this wave has -> every wave
+      {
+        double* xd = Xt + W_ * PS + lr * SS + lk;
 #pragma unroll
-      for (int j = 0; j < MK; ++j) {
-        qux[j] = accB[CT - 1][R0 + j];
-        QuxS[(4 * j + lk) * QS + 16 * wave + lr] = qux[j];
+        for (int reg = 0; reg < 4; ++reg) xd[4 * reg] = bo[reg];
+        if constexpr (kHasU || kQuxDiag || kQuxOff) {
+          const d4_t& src = kHasU ? bu : (kQuxDiag ? bd : bo);
+#pragma unroll
+          for (int j = 0; j < MK; ++j) QuxS[(4 * j + lk) * QS + col] = src[R0 + j];
+        }
+        if constexpr (!SPLIT && W_ == CT - 1) {
+          // compact layout: nobody computes the tile (CT-1, Q1) that holds Qux's columns of tile Q1 - they are the
+          // mirror of this wave's off-diagonal tile (Q1, CT-1): rows 4 reg + lk, columns QO.. = u
+          if (lr >= QO) {
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) QuxS[(lr - QO) * QS + 16 * Q1 + 4 * reg + lk] = bo[reg];
+          }
+        }
       }
       BP_TICK(2);
       lds_barrier();
       BP_TICK(3);
-      // ---- K[:, w] = Quu^{-1} Qux[:, w] (:660), Vxx'[:, w] = Qxx[:, w] + 2Q - Qux^T K[:, w] (:667)
-      double wa[MK], qa[RT][MK];
+      // ---- K[:, W] = Quu^{-1} Qux[:, W] (:660), Vxx'[:, W] = Qxx[:, W] + 2Q - Qux^T K[:, W] (:667)
+      double wa[MK], qux[MK], qa[RT][MK], fu_[KN];
+      d4_t cm;
 #pragma unroll
-      for (int j = 0; j < MK; ++j) wa[j] = Ws[lr * WSS + 4 * j + lk];
+      for (int j = 0; j < MK; ++j) { wa[j] = Ws[lr * WSS + 4 * j + lk]; qux[j] = QuxS[(4 * j + lk) * QS + col]; }
 #pragma unroll
       for (int q = 0; q < RT; ++q)
 #pragma unroll
-        for (int j = 0; j < MK; ++j) qa[q][j] = QuxS[(4 * j + lk) * QS + 16 * q + lr];
+        for (int j = 0; j < MK; ++j) qa[q][j] = -QuxS[(4 * j + lk) * QS + 16 * q + lr];
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) cm[reg] = Xt[Q2 * PS + (4 * reg + lk) * SS + lr];
+      if (t > 0) load_fu(fu_, Fn);
       __builtin_amdgcn_sched_barrier(0);
       d4_t kt = zero4;
 #pragma unroll
       for (int j = 0; j < MK; ++j) kt = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[j], qux[j], kt, 0, 0, 0);
-      d4_t accD[RT];
 #pragma unroll
-      for (int q = 0; q < RT; ++q)
+      for (int reg = 0; reg < 4; ++reg) {
+        vc[W_][reg] = bd[reg] + q2[W_][reg];
+        vc[Q1][reg] = bo[reg] + q2[Q1][reg];
+        vc[Q2][reg] = cm[reg] + q2[Q2][reg];
+      }
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) accD[q][reg] = accB[q][reg] + q2[q][reg];
-      const int col = 16 * wave + lr;
-      const bool col_ok = col < n;
+      for (int j = 0; j < MK; ++j)
+#pragma unroll
+        for (int q = 0; q < RT; ++q) vc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[q][j], kt[j], vc[q], 0, 0, 0);
       if (col_ok) {
         double* Kg = v.K + (size_t)t * m * n + col;          // K_t[4 reg + lk][col]
 #pragma unroll
         for (int j = 0; j < MK; ++j) Kg[(4 * j + lk) * n] = kt[j];
       }
-      double nk[MK];
-#pragma unroll
-      for (int j = 0; j < MK; ++j) nk[j] = -kt[j];
-#pragma unroll
-      for (int j = 0; j < MK; ++j)
-#pragma unroll
-        for (int q = 0; q < RT; ++q) accD[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[q][j], nk[j], accD[q], 0, 0, 0);
-      double* d_base = Vxx + lk * VS + 16 * wave + lr;
+      double* d_base = Vxx + lk * VS + col;
 #pragma unroll
       for (int q = 0; q < RT; ++q) {
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
           const int ib = 16 * q + 4 * reg;
           const bool ok = col_ok && (ib + 3 < n || (ib < n && ib + lk < n));
-          if (ok) d_base[ib * VS] = accD[q][reg];
+          if (ok) d_base[ib * VS] = vc[q][reg];
         }
       }
       BP_TICK(4);
-      // ---- this wave's share of the NEXT step's Quu, from the Vxx' it still holds (rows / columns past n: the
-      //      k-steps stop at the contraction length, and what lies between n and it is exact zeros - F's padding)
-      if (t > 0) quu_share(accD, Fn);
+      // ---- this wave's share of the NEXT step's Quu, from the Vxx' it holds (rows / columns past n: the k-steps stop
+      //      at the contraction length, and what lies between n and it is exact zeros - F's padding)
+      if (t > 0) quu_share(vc, fu_);
       BP_TICK(12);
-    } else {
-      // ---- solver wave: Quu = 2R + the three shares (:654), inverted one row per lane; the step's first-order column
+      lds_barrier();
+      BP_TICK(11);
+    }
+  };
+
+  // ------------------------------------------------------------------------------------------------------------
+  // Solver wave: Quu = 2R + the three shares (:654), inverted one row per lane; the first-order terms; F's pipeline.
+  // ------------------------------------------------------------------------------------------------------------
+  auto solver_role = [&]() __attribute__((always_inline)) {
+    // first-order column of step ts: l_{x,u} + F^T Vx (:651-652); F_ts (buffer Fb) and Vx are in LDS
+    auto first_order = [&](int ts, const double* Fb) __attribute__((always_inline)) {
+      if (lane < nm) {
+        double s = Lxu[ts * nm + lane];
+        const int hp = lane < n ? lane : UC + (lane - n);    // this entry's column of F
+        constexpr int CH = (NK % 12 == 0) ? 12 : 4;          // a chunk's LDS reads are in flight together (rows >= n: zeros)
+#pragma unroll
+        for (int k0 = 0; k0 < NK; k0 += CH) {
+          double fv[CH], vv[CH];
+#pragma unroll
+          for (int k = 0; k < CH; ++k) { fv[k] = Fb[(k0 + k) * FS + hp]; vv[k] = Vx[k0 + k]; }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int k = 0; k < CH; ++k) s += fv[k] * vv[k];
+        }
+        Fo[hp] = s;
+      }
+    };
+    if (N >= 3) publish(F + FB1);
+    if (N >= 4) fetch(N - 4);
+    first_order(N - 2, F);
+    // this lane's row of luu = 2R (lanes >= m of each 16-lane row shadow the last row)
+    const int si = lr < m ? lr : m - 1;
+    double r2[m];
+#pragma unroll
+    for (int j = 0; j < m; ++j) r2[j] = 2.0 * R[si * m + j];
+    __syncthreads();
+    for (int t = N - 2; t >= 0; --t) {
+      BP_TICK(0);
+      const double* Fc = F + ((N - 2 - t) & 1) * FB1;         // F_t
+      const double* Fn = F + ((N - 1 - t) & 1) * FB1;         // F_{t-1}
       double arow[m];
       {
         const double* p0 = Pq + (QO + si) * SS + QO;
@@ -1378,8 +1409,6 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
         for (int j = 0; j < m; ++j) Ws[lane * WSS + j] = sc * arow[j];
       }
       BP_TICK(6);
-      first_order(t, Fc);
-      BP_TICK(7);
       lds_barrier();
       BP_TICK(8);
       // kappa = Quu^{-1} Qu (:659), dV = Qu^T kappa (:663), Vx' = Qx - Qux^T kappa (:666)
@@ -1412,10 +1441,20 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
         if (t > 2) fetch(t - 3);
       }
       BP_TICK(10);
+      if (t > 0) {
+        wave_lds_fence();
+        first_order(t - 1, Fn);                              // the next step's, from the Vx' just formed
+      }
+      BP_TICK(7);
+      lds_barrier();
+      BP_TICK(11);
     }
-    lds_barrier();
-    BP_TICK(11);
-  }
+  };
+
+  if (wave == 0) matrix_role(std::integral_constant<int, 0>{});
+  else if (wave == 1) matrix_role(std::integral_constant<int, 1>{});
+  else if (wave == 2) matrix_role(std::integral_constant<int, 2>{});
+  else solver_role();
 }
 
 template <class M, int JAC, int MODE>
