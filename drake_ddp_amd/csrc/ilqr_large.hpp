@@ -13,11 +13,10 @@
 //            central differences or forward-mode duals, only the dofs that read the
 //            perturbed input when the model declares its sparsity; shared key-point code;
 //   backward (ilqr.py:623-667): per step  T1 = Vxx F,  H = F^T T1  with  F = [fx | fu]
-//            (one (n+m)x(n+m) product yields Qxx,Qux,Quu at once) as 16x16x4 fp64 MFMA
-//            tiles on three matrix-core waves, while a fourth "solver" wave factorizes
-//            Quu = 2R + fu^T Vxx fu (LDL^T, one row per lane, DPP broadcasts), substitutes
-//            forward for Y = L^{-1}[Qux|Qu] and finishes the gains off the critical path;
-//            Vxx <- Qxx - Y^T D^{-1} Y.  See large_backward().
+//            (one (n+m)x(n+m) product yields Qxx and Qux at once) as 16x16x4 fp64 MFMA tiles on three matrix-core
+//            waves that keep their column tile in the accumulators from product to product, while a fourth "solver"
+//            wave inverts Quu = 2R + fu^T Vxx fu (Gauss-Jordan, one row per lane, DPP broadcasts) beside them;
+//            K = Quu^{-1} Qux and Vxx <- Qxx - Qux^T K again on the matrix core.  See large_backward().
 // The (B,...) arrays of this path are time-major in HBM; mi_ilqr_get/_set transpose
 // to/from the reference's time-last layout at the boundary.
 #pragma once
@@ -149,6 +148,21 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
   return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// The model's parameters, dt and the difference step as scalars of their OWN.  Left inside the kernel-argument block
+// they belong to a 16-register tuple that the register allocator spills and restores as a whole once scalar registers
+// run out - 16 v_readlane per use inside the step loops of the quadruped kernels (9 uses per rollout step of the 3-D
+// quadruped: 144 of its 1319 instructions).  Opaque copies are allocated pair by pair.
+template <class M>
+struct ModelScalars {
+  double p[M::n_params], dt, fd_h;
+  __device__ __forceinline__ explicit ModelScalars(const KArgs& a) {
+#pragma unroll
+    for (int i = 0; i < M::n_params; ++i) { p[i] = a.params[i]; asm volatile("" : "+s"(p[i])); }
+    dt = a.dt; asm volatile("" : "+s"(dt));
+    fd_h = a.fd_h; asm volatile("" : "+s"(fd_h));
+  }
+};
+
 // One line-search trial (ilqr.py:306-327).  Returns L on every thread; trajectory -> Xn/Un.
 // Per step: (1) 16 lanes per control row form K_t(x-x_bar) partial dots — K_t, x_bar_t,
 // u_bar_t, kappa_t come from HBM/L2 and are prefetched one step ahead into registers;
@@ -203,6 +217,9 @@ __device__ inline double large_rollout(const LView<M::n, M::m>& v, double* lds, 
   double* r2buf = lds + Ly::oT1 + 64;                                  // [2][64]
   static_assert(n * Ly::TS >= 192, "dx + two half-row scratch vectors inside T1");
   double r1_prev = 0.0;
+  const ModelScalars<M> ms(a);
+  const double* prm = ms.p;
+  const double dt_ = ms.dt;
   if (tid < n) { xs[tid] = x0g[tid]; v.Xn[tid] = x0g[tid]; }
   double acc = 0.0;                    // per-thread cost partial over all time steps
   bool bad = false;                    // this thread saw an infeasible step (models that can fail)
@@ -255,10 +272,10 @@ __device__ inline double large_rollout(const LView<M::n, M::m>& v, double* lds, 
         M::template trunk_state<double>(xc, tr);
         typename M::template Agg<double> ag;
         typename M::template Saved<double> sv;
-        M::template chain_up<double>(ch, tr, xc, us, a.params, ag, sv);
+        M::template chain_up<double>(ch, tr, xc, us, prm, ag, sv);
         const double keep = tid < M::kChains ? 1.0 : 0.0;
         typename M::template Agg<double> tot;
-        M::template trunk_agg<double>(a.params, tot);
+        M::template trunk_agg<double>(prm, tot);
         tot.J += row16_sum(keep * ag.J); tot.hx += row16_sum(keep * ag.hx); tot.hz += row16_sum(keep * ag.hz);
         tot.mxx += row16_sum(keep * ag.mxx); tot.mxz += row16_sum(keep * ag.mxz); tot.mzz += row16_sum(keep * ag.mzz);
         tot.bn += row16_sum(keep * ag.bn); tot.bx += row16_sum(keep * ag.bx); tot.bz += row16_sum(keep * ag.bz);
@@ -270,20 +287,20 @@ __device__ inline double large_rollout(const LView<M::n, M::m>& v, double* lds, 
 #pragma unroll
           for (int b_ = 0; b_ < 3; ++b_) {
             const int i = 3 + 3 * tid + b_;
-            const double vn_ = xc[M::nq + i] + a.dt * q3[b_];
-            const double qn_ = xc[i] + a.dt * vn_;
+            const double vn_ = xc[M::nq + i] + dt_ * q3[b_];
+            const double qn_ = xc[i] + dt_ * vn_;
             xn_[i] = qn_; xn_[M::nq + i] = vn_;
             v.Xn[(size_t)(t + 1) * n + i] = qn_; v.Xn[(size_t)(t + 1) * n + M::nq + i] = vn_;
-            bad = bad || M::infeasible_velocity(vn_, a.params);
+            bad = bad || M::infeasible_velocity(vn_, prm);
           }
         }
         if (tid < 3) {                                     // the trunk's own coordinates: x, z, pitch
           const double acc_ = tid == 0 ? ax : (tid == 1 ? az : alpha);
-          const double vn_ = xc[M::nq + tid] + a.dt * acc_;
-          const double qn_ = xc[tid] + a.dt * vn_;
+          const double vn_ = xc[M::nq + tid] + dt_ * acc_;
+          const double qn_ = xc[tid] + dt_ * vn_;
           xn_[tid] = qn_; xn_[M::nq + tid] = vn_;
           v.Xn[(size_t)(t + 1) * n + tid] = qn_; v.Xn[(size_t)(t + 1) * n + M::nq + tid] = vn_;
-          bad = bad || M::infeasible_velocity(vn_, a.params);
+          bad = bad || M::infeasible_velocity(vn_, prm);
         }
         dyn_done = true;
       }
@@ -297,37 +314,37 @@ __device__ inline double large_rollout(const LView<M::n, M::m>& v, double* lds, 
         double Rm[3][3];
         M::template rotation<double>(xc, Rm);
         typename M::template LegOut<double> lo;
-        M::template leg<double>(k, Rm, xc, us, a.params, lo);
+        M::template leg<double>(k, Rm, xc, us, prm, lo);
         const double keep = tid < M::kLegs ? 1.0 : 0.0;
         double Fw[3], Tq[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) { Fw[i] = row16_sum(keep * lo.fw[i]); Tq[i] = row16_sum(keep * lo.tq[i]); }
         double xt[n];
-        M::template trunk<double>(xc, Fw, Tq, xt, a.params, a.dt);
+        M::template trunk<double>(xc, Fw, Tq, xt, prm, dt_);
         double* Xo = v.Xn + (size_t)(t + 1) * n;
         if (tid < M::kLegs) {
 #pragma unroll
           for (int i = 0; i < 3; ++i) {
             const int j = 3 * k + i;
-            const double jdn = xc[25 + j] + a.dt * lo.ja[i];
-            const double jn = xc[7 + j] + a.dt * jdn;
+            const double jdn = xc[25 + j] + dt_ * lo.ja[i];
+            const double jn = xc[7 + j] + dt_ * jdn;
             xn_[25 + j] = jdn; xn_[7 + j] = jn;
             Xo[25 + j] = jdn; Xo[7 + j] = jn;
-            bad = bad || M::infeasible_velocity(jdn, a.params);
+            bad = bad || M::infeasible_velocity(jdn, prm);
           }
         }
         if (tid == 0) {
 #pragma unroll
           for (int i = 0; i < 7; ++i) { xn_[i] = xt[i]; Xo[i] = xt[i]; }
 #pragma unroll
-          for (int i = 19; i < 25; ++i) { xn_[i] = xt[i]; Xo[i] = xt[i]; bad = bad || M::infeasible_velocity(xt[i], a.params); }
+          for (int i = 19; i < 25; ++i) { xn_[i] = xt[i]; Xo[i] = xt[i]; bad = bad || M::infeasible_velocity(xt[i], prm); }
         }
         dyn_done = true;
       }
     } else if constexpr (IsWholeStepModel<M>::value) {
       if (tid == 0) {                                      // (plugin models without cooperative hooks)
         double xt[n];
-        M::template step<double>(xc, us, xt, a.params, a.dt);
+        M::template step<double>(xc, us, xt, prm, dt_);
 #pragma unroll
         for (int i = 0; i < n; ++i) { xn_[i] = xt[i]; v.Xn[(size_t)(t + 1) * n + i] = xt[i]; }
         dyn_done = true;
@@ -335,7 +352,7 @@ __device__ inline double large_rollout(const LView<M::n, M::m>& v, double* lds, 
     } else {
       if (tid < M::nq) {                                   // one lane per degree of freedom
         double qn_ = 0.0, vn_ = 0.0;
-        M::template dof<double>(tid, xc, us, qn_, vn_, a.params, a.dt);
+        M::template dof<double>(tid, xc, us, qn_, vn_, prm, dt_);
         xn_[tid] = qn_; xn_[M::nq + tid] = vn_;
         v.Xn[(size_t)(t + 1) * n + tid] = qn_;
         v.Xn[(size_t)(t + 1) * n + M::nq + tid] = vn_;
@@ -446,7 +463,8 @@ template <class M, int JAC, bool COH = false>
 __device__ __forceinline__ void large_jac_at_sparse(const LView<M::n, M::m>& v, const KArgs& a, const int* list, int count,
                                                     const double* Xsrc, const double* Usrc, int first = 0, int stride = 1) {
   constexpr int n = M::n, m = M::m, nc = n + m, nq = M::nq;
-  const double h = a.fd_h, inv2h = 1.0 / (2.0 * h);
+  const ModelScalars<M> ms(a);
+  const double h = ms.fd_h, inv2h = 1.0 / (2.0 * h);
   for (int it = first * kLargeThreads + threadIdx.x; it < count * nc; it += stride * kLargeThreads) {
     const int ki = it / nc, col = it - ki * nc;
     const int t = list[ki];
@@ -470,13 +488,13 @@ __device__ __forceinline__ void large_jac_at_sparse(const LView<M::n, M::m>& v, 
         double dq, dv;
         if (JAC == MI_JAC_FD_CENTRAL) {
           double qp, vp, qm, vm;
-          M::template dof<double>(i, PertAcc{xg, col, h}, PertAcc{ug, col - n, h}, qp, vp, a.params, a.dt);
-          M::template dof<double>(i, PertAcc{xg, col, -h}, PertAcc{ug, col - n, -h}, qm, vm, a.params, a.dt);
+          M::template dof<double>(i, PertAcc{xg, col, h}, PertAcc{ug, col - n, h}, qp, vp, ms.p, ms.dt);
+          M::template dof<double>(i, PertAcc{xg, col, -h}, PertAcc{ug, col - n, -h}, qm, vm, ms.p, ms.dt);
           dq = (qp - qm) * inv2h;
           dv = (vp - vm) * inv2h;
         } else {
           Dual1 qd, vd;
-          M::template dof<Dual1>(i, SeedAcc{xg, col}, SeedAcc{ug, col - n}, qd, vd, a.params, a.dt);
+          M::template dof<Dual1>(i, SeedAcc{xg, col}, SeedAcc{ug, col - n}, qd, vd, ms.p, ms.dt);
           dq = qd.d;
           dv = vd.d;
         }
@@ -501,7 +519,8 @@ __device__ __forceinline__ void large_jac_at_tree(const LView<M::n, M::m>& v, co
                                                   const double* Xsrc, const double* Usrc, int xstride, int ustride, double* cache,
                                                   int first = 0, int stride = 1) {
   constexpr int n = M::n, m = M::m, nc = n + m, nq = M::nq, NCH = M::kChains;
-  const double h = a.fd_h, inv2h = 1.0 / (2.0 * h), dt = a.dt;
+  const ModelScalars<M> ms(a);
+  const double h = ms.fd_h, inv2h = 1.0 / (2.0 * h), dt = ms.dt;
   using AggD = typename M::template Agg<double>;
   if (JAC == MI_JAC_FD_CENTRAL) {
     for (int it = threadIdx.x; it < count * NCH; it += kLargeThreads) {
@@ -513,7 +532,7 @@ __device__ __forceinline__ void large_jac_at_tree(const LView<M::n, M::m>& v, co
       M::template trunk_state<double>(xg, tr);
       AggD ag;
       typename M::template Saved<double> sv;
-      M::template chain_up<double>(c, tr, xg, ug, a.params, ag, sv);
+      M::template chain_up<double>(c, tr, xg, ug, ms.p, ag, sv);
       double* cc = cache + (size_t)it * 9;
       cc[0] = ag.J; cc[1] = ag.hx; cc[2] = ag.hz; cc[3] = ag.mxx; cc[4] = ag.mxz; cc[5] = ag.mzz; cc[6] = ag.bn; cc[7] = ag.bx; cc[8] = ag.bz;
     }
@@ -540,14 +559,14 @@ __device__ __forceinline__ void large_jac_at_tree(const LView<M::n, M::m>& v, co
       M::template trunk_state<double>(xp, trp);
       M::template trunk_state<double>(xm, trm);
       AggD totp, totm;
-      M::template trunk_agg<double>(a.params, totp);
-      M::template trunk_agg<double>(a.params, totm);
+      M::template trunk_agg<double>(ms.p, totp);
+      M::template trunk_agg<double>(ms.p, totm);
       for (int c = 0; c < NCH; ++c) {
         AggD agp, agm;
         if (owner < 0 || owner == c) {
           typename M::template Saved<double> sv;
-          M::template chain_up<double>(c, trp, xp, up, a.params, agp, sv);
-          M::template chain_up<double>(c, trm, xm, um, a.params, agm, sv);
+          M::template chain_up<double>(c, trp, xp, up, ms.p, agp, sv);
+          M::template chain_up<double>(c, trm, xm, um, ms.p, agm, sv);
         } else {
           const double* cc = cache + ((size_t)ki * NCH + c) * 9;
           agp.J = cc[0]; agp.hx = cc[1]; agp.hz = cc[2]; agp.mxx = cc[3]; agp.mxz = cc[4]; agp.mzz = cc[5];
@@ -572,12 +591,12 @@ __device__ __forceinline__ void large_jac_at_tree(const LView<M::n, M::m>& v, co
         AggD ag;
         typename M::template Saved<double> sv;
         if (owner < 0 || owner == c) {
-          M::template chain_up<double>(c, trp, xp, up, a.params, ag, sv);
+          M::template chain_up<double>(c, trp, xp, up, ms.p, ag, sv);
           M::template chain_down<double>(sv, alp, axp, azp, q3p);
-          M::template chain_up<double>(c, trm, xm, um, a.params, ag, sv);
+          M::template chain_up<double>(c, trm, xm, um, ms.p, ag, sv);
           M::template chain_down<double>(sv, alm, axm, azm, q3m);
         } else {
-          M::template chain_up<double>(c, trp, xp, up, a.params, ag, sv);      // unperturbed for this chain: trp == trm, same joints
+          M::template chain_up<double>(c, trp, xp, up, ms.p, ag, sv);      // unperturbed for this chain: trp == trm, same joints
           M::template chain_down<double>(sv, alp, axp, azp, q3p);
           M::template chain_down<double>(sv, alm, axm, azm, q3m);
         }
@@ -588,11 +607,11 @@ __device__ __forceinline__ void large_jac_at_tree(const LView<M::n, M::m>& v, co
       typename M::template Trunk<Dual1> tr;
       M::template trunk_state<Dual1>(xs, tr);
       typename M::template Agg<Dual1> tot;
-      M::template trunk_agg<Dual1>(a.params, tot);
+      M::template trunk_agg<Dual1>(ms.p, tot);
       for (int c = 0; c < NCH; ++c) {
         typename M::template Agg<Dual1> ag;
         typename M::template Saved<Dual1> sv;
-        M::template chain_up<Dual1>(c, tr, xs, us, a.params, ag, sv);
+        M::template chain_up<Dual1>(c, tr, xs, us, ms.p, ag, sv);
         M::agg_add(tot, ag);
       }
       Dual1 ax, az, al;
@@ -608,7 +627,7 @@ __device__ __forceinline__ void large_jac_at_tree(const LView<M::n, M::m>& v, co
         typename M::template Agg<Dual1> ag;
         typename M::template Saved<Dual1> sv;
         Dual1 q3[3];
-        M::template chain_up<Dual1>(c, tr, xs, us, a.params, ag, sv);
+        M::template chain_up<Dual1>(c, tr, xs, us, ms.p, ag, sv);
         M::template chain_down<Dual1>(sv, al, ax, az, q3);
         emit(3 + 3 * c, q3[0]); emit(4 + 3 * c, q3[1]); emit(5 + 3 * c, q3[2]);
       }
@@ -630,7 +649,8 @@ __device__ __forceinline__ void large_jac_at_legs(const LView<M::n, M::m>& v, co
                                                   const double* Xsrc, const double* Usrc, int xstride, int ustride,
                                                   int first = 0, int cstride = 1) {
   constexpr int n = M::n, m = M::m, nc = n + m;
-  const double h = a.fd_h, inv2h = 1.0 / (2.0 * h), dt = a.dt;
+  const ModelScalars<M> ms(a);
+  const double h = ms.fd_h, inv2h = 1.0 / (2.0 * h), dt = ms.dt;
   for (int it = first * kLargeThreads + threadIdx.x; it < count * nc; it += cstride * kLargeThreads) {
     const int rank = it / count, ki = it - rank * count;
     const int col = M::input_by_owner(rank);
@@ -655,8 +675,8 @@ __device__ __forceinline__ void large_jac_at_legs(const LView<M::n, M::m>& v, co
         for (int j = 0; j < 2; ++j) {
           const int k = half + 2 * j;                           // legs 0, 2 | 1, 3
           typename M::template LegOut<double> lp, lm;
-          M::template leg<double>(k, Rp, xp, up, a.params, lp);
-          if (owner < 0 || owner == k) M::template leg<double>(k, Rm, xm, um, a.params, lm);
+          M::template leg<double>(k, Rp, xp, up, ms.p, lp);
+          if (owner < 0 || owner == k) M::template leg<double>(k, Rm, xm, um, ms.p, lm);
           else lm = lp;                                         // identical inputs: identical outputs
 #pragma unroll
           for (int i = 0; i < 3; ++i) {
@@ -676,8 +696,8 @@ __device__ __forceinline__ void large_jac_at_legs(const LView<M::n, M::m>& v, co
         }
       }
       double tp[n], tm[n];                                      // (only the trunk's 13 entries are ever touched)
-      M::template trunk<double>(xp, Fp, Tp, tp, a.params, dt);
-      M::template trunk<double>(xm, Fm, Tm, tm, a.params, dt);
+      M::template trunk<double>(xp, Fp, Tp, tp, ms.p, dt);
+      M::template trunk<double>(xm, Fm, Tm, tm, ms.p, dt);
 #pragma unroll
       for (int i = 0; i < 7; ++i) st_shared<COH>(o + i * stride, (tp[i] - tm[i]) * inv2h);
 #pragma unroll
@@ -694,7 +714,7 @@ __device__ __forceinline__ void large_jac_at_legs(const LView<M::n, M::m>& v, co
         for (int j = 0; j < 2; ++j) {
           const int k = half + 2 * j;
           typename M::template LegOut<Dual1> lo;
-          M::template leg<Dual1>(k, R, xs, us, a.params, lo);
+          M::template leg<Dual1>(k, R, xs, us, ms.p, lo);
 #pragma unroll
           for (int i = 0; i < 3; ++i) {
             const int q = 3 * k + i;
@@ -711,7 +731,7 @@ __device__ __forceinline__ void large_jac_at_legs(const LView<M::n, M::m>& v, co
         }
       }
       Dual1 tn[n];
-      M::template trunk<Dual1>(xs, F, Tq, tn, a.params, dt);
+      M::template trunk<Dual1>(xs, F, Tq, tn, ms.p, dt);
 #pragma unroll
       for (int i = 0; i < 7; ++i) st_shared<COH>(o + i * stride, tn[i].d);
 #pragma unroll
@@ -723,7 +743,8 @@ __device__ __forceinline__ void large_jac_at_legs(const LView<M::n, M::m>& v, co
 template <class M, int JAC>
 __device__ __forceinline__ void large_jac_at(const LView<M::n, M::m>& v, const KArgs& a, const int* list, int count) {
   constexpr int n = M::n, m = M::m, nc = n + m;
-  const double h = a.fd_h, inv2h = 1.0 / (2.0 * h);
+  const ModelScalars<M> ms(a);
+  const double h = ms.fd_h, inv2h = 1.0 / (2.0 * h);
   for (int it = threadIdx.x; it < count * nc; it += kLargeThreads) {
     const int ki = it / nc, col = it - ki * nc;
     const int t = list[ki];
@@ -736,12 +757,12 @@ __device__ __forceinline__ void large_jac_at(const LView<M::n, M::m>& v, const K
       for (int i = 0; i < n; ++i) x[i] = (col == i) ? xg[i] + h : xg[i];
 #pragma unroll
       for (int k = 0; k < m; ++k) u[k] = (col == n + k) ? ug[k] + h : ug[k];
-      M::template step<double>(x, u, d, a.params, a.dt);
+      M::template step<double>(x, u, d, ms.p, ms.dt);
 #pragma unroll
       for (int i = 0; i < n; ++i) x[i] = (col == i) ? xg[i] - h : xg[i];
 #pragma unroll
       for (int k = 0; k < m; ++k) u[k] = (col == n + k) ? ug[k] - h : ug[k];
-      M::template step<double>(x, u, f, a.params, a.dt);
+      M::template step<double>(x, u, f, ms.p, ms.dt);
 #pragma unroll
       for (int i = 0; i < n; ++i) d[i] = (d[i] - f[i]) * inv2h;
     } else {
@@ -750,7 +771,7 @@ __device__ __forceinline__ void large_jac_at(const LView<M::n, M::m>& v, const K
       for (int i = 0; i < n; ++i) xd[i] = Dual1(xg[i], (col == i) ? 1.0 : 0.0);
 #pragma unroll
       for (int k = 0; k < m; ++k) ud[k] = Dual1(ug[k], (col == n + k) ? 1.0 : 0.0);
-      M::template step<Dual1>(xd, ud, fd, a.params, a.dt);
+      M::template step<Dual1>(xd, ud, fd, ms.p, ms.dt);
 #pragma unroll
       for (int i = 0; i < n; ++i) d[i] = fd[i].d;
     }
@@ -792,119 +813,14 @@ struct TileOps {
   }
 };
 
-// Right-looking LDL^T of an m x m matrix held one ROW PER LANE (lane i of a 16-lane row holds
-// A[i][0..m-1]); pivots and column entries travel by DPP row_share, no LDS, no barriers.
-// On exit lane i holds L[i][k] in a[k] for k < i, and every lane holds 1/D[k] in dinv[k].
-// The serial part is pivot -> reciprocal (16-cycle v_rcp_f64 + four dependent FMAs) -> column
-// scale -> next pivot, and the wave issues in order: each step updates column K+1 first, starts
-// the next pivot's reciprocal, and places one independent column update between every two
-// dependent instructions of that reciprocal (sched_barrier pins the order).
-template <int m, int K, int J>
-__device__ __forceinline__ void ldl_update(double (&a)[m], double lik) {
-  if constexpr (J < m) {
-    const double ajk = row_share<J>(a[K]);          // A[J][K] before scaling = D[K] * L[J][K]
-    a[J] = fma(-lik, ajk, a[J]);
-  }
-}
-template <int m, int K, int J>
-struct LdlRest {
-  static __device__ __forceinline__ void run(double (&a)[m], double lik) {
-    ldl_update<m, K, J>(a, lik);
-    LdlRest<m, K, J + 1>::run(a, lik);
-  }
-};
-template <int m, int K>
-struct LdlRest<m, K, m> {
-  static __device__ __forceinline__ void run(double (&)[m], double) {}
-};
-template <int m, int K>
-struct LdlOuter {
-  // `inv` = 1 / D[K], already computed
-  static __device__ __forceinline__ void run(double (&a)[m], double (&dinv)[m], double inv) {
-    dinv[K] = inv;
-    const double lik = a[K] * inv;
-    double r = 0.0;
-    if constexpr (K + 1 < m) {
-      ldl_update<m, K, K + 1>(a, lik);
-      ldl_update<m, K, K + 2>(a, lik);              // also covers the DPP-after-VALU wait states of the pivot read
-      __builtin_amdgcn_sched_barrier(0);
-      const double d = row_share<K + 1>(a[K + 1]);
-      r = __builtin_amdgcn_rcp(d);
-      ldl_update<m, K, K + 3>(a, lik);
-      ldl_update<m, K, K + 4>(a, lik);
-      __builtin_amdgcn_sched_barrier(0);
-      double e = fma(-d, r, 1.0);
-      ldl_update<m, K, K + 5>(a, lik);
-      __builtin_amdgcn_sched_barrier(0);
-      r = fma(r, e, r);
-      ldl_update<m, K, K + 6>(a, lik);
-      __builtin_amdgcn_sched_barrier(0);
-      e = fma(-d, r, 1.0);
-      ldl_update<m, K, K + 7>(a, lik);
-      __builtin_amdgcn_sched_barrier(0);
-      r = fma(r, e, r);                             // == fast_rcp(d)
-      LdlRest<m, K, (K + 8 < m ? K + 8 : m)>::run(a, lik);
-    }
-    a[K] = lik;
-    LdlOuter<m, K + 1>::run(a, dinv, r);
-  }
-  static __device__ __forceinline__ void run(double (&a)[m], double (&dinv)[m]) {
-    static_assert(K == 0, "entry point");
-    run(a, dinv, fast_rcp(row_share<0>(a[0])));
-  }
-};
-template <int m>
-struct LdlOuter<m, m> {
-  static __device__ __forceinline__ void run(double (&)[m], double (&)[m], double) {}
-};
-
-// Triangular solves with L held one row per lane (lane i: a[k] = L[i][k], k < i) and one
-// right-hand side per lane: y <- L^{-1} y and z <- L^{-T} z.  L[I][K] = row_share<I>(a[K]).
-template <int m, int I, int K>
-struct FwdRow {
-  static __device__ __forceinline__ void run(const double (&a)[m], double (&y)[m]) {
-    if constexpr (K < I) {
-      y[I] = fma(-row_share<I>(a[K]), y[K], y[I]);
-      FwdRow<m, I, K + 1>::run(a, y);
-    }
-  }
-};
-template <int m, int I>
-struct FwdSubst {
-  static __device__ __forceinline__ void run(const double (&a)[m], double (&y)[m]) {
-    if constexpr (I < m) {
-      FwdRow<m, I, 0>::run(a, y);
-      FwdSubst<m, I + 1>::run(a, y);
-    }
-  }
-};
-template <int m, int I, int K>
-struct BackRow {
-  static __device__ __forceinline__ void run(const double (&a)[m], double (&z)[m]) {
-    if constexpr (K < m) {
-      z[I] = fma(-row_share<K>(a[I]), z[K], z[I]);          // L[K][I]
-      BackRow<m, I, K + 1>::run(a, z);
-    }
-  }
-};
-template <int m, int I>
-struct BackSubst {
-  static __device__ __forceinline__ void run(const double (&a)[m], double (&z)[m]) {
-    if constexpr (I >= 0) {
-      BackRow<m, I, I + 1>::run(a, z);
-      BackSubst<m, I - 1>::run(a, z);
-    }
-  }
-};
-
 // In-place Gauss-Jordan inverse (no pivoting: the matrix is symmetric positive definite) of an m x m matrix held one
 // ROW PER LANE (lane i of a 16-lane row holds A[i][0..m-1]); the pivot row travels by DPP row_share, no LDS, no
 // barriers.  Row scaling is deferred: lane i keeps a factor s (1 until its own pivot, 1 / pivot after) and the true
 // row is s * a - the elimination  a_i[j] -= (a_i[k] / p) a_k[j]  of the other lanes' rows does not see their factors,
 // and the pivot lane itself only sets a[k] = 1.  On exit  A^{-1}[i][j] = s * a[j]  on lane i.
-// As in the LDL^T above the serial part is pivot -> reciprocal -> multiplier -> next pivot: each step updates the
-// column of the next pivot first, starts that pivot's reciprocal and places the other column updates between its
-// dependent instructions.  Columns are visited in the order K+1, K+2, ..., K-1 (mod m).
+// The serial part is pivot -> reciprocal (16-cycle v_rcp_f64 + four dependent FMAs) -> multiplier -> next pivot, and the
+// wave issues in order: each step updates the column of the next pivot first, starts that pivot's reciprocal and places
+// the other column updates between its dependent instructions (sched_barrier pins the order).  Columns are visited in the order K+1, K+2, ..., K-1 (mod m).
 template <int m, int K, int NTH>
 __device__ __forceinline__ void gj_update(double (&a)[m], double g) {
   if constexpr (NTH < m) {
@@ -971,18 +887,16 @@ struct GjOuter<m, m> {
 // Backward Riccati pass (ilqr.py:623-667), cost expansion (:161-206) fused.
 //
 // Per time step, with F = [fx | fu] (n x (n+m)):
-//     T1 = Vxx F                      (n x (n+m))       9 tiles x 9 k-steps   (phase A)
-//     H  = F^T T1                     ((n+m) x (n+m)) = [[Qxx-lxx, . ],[Qux, Quu-luu]]  (phase B)
-//     Quu = L D L^T,  Y = L^{-1} [Qux | Qu]             solver wave            (phases B, C)
-//     Vxx' = Qxx - Y^T D^{-1} Y       (n x n)           9 tiles x 3 k-steps   (phase D)
-//     K = L^{-T} D^{-1} Y             gains, off the recursion's critical path (next phase A)
-// The products run as 16x16 tiles of v_mfma_f64_16x16x4_f64, three tiles per matrix-core
-// wave.  On gfx950 the fp64 matrix rate equals the fp64 VALU rate (64 cycles per 16x16x4 =
-// 16 FMA/clk/SIMD, tools/ubench/mfma_cu.hip; 76-79 cycles when every operand comes from LDS,
-// tools/ubench/mfma_lds.hip), so the point of the matrix core here is OPERAND DELIVERY: two
-// 8-byte LDS reads per lane feed 1024 FMAs, where a VALU formulation needs a (broadcast) LDS
-// read per 1-2 FMAs and is LDS-issue-bound at one wave per SIMD (tools/ubench/t1.hip: 4.5-10.7k
-// cycles for T1 alone vs ~2.1k here).
+//     T1  = Vxx F[:, x]               (n x n)      9 tiles x KN k-steps
+//     H   = F^T T1                    rows x: Qxx - lxx (symmetric: 6 tiles computed, 3 mirrored), rows u: Qux
+//     Quu = 2R + fu^T Vxx fu          from the Vxx' accumulators of the previous step; Quu^{-1} on the solver wave
+//     K   = Quu^{-1} Qux,  kappa = Quu^{-1} Qu                                            (:659-660)
+//     Vxx' = Qxx - Qux^T K,  Vx' = Qx - Qux^T kappa                                        (:666-667)
+// The products run as 16x16 tiles of v_mfma_f64_16x16x4_f64.  On gfx950 the fp64 matrix rate equals the fp64 VALU
+// rate (64 cycles per 16x16x4 = 16 FMA/clk/SIMD, tools/ubench/mfma_cu.hip), so the point of the matrix core here is
+// OPERAND DELIVERY: two 8-byte operands per lane feed 1024 FMAs, where a VALU formulation needs a (broadcast) LDS
+// read per 1-2 FMAs and is LDS-issue-bound at one wave per SIMD (tools/ubench/t1.hip: 4.5-10.7 k cycles for T1
+// alone) - and since round 3 most operands do not even come from LDS: see "Fused chain" below.
 template <class M>
 __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, long long* bp_acc = nullptr, bool lx_ready = false) {
   constexpr int n = M::n, m = M::m, nm = n + m;
@@ -1094,7 +1008,7 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
     __syncthreads();
     if (wave == 0) BP_TICK(7);
     // the zero padding the tiles rely on (F's pad columns; H for tidiness)
-    for (int e = tid; e < NK * FS; e += kLargeThreads) F[e] = 0.0;
+    for (int e = tid; e < NK * FS; e += kLargeThreads) { F[e] = 0.0; F[(Ly::oT1 - Ly::oF) + e] = 0.0; }   // both F buffers (the second one is the T1 area)
     for (int e = tid; e < Ly::NMP * TS; e += kLargeThreads) H[e] = 0.0;
   }
   __syncthreads();
@@ -1171,13 +1085,16 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
   };
-  for (int e = tid; e < NK * FS; e += kLargeThreads) F[FB1 + e] = 0.0;     // the second buffer's zero padding
   for (int e = tid; e < 16 * WSS; e += kLargeThreads) Ws[e] = 0.0;
+  // the first two F's, fetched by two waves at once (one L2 round trip - after a clustered linearization the Jacobians
+  // come from other XCDs' write-through stores - instead of two); the solver wave then has the third in flight
   if (wave == 3) {
     fetch(N - 2); publish(F);
-    if (N >= 3) fetch(N - 3);
+    if (N >= 4) fetch(N - 4);
+  } else if (wave == 2 && N >= 3) {
+    fetch(N - 3); publish(F + FB1);
   }
-  __syncthreads();                                            // (buffer 1's padding is in place)
+  __syncthreads();
   BP_TICK(15);
 
   // ------------------------------------------------------------------------------------------------------------
@@ -1369,21 +1286,26 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
       if (lane < nm) {
         double s = Lxu[ts * nm + lane];
         const int hp = lane < n ? lane : UC + (lane - n);    // this entry's column of F
-        constexpr int CH = (NK % 12 == 0) ? 12 : 4;          // a chunk's LDS reads are in flight together (rows >= n: zeros)
+        // chunks of the contraction (rows >= n: zeros), software-pipelined: the next chunk's LDS reads are in flight
+        // while this chunk's multiply-adds run - one exposed LDS latency per call instead of one per chunk
+        constexpr int CH = (NK % 12 == 0) ? 12 : ((NK % 10 == 0) ? 10 : 4), NC = NK / CH;
+        double fv[2][CH], vv[2][CH];
 #pragma unroll
-        for (int k0 = 0; k0 < NK; k0 += CH) {
-          double fv[CH], vv[CH];
+        for (int k = 0; k < CH; ++k) { fv[0][k] = Fb[k * FS + hp]; vv[0][k] = Vx[k]; }
 #pragma unroll
-          for (int k = 0; k < CH; ++k) { fv[k] = Fb[(k0 + k) * FS + hp]; vv[k] = Vx[k0 + k]; }
+        for (int c = 0; c < NC; ++c) {
+          if (c + 1 < NC) {
+#pragma unroll
+            for (int k = 0; k < CH; ++k) { fv[(c + 1) & 1][k] = Fb[((c + 1) * CH + k) * FS + hp]; vv[(c + 1) & 1][k] = Vx[(c + 1) * CH + k]; }
+          }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int k = 0; k < CH; ++k) s += fv[k] * vv[k];
+          for (int k = 0; k < CH; ++k) s += fv[c & 1][k] * vv[c & 1][k];
+          __builtin_amdgcn_sched_barrier(0);
         }
         Fo[hp] = s;
       }
     };
-    if (N >= 3) publish(F + FB1);
-    if (N >= 4) fetch(N - 4);
     first_order(N - 2, F);
     // this lane's row of luu = 2R (lanes >= m of each 16-lane row shadow the last row)
     const int si = lr < m ? lr : m - 1;

@@ -3,7 +3,7 @@
 Builds its own -DMI_PROF_BACKWARD library (lib/libmi_ilqr_bpprof.so: per-wave stopwatches between the phases, thread 0 =
 a matrix-core wave, thread 192 = the solver wave) and prints cycles per step.
 
-    python tools/bp_prof.py [synth36|quad3d]
+    python tools/bp_prof.py [synth36|quad|quad3d]
 """
 import os, sys
 sys.path.insert(0, ".")
@@ -19,6 +19,8 @@ from drake_ddp_amd.models import ModelSystem
 which = sys.argv[1] if len(sys.argv) > 1 else "synth36"
 if which == "quad3d":
     q = W.quad3d_problem(); x0 = W.quad3d_batch_x0(1); ug = W.quad3d_u_guess(q["N"])
+elif which == "quad":
+    q = W.planar_quad_problem(); x0 = W.planar_quad_batch_x0(1); ug = W.planar_quad_u_guess(q["N"])
 else:
     q = W.synth36_problem(); x0 = W.synth36_batch_x0(64)[:1]; ug = W.synth36_u_guess(q["N"])
 N = q["N"]

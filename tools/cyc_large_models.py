@@ -1,4 +1,4 @@
-"""Per-stage cycles of the workgroup-per-problem kernels (planar quadruped, synthetic chain) at B = 64 and 8:
+"""Per-stage cycles of the workgroup-per-problem kernels (planar quadruped, 3-D quadruped, synthetic chain) at B = 64 and 8:
 line search, linearization, backward pass per iteration (in-kernel stopwatches)."""
 import sys, os, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -6,6 +6,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from drake_ddp_amd import workloads as W
 from test_gpu_parity import make_solver
 for name, prob, x0, ug in (("quad", W.planar_quad_problem(), W.planar_quad_batch_x0(64), W.planar_quad_u_guess(40)),
+                           ("quad3d", W.quad3d_problem(), W.quad3d_batch_x0(64), W.quad3d_u_guess(W.quad3d_problem()["N"])),
                            ("synth36", W.synth36_problem(), W.synth36_batch_x0(64), W.synth36_u_guess(40))):
     for B in (64, 8):
         s = make_solver(prob, B=B, jac="fd")
