@@ -151,15 +151,16 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
 // The model's parameters, dt and the difference step as scalars of their OWN.  Left inside the kernel-argument block
 // they belong to a 16-register tuple that the register allocator spills and restores as a whole once scalar registers
 // run out - 16 v_readlane per use inside the step loops of the quadruped kernels (9 uses per rollout step of the 3-D
-// quadruped: 144 of its 1319 instructions).  Opaque copies are allocated pair by pair.
+// quadruped: 144 of its 1319 instructions).  Opaque copies are allocated pair by pair.  (Models with a handful of
+// parameters keep the plain reads: for the 4-parameter chain the copies measured 4 % slower in the MPC kernel.)
 template <class M>
 struct ModelScalars {
   double p[M::n_params], dt, fd_h;
   __device__ __forceinline__ explicit ModelScalars(const KArgs& a) {
 #pragma unroll
-    for (int i = 0; i < M::n_params; ++i) { p[i] = a.params[i]; asm volatile("" : "+s"(p[i])); }
-    dt = a.dt; asm volatile("" : "+s"(dt));
-    fd_h = a.fd_h; asm volatile("" : "+s"(fd_h));
+    for (int i = 0; i < M::n_params; ++i) { p[i] = a.params[i]; if constexpr (M::n_params > 4) asm volatile("" : "+s"(p[i])); }
+    dt = a.dt; if constexpr (M::n_params > 4) asm volatile("" : "+s"(dt));
+    fd_h = a.fd_h; if constexpr (M::n_params > 4) asm volatile("" : "+s"(fd_h));
   }
 };
 
