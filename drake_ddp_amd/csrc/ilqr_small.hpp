@@ -508,10 +508,10 @@ __device__ inline void traj_cost(const WS& w, const Consts<M>& c, double eps, do
 // result is the next guess.  Started from the previous nominal trajectory, the iteration converges
 // quadratically: 4 sweeps (5 early in a solve) bring the update below 1e-9, after which the error
 // is at round-off (prototype against the sequential rollout: 1e-14 absolute, tools/... DESIGN.md).
-// Finally every lane re-runs its own chunk with the plain fp64 step from its converged start and
-// stores x_{t+1}, u_t: inside a chunk the stored trajectory satisfies the dynamics exactly, across
-// the 49 chunk edges to ~1e-14.  Not converged within the cap (cold starts, the first iteration of
-// hard problems) -> the caller falls back to the sequential rollout.
+// The last sweep's result IS the trial trajectory (its linearized update misses the exact step by the quadratic
+// remainder of a correction below 1e-7: round-off); one exact model step per lane - its last - checks that a
+// posteriori.  Not converged within the cap (cold starts, the first iteration of hard problems), or the check
+// fails -> the caller falls back to the sequential rollout.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ double lane_read_f64(double v, int src);
 
@@ -741,6 +741,7 @@ __device__ inline int rollout_newton_impl(const WS& w, const Consts<M>& c, const
   double Gs[CH][n][n];                                       // closed-loop Jacobians of the last full sweep
   double prev_upd = __builtin_inf();
   bool have_g = false, last_frozen = false;
+  double x_end[n] = {0.0, 0.0};                              // the state after this lane's last step, as of the last sweep
   for (int sweep = 0; sweep < kMaxSweeps && !converged; ++sweep) {
 #ifdef MI_PROF_NEWTON
     ++nsw;
@@ -805,6 +806,8 @@ __device__ inline int rollout_newton_impl(const WS& w, const Consts<M>& c, const
       const double n1 = fma(loc[k].G[1][0], ds[0], fma(loc[k].G[1][1], ds[1], loc[k].c[1]));
       ds[0] = n0; ds[1] = n1;
     }
+    // the corrected state after the lane's last step: (the next lane's first guess, as this sweep saw it) + its correction
+    x_end[0] = nx0 + ds[0]; x_end[1] = nx1 + ds[1];
     // NaN -> not converged: a NaN anywhere in this lane's corrections has travelled down the chain into the
     // last one (v_max_f64 above drops NaN operands, so it is tested here, once)
     if (valid[0]) upd = (ds[0] == ds[0] && ds[1] == ds[1]) ? upd : __builtin_inf();
@@ -825,20 +828,25 @@ __device__ inline int rollout_newton_impl(const WS& w, const Consts<M>& c, const
   if (lane == 0) { mi_dbg_vals[0] = (double)(pn1 - pn0); mi_dbg_vals[1] = nsw; }
 #endif
   if (!converged) return NEWTON_FAILED;
-  // A-posteriori guard of the stopping rule: the final pass re-steps every lane chunk exactly from its
-  // converged start, so the only place the stored trajectory can fail to be a rollout of u under f
-  // (ilqr.py:313-316) is a chunk edge - this lane's end state against the next lane's start.  The update
-  // test above leaves that defect at round-off when the sweeps contract quadratically with a moderate
-  // constant (measured on C2); for dynamics or gains where they do not, the defect shows it and the
-  // caller falls back to the sequential rollout.  One wave_shl DPP move + one wave maximum.
-  auto edges_closed = [&](const double (&xe)[n]) __attribute__((always_inline)) -> bool {
+  // The trial trajectory IS the last sweep's result: its update applied the linearized recurrence, i.e.
+  //   x_{t+1} = g_t(X_t) + G_t (x_t - X_t),
+  // to corrections below kTol = 1e-7, so it misses the exact step x_{t+1} = g_t(x_t) (ilqr.py:313-316) by the
+  // quadratic remainder ~c |x_t - X_t|^2 (c = 0.03 on C2: < 3e-16; a chord sweep leaves 2c u_full u_chord, < 1e-13
+  // by its entry rule) - the size of the chunk-edge defect the earlier re-step of every chunk left at its 49 edges,
+  // without that re-step's four model evaluations per lane.  A-posteriori guard of the stopping rule, model by
+  // model and trial by trial: ONE exact step per lane, its last, against the state the trajectory holds there; for
+  // dynamics or gains where the sweeps do not contract as measured the defect shows it and the caller falls back
+  // to the sequential rollout.
+  auto dynamics_hold = [&]() __attribute__((always_inline)) -> bool {
     constexpr double kEdgeTol = 1e-11;
-    const double nx0 = dpp_f64_or_zero<0x130, 0xF>(X[0][0]), nx1 = dpp_f64_or_zero<0x130, 0xF>(X[0][1]);   // wave_shl:1
     double dfc = 0.0;
-    if (t0 + CH < steps) {                                     // the next lane holds a valid step
-      const double d = fmax(fabs(xe[0] - nx0), fabs(xe[1] - nx1));
+    if (valid[CH - 1]) {
+      double u[m], xe[n];
+      u[0] = dd[CH - 1] - (Kk[CH - 1][0] * (X[CH - 1][0] - xb[CH - 1][0]) + Kk[CH - 1][1] * (X[CH - 1][1] - xb[CH - 1][1]));
+      M::template step<double>(X[CH - 1], u, xe, a.params, a.dt);
+      const double d = fmax(fabs(xe[0] - x_end[0]), fabs(xe[1] - x_end[1]));
       const double sc = fmax(1.0, fmax(fabs(xe[0]), fabs(xe[1])));
-      dfc = (d <= kEdgeTol * sc) ? 0.0 : 1.0;                  // NaN -> open
+      dfc = (d <= kEdgeTol * sc) ? 0.0 : 1.0;                  // NaN -> does not hold
     }
     dfc = fmax(dfc, row_ror_f64<8>(dfc));
     dfc = fmax(dfc, row_ror_f64<4>(dfc));
@@ -846,28 +854,24 @@ __device__ inline int rollout_newton_impl(const WS& w, const Consts<M>& c, const
     dfc = fmax(dfc, row_ror_f64<1>(dfc));
     return fmax(fmax(readlane_f64(dfc, 0), readlane_f64(dfc, 16)), fmax(readlane_f64(dfc, 32), readlane_f64(dfc, 48))) == 0.0;
   };
-  // final pass: the plain fp64 step over this lane's chunk from its converged start (ilqr.py:313-316)
+  if (!dynamics_hold()) return NEWTON_FAILED;                  // (the caller's sequential rollout takes over)
+  // final pass over this lane's steps: controls (and, fused, the cost) from the trajectory in registers
   if (fuse == 0) {
     if (lane == 0) {
 #pragma unroll
       for (int i = 0; i < n; ++i) w.T[Ly::XN + i] = x0r[i];
     }
-    double x[n] = {X[0][0], X[0][1]};
 #pragma unroll
     for (int k = 0; k < CH; ++k) {
       if (valid[k]) {
         const int t = t0 + k;
-        double u[m], xn[n];
-        u[0] = dd[k] - (Kk[k][0] * (x[0] - xb[k][0]) + Kk[k][1] * (x[1] - xb[k][1]));
-        M::template step<double>(x, u, xn, a.params, a.dt);
+        const double u0 = dd[k] - (Kk[k][0] * (X[k][0] - xb[k][0]) + Kk[k][1] * (X[k][1] - xb[k][1]));
         double* tr = w.T + t * Ly::TS;
-        tr[Ly::UN] = u[0];
-        tr[Ly::TS + Ly::XN + 0] = xn[0];
-        tr[Ly::TS + Ly::XN + 1] = xn[1];
-        x[0] = xn[0]; x[1] = xn[1];
+        tr[Ly::UN] = u0;
+        tr[Ly::TS + Ly::XN + 0] = (k + 1 < CH) ? X[(k + 1 < CH) ? k + 1 : k][0] : x_end[0];
+        tr[Ly::TS + Ly::XN + 1] = (k + 1 < CH) ? X[(k + 1 < CH) ? k + 1 : k][1] : x_end[1];
       }
     }
-    if (!edges_closed(x)) return NEWTON_FAILED;                // (the caller's sequential rollout rewrites T)
 #ifdef MI_PROF_NEWTON
     if (lane == 0) mi_dbg_vals[2] = (double)(clock64() - pn1);
 #endif
@@ -875,27 +879,22 @@ __device__ inline int rollout_newton_impl(const WS& w, const Consts<M>& c, const
   }
   double xk[CH][n], uk[CH][m], xlast[n] = {0.0, 0.0};
   double cost = 0.0, dvs = 0.0;
-  {
-    double x[n] = {X[0][0], X[0][1]};
 #pragma unroll
-    for (int k = 0; k < CH; ++k) {
-      xk[k][0] = x[0]; xk[k][1] = x[1]; uk[k][0] = 0.0;
-      if (valid[k]) {
-        const int t = t0 + k;
-        double u[m], xn[n];
-        u[0] = dd[k] - (Kk[k][0] * (x[0] - xb[k][0]) + Kk[k][1] * (x[1] - xb[k][1]));
-        M::template step<double>(x, u, xn, a.params, a.dt);
-        uk[k][0] = u[0];
-        cost += stage_cost<M>(c, x, u);                        // ilqr.py:325
-        dvs += w.G[t * Ly::GS + Ly::DV];                       // :326
-        if (t == steps - 1) {                                  // :327
-          cost += terminal_cost<M>(c, xn);
-          xlast[0] = xn[0]; xlast[1] = xn[1];
-        }
-        x[0] = xn[0]; x[1] = xn[1];
+  for (int k = 0; k < CH; ++k) {
+    xk[k][0] = X[k][0]; xk[k][1] = X[k][1]; uk[k][0] = 0.0;
+    if (valid[k]) {
+      const int t = t0 + k;
+      double u[m];
+      u[0] = dd[k] - (Kk[k][0] * (X[k][0] - xb[k][0]) + Kk[k][1] * (X[k][1] - xb[k][1]));
+      uk[k][0] = u[0];
+      cost += stage_cost<M>(c, X[k], u);                       // ilqr.py:325
+      dvs += w.G[t * Ly::GS + Ly::DV];                         // :326
+      if (t == steps - 1) {                                    // :327
+        const double xn[n] = {(k + 1 < CH) ? X[(k + 1 < CH) ? k + 1 : k][0] : x_end[0], (k + 1 < CH) ? X[(k + 1 < CH) ? k + 1 : k][1] : x_end[1]};
+        cost += terminal_cost<M>(c, xn);
+        xlast[0] = xn[0]; xlast[1] = xn[1];
       }
     }
-    if (!edges_closed(x)) return NEWTON_FAILED;
   }
   const double L = wave_sum(cost);
   const double ex = -eps * (1.0 - eps / 2.0) * wave_sum(dvs);
