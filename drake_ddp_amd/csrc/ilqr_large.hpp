@@ -1157,24 +1157,43 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
       const double* Fc = F + ((N - 2 - t) & 1) * FB1;         // F_t
       const double* Fn = F + ((N - 1 - t) & 1) * FB1;         // F_{t-1}, published a step ago
       // ---- T1[:, W] = Vxx F[:, W].  Row tile W of Vxx is this wave's own column tile, mirrored: already in registers
-      //      (vc, from the previous step); the other two row tiles and F come from LDS, a group of k-steps ahead.
-      const double* a1 = Vxx + (16 * Q1 + lr) * VS + lk;
-      const double* a2 = Vxx + (16 * Q2 + lr) * VS + lk;
+      //      (vc, from the previous step); the other row tiles and F come from LDS, a group of k-steps ahead.
+      //      THE LAST ROW TILE IS THIN: of its 16 rows only NK - 32 (4 or 8) exist as k-steps of the next product, so it
+      //      is computed in groups of four rows by v_mfma_f64_4x4x4_4b (four 4x4x4 blocks = 4 rows x 16 columns, 16
+      //      cycles instead of 64; tools/ubench/mfma4x4.hip): block b, row i, k at lane 16k + 4b + i for A and B - with
+      //      every block given the same four rows of Vxx, B is the 16x16x4 product's operand register unchanged, and the
+      //      result lands lane for lane where result register g of the 16x16x4 tile would.
+      constexpr int LT = RT - 1, G4 = (NK - 16 * LT) / 4;      // the thin tile and its groups of four rows
+      static_assert(G4 >= 1 && G4 <= 2, "thin last row tile: 4 or 8 rows");
+      constexpr int F1 = (W_ == 1) ? Q2 : Q1;                  // full row tiles read from LDS: one (two for the wave that owns the thin tile)
+      constexpr bool kTwoFull = W_ == LT;
+      const double* a1 = Vxx + (16 * F1 + lr) * VS + lk;
+      const double* a2 = Vxx + (16 * Q2 + lr) * VS + lk;     // (kTwoFull only)
+      const double* at = Vxx + (16 * LT + (lr & 3)) * VS + lk;
       const double* b_base = Fc + lk * FS + 16 * W_ + lr;    // also A = F^T of the diagonal tile: A[p][k] = F[k][16W + p]
       const double* f1 = Fc + lk * FS + 16 * Q1 + lr;        // A = F^T, row tile Q1
       const double* f3 = Fc + lk * FS + 16 * (CT - 1) + lr;  // A = F^T, u's row tile (split layout)
-      double va1[KN], va2[KN], fb[KN], fo[KN], fuu[kHasU ? KN : 1];
+      double va1[KN], va2[kTwoFull ? KN : 1], vt[G4][KN], fb[KN], fo[KN], fuu[kHasU ? KN : 1];
       auto load_group = [&](int g) __attribute__((always_inline)) {
 #pragma unroll
-        for (int ks = g * GS; ks < (g + 1) * GS && ks < KN; ++ks) { fb[ks] = b_base[ks * 4 * FS]; va1[ks] = a1[4 * ks]; va2[ks] = a2[4 * ks]; }
+        for (int ks = g * GS; ks < (g + 1) * GS && ks < KN; ++ks) {
+          fb[ks] = b_base[ks * 4 * FS];
+          va1[ks] = a1[4 * ks];
+          if constexpr (kTwoFull) va2[ks] = a2[4 * ks];
+#pragma unroll
+          for (int g4 = 0; g4 < G4; ++g4) vt[g4][ks] = at[4 * g4 * VS + 4 * ks];
+        }
       };
       auto load_fa = [&](int g) __attribute__((always_inline)) {
 #pragma unroll
         for (int ks = g * GS; ks < (g + 1) * GS && ks < KN; ++ks) { fo[ks] = f1[ks * 4 * FS]; if constexpr (kHasU) fuu[ks] = f3[ks * 4 * FS]; }
       };
       d4_t accA[RT];
+      double thin[G4];
 #pragma unroll
       for (int q = 0; q < RT; ++q) accA[q] = zero4;
+#pragma unroll
+      for (int g4 = 0; g4 < G4; ++g4) thin[g4] = 0.0;
       load_group(0);
       load_group(1);
       __builtin_amdgcn_sched_barrier(0);
@@ -1184,12 +1203,16 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = g * GS; ks < (g + 1) * GS && ks < KN; ++ks) {
-          accA[W_] = __builtin_amdgcn_mfma_f64_16x16x4f64(vc[ks >> 2][ks & 3], fb[ks], accA[W_], 0, 0, 0);
-          accA[Q1] = __builtin_amdgcn_mfma_f64_16x16x4f64(va1[ks], fb[ks], accA[Q1], 0, 0, 0);
-          accA[Q2] = __builtin_amdgcn_mfma_f64_16x16x4f64(va2[ks], fb[ks], accA[Q2], 0, 0, 0);
+          if constexpr (!kTwoFull) accA[W_] = __builtin_amdgcn_mfma_f64_16x16x4f64(vc[ks >> 2][ks & 3], fb[ks], accA[W_], 0, 0, 0);
+          accA[F1] = __builtin_amdgcn_mfma_f64_16x16x4f64(va1[ks], fb[ks], accA[F1], 0, 0, 0);
+          if constexpr (kTwoFull) accA[Q2] = __builtin_amdgcn_mfma_f64_16x16x4f64(va2[ks], fb[ks], accA[Q2], 0, 0, 0);
+#pragma unroll
+          for (int g4 = 0; g4 < G4; ++g4) thin[g4] = __builtin_amdgcn_mfma_f64_4x4x4f64(vt[g4][ks], fb[ks], thin[g4], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+#pragma unroll
+      for (int g4 = 0; g4 < G4; ++g4) accA[LT][g4] = thin[g4];
       BP_TICK(1);
       // ---- H[:, W] = F^T T1[:, W], T1 from the accumulators: the diagonal tile, one off-diagonal tile, u's rows
       d4_t bd = zero4, bo = zero4, bu = zero4;
@@ -1233,9 +1256,14 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
 #pragma unroll
       for (int j = 0; j < MK; ++j) { wa[j] = Ws[lr * WSS + 4 * j + lk]; qux[j] = QuxS[(4 * j + lk) * QS + col]; }
 #pragma unroll
-      for (int q = 0; q < RT; ++q)
+      for (int q = 0; q < LT; ++q)
 #pragma unroll
         for (int j = 0; j < MK; ++j) qa[q][j] = -QuxS[(4 * j + lk) * QS + 16 * q + lr];
+      double qt[G4][MK];                                     // the thin row tile's A operand: four rows per group, every block the same
+#pragma unroll
+      for (int g4 = 0; g4 < G4; ++g4)
+#pragma unroll
+        for (int j = 0; j < MK; ++j) qt[g4][j] = -QuxS[(4 * j + lk) * QS + 16 * LT + 4 * g4 + (lr & 3)];
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) cm[reg] = Xt[Q2 * PS + (4 * reg + lk) * SS + lr];
       if (t > 0) load_fu(fu_, Fn);
@@ -1249,10 +1277,19 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
         vc[Q1][reg] = bo[reg] + q2[Q1][reg];
         vc[Q2][reg] = cm[reg] + q2[Q2][reg];
       }
+      double thd[G4];
 #pragma unroll
-      for (int j = 0; j < MK; ++j)
+      for (int g4 = 0; g4 < G4; ++g4) thd[g4] = vc[LT][g4];
 #pragma unroll
-        for (int q = 0; q < RT; ++q) vc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[q][j], kt[j], vc[q], 0, 0, 0);
+      for (int j = 0; j < MK; ++j) {
+#pragma unroll
+        for (int q = 0; q < LT; ++q) vc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[q][j], kt[j], vc[q], 0, 0, 0);
+#pragma unroll
+        for (int g4 = 0; g4 < G4; ++g4) thd[g4] = __builtin_amdgcn_mfma_f64_4x4x4f64(qt[g4][j], kt[j], thd[g4], 0, 0, 0);
+      }
+      vc[LT] = zero4;                                        // (rows past the thin tile's groups: never k-steps, never stored)
+#pragma unroll
+      for (int g4 = 0; g4 < G4; ++g4) vc[LT][g4] = thd[g4];
       if (col_ok) {
         double* Kg = v.K + (size_t)t * m * n + col;          // K_t[4 reg + lk][col]
 #pragma unroll
