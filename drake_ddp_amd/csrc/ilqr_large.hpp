@@ -788,7 +788,11 @@ __device__ __forceinline__ void large_jac_at(const LView<M::n, M::m>& v, const K
   }
 }
 
-#ifdef MI_PROF_BACKWARD
+#if defined(MI_PROF_BACKWARD) && defined(MI_PROF_BACKWARD_LIGHT)
+// light mode: only the stopwatches on either side of the two barriers of a step - busy / wait per half-step and wave, at
+// next to no perturbation (a wave reads the clock where it is about to wait anyway); tools/bp_prof.py --light
+#define BP_TICK(k) do { if ((k) == 2 || (k) == 3 || (k) == 12 || (k) == 11 || (k) == 6 || (k) == 8 || (k) == 7) { const long long c_ = clock64(); if (bp_acc) bp_acc[k] += c_ - bp_last; bp_last = c_; } } while (0)
+#elif defined(MI_PROF_BACKWARD)
 #define BP_TICK(k) do { const long long c_ = clock64(); if (bp_acc) bp_acc[k] += c_ - bp_last; bp_last = c_; } while (0)
 #else
 #define BP_TICK(k) do {} while (0)

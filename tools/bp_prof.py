@@ -3,13 +3,15 @@
 Builds its own -DMI_PROF_BACKWARD library (lib/libmi_ilqr_bpprof.so: per-wave stopwatches between the phases, thread 0 =
 a matrix-core wave, thread 192 = the solver wave) and prints cycles per step.
 
-    python tools/bp_prof.py [synth36|quad|quad3d]
+    python tools/bp_prof.py [--light] [synth36|quad|quad3d]
 """
 import os, sys
 sys.path.insert(0, ".")
 from drake_ddp_amd import build as B
-lib = os.path.join(B.LIBDIR, "libmi_ilqr_bpprof.so")
-B.build(verbose=False, extra=["-DMI_PROF_BACKWARD"], lib=lib)
+light = "--light" in sys.argv
+if light: sys.argv.remove("--light")
+lib = os.path.join(B.LIBDIR, "libmi_ilqr_bpprof%s.so" % ("_light" if light else ""))
+B.build(verbose=False, extra=["-DMI_PROF_BACKWARD"] + (["-DMI_PROF_BACKWARD_LIGHT"] if light else []), lib=lib)
 os.environ["MI_ILQR_LIB"] = lib
 import numpy as np
 from drake_ddp_amd import workloads as W
@@ -32,6 +34,11 @@ H = s.history[0]; cap = H.shape[0]
 st = N - 1
 w0 = H[cap - 4:cap].reshape(-1) / st; w3 = H[cap - 8:cap - 4].reshape(-1) / st
 print(f"{which}: n = {q['x_nom'].size}, {st} steps; cycles per step")
+if light:
+    print("light mode (stopwatches at the barriers only): first half-step busy | wait || second half-step busy | wait")
+    print("  matrix-core wave 0: %.0f | %.0f || %.0f | %.0f   (sum %.0f)" % (w0[2], w0[3], w0[12], w0[11], w0[[2, 3, 12, 11]].sum()))
+    print("  solver wave:        %.0f | %.0f || %.0f | %.0f   (sum %.0f)" % (w3[6], w3[8], w3[7], w3[11], w3[[6, 8, 7, 11]].sum()))
+    sys.exit(0)
 print("matrix-core wave 0: T1 = Vxx F %.0f | H = F^T T1 + Qux store %.0f | wait %.0f || K, Vxx' + stores %.0f | share of the next Quu %.0f | wait %.0f   (sum %.0f)"
       % (w0[1], w0[2], w0[3], w0[4], w0[12], w0[11], w0[[0, 1, 2, 3, 4, 11, 12]].sum()))
 print("solver wave:        gather Quu %.0f | Gauss-Jordan + store %.0f | wait %.0f || kappa, dV, Vx' %.0f | publish F, prefetch %.0f | next first-order column %.0f | wait %.0f   (sum %.0f)"
