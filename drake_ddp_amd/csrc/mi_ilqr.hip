@@ -104,14 +104,17 @@ KArgs make_args(const mi_ilqr* h) {
   // rollout and sweep), so a second resident wave per SIMD does not fit and extra waves would queue.
   // MI_ILQR_NO_HELPER=1 turns them off (A/B measurements).
   static const bool no_helper = [] { const char* e = std::getenv("MI_ILQR_NO_HELPER"); return e && e[0] == '1'; }();
-  a.helpers = 0;
-  if (!no_helper && !h->large && !h->batch_minor && h->d.keypoint_method == MI_KP_SET_INTERVAL && h->d.minN == 1 &&
-      (h->N - 1) * (h->n + h->m) > 128)
-    a.helpers = h->B <= 256 ? 3 : (h->B <= 512 ? 1 : 0);
   static const bool seq_bp = [] { const char* e = std::getenv("MI_ILQR_SEQ_BACKWARD"); return e && e[0] == '1'; }();
   a.seq_backward = h->exact_backward ? 2 : (seq_bp ? 1 : 0);
   static const bool seq_ro = [] { const char* e = std::getenv("MI_ILQR_SEQ_ROLLOUT"); return e && e[0] == '1'; }();
   a.newton_rollout = seq_ro ? 0 : 1;
+  // (not for n = 2 with the time-parallel rollout: its final pass differentiates the steps it holds in registers,
+  //  which beats sharing them - C2's batch at B = 512: 0.141 ms without helpers, 0.149 ms with one; tools/helper_ab.py)
+  const bool fused_linearization = h->n == 2 && h->m == 1 && h->N - 1 <= 256 && a.newton_rollout != 0;
+  a.helpers = 0;
+  if (!no_helper && !h->large && !h->batch_minor && h->d.keypoint_method == MI_KP_SET_INTERVAL && h->d.minN == 1 &&
+      (h->N - 1) * (h->n + h->m) > 128 && !fused_linearization)
+    a.helpers = h->B <= 256 ? 3 : (h->B <= 512 ? 1 : 0);
   // wave-per-problem kernels aggregate the batch statistics themselves (MODE_SOLVE / MODE_MPC)
   const bool own_stats = stats_in_kernel(h);
   a.stats_out = own_stats ? h->d_stats : nullptr;

@@ -252,7 +252,9 @@ def test_randomized_configs_vs_c_oracle(seed):
 @pytest.mark.parametrize("cfg,B", [("pendulum", 300), ("wall", 5)])
 def test_helper_wavefronts_do_not_change_results(cfg, B, tmp_path):
     """The team linearization (helper wavefronts, one or three per problem) computes the same items
-    with the same code: every output must be bitwise identical to the single-wave kernel."""
+    with the same code: every output must be bitwise identical to the single-wave kernel.  (n = 2 only gets helpers
+    when its time-parallel rollout - whose final pass differentiates the steps it holds itself, the faster form - is
+    switched off: MI_ILQR_SEQ_ROLLOUT=1 on both sides of the pendulum case.)"""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -269,9 +271,10 @@ x, u, _, L = s.Solve()
 np.savez(sys.argv[1], x=x, u=u, L=L, K=s.K, kappa=s.kappa, fx=s.fx, fu=s.fu, it=s.iterations, ls=s.ls_trials, kp=s.keypoint_count, kpl=s.keypoint_list)
 """
     outs = []
+    common = {"MI_ILQR_SEQ_ROLLOUT": "1"} if cfg == "pendulum" else {}
     for tag, env in (("team", {}), ("solo", {"MI_ILQR_NO_HELPER": "1"})):
         f = str(tmp_path / f"{tag}.npz")
-        r = subprocess.run([sys.executable, "-c", script, f], capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
+        r = subprocess.run([sys.executable, "-c", script, f], capture_output=True, text=True, timeout=300, env=dict(os.environ, **common, **env))
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(np.load(f))
     for k in outs[0].files:
