@@ -922,8 +922,8 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
   double* Vxx = lds + Ly::oVxx;      // [NP][VS], rows >= n are zero
   double* Vx = lds + Ly::oVx;
   double* F = lds + Ly::oF;          // [n][FS]  = [fx | fu | 0-pad]
-  double* T1 = lds + Ly::oT1;        // [n][TS]  = [Vxx F | . | Vx at column FS]; later rows 0..m-1 hold [K | kappa]
-  double* H = lds + Ly::oH;          // [NMP][TS] = F^T T1, first-order terms in column FS
+  double* T1 = lds + Ly::oT1;        // the area T1 = Vxx F used to occupy: staging in the prologue, then the SECOND F buffer
+  double* H = lds + Ly::oH;          // the area H = F^T T1 used to occupy: staging, then the waves' exchange buffers (below)
   double* QT = lds + Ly::oQT;        // Q^T (compact layout only: the horizon's cost-gradient product)
 #ifdef MI_PROF_BACKWARD
   long long bp_last = clock64();
@@ -1012,15 +1012,15 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
     if (wave == 0) BP_TICK(6);
     __syncthreads();
     if (wave == 0) BP_TICK(7);
-    // the zero padding the tiles rely on (F's pad columns; H for tidiness)
+    // the zero padding the tiles rely on (F's pad rows and columns, in both buffers; the exchange area where H used to be)
     for (int e = tid; e < NK * FS; e += kLargeThreads) { F[e] = 0.0; F[(Ly::oT1 - Ly::oF) + e] = 0.0; }   // both F buffers (the second one is the T1 area)
     for (int e = tid; e < Ly::NMP * TS; e += kLargeThreads) H[e] = 0.0;
   }
   __syncthreads();
   BP_TICK(14);
-  // The spare wave (wave 3) prefetches the WHOLE next F = [fx_t | fu_t] (contiguous n*n and n*m
-  // blocks in HBM) as 16-byte pairs into registers during the T1 phase and publishes it to LDS
-  // during the last phase: the three matrix-core waves never touch global memory in the loop.
+  // The solver wave runs F's pipeline: a WHOLE F = [fx_t | fu_t] (contiguous n*n and n*m blocks in HBM) is fetched as
+  // 16-byte pairs into registers three steps ahead and published to one of two LDS buffers two steps ahead, always in
+  // the second half of a step - the three matrix-core waves only touch global memory to store K.
   // (16-byte pairs where the rows allow it - n, m even; single doubles otherwise, e.g. n = 37)
   constexpr int W = (n % 2 == 0 && m % 2 == 0 && FS % 2 == 0 && Ly::oF % 2 == 0 && Ly::oT1 % 2 == 0) ? 2 : 1;
   constexpr int PFX = n * n / W, PFU = n * m / W;                       // pairs (or single doubles)
