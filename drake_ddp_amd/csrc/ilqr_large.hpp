@@ -1168,7 +1168,7 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
       //      every block given the same four rows of Vxx, B is the 16x16x4 product's operand register unchanged, and the
       //      result lands lane for lane where result register g of the 16x16x4 tile would.
       constexpr int LT = RT - 1, G4 = (NK - 16 * LT) / 4;      // the thin tile and its groups of four rows
-      static_assert(G4 >= 1 && G4 <= 2, "thin last row tile: 4 or 8 rows");
+      static_assert(G4 >= 1 && G4 <= 4, "thin last row tile: groups of four rows");
       constexpr int F1 = (W_ == 1) ? Q2 : Q1;                  // full row tiles read from LDS: one (two for the wave that owns the thin tile)
       constexpr bool kTwoFull = W_ == LT;
       const double* a1 = Vxx + (16 * F1 + lr) * VS + lk;

@@ -51,6 +51,51 @@ SYNTH36P_BODY = """    const double ks = p[0], c = p[1], kc = p[2], bu = p[3];
 SYNTH36P_DEFAULTS = [4.0, 0.5, 6.0, 0.1]
 
 
+# A chain of nq coupled pendula with its last 12 actuated - the matrix-core family at other state dimensions than the two
+# the library ships (n = 2 nq, e.g. 34 and 40: split tile layout with one resp. two four-row groups in the thin last row tile).
+def chain_body(nq):
+    return """    const double ks = p[0], c = p[1], kc = p[2];
+    constexpr int nq = %d;
+    for (int i = 0; i < nq; ++i) {
+      const T qi = x[i], vi = x[nq + i];
+      T a = -ks * mi_sin(qi) - c * vi;
+      if (i < nq - 1) a = a + kc * mi_sin(x[i + 1] - qi);
+      if (i > 0) a = a - kc * mi_sin(qi - x[i - 1]);
+      if (i >= nq - 12) a = a + u[i - (nq - 12)];
+      const T vn = vi + dt * a;
+      xn[nq + i] = vn; xn[i] = qi + dt * vn;
+    }""" % nq
+
+
+CHAIN_DEFAULTS = [4.0, 0.5, 6.0]
+
+
+def chain_step(nq):
+    def step(x, u, p, dt):
+        from oracle import dual as D
+        ks, c, kc = p[0], p[1], p[2]
+        out = [None] * (2 * nq)
+        for i in range(nq):
+            qi, vi = x[i], x[nq + i]
+            a = -ks * D.sin(qi) - c * vi
+            if i < nq - 1:
+                a = a + kc * D.sin(x[i + 1] - qi)
+            if i > 0:
+                a = a - kc * D.sin(qi - x[i - 1])
+            if i >= nq - 12:
+                a = a + u[i - (nq - 12)]
+            vn = vi + dt * a
+            out[nq + i] = vn
+            out[i] = qi + dt * vn
+        return out
+    return step
+
+
+def build_chain(nq, verbose=False):
+    from drake_ddp_amd import plugin
+    return plugin.build_model("chain%d" % nq, 2 * nq, 12, chain_body(nq), CHAIN_DEFAULTS, family="large", verbose=verbose)
+
+
 def vdp_step(x, u, p, dt):
     q, v = x[0], x[1]
     a = p[0] * (1.0 - q * q) * v - q + u[0]
@@ -74,7 +119,8 @@ def build_all(verbose=False):
     from drake_ddp_amd import plugin
     return {"vdp": plugin.build_model("vdp", 2, 1, VDP_BODY, VDP_DEFAULTS, verbose=verbose),
             "chain3": plugin.build_model("chain3", 6, 2, CHAIN3_BODY, CHAIN3_DEFAULTS, verbose=verbose),
-            "synth36p": plugin.build_model("synth36p", 36, 12, SYNTH36P_BODY, SYNTH36P_DEFAULTS, family="large", verbose=verbose)}
+            "synth36p": plugin.build_model("synth36p", 36, 12, SYNTH36P_BODY, SYNTH36P_DEFAULTS, family="large", verbose=verbose),
+            "chain17": build_chain(17, verbose=verbose), "chain20": build_chain(20, verbose=verbose)}
 
 
 if __name__ == "__main__":

@@ -159,7 +159,7 @@ int mi_ilqr_model_info(int model_id, int32_t* n, int32_t* m, int32_t* n_params, 
  * library this record; the returned id (>= MI_MODEL_PLUGIN_BASE) is used as mi_ilqr_desc.model_id like a built-in one.
  *   family 0: wave-per-problem kernels (state in LDS; any n, m <= 2 - n = 2 takes the time-parallel passes, n = 3..4 the
  *             matrix-core backward step, other n the scalar recursion);
- *   family 1: workgroup-per-problem kernels (32 < n <= 48, m <= 16, 2 m <= n; dynamics as `step` per Jacobian column and a
+ *   family 1: workgroup-per-problem kernels (32 < n <= 40, m <= 16, m % 4 == 0, 2 m <= n; dynamics as `step` per Jacobian column and a
  *             one-lane step in the rollout unless the model provides the cooperative hooks of csrc/models.hpp).
  * Plugin models are served by these two families only (no lane-per-problem THROUGHPUT kernels). */
 enum { MI_MODEL_PLUGIN_BASE = 100, MI_ILQR_MAX_PLUGINS = 32 };

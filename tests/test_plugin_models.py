@@ -99,7 +99,7 @@ def test_plugin_model_solves_like_the_oracle(name, jac):
 
 @pytest.mark.gpu
 def test_plugin_on_the_matrix_core_family_solves_like_the_builtin_model():
-    """Family 1 of the open interface (workgroup-per-problem kernels, 32 < n <= 48): the built-in 36-state chain written
+    """Family 1 of the open interface (workgroup-per-problem kernels, 32 < n <= 40): the built-in 36-state chain written
     again as a plugin in whole-step form - one lane advances the dynamics in the rollout, dense whole-step Jacobian columns -
     must reproduce the built-in model's solve and MPC loop (same formulas, other evaluation order of the linearization:
     counts exact, costs 1e-9, trajectories 1e-8)."""
@@ -126,3 +126,46 @@ def test_plugin_on_the_matrix_core_family_solves_like_the_builtin_model():
     assert np.array_equal(a[2], b[2]) and np.array_equal(a[3][:, :, -1], b[3][:, :, -1])
     assert np.max(np.abs(a[1] - b[1]) / np.abs(a[1])) < 1e-9 and np.max(np.abs(a[0] - b[0])) < 1e-8
     assert np.max(np.abs(a[3][:, :, -2] - b[3][:, :, -2]) / np.abs(a[3][:, :, -2])) < 1e-8 and np.max(np.abs(a[4] - b[4])) < 1e-7
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nq", [17, 20])
+def test_matrix_core_family_at_other_state_dimensions(nq):
+    """Family 1 beyond the two shapes the library ships: chains of 17 and 20 pendula (n = 34, 40; m = 12) - the split
+    tile layout with one resp. two four-row groups in the thin last row tile of the backward pass (n = 34: a state
+    dimension that is not a multiple of four; n = 40: the largest the by-value kernel arguments admit).  Forward-mode duals
+    against the NumPy oracle driven by the Python statement of the same update, after two iterations (round-off) and at
+    convergence (cost)."""
+    import models as PM
+    from drake_ddp_amd.ilqr import BatchedIterativeLQR
+    from oracle import models_np as M
+    from oracle.ilqr_np import OracleILQR
+    n, m, dt, N, B = 2 * nq, 12, 0.02, 24, 3
+    sys_ = PM.build_chain(nq)(dt)
+    rng = np.random.default_rng(nq)
+    x_nom = np.zeros(n)
+    x0 = 0.4 * rng.standard_normal((B, n))
+    ug = 0.2 * rng.standard_normal((B, m, N - 1))
+    Q = dt * np.diag(10.0 ** rng.uniform(-1, 0.5, n))
+    R = dt * 0.05 * np.eye(m)
+    Qf = np.diag(10.0 ** rng.uniform(0, 1, n))
+    model = M.Model.custom(n, m, PM.chain_step(nq), sys_.params, dt)
+    for cap in (2, 100000):
+        s = BatchedIterativeLQR(sys_, N, B, delta=1e-3, beta=0.7, gamma=0.0, jacobian_mode="ad", **({"max_iters": cap} if cap == 2 else {}))
+        s.SetTargetState(x_nom); s.SetRunningCost(Q, R); s.SetTerminalCost(Qf)
+        s.SetInitialState(x0); s.SetInitialGuess(ug)
+        try:
+            s.Solve()
+        except RuntimeError:
+            assert cap == 2
+        for b in range(B):
+            o = OracleILQR(model, N, 1e-3, 0.7, 0.0, jacobian="ad", max_iters=cap)
+            o.set_problem(x0[b], x_nom, Q, R, Qf, ug[b])
+            xo, uo, Lo, hist = o.solve()
+            if cap == 2:
+                assert s.iterations[b] == len(hist) and [h[1] for h in hist] == list(s.history[b][:len(hist), 1])
+                sc = lambda a_: max(1.0, float(np.max(np.abs(a_))))
+                assert np.max(np.abs(s.x_bar[b] - xo)) < 1e-11 * sc(xo) and np.max(np.abs(s.K[b] - o.K)) < 1e-10 * sc(o.K)
+                assert np.max(np.abs(s.kappa[b] - o.kappa)) < 1e-10 * sc(o.kappa)
+            else:
+                assert s.status[b] == 0 and abs(s.cost[b] - Lo) < 1e-10 * abs(Lo)
