@@ -45,10 +45,13 @@ struct LLay {
   // holds the tail of x together with all of u (n = 36, m = 12: three tiles).  SPLIT (that tile would not start inside
   // x, or n is not a multiple of 4: n = 37): x is padded to whole tiles and u gets a tile of its own - the pad
   // rows / columns are zero and never stored, so Quu still sits at the corner of the last diagonal tile.
+  // MID (n <= 32: one or two row tiles, any m <= 16 - mid_backward): always split, and always 48 columns - a row stride
+  // of 48 doubles keeps the four rows of a k-step on disjoint banks for the 64-bit reads (32 would put them on the same).
+  static constexpr bool kMid = n <= 32;
   static constexpr int NMPc = ((nm + 15) / 16) * 16;
-  static constexpr bool kSplit = !(NMPc - 16 <= n && n % 4 == 0);
+  static constexpr bool kSplit = kMid || !(NMPc - 16 <= n && n % 4 == 0);
   static constexpr int UC = kSplit ? NP : n;               // column of u_0
-  static constexpr int NMP = kSplit ? NP + ((m + 15) / 16) * 16 : NMPc;
+  static constexpr int NMP = kMid ? 48 : (kSplit ? NP + ((m + 15) / 16) * 16 : NMPc);
   static constexpr int TS = NMP + 4;                       // row stride of T1 / H: whole tiles + the Vx/first-order column
   static constexpr int VS = NK | 1;                        // odd row stride of Vxx: conflict-free column-of-tile reads
   static constexpr int oQ = 0, oQf = oQ + n * n, oR = oQf + n * n, oXnom = oR + m * m, oQn = oXnom + n,
@@ -205,7 +208,7 @@ __device__ inline double large_rollout(const LView<M::n, M::m>& v, double* lds, 
   // LDS reads + 36 subtractions per step each, and their wave was the step's critical path (1981 of the synthetic
   // chain's 2685 cycles per step, against 1065 for the dynamics wave); same operands, same bits.
   double* dxc = lds + Ly::oT1;
-  static_assert(n <= 64 && n * Ly::TS >= 64, "an n-vector inside T1");
+  static_assert(n <= 64 && Ly::NK * Ly::TS >= 64, "an n-vector inside T1");
   const bool drole = tid >= 192 && tid < 192 + n;
   const double xnr = drole ? xnom[tid - 192] : 0.0;
   // The cost rows have (Q (x_t - x_nom))_i and (R u_t)_k in hand: twice that IS lx_t / lu_t of the trial (symmetric
@@ -216,7 +219,7 @@ __device__ inline double large_rollout(const LView<M::n, M::m>& v, double* lds, 
   constexpr bool kLx = kLxFromRollout<M>;
   double* Lxu = lds + Ly::doubles;
   double* r2buf = lds + Ly::oT1 + 64;                                  // [2][64]
-  static_assert(n * Ly::TS >= 192, "dx + two half-row scratch vectors inside T1");
+  static_assert(Ly::NK * Ly::TS >= 192, "dx + two half-row scratch vectors inside T1");
   double r1_prev = 0.0;
   const ModelScalars<M> ms(a);
   const double* prm = ms.p;
@@ -1421,6 +1424,330 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
   else solver_role();
 }
 
+// Backward Riccati pass (ilqr.py:623-667, cost expansion :161-206 fused) for MID-SIZE models: 1 <= n <= 32 (one or two 16-row
+// tiles of Vxx), any 1 <= m <= 16 - a quadrotor (12, 4), a 7-joint arm (14, 7), the arm + free body of kinova_gen3.py /
+// panda_fr3.py (27, 7).  The same matrix-core formulation as large_backward, cut differently: u ALWAYS has a column tile of
+// its own (zero-padded to 16 - the padding never reaches a result: pad columns of F are zero, so the pad rows of Qux, the pad
+// rows / columns of Quu - luu and of Quu^{-1} are exact zeros), and every wave owns one COLUMN TILE of F = [fx | fu]:
+//
+//   step t, first half                                                    | second half
+//   x-wave w (w < RT):  T1[:, w] = Vxx F_t[:, w]            (accumulators)  | K[:, w] = Quu^{-1} Qux[:, w]  -> HBM        (:660)
+//                       Qxx[:, w] - lxx = F_t[:, x]^T T1[:, w]             | Vxx'[:, w] = Qxx[:, w] + 2Q - Qux^T K[:, w] -> LDS (:667)
+//                       Qux[:, w] = fu_t^T T1[:, w]  -> LDS                |
+//   u-wave:             T1u = Vxx fu_t,  Quu = 2R + fu_t^T T1u    (:654)   | kappa = Quu^{-1} Qu (:659), dV (:663),
+//                       Quu^{-1}: Gauss-Jordan, one row per lane (GjOuter) | Vx' = Qx - Qux^T kappa (:666); first-order column of
+//                       -> LDS                                             | step t-1: l + F_{t-1}^T Vx' (:651-652)
+//   pipeline wave:      (F_{t-3} in flight from HBM)                       | F_{t-2} -> the LDS buffer F_t leaves, fetch F_{t-3}
+//
+// The D layout of one 16x16x4 product is the B-operand layout of the next (large_backward: "Fused chain"), so T1, the H
+// column and K stay in registers; Vxx is read and written in full (no symmetry is assumed of it - every entry of Vxx' is
+// computed once, by the wave that owns its column, like the reference's dense update).  Two barriers per step.
+template <class M>
+__device__ inline void mid_backward(const LView<M::n, M::m>& v, double* lds, bool lx_ready = false) {
+  constexpr int n = M::n, m = M::m, nm = n + m;
+  using Ly = LLay<n, m>;
+  static_assert(Ly::kMid && Ly::kSplit && m >= 1 && m <= 16, "mid-size family: n <= 32, m <= 16");
+  constexpr int VS = Ly::VS, FS = Ly::NMP, NP = Ly::NP, RT = NP / 16, UC = Ly::UC, KN = Ly::KN, NK = Ly::NK;
+  constexpr int MK = (m + 3) / 4;                            // k-steps over the controls
+  constexpr int WU = RT, WP = RT + 1;                        // the u-wave and the pipeline wave
+  static_assert(RT >= 1 && RT <= 2 && WP <= 3, "one or two x-waves + the u-wave + the pipeline wave");
+  const int tid = threadIdx.x, N = v.N, wave = tid >> 6, lane = tid & 63;
+  const int lr = lane & 15, lk = lane >> 4;
+  const double* Q = lds + Ly::oQ;
+  const double* R = lds + Ly::oR;
+  const double* Qf = lds + Ly::oQf;
+  const double* qn = lds + Ly::oQn;
+  const double* qfn = lds + Ly::oQfn;
+  double* Vxx = lds + Ly::oVxx;      // [NP][VS], rows / columns >= n zero
+  double* Vx = lds + Ly::oVx;        // [NK], entries >= n zero
+  double* F = lds + Ly::oF;          // [NK][FS] = [fx | 0 | fu | 0], two buffers (the second one in the T1 area)
+  double* H = lds + Ly::oH;          // exchange buffers
+  double* Lxu = lds + Ly::doubles;   // [N-1][n+m] cost gradients lx_t | lu_t
+  constexpr int FB1 = Ly::oT1 - Ly::oF;
+  static_assert(NK * FS <= NK * Ly::TS, "the second F buffer lives in the T1 area");
+  constexpr int QS = 48, WSS = 17, SS = 17;
+  double* QuxS = H;                  // [16][QS]  Qux_t (rows >= m zero)
+  double* Ws = QuxS + 16 * QS;       // [16][WSS] Quu^{-1} (rows / columns >= m zero)
+  double* Kap = Ws + 16 * WSS;       // [16]      kappa_t
+  double* Fo = Kap + 16;             // [FS]      first-order column: Qx (entries < n), Qu (entries UC..UC+m)
+  double* Sq = Fo + FS;              // [16][SS]  Quu - luu, from the accumulator layout to one row per lane
+  constexpr int kExch = 16 * QS + 16 * WSS + 16 + FS + 16 * SS;
+  static_assert(kExch <= Ly::NMP * Ly::TS, "the exchange buffers live in the H area");
+  const d4_t zero4 = {0.0, 0.0, 0.0, 0.0};
+  auto wave_lds_fence = [&]() __attribute__((always_inline)) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+  };
+
+  // terminal: Vx = 2 Qf x_T - 2 x_nom^T Qf ; Vxx = 2 Qf   (ilqr.py:203-204, :638); pads = 0
+  for (int e = tid; e < NP * VS; e += kLargeThreads) {
+    const int i = e / VS, j = e - i * VS;
+    Vxx[e] = (i < n && j < n) ? 2.0 * Qf[i * n + j] : 0.0;
+  }
+  if (tid >= n && tid < NK) Vx[tid] = 0.0;
+  if (tid < n) {
+    const double* xT = v.X + (size_t)(N - 1) * n;
+    double s = 0.0;
+    for (int j = 0; j < n; ++j) s += (2.0 * Qf[tid * n + j]) * xT[j];
+    Vx[tid] = s - qfn[tid];
+  }
+  // cost gradients for all steps (ilqr.py:180-181), unless the accepted trial's rollout left them (large_rollout)
+  if (!lx_ready) {
+    for (int idx = tid; idx < (N - 1) * nm; idx += kLargeThreads) {
+      const int tt = idx / nm, pp = idx - tt * nm;
+      double s_;
+      if (pp < n) {
+        const double* xg = v.X + (size_t)tt * n;
+        s_ = -qn[pp];
+        for (int j = 0; j < n; ++j) s_ += (2.0 * Q[pp * n + j]) * xg[j];
+      } else {
+        const double* ug = v.U + (size_t)tt * m;
+        s_ = 0.0;
+        for (int j = 0; j < m; ++j) s_ += (2.0 * R[(pp - n) * m + j]) * ug[j];
+      }
+      Lxu[idx] = s_;
+    }
+  }
+  __syncthreads();                                           // (the rollout's scratch inside the T1 area is dead now)
+  for (int e = tid; e < NK * FS; e += kLargeThreads) { F[e] = 0.0; F[FB1 + e] = 0.0; }
+  for (int e = tid; e < kExch; e += kLargeThreads) H[e] = 0.0;
+  __syncthreads();
+
+  // F's pipeline (the pipeline wave): a whole F_t = [fx_t | fu_t] (contiguous n*n and n*m blocks in HBM) goes to registers
+  // three steps ahead and to the LDS buffer that F_{t+2} leaves two steps ahead.
+  constexpr int W = (n % 2 == 0 && m % 2 == 0 && FS % 2 == 0 && Ly::oF % 2 == 0 && Ly::oT1 % 2 == 0 && UC % 2 == 0) ? 2 : 1;
+  constexpr int PFX = n * n / W, PFU = n * m / W;
+  constexpr int NFX = (PFX + 63) / 64, NFU = (PFU + 63) / 64;
+  typedef double d2_t __attribute__((ext_vector_type(2)));
+  using fw_t = std::conditional_t<W == 2, d2_t, double>;
+  auto pipeline_role = [&]() __attribute__((always_inline)) {
+    fw_t frx[NFX], fru[NFU];
+    int fx_off[NFX], fu_off[NFU];
+#pragma unroll
+    for (int r = 0; r < NFX; ++r) { int e = W * (lane + 64 * r); e = e < n * n ? e : n * n - W; fx_off[r] = (e / n) * FS + (e % n); }
+#pragma unroll
+    for (int r = 0; r < NFU; ++r) { int e = W * (lane + 64 * r); e = e < n * m ? e : n * m - W; fu_off[r] = (e / m) * FS + UC + (e % m); }
+    auto fetch = [&](int t) __attribute__((always_inline)) {
+      const fw_t* fxg = reinterpret_cast<const fw_t*>(v.Fx + (size_t)t * n * n);
+      const fw_t* fug = reinterpret_cast<const fw_t*>(v.Fu + (size_t)t * n * m);
+#pragma unroll
+      for (int r = 0; r < NFX; ++r) { const int pi = lane + 64 * r; frx[r] = fxg[pi < PFX ? pi : PFX - 1]; }
+#pragma unroll
+      for (int r = 0; r < NFU; ++r) { const int pi = lane + 64 * r; fru[r] = fug[pi < PFU ? pi : PFU - 1]; }
+    };
+    auto publish = [&](double* Fb) __attribute__((always_inline)) {     // clamped duplicates rewrite the last element with itself
+#pragma unroll
+      for (int r = 0; r < NFX; ++r) *reinterpret_cast<fw_t*>(Fb + fx_off[r]) = frx[r];
+#pragma unroll
+      for (int r = 0; r < NFU; ++r) *reinterpret_cast<fw_t*>(Fb + fu_off[r]) = fru[r];
+    };
+    fetch(N - 2); publish(F);
+    if (N >= 3) { fetch(N - 3); publish(F + FB1); }
+    if (N >= 4) fetch(N - 4);
+    __syncthreads();                                         // (A) F_{N-2}, F_{N-3} in LDS
+    __syncthreads();                                         // (B)
+    for (int t = N - 2; t >= 0; --t) {
+      lds_barrier();
+      if (t >= 2) {
+        publish(F + ((N - 2 - t) & 1) * FB1);                // F_{t-2} replaces F_t, which nobody reads any more
+        if (t >= 3) fetch(t - 3);
+      }
+      lds_barrier();
+    }
+  };
+
+  // x-wave W_: column tile W_ of F (columns 16 W_ .. of x)
+  auto x_role = [&](auto wc) __attribute__((always_inline)) {
+    constexpr int W_ = decltype(wc)::value;
+    const int col = 16 * W_ + lr;
+    const bool col_ok = col < n;
+    double q2[RT][4];                                        // lxx = 2Q entries of this lane's Vxx' results
+#pragma unroll
+    for (int q = 0; q < RT; ++q)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int row = 16 * q + 4 * reg + lk;
+        q2[q][reg] = (row < n && col_ok) ? 2.0 * Q[row * n + col] : 0.0;
+      }
+    __syncthreads();                                         // (A)
+    __syncthreads();                                         // (B)
+    for (int t = N - 2; t >= 0; --t) {
+      const double* Fc = F + ((N - 2 - t) & 1) * FB1;         // F_t
+      // ---- T1[:, W] = Vxx F[:, W]
+      double fb[KN];
+      const double* b_base = Fc + lk * FS + col;
+#pragma unroll
+      for (int ks = 0; ks < KN; ++ks) fb[ks] = b_base[ks * 4 * FS];
+      d4_t accA[RT];
+#pragma unroll
+      for (int q = 0; q < RT; ++q) {
+        const double* ap = Vxx + (16 * q + lr) * VS + lk;
+        double va[KN];
+#pragma unroll
+        for (int ks = 0; ks < KN; ++ks) va[ks] = ap[4 * ks];
+        d4_t acc = zero4;
+#pragma unroll
+        for (int ks = 0; ks < KN; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[ks], fb[ks], acc, 0, 0, 0);
+        accA[q] = acc;
+      }
+      // ---- H[:, W] = F^T T1[:, W]: the x row tiles (Qxx - lxx) and u's row tile (Qux)
+      d4_t hx[RT], hu = zero4;
+#pragma unroll
+      for (int q = 0; q < RT; ++q) {
+        const double* ap = Fc + lk * FS + 16 * q + lr;       // A = F^T: A[p][k] = F[k][16 q + p]
+        double fa[KN];
+#pragma unroll
+        for (int ks = 0; ks < KN; ++ks) fa[ks] = ap[ks * 4 * FS];
+        d4_t acc = zero4;
+#pragma unroll
+        for (int ks = 0; ks < KN; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[ks], accA[ks >> 2][ks & 3], acc, 0, 0, 0);
+        hx[q] = acc;
+      }
+      {
+        const double* ap = Fc + lk * FS + UC + lr;
+        double fa[KN];
+#pragma unroll
+        for (int ks = 0; ks < KN; ++ks) fa[ks] = ap[ks * 4 * FS];
+#pragma unroll
+        for (int ks = 0; ks < KN; ++ks) hu = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[ks], accA[ks >> 2][ks & 3], hu, 0, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < MK; ++j) QuxS[(4 * j + lk) * QS + col] = hu[j];
+      lds_barrier();
+      // ---- K[:, W] = Quu^{-1} Qux[:, W] (:660)
+      double wa[MK];
+#pragma unroll
+      for (int j = 0; j < MK; ++j) wa[j] = Ws[lr * WSS + 4 * j + lk];
+      d4_t kt = zero4;
+#pragma unroll
+      for (int j = 0; j < MK; ++j) kt = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[j], hu[j], kt, 0, 0, 0);
+      if (col_ok) {
+        double* Kg = v.K + (size_t)t * m * n + col;          // K_t[4 j + lk][col]
+#pragma unroll
+        for (int j = 0; j < MK; ++j) if (4 * j + lk < m) Kg[(4 * j + lk) * n] = kt[j];
+      }
+      // ---- Vxx'[:, W] = Qxx[:, W] - Qux^T K[:, W] (:667)
+#pragma unroll
+      for (int q = 0; q < RT; ++q) {
+        double qa[MK];
+#pragma unroll
+        for (int j = 0; j < MK; ++j) qa[j] = -QuxS[(4 * j + lk) * QS + 16 * q + lr];
+        d4_t vq;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) vq[reg] = hx[q][reg] + q2[q][reg];
+#pragma unroll
+        for (int j = 0; j < MK; ++j) vq = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[j], kt[j], vq, 0, 0, 0);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int row = 16 * q + 4 * reg + lk;
+          if (row < n && col_ok) Vxx[row * VS + col] = vq[reg];
+        }
+      }
+      lds_barrier();
+    }
+  };
+
+  // u-wave: Quu and its inverse, the first-order terms
+  auto u_role = [&]() __attribute__((always_inline)) {
+    auto first_order = [&](int ts, const double* Fb) __attribute__((always_inline)) {   // l_{x,u} + F^T Vx (:651-652)
+      if (lane < nm) {
+        double s = Lxu[ts * nm + lane];
+        const int hp = lane < n ? lane : UC + (lane - n);    // this entry's column of F
+#pragma unroll
+        for (int k = 0; k < NK; ++k) s += Fb[k * FS + hp] * Vx[k];
+        Fo[hp] = s;
+      }
+    };
+    const int si = lr < m ? lr : m - 1;                      // lanes >= m of each 16-lane row shadow the last row
+    double r2[m];
+#pragma unroll
+    for (int j = 0; j < m; ++j) r2[j] = 2.0 * R[si * m + j];
+    __syncthreads();                                         // (A)
+    first_order(N - 2, F);
+    __syncthreads();                                         // (B)
+    for (int t = N - 2; t >= 0; --t) {
+      const double* Fc = F + ((N - 2 - t) & 1) * FB1;         // F_t
+      const double* Fn = F + ((N - 1 - t) & 1) * FB1;         // F_{t-1}
+      // ---- Quu - luu = fu^T (Vxx fu)
+      double fu_[KN];
+      const double* ub = Fc + lk * FS + UC + lr;             // B[k][c] = fu[k][c]; also A = fu^T: A[p][k] = fu[k][p]
+#pragma unroll
+      for (int ks = 0; ks < KN; ++ks) fu_[ks] = ub[ks * 4 * FS];
+      d4_t accU[RT];
+#pragma unroll
+      for (int q = 0; q < RT; ++q) {
+        const double* ap = Vxx + (16 * q + lr) * VS + lk;
+        double va[KN];
+#pragma unroll
+        for (int ks = 0; ks < KN; ++ks) va[ks] = ap[4 * ks];
+        d4_t acc = zero4;
+#pragma unroll
+        for (int ks = 0; ks < KN; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[ks], fu_[ks], acc, 0, 0, 0);
+        accU[q] = acc;
+      }
+      d4_t quu = zero4;
+#pragma unroll
+      for (int ks = 0; ks < KN; ++ks) quu = __builtin_amdgcn_mfma_f64_16x16x4f64(fu_[ks], accU[ks >> 2][ks & 3], quu, 0, 0, 0);
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) Sq[(4 * reg + lk) * SS + lr] = quu[reg];
+      wave_lds_fence();
+      double arow[m];
+#pragma unroll
+      for (int j = 0; j < m; ++j) arow[j] = r2[j] + Sq[si * SS + j];          // Quu = luu + fu^T Vxx fu (:654)
+      double sc = 1.0;
+      GjOuter<m, 0>::run(arow, sc, si);                      // Quu^{-1}[si][j] = sc * arow[j] (:655)
+      if (lane < m) {
+#pragma unroll
+        for (int j = 0; j < m; ++j) Ws[lane * WSS + j] = sc * arow[j];
+      }
+      lds_barrier();
+      // ---- kappa = Quu^{-1} Qu (:659), dV = Qu^T kappa (:663), Vx' = Qx - Qux^T kappa (:666)
+      {
+        double kp = 0.0;
+#pragma unroll
+        for (int j = 0; j < m; ++j) kp = fma(arow[j], Fo[UC + j], kp);
+        kp *= sc;
+        const double dv = row16_sum(lr < m ? Fo[UC + si] * kp : 0.0);
+        if (lane < m) { Kap[lane] = kp; v.kap[(size_t)t * m + lane] = kp; }
+        if (lane == 0) v.dV[t] = dv;
+      }
+      wave_lds_fence();
+      if (lane < n) {
+        double s = Fo[lane];
+#pragma unroll
+        for (int a_ = 0; a_ < m; ++a_) s -= QuxS[a_ * QS + lane] * Kap[a_];
+        Vx[lane] = s;
+      }
+      if (t > 0) {
+        wave_lds_fence();
+        first_order(t - 1, Fn);                              // the next step's, from the Vx' just formed
+      }
+      lds_barrier();
+    }
+  };
+
+  if (wave == WU) u_role();
+  else if (wave == WP) pipeline_role();
+  else if (wave == 0) x_role(std::integral_constant<int, 0>{});
+  else {
+    if constexpr (RT == 2) {
+      x_role(std::integral_constant<int, 1>{});
+    } else {                                                 // (n <= 16: the fourth wave only keeps the barriers' count)
+      __syncthreads();
+      __syncthreads();
+      for (int t = N - 2; t >= 0; --t) { lds_barrier(); lds_barrier(); }
+    }
+  }
+}
+
+// The backward pass of a model's size class.
+template <class M>
+__device__ __forceinline__ void backward_pass(const LView<M::n, M::m>& v, double* lds, long long* bp_acc, bool lx_ready) {
+  if constexpr (LLay<M::n, M::m>::kMid) mid_backward<M>(v, lds, lx_ready);
+  else large_backward<M>(v, lds, bp_acc, lx_ready);
+}
+
 template <class M, int JAC, int MODE>
 __global__ void __launch_bounds__(kLargeThreads) ilqr_large_kernel(const KArgs a) {
   constexpr int n = M::n, m = M::m;
@@ -1621,7 +1948,7 @@ __global__ void __launch_bounds__(kLargeThreads) ilqr_large_kernel(const KArgs a
     return;
   }
   if (MODE == MODE_BACKWARD) {
-    large_backward<M>(v, lds);
+    backward_pass<M>(v, lds, nullptr, false);
     return;
   }
 
@@ -1708,13 +2035,13 @@ __global__ void __launch_bounds__(kLargeThreads) ilqr_large_kernel(const KArgs a
       // profiling build only: 16 phase accumulators of thread 0 (a matrix-core wave) and of thread
       // 192 (the spare wave) land in the last 8 rows of the history buffer (tools/bp_prof.py)
       long long bpa[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-      if (MODE != MODE_FORWARD) { large_backward<M>(v, lds, bpa, kLxFromRollout<M>); __syncthreads(); }
+      if (MODE != MODE_FORWARD) { backward_pass<M>(v, lds, bpa, kLxFromRollout<M>); __syncthreads(); }
       if ((tid == 0 || tid == 192) && iters == 0 && it_this == 0) {
         double* hp = a.hist + (size_t)b * a.hist_cap * 4 + 4 * (a.hist_cap - (tid == 0 ? 4 : 8));
         for (int q_ = 0; q_ < 16; ++q_) hp[q_] = (double)bpa[q_];
       }
 #else
-      if (MODE != MODE_FORWARD) { large_backward<M>(v, lds, nullptr, kLxFromRollout<M>); __syncthreads(); }      // :697
+      if (MODE != MODE_FORWARD) { backward_pass<M>(v, lds, nullptr, kLxFromRollout<M>); __syncthreads(); }      // :697
 #endif
       const long long c3 = clock64();
       c_ls += c1 - c0; c_lin += c2 - c1; c_bp += c3 - c2;

@@ -1,12 +1,15 @@
 """Two models that are NOT compiled into libmi_ilqr.so, written the way a user of the open model interface writes them
-(drake_ddp_amd/plugin.py, include/mi_ilqr.h: mi_ilqr_register_model): the C++ body of the discrete update for the device
-and - for the tests - the same update as a float-or-dual Python function for the oracle.
+(drake_ddp_amd/plugin.py, include/mi_ilqr.h: mi_ilqr_register_model): the C++ body of the discrete update for the device.
+(The tests keep the same updates as float-or-dual Python functions for the oracle: tests/plugin_steps.py.)
 
   vdp     n = 2, m = 1   controlled Van der Pol oscillator, params [mu]
                          (an n = 2 model: served by the time-parallel rollout and Riccati scan, like the pendulum)
   chain3  n = 6, m = 2   three coupled pendula, the outer two actuated, params [ks, c, kc]
                          (a shape no built-in model has: served by the generic scalar passes of the wave-per-problem kernel)
   synth36p n = 36, m = 12 the built-in 36-state chain re-stated as a plugin (whole-step form) for the matrix-core family
+  chainx   any (n, m)     nq coupled pendula with the last m actuated + ne first-order "filter" states (n = 2 nq + ne): the
+                         mid-size workgroup-per-problem family (n <= 32, any m <= 16) at whatever shape a test asks for -
+                         (12, 4) a quadrotor's, (14, 7) a 7-joint arm's, (27, 7) kinova_gen3.py's arm + free body
 """
 import os
 import sys
@@ -70,57 +73,58 @@ def chain_body(nq):
 CHAIN_DEFAULTS = [4.0, 0.5, 6.0]
 
 
-def chain_step(nq):
-    def step(x, u, p, dt):
-        from oracle import dual as D
-        ks, c, kc = p[0], p[1], p[2]
-        out = [None] * (2 * nq)
-        for i in range(nq):
-            qi, vi = x[i], x[nq + i]
-            a = -ks * D.sin(qi) - c * vi
-            if i < nq - 1:
-                a = a + kc * D.sin(x[i + 1] - qi)
-            if i > 0:
-                a = a - kc * D.sin(qi - x[i - 1])
-            if i >= nq - 12:
-                a = a + u[i - (nq - 12)]
-            vn = vi + dt * a
-            out[nq + i] = vn
-            out[i] = qi + dt * vn
-        return out
-    return step
+# nq coupled pendula, the last m of them actuated, + ne first-order states e_j' = -a e_j + sin(q_{j mod nq}) + u_{j mod m}:
+# n = 2 nq + ne, any m <= nq - the shapes of the mid-size family (params [ks, c, kc, a]).
+def chainx_body(nq, m, ne):
+    return """    const double ks = p[0], c = p[1], kc = p[2], ae = p[3];
+    constexpr int nq = %d, mu = %d, ne = %d;
+    for (int i = 0; i < nq; ++i) {
+      const T qi = x[i], vi = x[nq + i];
+      T a = -ks * mi_sin(qi) - c * vi;
+      if (i < nq - 1) a = a + kc * mi_sin(x[i + 1] - qi);
+      if (i > 0) a = a - kc * mi_sin(qi - x[i - 1]);
+      if (i >= nq - mu) a = a + u[i - (nq - mu)];
+      const T vn = vi + dt * a;
+      xn[nq + i] = vn; xn[i] = qi + dt * vn;
+    }
+    for (int j = 0; j < ne; ++j) {
+      const T e = x[2 * nq + j];
+      xn[2 * nq + j] = e + dt * (mi_sin(x[j %% nq]) - ae * e + u[j %% mu]);
+    }""" % (nq, m, ne)
+
+
+CHAINX_DEFAULTS = [4.0, 0.5, 6.0, 2.0]
+
+
+def chainx_spec(nq, m, ne=0):
+    return ("chainx_%d_%d_%d" % (nq, m, ne), 2 * nq + ne, m, chainx_body(nq, m, ne), CHAINX_DEFAULTS, "large")
+
+
+def build_chainx(nq, m, ne=0, verbose=False):
+    from drake_ddp_amd import plugin
+    return plugin.build_model(*chainx_spec(nq, m, ne), verbose=verbose)
+
+
+# the shapes the tests and __graft_entry__.build() use: (nq, m, ne) -> (n, m) = (12, 4), (14, 7), (27, 7), (32, 16), (9, 4), (7, 3), (16, 1)
+CHAINX_SHAPES = [(6, 4, 0), (7, 7, 0), (10, 7, 7), (16, 16, 0), (4, 4, 1), (3, 3, 1), (8, 1, 0)]
+
+
+def chain_spec(nq):
+    return ("chain%d" % nq, 2 * nq, 12, chain_body(nq), CHAIN_DEFAULTS, "large")
 
 
 def build_chain(nq, verbose=False):
     from drake_ddp_amd import plugin
-    return plugin.build_model("chain%d" % nq, 2 * nq, 12, chain_body(nq), CHAIN_DEFAULTS, family="large", verbose=verbose)
-
-
-def vdp_step(x, u, p, dt):
-    q, v = x[0], x[1]
-    a = p[0] * (1.0 - q * q) * v - q + u[0]
-    vn = v + dt * a
-    return [q + dt * vn, vn]
-
-
-def chain3_step(x, u, p, dt):
-    from oracle import dual as D
-    ks, c, kc = p[0], p[1], p[2]
-    l01, l12 = D.sin(x[1] - x[0]), D.sin(x[2] - x[1])
-    a0 = -ks * D.sin(x[0]) - c * x[3] + kc * l01 + u[0]
-    a1 = -ks * D.sin(x[1]) - c * x[4] + kc * l12 - kc * l01
-    a2 = -ks * D.sin(x[2]) - c * x[5] - kc * l12 + u[1]
-    v0, v1, v2 = x[3] + dt * a0, x[4] + dt * a1, x[5] + dt * a2
-    return [x[0] + dt * v0, x[1] + dt * v1, x[2] + dt * v2, v0, v1, v2]
+    return plugin.build_model(*chain_spec(nq), verbose=verbose)
 
 
 def build_all(verbose=False):
-    """Compile the plugins (hipcc, ~15-40 s each the first time) and return their ModelSystem factories."""
+    """Compile the plugins (one hipcc each, in parallel: 10-40 s the first time) and return their ModelSystem factories."""
     from drake_ddp_amd import plugin
-    return {"vdp": plugin.build_model("vdp", 2, 1, VDP_BODY, VDP_DEFAULTS, verbose=verbose),
-            "chain3": plugin.build_model("chain3", 6, 2, CHAIN3_BODY, CHAIN3_DEFAULTS, verbose=verbose),
-            "synth36p": plugin.build_model("synth36p", 36, 12, SYNTH36P_BODY, SYNTH36P_DEFAULTS, family="large", verbose=verbose),
-            "chain17": build_chain(17, verbose=verbose), "chain20": build_chain(20, verbose=verbose)}
+    specs = [("vdp", 2, 1, VDP_BODY, VDP_DEFAULTS, "small"), ("chain3", 6, 2, CHAIN3_BODY, CHAIN3_DEFAULTS, "small"),
+             ("synth36p", 36, 12, SYNTH36P_BODY, SYNTH36P_DEFAULTS, "large"), chain_spec(17), chain_spec(20)]
+    specs += [chainx_spec(*sh) for sh in CHAINX_SHAPES]
+    return plugin.build_models(specs, verbose=verbose)
 
 
 if __name__ == "__main__":

@@ -60,3 +60,57 @@ def assert_flip_budget(name, same, detail=None):
     import numpy as _np
     flipped = int((~_np.asarray(same, bool)).sum())
     assert flipped <= FLIP_BUDGET[name], (name, f"{flipped} problems deviate, budget {FLIP_BUDGET[name]}", detail)
+
+
+def backward_extended(o):
+    """The reference's backward pass (ilqr.py:623-667) on an OracleILQR's current x_bar / u_bar / fx / fu in EXTENDED precision
+    (x86 80-bit long double, 64-bit mantissa): the yardstick for a backward pass's round-off - the fp64 NumPy oracle's own
+    distance from it says how many digits the PROBLEM leaves (cond(Quu), the dynamic range of Vxx), the device's distance
+    from it is then judged against that.  Returns (K (m,n,N-1), kappa (m,N-1), dV (N-1), max cond(Quu))."""
+    ld = np.longdouble
+
+    def inv_ld(A):
+        k = A.shape[0]
+        M_ = np.concatenate([A.astype(ld), np.eye(k, dtype=ld)], axis=1)
+        for c in range(k):
+            p = c + int(np.argmax(np.abs(M_[c:, c])))
+            M_[[c, p]] = M_[[p, c]]
+            M_[c] = M_[c] / M_[c, c]
+            for r in range(k):
+                if r != c:
+                    M_[r] = M_[r] - M_[r, c] * M_[c]
+        return M_[:, k:]
+
+    Q, R, Qf, x_nom = (np.asarray(a, dtype=ld) for a in (o.Q, o.R, o.Qf, o.x_nom))
+    xb, ub, fxa, fua = (np.asarray(a, dtype=ld) for a in (o.x_bar, o.u_bar, o.fx, o.fu))
+    n, m, N = o.n, o.m, o.N
+    K = np.zeros((m, n, N - 1), dtype=ld); kappa = np.zeros((m, N - 1), dtype=ld); dV = np.zeros(N - 1, dtype=ld)
+    Vx = 2 * Qf @ xb[:, -1] - 2 * x_nom @ Qf
+    Vxx = 2 * Qf
+    cond = 0.0
+    for t in range(N - 2, -1, -1):
+        fx, fu = fxa[:, :, t], fua[:, :, t]
+        lx = 2 * Q @ xb[:, t] - 2 * x_nom @ Q
+        lu = 2 * R @ ub[:, t]
+        Qx, Qu = lx + fx.T @ Vx, lu + fu.T @ Vx
+        Qxx, Quu, Qux = 2 * Q + fx.T @ Vxx @ fx, 2 * R + fu.T @ Vxx @ fu, fu.T @ Vxx @ fx
+        cond = max(cond, float(np.linalg.cond(Quu.astype(np.float64))))
+        Qi = inv_ld(Quu)
+        kappa[:, t] = Qi @ Qu
+        K[:, :, t] = Qi @ Qux
+        dV[t] = Qu @ Qi @ Qu
+        Vx = Qx - Qu @ Qi @ Qux
+        Vxx = Qxx - Qux.T @ Qi @ Qux
+    return K, kappa, dV, cond
+
+
+def backward_errors(dev, o):
+    """(device's, fp64 oracle's) worst relative distance from the extended-precision backward pass over K, kappa, dV, and
+    max cond(Quu).  `dev` = (K, kappa, dV) of the device for the oracle `o`'s inputs; o.backward() must have run."""
+    Kx, kx, dx, cond = backward_extended(o)
+    e_dev = e_ref = 0.0
+    for d_, r_, x_ in zip(dev, (o.K, o.kappa, o.dV), (Kx, kx, dx)):
+        sc = float(np.max(np.abs(x_)))
+        e_dev = max(e_dev, float(np.max(np.abs(d_ - x_))) / sc)
+        e_ref = max(e_ref, float(np.max(np.abs(r_ - x_))) / sc)
+    return e_dev, e_ref, cond

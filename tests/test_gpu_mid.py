@@ -1,0 +1,199 @@
+"""The MID-SIZE workgroup-per-problem family (ilqr_large.hpp: mid_backward): 4 < n <= 32 with ANY m <= 16 - the shapes the
+reference class accepts (ilqr.py:57-58 takes whatever the system reports) that neither the wave-per-problem kernels
+(m <= 2) nor the n = 36 / 37 kernels cover: a quadrotor's (12, 4), a 7-joint arm's (14, 7), kinova_gen3.py's arm + free body
+(27, 7), the family's corners (32, 16), (16, 1), odd state dimensions (7, 3), (9, 4).  Plugin models of those shapes
+(examples/plugins/models.py: chainx) against the NumPy oracle driven by the same update in Python (tests/plugin_steps.py)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "examples", "plugins"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+SHAPES = [(6, 4, 0), (7, 7, 0), (10, 7, 7), (16, 16, 0), (4, 4, 1), (3, 3, 1), (8, 1, 0)]    # (nq, m, ne): n = 2 nq + ne
+IDS = ["n%d_m%d" % (2 * nq + ne, m) for nq, m, ne in SHAPES]
+
+
+def test_mid_family_registers_the_reviewed_shapes():
+    """mi_ilqr_register_model accepts (n, m) in {(12, 4), (14, 7), (27, 7)} and the family's corners on family 1; a model with
+    more than 16 inputs, or 32 < n <= 40 outside the large kernels' wave roles, is still refused.  No device needed."""
+    import ctypes as C
+    import models as PM
+    from drake_ddp_amd import _capi, plugin
+    assert PM.CHAINX_SHAPES == SHAPES
+    make = PM.build_all()
+    for nq, m, ne in SHAPES:
+        s = make["chainx_%d_%d_%d" % (nq, m, ne)](0.01)
+        assert s.model_id >= 100 and (s.n, s.m) == (2 * nq + ne, m)
+    lib = _capi.load()
+    good = plugin._Plugin()
+    plug = C.CDLL(plugin.plugin_path("vdp", plugin.source("vdp", 2, 1, PM.VDP_BODY, PM.VDP_DEFAULTS)))
+    plug.mi_plugin_describe.argtypes = [C.POINTER(plugin._Plugin)]
+    plug.mi_plugin_describe(C.byref(good))
+    mid = C.c_int32()
+    for n, m, ok in ((12, 17, False), (36, 10, False), (36, 20, False), (41, 4, False)):
+        rec = plugin._Plugin(abi_version=good.abi_version, kernel_args_bytes=good.kernel_args_bytes, n=n, m=m, n_params=0, family=1, launch=1, lds_bytes=1)
+        rc = lib.mi_ilqr_register_model(C.byref(rec), C.byref(mid))
+        assert rc in (_capi.E_UNSUPPORTED, _capi.E_BAD_SHAPE), (n, m, rc)
+    assert plugin.resolve_family(27, 7, "auto") == "large" and plugin.resolve_family(4, 1, "auto") == "small"
+
+
+def _random_spd(rng, k, lo, hi):
+    A = rng.standard_normal((k, k))
+    Qm, _ = np.linalg.qr(A)
+    return (Qm * 10.0 ** rng.uniform(lo, hi, k)) @ Qm.T
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", SHAPES, ids=IDS)
+def test_mid_backward_pass_on_random_inputs(shape):
+    """Stage level with identical inputs: random trajectories, random Jacobians (identity + noise), DENSE random symmetric
+    positive definite Q, R, Qf over four decades; five horizons including the shortest the library accepts (every start-up
+    branch of F's pipeline).  K, kappa, dV against the reference's recursion in EXTENDED precision (tests/common.py):
+    1e-11 or 20 x the fp64 NumPy oracle's own distance from it, whichever is larger - observed on MI355X:
+    the device is closer to the extended-precision result than NumPy's fp64 pass in six of the seven shapes."""
+    import models as PM
+    import plugin_steps as PS
+    from drake_ddp_amd.ilqr import BatchedIterativeLQR
+    from oracle import models_np as M
+    from oracle.ilqr_np import OracleILQR
+    from common import backward_errors
+    nq, m, ne = shape
+    n = 2 * nq + ne
+    sys_ = PM.build_chainx(nq, m, ne)(0.02)
+    model = M.Model.custom(n, m, PS.chainx_step(nq, m, ne), sys_.params, 0.02)
+    rng = np.random.default_rng(100 * n + m)
+    worst = worst_ref = worst_cond = 0.0
+    for N in (4, 5, 6, 7, 33):
+        B = 3
+        Q, R, Qf = _random_spd(rng, n, -3, 0), _random_spd(rng, m, -2.5, 0), _random_spd(rng, n, -1, 1)
+        Q, R, Qf = 0.5 * (Q + Q.T), 0.5 * (R + R.T), 0.5 * (Qf + Qf.T)
+        x_nom = rng.standard_normal(n)
+        xb = rng.standard_normal((B, n, N))
+        ub = rng.standard_normal((B, m, N - 1))
+        fx = np.eye(n)[None, :, :, None] + (0.5 / np.sqrt(n)) * rng.standard_normal((B, n, n, N - 1))
+        fu = 0.3 * rng.standard_normal((B, n, m, N - 1))
+        s = BatchedIterativeLQR(sys_, N, B, jacobian_mode="ad")
+        s.SetTargetState(x_nom); s.SetRunningCost(Q, R); s.SetTerminalCost(Qf)
+        s.SetInitialState(xb[:, :, 0]); s.SetInitialGuess(ub)
+        s.set_state(x_bar=xb, u_bar=ub, fx=fx, fu=fu)
+        s.stage_backward()
+        K, kap, dV = s.K, s.kappa, s.dV_coeff
+        for b in range(B):
+            o = OracleILQR(model, N)
+            o.set_problem(xb[b, :, 0], x_nom, Q, R, Qf, ub[b])
+            o.x_bar, o.fx, o.fu = xb[b], fx[b], fu[b]
+            o.backward()
+            # judged against the extended-precision pass: 1e-11 or, where the problem itself leaves fewer
+            # digits (cond(Quu), the dynamic range of Vxx over the horizon), 20 x the fp64 NumPy oracle's own distance
+            e_dev, e_ref, cond = backward_errors((K[b], kap[b], dV[b]), o)
+            worst, worst_ref, worst_cond = max(worst, e_dev), max(worst_ref, e_ref), max(worst_cond, cond)
+            assert e_dev < max(1e-11, 20 * e_ref), (shape, N, b, e_dev, e_ref, cond)
+    print(f"mid backward {IDS[SHAPES.index(shape)]}: worst relative error vs extended precision {worst:.2e} (NumPy fp64 oracle: {worst_ref:.2e}; max cond(Quu) {worst_cond:.1e})")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", SHAPES, ids=IDS)
+def test_mid_family_solves_like_the_oracle(shape):
+    """End to end on a plugin model of the shape: forward-mode duals after two iterations (round-off level: x_bar 1e-11,
+    K / kappa 1e-10) and at convergence (iterations, step sizes and trial counts exact, cost 1e-10); central differences
+    at convergence (counts exact, cost 1e-8, trajectories 1e-6: SURVEY 8(c))."""
+    import models as PM
+    import plugin_steps as PS
+    from drake_ddp_amd.ilqr import BatchedIterativeLQR
+    from oracle import models_np as M
+    from oracle.ilqr_np import OracleILQR
+    nq, m, ne = shape
+    n = 2 * nq + ne
+    dt, N, B = 0.02, 24, 3
+    sys_ = PM.build_chainx(nq, m, ne)(dt)
+    rng = np.random.default_rng(n * 17 + m)
+    x_nom = np.zeros(n)
+    x0 = 0.4 * rng.standard_normal((B, n))
+    ug = 0.2 * rng.standard_normal((B, m, N - 1))
+    Q = dt * np.diag(10.0 ** rng.uniform(-1, 0.5, n))
+    R = dt * 0.05 * np.eye(m)
+    Qf = np.diag(10.0 ** rng.uniform(0, 1, n))
+    model = M.Model.custom(n, m, PS.chainx_step(nq, m, ne), sys_.params, dt)
+    for jac, cap in (("ad", 2), ("ad", 100000), ("fd", 100000)):
+        s = BatchedIterativeLQR(sys_, N, B, delta=1e-3, beta=0.7, gamma=0.0, jacobian_mode=jac, **({"max_iters": cap} if cap == 2 else {}))
+        s.SetTargetState(x_nom); s.SetRunningCost(Q, R); s.SetTerminalCost(Qf)
+        s.SetInitialState(x0); s.SetInitialGuess(ug)
+        try:
+            s.Solve()
+        except RuntimeError:
+            assert cap == 2
+        for b in range(B):
+            o = OracleILQR(model, N, 1e-3, 0.7, 0.0, jacobian=jac, fd_step=1e-5, max_iters=cap)
+            o.set_problem(x0[b], x_nom, Q, R, Qf, ug[b])
+            xo, uo, Lo, hist = o.solve()
+            hist = np.array(hist)
+            assert s.iterations[b] == len(hist) and np.array_equal(s.history[b][:len(hist), 1:3], hist[:, 1:3]), (jac, cap, b)
+            sc = lambda a_: max(1.0, float(np.max(np.abs(a_))))
+            if cap == 2:
+                assert np.max(np.abs(s.x_bar[b] - xo)) < 1e-11 * sc(xo) and np.max(np.abs(s.K[b] - o.K)) < 1e-10 * sc(o.K)
+                assert np.max(np.abs(s.kappa[b] - o.kappa)) < 1e-10 * sc(o.kappa)
+            elif jac == "ad":
+                assert s.status[b] == 0 and abs(s.cost[b] - Lo) < 1e-10 * abs(Lo)
+                assert np.max(np.abs(s.x_bar[b] - xo)) < 1e-8 * sc(xo) and np.max(np.abs(s.K[b] - o.K)) < 1e-7 * sc(o.K)
+            else:
+                assert s.status[b] == 0 and abs(s.cost[b] - Lo) < 1e-8 * abs(Lo)
+                assert np.max(np.abs(s.x_bar[b] - xo)) < 1e-6 * sc(xo) and np.max(np.abs(s.u_bar[b] - uo)) < 1e-6 * sc(uo)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(6, 4, 0), (10, 7, 7)], ids=["n12_m4", "n27_m7"])
+def test_mid_family_mpc_loop_and_keypoints(shape):
+    """The receding-horizon loop on the device (mi_ilqr_mpc_run: stale-gain first rollouts) and the key-point
+    methods (shared code of the workgroup-per-problem kernels) on mid-size shapes: per-re-solve iteration counts exact,
+    costs 1e-8; setInterval(3) key-point lists exact."""
+    import models as PM
+    import plugin_steps as PS
+    from drake_ddp_amd import utils_derivs_interpolation as U
+    from drake_ddp_amd.ilqr import BatchedIterativeLQR
+    from drake_ddp_amd.workloads import mpc_shift
+    from oracle import models_np as M
+    from oracle.ilqr_np import OracleILQR, KeypointCfg
+    nq, m, ne = shape
+    n = 2 * nq + ne
+    dt, N, B = 0.02, 30, 4
+    sys_ = PM.build_chainx(nq, m, ne)(dt)
+    rng = np.random.default_rng(n + 3 * m)
+    x_nom = np.zeros(n)
+    x0 = 0.3 * rng.standard_normal((B, n))
+    ug = 0.1 * rng.standard_normal((m, N - 1))
+    Q, R, Qf = dt * np.eye(n), dt * 0.05 * np.eye(m), 5.0 * np.eye(n)
+    model = M.Model.custom(n, m, PS.chainx_step(nq, m, ne), sys_.params, dt)
+    s = BatchedIterativeLQR(sys_, N, B, delta=1e-3, beta=0.6, gamma=0.0, jacobian_mode="fd")
+    s.SetTargetState(x_nom); s.SetRunningCost(Q, R); s.SetTerminalCost(Qf)
+    s.SetInitialState(x0); s.SetInitialGuess(ug)
+    s.Solve()
+    it0 = s.iterations.copy()
+    s.MPCRun(4, 3)
+    log = s.mpc_log
+    for b in range(B):
+        o = OracleILQR(model, N, 1e-3, 0.6, 0.0, jacobian="fd", fd_step=1e-5)
+        o.set_problem(x0[b], x_nom, Q, R, Qf, ug)
+        xo, uo, Lo, hist = o.solve()
+        assert len(hist) == it0[b], b
+        for r in range(4):
+            x0r, ugr = mpc_shift(xo, uo, 3)
+            o.set_problem(x0r, x_nom, Q, R, Qf, ugr)
+            xo, uo, Lo, hist = o.solve()
+            assert log[b, r, -1] == len(hist) and abs(log[b, r, -2] - Lo) < 1e-8 * abs(Lo), (b, r)
+            assert np.max(np.abs(log[b, r, :n] - x0r)) < 1e-6
+    kp = U.derivs_interpolation("setInterval", 3, 0, 0, 0)
+    s = BatchedIterativeLQR(sys_, N, B, delta=1e-3, beta=0.6, gamma=0.0, jacobian_mode="ad", derivs_keypoint_method=kp)
+    s.SetTargetState(x_nom); s.SetRunningCost(Q, R); s.SetTerminalCost(Qf)
+    s.SetInitialState(x0); s.SetInitialGuess(ug)
+    s.Solve()
+    for b in range(B):
+        o = OracleILQR(model, N, 1e-3, 0.6, 0.0, keypoint=KeypointCfg("setInterval", 3, 0, 0.0, 0.0), jacobian="ad")
+        o.set_problem(x0[b], x_nom, Q, R, Qf, ug)
+        xo, uo, Lo, hist = o.solve()
+        nk = int(s.keypoint_count[b])
+        assert len(hist) == s.iterations[b] and list(s.keypoint_list[b][:nk]) == list(o.keypoints), b
+        assert abs(s.cost[b] - Lo) < 1e-9 * abs(Lo)

@@ -10,6 +10,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "examples", "plugins"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def test_plugin_registers_without_a_gpu():
@@ -73,7 +74,8 @@ def test_plugin_model_solves_like_the_oracle(name, jac):
     s.SetInitialState(x0); s.SetInitialGuess(ug)
     x, u, _, L = s.Solve()
     assert (s.status == 0).all()
-    step_fn = {"vdp": PM.vdp_step, "chain3": PM.chain3_step}[name]
+    import plugin_steps as PS
+    step_fn = {"vdp": PS.vdp_step, "chain3": PS.chain3_step}[name]
     model = M.Model.custom(n, m, step_fn, sys_.params, dt)
     tolL = 1e-9 if jac == "ad" else 1e-8
     oracles = []
@@ -149,7 +151,8 @@ def test_matrix_core_family_at_other_state_dimensions(nq):
     Q = dt * np.diag(10.0 ** rng.uniform(-1, 0.5, n))
     R = dt * 0.05 * np.eye(m)
     Qf = np.diag(10.0 ** rng.uniform(0, 1, n))
-    model = M.Model.custom(n, m, PM.chain_step(nq), sys_.params, dt)
+    import plugin_steps as PS
+    model = M.Model.custom(n, m, PS.chain_step(nq), sys_.params, dt)
     for cap in (2, 100000):
         s = BatchedIterativeLQR(sys_, N, B, delta=1e-3, beta=0.7, gamma=0.0, jacobian_mode="ad", **({"max_iters": cap} if cap == 2 else {}))
         s.SetTargetState(x_nom); s.SetRunningCost(Q, R); s.SetTerminalCost(Qf)
