@@ -43,6 +43,8 @@ __device__ inline double mi_sin(double a) { return fast_sin(a); }
 __device__ inline double mi_cos(double a) { return fast_cos(a); }
 __device__ inline double mi_rcp(double a) { return fast_rcp(a); }
 __device__ inline Dual1 mi_rcp(Dual1 a) { const double r = fast_rcp(a.v); return {r, -(r * r) * a.d}; }
+__device__ inline double mi_sqrt(double a) { return sqrt(a); }
+__device__ inline Dual1 mi_sqrt(Dual1 a) { const double r = sqrt(a.v); return {r, a.d * fast_rcp(2.0 * r)}; }
 __device__ inline double mi_exp(double a) { return exp(a); }
 __device__ inline double mi_log1p(double a) { return log1p(a); }
 __device__ inline Dual1 mi_sin(Dual1 a) { return {fast_sin(a.v), fast_cos(a.v) * a.d}; }

@@ -53,8 +53,9 @@ const ModelInfo* model_info(int id) {
       {36, 12, 4, {4.0, 0.5, 6.0, 0.1}},
       {36, 12, 9, {9.81, 4000.0, 0.004, 0.3, 0.15, 0.05, 0.02, 2.0, 60.0}},
       {37, 12, 14, {9.81, 4000.0, 0.004, 0.3, 0.15, 0.3, 60.0, 9.0, 0.07, 0.26, 0.28, 0.06, 0.06, 0.04}},
+      {27, 7, 15, {9.81, 1500.0, 0.005, 0.5, 1.0, 0.5, 0.2, 0.1, 0.05, 1.0, 0.8, 0.6, 0.3, 0.1, 0.04}},
   };
-  if (id < 0 || id > 6) return nullptr;
+  if (id < 0 || id > 7) return nullptr;
   return &table[id];
 }
 
@@ -75,6 +76,7 @@ size_t large_lds(int model_id, int N) {
     case MI_MODEL_SYNTH36: return large_lds_bytes<Synth36::n, Synth36::m>(N);
     case MI_MODEL_PLANAR_QUAD: return large_lds_bytes<PlanarQuad::n, PlanarQuad::m>(N);
     case MI_MODEL_QUAD3D: return large_lds_bytes<Quad3D::n, Quad3D::m>(N);
+    case MI_MODEL_ARM27: return large_lds_bytes<Arm27::n, Arm27::m>(N);
     default: return 0;
   }
 }
@@ -161,6 +163,7 @@ int launch(mi_ilqr* h, int mode) {
     case MI_MODEL_SYNTH36: rc = launch_synth36(h, mode, a); break;
     case MI_MODEL_PLANAR_QUAD: rc = launch_planar_quad(h, mode, a); break;
     case MI_MODEL_QUAD3D: rc = launch_quad3d(h, mode, a); break;
+    case MI_MODEL_ARM27: rc = launch_arm27(h, mode, a); break;
     default:
       if (const PluginSlot* ps = plugin_of(h->d.model_id)) { rc = ps->p.launch(h, mode, &a); break; }
       return MI_ILQR_E_UNSUPPORTED;

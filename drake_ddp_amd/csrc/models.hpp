@@ -467,4 +467,134 @@ struct Quad3D {
   __device__ static inline bool infeasible_velocity(double vn, const double* p) { return !(fabs(vn) <= p[6]); }
 };
 
+// 7-joint arm pushing a free ball - the state kinova_gen3.py:52-70 / panda_fr3.py stack: 14 positions (7 joint angles | the
+// ball's unit quaternion w,x,y,z | the ball's position) + 13 velocities (7 joint rates | the ball's angular | linear velocity,
+// world frame), 7 joint torques: n = 27, m = 7.  The same formulas, in the same operation order, as
+// oracle/models_np.py:arm27_kinematics / arm27_step and oracle/ilqr_oracle.c.  params [g, k, sigma, dn, mu, b_joint, m_ball,
+// r_ball, r_ee, m_elbow, m_hand, I_shoulder, I_elbow, I_wrist, ee_off].  Gen3-shaped kinematics (joint axes alternate z, y,
+// ... in the moving frame, link offsets along the local z axis); the actuators' reflected inertia stands for the joint-space
+// inertia (the approximation Quad3D's legs make), the links' weight is kept as two point masses (elbow, hand); the ball is a
+// rigid sphere with compliant contacts against the ground and against the hand's sphere (smooth penalty, normal damping,
+// load-proportional viscous friction at the contact point); the hand receives the opposite force through J^T.
+// Served by the mid-size workgroup-per-problem kernels (ilqr_large.hpp: mid_backward).
+struct Arm27 {
+  static constexpr int n = 27, m = 7, n_params = 15;
+  static constexpr bool kWholeStep = true;
+  static constexpr double kH0 = 0.28, kL1 = 0.42, kL2 = 0.31, kL3 = 0.27;
+  template <class T>
+  __device__ static inline void cross(const T (&a)[3], const T (&b)[3], T (&o)[3]) {
+    o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+  }
+  template <class T>
+  __device__ static inline void step(const T* x, const T* u, T* xn, const double* p, double dt) {
+    const double g = p[0], kc = p[1], sig = p[2], dn = p[3], mu = p[4], bj = p[5];
+    const double mb = p[6], rb = p[7], re = p[8], m_el = p[9], m_hd = p[10];
+    // ---- kinematics: hand and elbow points, joint axes and origins in the world frame
+    T ex[3] = {T(1.0), T(0.0), T(0.0)}, ey[3] = {T(0.0), T(1.0), T(0.0)}, ez[3] = {T(0.0), T(0.0), T(1.0)};
+    T pos[3] = {T(0.0), T(0.0), T(kH0)}, elbow[3], hand[3], axes[7][3], orgs[7][3];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const T s = mi_sin(x[i]), c = mi_cos(x[i]);
+      if (i % 2 == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { axes[i][k] = ez[k]; orgs[i][k] = pos[k]; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const T a = c * ex[k] + s * ey[k], b = c * ey[k] - s * ex[k]; ex[k] = a; ey[k] = b; }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { axes[i][k] = ey[k]; orgs[i][k] = pos[k]; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const T a = c * ex[k] - s * ez[k], b = c * ez[k] + s * ex[k]; ex[k] = a; ez[k] = b; }
+      }
+      if (i == 2) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { pos[k] = pos[k] + kL1 * ez[k]; elbow[k] = pos[k]; }
+      } else if (i == 4) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pos[k] = pos[k] + kL2 * ez[k];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) hand[k] = pos[k] + (p[14] * ex[k] + kL3 * ez[k]);
+    T J[7][3], JEz[3];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      T r[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) r[k] = hand[k] - orgs[i][k];
+      cross(axes[i], r, J[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      T r[3], t3[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) r[k] = elbow[k] - orgs[i][k];
+      cross(axes[i], r, t3);
+      JEz[i] = t3[2];
+    }
+    const T* qd = x + 14;
+    T vh[3], d[3], nr[3], om[3], vb[3], pb[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      vh[k] = ((J[0][k] * qd[0] + J[1][k] * qd[1]) + (J[2][k] * qd[2] + J[3][k] * qd[3])) + ((J[4][k] * qd[4] + J[5][k] * qd[5]) + J[6][k] * qd[6]);
+      pb[k] = x[11 + k]; om[k] = x[21 + k]; vb[k] = x[24 + k];
+      d[k] = pb[k] - hand[k];
+    }
+    // ---- hand - ball contact
+    const T dist = mi_sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    const T idist = mi_rcp(dist);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) nr[k] = d[k] * idist;
+    const T phi = dist - (rb + re);
+    const T fn0 = (kc * sig) * mi_softplus(-phi * (1.0 / sig));
+    T wxn[3], rel[3], vt[3], Fc[3], nxv[3], tc[3];
+    cross(om, nr, wxn);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) rel[k] = vb[k] - rb * wxn[k] - vh[k];
+    const T vn = rel[0] * nr[0] + rel[1] * nr[1] + rel[2] * nr[2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) vt[k] = rel[k] - vn * nr[k];
+    const T fnn = fn0 * (1.0 - dn * vn);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) Fc[k] = fnn * nr[k] - (mu * fn0) * vt[k];
+    cross(nr, vt, nxv);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) tc[k] = (rb * mu) * fn0 * nxv[k];
+    // ---- ball - ground contact
+    const T fg0 = (kc * sig) * mi_softplus(-(pb[2] - rb) * (1.0 / sig));
+    const T vcx = vb[0] - rb * om[1], vcy = vb[1] + rb * om[0];
+    const T Fg[3] = {-(mu * fg0) * vcx, -(mu * fg0) * vcy, fg0 * (1.0 - dn * vb[2])};
+    const T tg[3] = {rb * Fg[1], -(rb * Fg[0]), T(0.0)};
+    // ---- joints
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const double iI = 1.0 / (i < 2 ? p[11] : (i < 4 ? p[12] : p[13]));
+      T grav = m_hd * J[i][2];
+      if (i < 3) grav = grav + m_el * JEz[i];
+      grav = g * grav;
+      const T jf = J[i][0] * Fc[0] + J[i][1] * Fc[1] + J[i][2] * Fc[2];
+      const T acc = (u[i] - bj * qd[i] - grav - jf) * iI;
+      const T qdn = qd[i] + dt * acc;
+      xn[14 + i] = qdn; xn[i] = x[i] + dt * qdn;
+    }
+    // ---- ball
+    const double ib = 1.0 / (0.4 * mb * rb * rb), imb = 1.0 / mb;
+    T omn[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      omn[k] = om[k] + dt * ((tc[k] + tg[k]) * ib);
+      T al = (Fc[k] + Fg[k]) * imb;
+      if (k == 2) al = al - g;
+      const T vbn = vb[k] + dt * al;
+      xn[11 + k] = pb[k] + dt * vbn; xn[21 + k] = omn[k]; xn[24 + k] = vbn;
+    }
+    const double hd = 0.5 * dt;
+    const T qw = x[7], qx = x[8], qy = x[9], qz = x[10];
+    xn[7] = qw + hd * (-(omn[0] * qx) - omn[1] * qy - omn[2] * qz);
+    xn[8] = qx + hd * (qw * omn[0] + (omn[1] * qz - omn[2] * qy));
+    xn[9] = qy + hd * (qw * omn[1] + (omn[2] * qx - omn[0] * qz));
+    xn[10] = qz + hd * (qw * omn[2] + (omn[0] * qy - omn[1] * qx));
+  }
+};
+
 }  // namespace mi

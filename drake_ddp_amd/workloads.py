@@ -8,7 +8,7 @@ Pure NumPy, importable without a GPU.
 """
 import numpy as np
 
-PENDULUM, ACROBOT, CARTPOLE, CARTPOLE_WALL, SYNTH36, PLANAR_QUAD, QUAD3D = 0, 1, 2, 3, 4, 5, 6
+PENDULUM, ACROBOT, CARTPOLE, CARTPOLE_WALL, SYNTH36, PLANAR_QUAD, QUAD3D, ARM27 = 0, 1, 2, 3, 4, 5, 6, 7
 SYNTH_TARGET_VEL = 1.0
 
 
@@ -200,6 +200,52 @@ def quad3d_batch_x0(B, seed=5):
 def quad3d_u_guess(N):
     """Constant standing torques (the u_stand of mini_cheetah.py:47-49,177)."""
     return np.repeat(_Q3_U_STAND[:, None], N - 1, axis=1)
+
+
+# ---- 7-joint arm + free ball (csrc/models.hpp: Arm27; oracle/models_np.py: arm27_step), n=27 m=7: the shape of kinova_gen3.py / panda_fr3.py
+ARM27_PUSH_TORQUE = 2.0                             # N m on the base yaw joint, added to the gravity compensation of the initial guess
+_A27_Q_START = np.array([-0.3067, 0.8748, 0.0, 1.2788, 0.0, 0.6632, 0.0])      # hand 4 cm beside the ball, at its height
+_A27_BALL_Z = 0.10603644421888478                   # radius 0.1 + 6 mm: the compliant ground carries the ball's weight
+_A27_U_GRAV = np.array([0.0, -8.101374106804624, 0.0, -2.4099460650944824, 0.0, -0.37867887819099333, 0.0])
+
+
+def arm27_start():
+    """kinova_gen3.py:52-70: x0 = [q_start | ball quaternion, position | 13 zero velocities]; the ball rests on the ground at
+    (0.6, 0, r), the hand beside it (the "side" scenario's push direction is +y)."""
+    return np.concatenate([_A27_Q_START, [1.0, 0.0, 0.0, 0.0, 0.6, 0.0, _A27_BALL_Z], np.zeros(13)])
+
+
+def arm27_problem(N=50):
+    """kinova_gen3.py:31-32 (T = 0.5, dt = 1e-2 -> N = 50), :66-87 ("side": ball target 0.15 m along +y; Q = diag([0 x 7 |
+    0,0,0,0,100,100,100 | 0.1 x 7 | 0.1 x 6]), R = 0.01 I, Qf = the same with 10 x the ball's velocity weights), passed as
+    dt*Q, dt*R, Qf (:262-263); beta = 0.5, delta = 1e-3, gamma = 0 (:258-259)."""
+    dt = 1e-2
+    q_ball = np.array([0.0, 0.0, 0.0, 0.0, 100.0, 100.0, 100.0])
+    Q = np.diag(np.hstack([np.zeros(7), q_ball, 0.1 * np.ones(7), 0.1 * np.ones(6)]))
+    R = 0.01 * np.eye(7)
+    Qf = np.diag(np.hstack([np.zeros(7), q_ball, 0.1 * np.ones(7), 10 * 0.1 * np.ones(6)]))
+    x_nom = arm27_start()
+    x_nom[12] += 0.15
+    return dict(name="arm_and_ball", model_id=ARM27, dt=dt, N=N, x_nom=x_nom,
+                Q=dt * Q, R=dt * R, Qf=Qf, delta=1e-3, beta=0.5, gamma=0.0)
+
+
+def arm27_batch_x0(B, seed=6):
+    """The start state with the ball moved on the ground and the arm's joints perturbed (rng seed 6)."""
+    rng = np.random.default_rng(seed)
+    x0 = np.tile(arm27_start(), (B, 1))
+    x0[:, 11:13] += rng.uniform(-0.01, 0.01, (B, 2))
+    x0[:, 0:7] += rng.uniform(-0.01, 0.01, (B, 7))
+    return x0
+
+
+def arm27_u_guess(N):
+    """Gravity compensation at the start configuration (kinova_gen3.py:268-275) plus ARM27_PUSH_TORQUE on the base yaw joint:
+    the build's point contact has no force (hence no gradient) at a distance, unlike the reference's hydroelastic bodies,
+    and pure gravity compensation leaves iLQR in the local optimum that never touches the ball."""
+    u = _A27_U_GRAV.copy()
+    u[0] += ARM27_PUSH_TORQUE
+    return np.repeat(u[:, None], N - 1, axis=1)
 
 
 def mpc_shift(x, u, replan):

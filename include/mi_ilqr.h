@@ -61,9 +61,12 @@ enum {
   MI_MODEL_PLANAR_QUAD = 5,    /* n=36 m=12: planar floating-base quadruped (articulated-body algorithm, ground
                                   contact); can declare a step INFEASIBLE - such a line-search trial costs +inf, as
                                   when Drake's update throws (ilqr.py:315-323) */
-  MI_MODEL_QUAD3D = 6          /* n=37 m=12: 3-D floating-base quadruped with mini_cheetah.py:41-52's state layout
+  MI_MODEL_QUAD3D = 6,         /* n=37 m=12: 3-D floating-base quadruped with mini_cheetah.py:41-52's state layout
                                   (unit quaternion | position | 12 joints | 18 velocities), feet contact; can declare a
                                   step infeasible like the planar one */
+  MI_MODEL_ARM27 = 7           /* n=27 m=7: 7-joint arm pushing a free ball - the state kinova_gen3.py:52-70 / panda_fr3.py
+                                  stack (7 joint angles | the ball's unit quaternion, position | 13 velocities); served by
+                                  the mid-size workgroup-per-problem kernels */
 };
 
 /* utils_derivs_interpolation.derivs_interpolation.keypoint_method
@@ -159,8 +162,10 @@ int mi_ilqr_model_info(int model_id, int32_t* n, int32_t* m, int32_t* n_params, 
  * library this record; the returned id (>= MI_MODEL_PLUGIN_BASE) is used as mi_ilqr_desc.model_id like a built-in one.
  *   family 0: wave-per-problem kernels (state in LDS; any n, m <= 2 - n = 2 takes the time-parallel passes, n = 3..4 the
  *             matrix-core backward step, other n the scalar recursion);
- *   family 1: workgroup-per-problem kernels (32 < n <= 40, m <= 16, m % 4 == 0, 2 m <= n; dynamics as `step` per Jacobian column and a
- *             one-lane step in the rollout unless the model provides the cooperative hooks of csrc/models.hpp).
+ *   family 1: workgroup-per-problem kernels - n <= 32 with ANY m <= 16 (one or two 16-row tiles: the shapes of a quadrotor
+ *             (12, 4), a 7-joint arm (14, 7), kinova_gen3.py's arm + free body (27, 7)), or 32 < n <= 40 with m <= 16,
+ *             m % 4 == 0, 2 m <= n; dynamics as `step` per Jacobian column and a one-lane step in the rollout unless the
+ *             model provides the cooperative hooks of csrc/models.hpp.
  * Plugin models are served by these two families only (no lane-per-problem THROUGHPUT kernels). */
 enum { MI_MODEL_PLUGIN_BASE = 100, MI_ILQR_MAX_PLUGINS = 32 };
 typedef struct {

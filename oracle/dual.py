@@ -22,6 +22,7 @@ class math:  # noqa: N801 - local shim with IEEE (non-raising) semantics
     cos = staticmethod(lambda a: float(np.cos(a)))
     exp = staticmethod(lambda a: float(np.exp(a)))
     log1p = staticmethod(lambda a: float(np.log1p(a)))
+    sqrt = staticmethod(lambda a: float(np.sqrt(a)))
 
 
 class Dual:
@@ -119,6 +120,13 @@ def log1p(a):
     if isinstance(a, Dual):
         return Dual(math.log1p(a.v), a.d / (1.0 + a.v))
     return math.log1p(a)
+
+
+def sqrt(a):
+    if isinstance(a, Dual):
+        r = math.sqrt(a.v)
+        return Dual(r, a.d / (2.0 * r))
+    return math.sqrt(a)
 
 
 def softplus(z):

@@ -251,5 +251,16 @@ def main():
     tight3[6] = 2.5
     single_solve("quad3d_infeasible_0", dict(c3f, params=tight3), x3[3], u3)
 
+    # (f)4, the mid-size shape: a 7-joint arm pushing a free ball - the state kinova_gen3.py:52-70 stacks (n = 27, m = 7),
+    # its cost (:73-87), horizon (T = 0.5, dt = 1e-2), delta = 1e-3, beta = 0.5 (:258-259) and gravity-compensation initial
+    # guess (:268-275); one receding-horizon re-solve sequence in the style of the MPC scripts
+    ca = P.arm27_problem()
+    xa = P.arm27_batch_x0(8)
+    ua = P.arm27_u_guess(ca["N"])
+    stage_level("arm27_stage", ca, P.arm27_start(), ua, n_iters=3)
+    single_solve("arm27_solve_0", ca, P.arm27_start(), ua)
+    single_solve("arm27_solve_1", ca, xa[1], ua)
+    mpc("arm27_mpc_0", ca, xa[2], ua, resolves=2, replan=5)
+
 if __name__ == "__main__":
     main()

@@ -21,6 +21,8 @@ Model ids / parameter vectors (must match include/mi_ilqr.h and models.hpp):
   5 PLANAR_QUAD    n=36 m=12  [g, k, sigma, dn, mu, b_leg, b_tail, k_tail, v_max]   (articulated, contact, can FAIL)
   6 QUAD3D         n=37 m=12  [g, k, sigma, dn, mu, b_joint, v_max, m_trunk, Ixx, Iyy, Izz, I_abad, I_hip, I_knee]
                               (3-D floating base with a unit-quaternion attitude, contact at four feet, can FAIL)
+  7 ARM27          n=27 m=7   [g, k, sigma, dn, mu, b_joint, m_ball, r_ball, r_ee, m_elbow, m_hand, I_shoulder, I_elbow, I_wrist, ee_off]
+                              (7-joint arm + a free ball with a unit-quaternion attitude: the state kinova_gen3.py:52-70 stacks)
 
 A model may declare a step INFEASIBLE (the analogue of Drake's discrete update throwing): ``Model.step``
 then raises RuntimeError, which the reference's line search catches (ilqr.py:315-323).
@@ -29,14 +31,14 @@ import numpy as np
 
 from . import dual as D
 
-PENDULUM, ACROBOT, CARTPOLE, CARTPOLE_WALL, SYNTH36, PLANAR_QUAD, QUAD3D = 0, 1, 2, 3, 4, 5, 6
+PENDULUM, ACROBOT, CARTPOLE, CARTPOLE_WALL, SYNTH36, PLANAR_QUAD, QUAD3D, ARM27 = 0, 1, 2, 3, 4, 5, 6, 7
 
 MODEL_DIMS = {PENDULUM: (2, 1), ACROBOT: (4, 1), CARTPOLE: (4, 1),
-              CARTPOLE_WALL: (4, 1), SYNTH36: (36, 12), PLANAR_QUAD: (36, 12), QUAD3D: (37, 12)}
+              CARTPOLE_WALL: (4, 1), SYNTH36: (36, 12), PLANAR_QUAD: (36, 12), QUAD3D: (37, 12), ARM27: (27, 7)}
 
 MODEL_NAMES = {PENDULUM: "pendulum", ACROBOT: "acrobot", CARTPOLE: "cart_pole",
                CARTPOLE_WALL: "cart_pole_with_wall", SYNTH36: "synth36", PLANAR_QUAD: "planar_quadruped",
-               QUAD3D: "quadruped_3d"}
+               QUAD3D: "quadruped_3d", ARM27: "arm_and_ball"}
 
 DEFAULT_PARAMS = {
     # m=1, l=0.5, b=0.1, g=9.81 (the shape of pendulum.py's plant; SURVEY.md §8c anchor)
@@ -56,6 +58,11 @@ DEFAULT_PARAMS = {
     # joint damping; |v| bound beyond which a step is infeasible; trunk mass and principal inertias (mini-cheetah
     # sized: 9 kg); reflected actuator inertias of the ab/ad, hip and knee joints
     QUAD3D: [9.81, 4000.0, 0.004, 0.3, 0.15, 0.3, 60.0, 9.0, 0.07, 0.26, 0.28, 0.06, 0.06, 0.04],
+    # gravity; contact penalty k*sigma*softplus(-phi/sigma) (ball-ground and hand-ball), normal damping dn, load-proportional
+    # viscous friction mu; joint damping; ball mass and radius; hand (end-effector sphere) radius; the two point masses that
+    # carry the links' weight (elbow, hand); reflected actuator inertias of the joint pairs (0,1), (2,3), (4,5,6); lateral
+    # offset of the hand point from the last joint's axis
+    ARM27: [9.81, 1500.0, 0.005, 0.5, 1.0, 0.5, 0.2, 0.1, 0.05, 1.0, 0.8, 0.6, 0.3, 0.1, 0.04],
 }
 
 
@@ -424,8 +431,118 @@ def quad3d_infeasible(xn, p):
     return False
 
 
+# ----------------------------------------------------------------------------------------------------
+# ARM27: a 7-joint arm that pushes a free ball - the state kinova_gen3.py:52-70 / panda_fr3.py stack: 14 positions (7 joint
+# angles | the ball's unit quaternion w,x,y,z | the ball's position) + 13 velocities (7 joint rates | the ball's angular |
+# linear velocity, world frame), 7 joint torques: n = 27, m = 7.  Build-owned like every model here (Drake and its URDFs are
+# absent).  Kinematics of a Gen3-shaped arm: joint axes alternate z, y, z, y, z, y, z in the moving frame, link offsets
+# along the local z axis (shoulder height, upper arm, forearm, hand); the hand point sits ee_off beside the last axis so
+# that every joint moves it.  Dynamics: the actuators' reflected inertia dominates the links' own (harmonic drives: the
+# approximation Quad3D's legs also make), so each joint is I_j q''_j = u_j - b q'_j + gravity_j + (J^T f)_j; the links' WEIGHT
+# is kept as two point masses (elbow, hand).  The ball is a rigid sphere (I = 2/5 m r^2) under gravity, a compliant contact
+# with the ground and one with the hand's sphere (smooth penalty along the centre line, normal damping, load-proportional
+# viscous friction acting at the contact point, so the ball rolls); the hand receives the opposite force through J^T.
+# The attitude quaternion is integrated as q+ = q + dt/2 (0, w+) (x) q and never renormalized inside a step.
+# ----------------------------------------------------------------------------------------------------
+A27_H0, A27_L1, A27_L2, A27_L3 = 0.28, 0.42, 0.31, 0.27
+
+
+def _cross(a, b):
+    return [a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]]
+
+
+def arm27_kinematics(q, p):
+    """Hand point, elbow point, joint axes a[7] and joint origins o[7] in the world frame."""
+    ex, ey, ez = [1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0]
+    pos = [0.0, 0.0, A27_H0]
+    axes, orgs = [], []
+    elbow = None
+    for i in range(7):
+        s, c = D.sin(q[i]), D.cos(q[i])
+        if i % 2 == 0:                        # about the local z axis
+            axes.append(list(ez)); orgs.append(list(pos))
+            ex, ey = [c * ex[k] + s * ey[k] for k in range(3)], [c * ey[k] - s * ex[k] for k in range(3)]
+        else:                                 # about the local y axis
+            axes.append(list(ey)); orgs.append(list(pos))
+            ex, ez = [c * ex[k] - s * ez[k] for k in range(3)], [c * ez[k] + s * ex[k] for k in range(3)]
+        if i == 2:
+            pos = [pos[k] + A27_L1 * ez[k] for k in range(3)]
+            elbow = list(pos)
+        elif i == 4:
+            pos = [pos[k] + A27_L2 * ez[k] for k in range(3)]
+    hand = [pos[k] + (p[14] * ex[k] + A27_L3 * ez[k]) for k in range(3)]
+    return hand, elbow, axes, orgs
+
+
+def arm27_step(x, u, p, dt):
+    g, kc, sig, dn, mu, bj = p[0], p[1], p[2], p[3], p[4], p[5]
+    mb, rb, re, m_el, m_hd = p[6], p[7], p[8], p[9], p[10]
+    Ij = [p[11], p[11], p[12], p[12], p[13], p[13], p[13]]
+    q, qd = x[0:7], x[14:21]
+    qw, qx, qy, qz = x[7], x[8], x[9], x[10]
+    pb, om, vb = x[11:14], x[21:24], x[24:27]
+    hand, elbow, axes, orgs = arm27_kinematics(q, p)
+    # Jacobian columns of the hand point (all joints) and of the elbow point (joints 0..2)
+    J = [_cross(axes[i], [hand[k] - orgs[i][k] for k in range(3)]) for i in range(7)]
+    JEz = [_cross(axes[i], [elbow[k] - orgs[i][k] for k in range(3)])[2] for i in range(3)]
+    vh = [((J[0][k] * qd[0] + J[1][k] * qd[1]) + (J[2][k] * qd[2] + J[3][k] * qd[3])) + ((J[4][k] * qd[4] + J[5][k] * qd[5]) + J[6][k] * qd[6])
+          for k in range(3)]
+    # hand - ball contact
+    d = [pb[k] - hand[k] for k in range(3)]
+    dist = D.sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2])
+    idist = 1.0 / dist
+    nr = [d[k] * idist for k in range(3)]
+    phi = dist - (rb + re)
+    fn0 = (kc * sig) * D.softplus(-phi / sig)
+    wxn = _cross(om, nr)
+    rel = [vb[k] - rb * wxn[k] - vh[k] for k in range(3)]       # ball's contact point (at -r_b n from its centre) against the hand
+    vn = rel[0] * nr[0] + rel[1] * nr[1] + rel[2] * nr[2]
+    vt = [rel[k] - vn * nr[k] for k in range(3)]
+    fnn = fn0 * (1.0 - dn * vn)
+    Fc = [fnn * nr[k] - (mu * fn0) * vt[k] for k in range(3)]    # on the ball; the hand receives -Fc
+    nxv = _cross(nr, vt)
+    tc = [(rb * mu) * fn0 * nxv[k] for k in range(3)]            # (-r_b n) x Fc
+    # ball - ground contact
+    fg0 = (kc * sig) * D.softplus(-(pb[2] - rb) / sig)
+    vcx, vcy = vb[0] - rb * om[1], vb[1] + rb * om[0]
+    Fg = [-(mu * fg0) * vcx, -(mu * fg0) * vcy, fg0 * (1.0 - dn * vb[2])]
+    tg = [rb * Fg[1], -(rb * Fg[0]), 0.0]
+    # joints
+    qdn, qn = [None] * 7, [None] * 7
+    for i in range(7):
+        grav = g * (m_hd * J[i][2] + (m_el * JEz[i] if i < 3 else 0.0))
+        jf = J[i][0] * Fc[0] + J[i][1] * Fc[1] + J[i][2] * Fc[2]
+        acc = (u[i] - bj * qd[i] - grav - jf) / Ij[i]
+        qdn[i] = qd[i] + dt * acc
+        qn[i] = q[i] + dt * qdn[i]
+    # ball
+    ib = 1.0 / (0.4 * mb * rb * rb)
+    omn = [om[k] + dt * ((tc[k] + tg[k]) * ib) for k in range(3)]
+    al = [(Fc[0] + Fg[0]) / mb, (Fc[1] + Fg[1]) / mb, (Fc[2] + Fg[2]) / mb - g]
+    vbn = [vb[k] + dt * al[k] for k in range(3)]
+    pbn = [pb[k] + dt * vbn[k] for k in range(3)]
+    hd = 0.5 * dt
+    quatn = [qw + hd * (-(omn[0] * qx) - omn[1] * qy - omn[2] * qz),
+             qx + hd * (qw * omn[0] + (omn[1] * qz - omn[2] * qy)),
+             qy + hd * (qw * omn[1] + (omn[2] * qx - omn[0] * qz)),
+             qz + hd * (qw * omn[2] + (omn[0] * qy - omn[1] * qx))]
+    return qn + quatn + pbn + qdn + omn + vbn
+
+
+def arm27_gravity_torques(q, p):
+    """Joint torques that hold the arm still away from the ball (kinova_gen3.py:268-275: the initial guess)."""
+    hand, elbow, axes, orgs = arm27_kinematics(list(q), p)
+    out = []
+    for i in range(7):
+        Jz = _cross(axes[i], [hand[k] - orgs[i][k] for k in range(3)])[2]
+        JEz = _cross(axes[i], [elbow[k] - orgs[i][k] for k in range(3)])[2] if i < 3 else 0.0
+        out.append(p[0] * (p[10] * Jz + p[9] * JEz))
+    return np.array(out, dtype=float)
+
+
 STEP_FUNCS = {PENDULUM: pendulum_step, ACROBOT: acrobot_step, CARTPOLE: cartpole_step,
-              CARTPOLE_WALL: cartpole_wall_step, SYNTH36: synth36_step, PLANAR_QUAD: planar_quad_step, QUAD3D: quad3d_step}
+              CARTPOLE_WALL: cartpole_wall_step, SYNTH36: synth36_step, PLANAR_QUAD: planar_quad_step, QUAD3D: quad3d_step,
+              ARM27: arm27_step}
 INFEASIBLE_FUNCS = {PLANAR_QUAD: planar_quad_infeasible, QUAD3D: quad3d_infeasible}
 
 

@@ -44,7 +44,7 @@ def test_c_oracle_vs_reference_golden_and_threads():
         assert rel_err(r1["K"][b], g["K"]) < 1e-5
 
 
-@pytest.mark.parametrize("name", ["acrobot_mpc_0", "acrobot_mpc_1", "synth36_mpc_0", "quad_mpc_0", "quad3d_mpc_0", "quad3d_mpc_1"])
+@pytest.mark.parametrize("name", ["acrobot_mpc_0", "acrobot_mpc_1", "synth36_mpc_0", "quad_mpc_0", "quad3d_mpc_0", "quad3d_mpc_1", "arm27_mpc_0"])
 def test_c_oracle_mpc_loop_vs_reference_golden(name):
     """oracle_mpc_batch (shift warm start, moving target, gains persisting across solves - SURVEY F10)
     against MPC sequences recorded from the unmodified reference (exact Jacobians there, central FD here:
@@ -59,13 +59,17 @@ def test_c_oracle_mpc_loop_vs_reference_golden(name):
     if "move_target" in g:
         step = np.zeros(n)
         step[int(g["move_target"][0])] = g["move_target"][1]
-        ug = {4: P.synth36_u_guess, 5: P.planar_quad_u_guess, 6: P.quad3d_u_guess}[prob["model_id"]](N)
+    if prob["model_id"] >= 4:
+        ug = {4: P.synth36_u_guess, 5: P.planar_quad_u_guess, 6: P.quad3d_u_guess, 7: P.arm27_u_guess}[prob["model_id"]](N)
     r = c_oracle.mpc_batch(M.Model(prob["model_id"], prob["dt"]), prob, g["x0"][None], ug, R, replan, target_step=step)
     assert r["status"][0] == 0
-    assert int(r["first"][0, 1]) == g["iters"][0] and abs(r["first"][0, 0] - g["Ls"][0]) < 1e-8 * abs(g["Ls"][0])
+    # (arm + ball: the hand-ball contact's curvature k / sigma^2 = 6e7 on a 0.2 kg ball makes the h^2 truncation term of the
+    #  central differences visible in the cost: 1.0e-7 relative observed against the reference's exact Jacobians)
+    tolL = 5e-7 if prob["model_id"] == 7 else 1e-8
+    assert int(r["first"][0, 1]) == g["iters"][0] and abs(r["first"][0, 0] - g["Ls"][0]) < tolL * abs(g["Ls"][0])
     log = r["log"][0]
     assert np.array_equal(log[:, -1].astype(int), g["iters"][1:])
-    assert rel_err(log[:, -2], g["Ls"][1:]) < 1e-8
+    assert rel_err(log[:, -2], g["Ls"][1:]) < tolL
     for k in range(R):
         want = g["xs"][k + 1][:, 0]                # (the acrobot optimum is flat: x moves at FD-noise level, 1e-6 relative)
         assert np.max(np.abs(log[k, :n] - want)) < 1e-6 * max(1.0, np.max(np.abs(want)))
@@ -74,9 +78,9 @@ def test_c_oracle_mpc_loop_vs_reference_golden(name):
 
 
 @pytest.mark.parametrize("name", ["quad_solve_0", "quad_infeasible_0", "quad_infeasible_1",
-                                  "quad3d_solve_0", "quad3d_solve_1", "quad3d_infeasible_0"])
+                                  "quad3d_solve_0", "quad3d_solve_1", "quad3d_infeasible_0", "arm27_solve_0", "arm27_solve_1"])
 def test_c_oracle_planar_quadruped_vs_reference_golden(name):
-    """The C restatement of the articulated-body model, of the 3-D quadruped and of the infeasible-step rule
+    """The C restatement of the articulated-body model, of the 3-D quadruped, of the arm + ball and of the infeasible-step rule
     (L = inf, ilqr.py:315-323) against solves recorded from the reference (exact Jacobians there, central FD here)."""
     from oracle import c_oracle, models_np as M
     g, prob = load_golden(name)
