@@ -354,6 +354,10 @@ def all_configs(rk, dev_index):
                           "1 + 100 re-solves x batch 64, moving target, device loop", q3,
                           W.quad3d_batch_x0(64), W.quad3d_u_guess(q3["N"]), reps=2,
                           mpc=(100, 4, (4, W.QUAD3D_TARGET_VEL * q3["dt"] * 4))))
+    a27 = W.arm27_problem()
+    out.append(run_config(rk, dev_index, "C6 arm + ball (7-joint arm pushing a free body: kinova_gen3.py's shape) n=27 m=7 N=50 MPC: "
+                          "1 + 20 re-solves x batch 64, device loop, mid-size kernels", a27,
+                          W.arm27_batch_x0(64), W.arm27_u_guess(a27["N"]), reps=2, mpc=(20, 5, None)))
     if rk.world == 1:
         out.append(run_config(rk, dev_index, "C5 shard of an 8-GPU run: batch 8 on this GPU", q,
                               W.synth36_batch_x0(64)[:8], W.synth36_u_guess(q["N"]), reps=2,

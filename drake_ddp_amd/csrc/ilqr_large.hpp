@@ -32,6 +32,7 @@
 namespace mi {
 
 constexpr int kLargeThreads = 256;
+constexpr int kPdFlag = 8;          // slot of the reduction scratch (LLay::oRed) where a backward pass leaves "a Quu was not positive definite"
 
 template <int n, int m>
 struct LLay {
@@ -849,8 +850,9 @@ struct GjRest<m, K, m> {
 };
 template <int m, int K>
 struct GjOuter {
-  // `inv` = 1 / pivot K, already computed; `i` = this lane's row
-  static __device__ __forceinline__ void run(double (&a)[m], double& s, int i, double inv) {
+  // `inv` = 1 / pivot K, already computed; `i` = this lane's row; `ok` stays true while every pivot is > 0 (and finite
+  // enough to compare): the matrix is positive definite exactly when all of them are
+  static __device__ __forceinline__ void run(double (&a)[m], double& s, int i, double inv, bool& ok) {
     const bool piv = i == K;
     const double g = piv ? 0.0 : a[K] * inv;
     double r = 0.0;
@@ -859,6 +861,7 @@ struct GjOuter {
       gj_update<m, K, 2>(a, g);                         // (also covers the DPP-after-VALU wait states of the pivot read)
       __builtin_amdgcn_sched_barrier(0);
       const double d = row_share<K + 1>(a[K + 1]);
+      ok = ok && (d > 0.0);
       r = __builtin_amdgcn_rcp(d);
       gj_update<m, K, 3>(a, g);
       gj_update<m, K, 4>(a, g);
@@ -879,16 +882,18 @@ struct GjOuter {
     }
     a[K] = piv ? 1.0 : -g;
     s = piv ? inv : s;
-    GjOuter<m, K + 1>::run(a, s, i, r);
+    GjOuter<m, K + 1>::run(a, s, i, r, ok);
   }
-  static __device__ __forceinline__ void run(double (&a)[m], double& s, int i) {
+  static __device__ __forceinline__ void run(double (&a)[m], double& s, int i, bool& ok) {
     static_assert(K == 0, "entry point");
-    run(a, s, i, fast_rcp(row_share<0>(a[0])));
+    const double d0 = row_share<0>(a[0]);
+    ok = ok && (d0 > 0.0);
+    run(a, s, i, fast_rcp(d0), ok);
   }
 };
 template <int m>
 struct GjOuter<m, m> {
-  static __device__ __forceinline__ void run(double (&)[m], double&, int, double) {}
+  static __device__ __forceinline__ void run(double (&)[m], double&, int, double, bool&) {}
 };
 
 
@@ -933,6 +938,7 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
 #endif
 
   // terminal: Vx = 2 Qf x_T - 2 x_nom^T Qf ; Vxx = 2 Qf   (ilqr.py:203-204, :638); pads = 0
+  if (tid == 0) lds[Ly::oRed + kPdFlag] = 0.0;
   for (int e = tid; e < NP * VS; e += kLargeThreads) {
     const int i = e / VS, j = e - i * VS;
     Vxx[e] = (i < n && j < n) ? 2.0 * Qf[i * n + j] : 0.0;
@@ -1357,6 +1363,7 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
     double r2[m];
 #pragma unroll
     for (int j = 0; j < m; ++j) r2[j] = 2.0 * R[si * m + j];
+    bool pd_ok = true;                                       // every Quu of the pass positive definite (GjOuter)
     __syncthreads();
     for (int t = N - 2; t >= 0; --t) {
       BP_TICK(0);
@@ -1370,7 +1377,7 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
       }
       BP_TICK(5);
       double sc = 1.0;
-      GjOuter<m, 0>::run(arow, sc, si);                      // Quu^{-1}[si][j] = sc * arow[j]
+      GjOuter<m, 0>::run(arow, sc, si, pd_ok);               // Quu^{-1}[si][j] = sc * arow[j]
       if (lane < m) {
 #pragma unroll
         for (int j = 0; j < m; ++j) Ws[lane * WSS + j] = sc * arow[j];
@@ -1416,6 +1423,7 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
       lds_barrier();
       BP_TICK(11);
     }
+    if (lane == 0 && !pd_ok) lds[Ly::oRed + kPdFlag] = 1.0;  // (read by the kernel after the pass: MI_STATUS_NOT_PD)
   };
 
   if (wave == 0) matrix_role(std::integral_constant<int, 0>{});
@@ -1481,6 +1489,7 @@ __device__ inline void mid_backward(const LView<M::n, M::m>& v, double* lds, boo
   };
 
   // terminal: Vx = 2 Qf x_T - 2 x_nom^T Qf ; Vxx = 2 Qf   (ilqr.py:203-204, :638); pads = 0
+  if (tid == 0) lds[Ly::oRed + kPdFlag] = 0.0;
   for (int e = tid; e < NP * VS; e += kLargeThreads) {
     const int i = e / VS, j = e - i * VS;
     Vxx[e] = (i < n && j < n) ? 2.0 * Qf[i * n + j] : 0.0;
@@ -1663,6 +1672,7 @@ __device__ inline void mid_backward(const LView<M::n, M::m>& v, double* lds, boo
     double r2[m];
 #pragma unroll
     for (int j = 0; j < m; ++j) r2[j] = 2.0 * R[si * m + j];
+    bool pd_ok = true;                                       // every Quu of the pass positive definite (GjOuter)
     __syncthreads();                                         // (A)
     first_order(N - 2, F);
     __syncthreads();                                         // (B)
@@ -1696,7 +1706,7 @@ __device__ inline void mid_backward(const LView<M::n, M::m>& v, double* lds, boo
 #pragma unroll
       for (int j = 0; j < m; ++j) arow[j] = r2[j] + Sq[si * SS + j];          // Quu = luu + fu^T Vxx fu (:654)
       double sc = 1.0;
-      GjOuter<m, 0>::run(arow, sc, si);                      // Quu^{-1}[si][j] = sc * arow[j] (:655)
+      GjOuter<m, 0>::run(arow, sc, si, pd_ok);               // Quu^{-1}[si][j] = sc * arow[j] (:655)
       if (lane < m) {
 #pragma unroll
         for (int j = 0; j < m; ++j) Ws[lane * WSS + j] = sc * arow[j];
@@ -1725,6 +1735,7 @@ __device__ inline void mid_backward(const LView<M::n, M::m>& v, double* lds, boo
       }
       lds_barrier();
     }
+    if (lane == 0 && !pd_ok) lds[Ly::oRed + kPdFlag] = 1.0;  // (read by the kernel after the pass: MI_STATUS_NOT_PD)
   };
 
   if (wave == WU) u_role();
@@ -1949,6 +1960,8 @@ __global__ void __launch_bounds__(kLargeThreads) ilqr_large_kernel(const KArgs a
   }
   if (MODE == MODE_BACKWARD) {
     backward_pass<M>(v, lds, nullptr, false);
+    __syncthreads();
+    if (tid == 0) a.status[b] = lds[Ly::oRed + kPdFlag] != 0.0 ? MI_STATUS_NOT_PD : MI_STATUS_CONVERGED;
     return;
   }
 
@@ -2044,6 +2057,7 @@ __global__ void __launch_bounds__(kLargeThreads) ilqr_large_kernel(const KArgs a
       if (MODE != MODE_FORWARD) { backward_pass<M>(v, lds, nullptr, kLxFromRollout<M>); __syncthreads(); }      // :697
 #endif
       const long long c3 = clock64();
+      const bool not_pd = MODE != MODE_FORWARD && lds[Ly::oRed + kPdFlag] != 0.0;     // a Quu of this backward pass was not positive definite
       c_ls += c1 - c0; c_lin += c2 - c1; c_bp += c3 - c2;
       if (tid == 0 && it_this < a.hist_cap) {                                        // history of the LAST solve
         hist[4 * it_this + 0] = L_new; hist[4 * it_this + 1] = eps;
@@ -2055,6 +2069,7 @@ __global__ void __launch_bounds__(kLargeThreads) ilqr_large_kernel(const KArgs a
       L = L_new;
       it_this += 1;
       if (MODE == MODE_FORWARD) break;
+      if (not_pd) { status = MI_STATUS_NOT_PD; break; }      // the gains of that pass are not to be used
     }
     iters += it_this;
     if (MODE == MODE_MPC) {

@@ -45,7 +45,7 @@ constexpr int kMaxStateDim = 40;   // largest model state (Synth36: 36), for by-
 // read after a blocking solve instead of four D2H copies).
 struct DevStats {
   long long total_iters, total_ls;
-  int n_conv, n_max, n_fail, max_iters_seen, best_index, n_internal;
+  int n_conv, n_max, n_fail, max_iters_seen, best_index, n_internal, n_not_pd, pad_;
   double best_cost;
 };
 
@@ -2028,7 +2028,7 @@ __device__ inline void batch_stats_by_last_workgroup(const KArgs& a, int b, doub
   if (lane == 0) {
     DevStats* o = a.stats_out;
     o->total_iters = it; o->total_ls = ls; o->n_conv = c; o->n_max = nm; o->n_fail = nf;
-    o->max_iters_seen = mxi; o->best_index = bi; o->best_cost = bc; o->n_internal = 0;   // (these kernels have no such exit)
+    o->max_iters_seen = mxi; o->best_index = bi; o->best_cost = bc; o->n_internal = 0; o->n_not_pd = 0;   // (these kernels have no such exits)
     __hip_atomic_store(a.done_counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
   }
 }

@@ -343,25 +343,26 @@ __global__ void __launch_bounds__(256) stats_kernel(const int32_t* iters, const 
     iters += o; status += o; ls += o; cost += o; out += slot;
   }
   __shared__ long long s_it[256], s_ls[256];
-  __shared__ int s_c[256], s_m[256], s_f[256], s_mx[256], s_bi[256], s_x[256];
+  __shared__ int s_c[256], s_m[256], s_f[256], s_mx[256], s_bi[256], s_x[256], s_p[256];
   __shared__ double s_bc[256];
   const int tid = threadIdx.x;
-  long long it = 0, l = 0; int c = 0, m = 0, f = 0, mx = 0, bi = -1, xi = 0; double bc = INFINITY;
+  long long it = 0, l = 0; int c = 0, m = 0, f = 0, mx = 0, bi = -1, xi = 0, npd = 0; double bc = INFINITY;
   for (int b = tid; b < B; b += 256) {
     it += iters[b]; l += ls[b];
     if (iters[b] > mx) mx = iters[b];
     if (status[b] == MI_STATUS_CONVERGED) { c++; if (cost[b] < bc) { bc = cost[b]; bi = b; } }
     else if (status[b] == MI_STATUS_MAX_ITERS) m++;
     else if (status[b] == MI_STATUS_INTERNAL) xi++;
+    else if (status[b] == MI_STATUS_NOT_PD) npd++;
     else f++;
   }
-  s_x[tid] = xi;
+  s_x[tid] = xi; s_p[tid] = npd;
   s_it[tid] = it; s_ls[tid] = l; s_c[tid] = c; s_m[tid] = m; s_f[tid] = f; s_mx[tid] = mx; s_bi[tid] = bi; s_bc[tid] = bc;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
     if (tid < o) {
       s_it[tid] += s_it[tid + o]; s_ls[tid] += s_ls[tid + o]; s_c[tid] += s_c[tid + o]; s_m[tid] += s_m[tid + o]; s_f[tid] += s_f[tid + o];
-      s_x[tid] += s_x[tid + o];
+      s_x[tid] += s_x[tid + o]; s_p[tid] += s_p[tid + o];
       if (s_mx[tid + o] > s_mx[tid]) s_mx[tid] = s_mx[tid + o];
       // ties resolve to the lower problem index, like a sequential scan
       if (s_bc[tid + o] < s_bc[tid] || (s_bc[tid + o] == s_bc[tid] && s_bi[tid + o] >= 0 && (s_bi[tid] < 0 || s_bi[tid + o] < s_bi[tid]))) { s_bc[tid] = s_bc[tid + o]; s_bi[tid] = s_bi[tid + o]; }
@@ -370,7 +371,7 @@ __global__ void __launch_bounds__(256) stats_kernel(const int32_t* iters, const 
   }
   if (tid == 0) {
     out->total_iters = s_it[0]; out->total_ls = s_ls[0]; out->n_conv = s_c[0]; out->n_max = s_m[0]; out->n_fail = s_f[0];
-    out->max_iters_seen = s_mx[0]; out->best_index = s_bi[0]; out->best_cost = s_bc[0]; out->n_internal = s_x[0];
+    out->max_iters_seen = s_mx[0]; out->best_index = s_bi[0]; out->best_cost = s_bc[0]; out->n_internal = s_x[0]; out->n_not_pd = s_p[0];
   }
 }
 
@@ -725,8 +726,20 @@ int mi_ilqr_set_cost(mi_ilqr_t* h, const double* Q, const double* R, const doubl
     const bool regular = is_sym_psd(cm.data(), (int)n, false) && is_sym_psd(cm.data() + n * n + m * m, (int)n, false) &&
                          is_sym_psd(cm.data() + n * n, (int)m, true);
     if (!regular && h->large) {
-      std::fprintf(stderr, "mi_ilqr_set_cost: the n = %d kernels need symmetric (to 8 ulp) positive semi-definite Q, Qf and positive definite R\n", (int)n);
-      return MI_ILQR_E_UNSUPPORTED;
+      // The workgroup-per-problem kernels need SYMMETRIC matrices (mirrored tiles, lx = 2 Q (x - x_nom) from the rollout's
+      // cost rows); definiteness they check where it matters - every Quu = 2R + fu^T Vxx fu of every backward pass must be
+      // positive definite, else the problem stops with MI_STATUS_NOT_PD (the reference would invert it all the same and
+      // carry on with gains that are no descent direction, ilqr.py:655).  So indefinite symmetric Q, Qf (and R) are accepted.
+      auto symmetric = [](const double* A, size_t k) {
+        for (size_t i = 0; i < k * k; ++i) if (!(std::fabs(A[i]) < INFINITY)) return false;
+        for (size_t i = 0; i < k; ++i)
+          for (size_t j = 0; j < i; ++j) if (A[i * k + j] != A[j * k + i]) return false;
+        return true;
+      };
+      if (!(symmetric(cm.data(), n) && symmetric(cm.data() + n * n, m) && symmetric(cm.data() + n * n + m * m, n))) {
+        std::fprintf(stderr, "mi_ilqr_set_cost: the workgroup-per-problem kernels (n = %d, m = %d) need symmetric (to 8 ulp) finite Q, R, Qf\n", (int)n, (int)m);
+        return MI_ILQR_E_UNSUPPORTED;
+      }
     }
     h->exact_backward = regular ? 0 : 1;
     // the device copy mirrors h_costmat: nothing to send when the caller repeats the matrices it set before
@@ -859,7 +872,7 @@ static void fill_stats(mi_ilqr* h, int slot, mi_ilqr_stats* st) {
   st->total_iters = ds.total_iters; st->total_ls_trials = ds.total_ls;
   st->n_converged = ds.n_conv; st->n_max_iters = ds.n_max; st->n_ls_failed = ds.n_fail;
   st->max_iters_seen = ds.max_iters_seen; st->best_cost = ds.best_cost; st->best_index = ds.best_index;
-  st->n_internal = ds.n_internal;
+  st->n_internal = ds.n_internal; st->n_not_pd = ds.n_not_pd;
   float ms = 0.f;
   if (h->ring_timed[slot] && hipEventElapsedTime(&ms, h->ring_ev0[slot], h->ring_ev1[slot]) == hipSuccess) st->kernel_ms = ms;
   // bytes_iter is affine in ls: sum over iterations = ls_total*roll + iters*(deriv+back)
@@ -985,7 +998,7 @@ int mi_ilqr_mpc_run(mi_ilqr_t* h, int32_t num_resolves, int32_t replan_steps, co
       if ((rc = mi_ilqr_solve(h, &st)) != MI_ILQR_OK) return rc;
       acc.total_iters += st.total_iters; acc.total_ls_trials += st.total_ls_trials; acc.kernel_ms += st.kernel_ms;
       acc.algorithmic_bytes += st.algorithmic_bytes;
-      acc.n_converged = st.n_converged; acc.n_max_iters = st.n_max_iters; acc.n_ls_failed = st.n_ls_failed; acc.n_internal = st.n_internal;
+      acc.n_converged = st.n_converged; acc.n_max_iters = st.n_max_iters; acc.n_ls_failed = st.n_ls_failed; acc.n_internal = st.n_internal; acc.n_not_pd = st.n_not_pd;
       if (st.max_iters_seen > acc.max_iters_seen) acc.max_iters_seen = st.max_iters_seen;
       acc.best_cost = st.best_cost; acc.best_index = st.best_index;
     }

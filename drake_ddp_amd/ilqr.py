@@ -234,6 +234,9 @@ class BatchedIterativeLQR:
         if stats is not None and stats.n_internal > 0:
             raise RuntimeError(f"{stats.n_internal} problem(s) aborted inside the device kernel (status {_capi.STATUS_INTERNAL}); "
                                "their results are not a solution")
+        if stats is not None and stats.n_not_pd > 0:
+            raise RuntimeError(f"{stats.n_not_pd} problem(s) met a Quu that is not positive definite in a backward pass (status "
+                               f"{_capi.STATUS_NOT_PD}: an indefinite cost expansion, or one ruined by round-off); their gains are not to be used")
 
     # ------------------------------------------------------------- Solve (ilqr.py:669-710)
     def Solve(self):
@@ -432,6 +435,9 @@ class IterativeLinearQuadraticRegulator(BatchedIterativeLQR):
             raise RuntimeError("linesearch failed after %s iterations" % n_trials)
         if status == _capi.STATUS_INTERNAL:
             raise RuntimeError("solve aborted inside the device kernel (cluster hand-shake lost); results are not a solution")
+        if status == _capi.STATUS_NOT_PD:
+            raise RuntimeError("Quu is not positive definite in the backward pass (indefinite cost expansion, or round-off); "
+                               "the reference would invert it all the same (ilqr.py:655) - its gains are no descent direction")
         return self.x_bar, self.u_bar, total_time, float(self.cost[0])
 
     def SaveSolution(self, fname):

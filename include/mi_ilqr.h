@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MI_ILQR_ABI_VERSION 5
+#define MI_ILQR_ABI_VERSION 6
 #define MI_ILQR_MAX_PARAMS 16
 
 /* Error codes (0 = OK).  The Python wrapper maps them onto the exception types
@@ -87,7 +87,13 @@ enum { MI_KERNEL_AUTO = 0, MI_KERNEL_LATENCY = 1, MI_KERNEL_THROUGHPUT = 2 };
 
 /* Per-problem status written by solve/forward. */
 enum { MI_STATUS_CONVERGED = 0, MI_STATUS_MAX_ITERS = 1, MI_STATUS_LINESEARCH_FAILED = 2,
-       MI_STATUS_INTERNAL = 3 /* a helper workgroup of the problem's cluster stopped answering (never seen) */ };
+       MI_STATUS_INTERNAL = 3, /* a helper workgroup of the problem's cluster stopped answering (never seen) */
+       /* 4: internal to the library */
+       MI_STATUS_NOT_PD = 5    /* workgroup-per-problem kernels (n >= 5 models with m > 2): a backward pass met a Quu that is not
+                                  positive definite (a pivot of its elimination <= 0 or not finite) - an indefinite cost
+                                  expansion or one ruined by round-off.  The reference inverts such a Quu all the same
+                                  (np.linalg.inv, ilqr.py:655) and carries on with gains that are no descent direction; here
+                                  the problem stops with this status (its gains are NOT to be used) */ };
 
 /* Selector for mi_ilqr_get / mi_ilqr_set / mi_ilqr_device_ptr. */
 enum {
@@ -145,7 +151,7 @@ typedef struct {
   double algorithmic_bytes;   /* sum_b sum_i bytes_iter(ls_{b,i}) — SURVEY.md §8d formula */
   int32_t n_internal;         /* problems aborted with MI_STATUS_INTERNAL (a lost cluster helper; counted apart from
                                * n_ls_failed since ABI 5: their x_bar / u_bar are NOT a solution) */
-  int32_t reserved_;
+  int32_t n_not_pd;           /* problems stopped with MI_STATUS_NOT_PD (ABI 6; the field was reserved before) */
 } mi_ilqr_stats;
 
 int mi_ilqr_abi_version(void);
@@ -184,10 +190,12 @@ void mi_ilqr_destroy(mi_ilqr_t* h);
 
 /* SetRunningCost / SetTerminalCost / SetTargetState (ilqr.py:111-146): Q (n,n), R (m,m),
  * Qf (n,n), x_nom (n), shared by the batch.  Any pointer may be NULL = keep.  Any matrices are accepted,
- * like the reference (lxx = 2Q, never symmetrized - ilqr.py:182): symmetric positive semi-definite Q, Qf and
- * positive definite R take the time-parallel / matrix-core backward passes, anything else the reference's
- * recursion verbatim (n <= 4), or MI_ILQR_E_UNSUPPORTED on the workgroup-per-problem kernel (n = 36), whose
- * Quu = L D L^T factorization has no such form. */
+ * like the reference (lxx = 2Q, never symmetrized - ilqr.py:182), by the wave- and lane-per-problem kernels: symmetric
+ * positive semi-definite Q, Qf and positive definite R take the time-parallel / matrix-core backward passes, anything else
+ * the reference's recursion verbatim.  The workgroup-per-problem kernels (models with m > 2 or n > 6: Arm27, the n = 36 / 37
+ * models, plugin family 1) need SYMMETRIC matrices (asymmetries up to 8 ulp of the largest entry are averaged away, larger
+ * ones: MI_ILQR_E_UNSUPPORTED); definiteness is not required of them - it is checked where it matters: a backward pass
+ * that meets a Quu which is not positive definite stops its problem with MI_STATUS_NOT_PD. */
 int mi_ilqr_set_cost(mi_ilqr_t* h, const double* Q, const double* R, const double* Qf, const double* x_nom);
 
 /* SetInitialState / SetInitialGuess (ilqr.py:102-109,148-156): x0 (B,n), u_guess (B,m,N-1).
