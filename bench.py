@@ -392,7 +392,64 @@ def boundary_inclusive(prob, x0, dev_index, reps=5):
     out = {"workload": "C2 through Solve(): host x0 + u_guess in, x_bar + u_bar + cost out"}
     out.update(run(False, np.zeros((B, 1, N - 1))))
     out["pinned_results_shared_guess"] = run(True, np.zeros((1, N - 1)))
+    out["default_call"] = "pinned_results=True is the constructor default of both classes since round 4; `pinned_results_shared_guess` is what a caller of the reference's own call shape gets"
+    out["C1_single_problem_through_Solve"] = class_surface_single(dev_index)
+    out["C3_through_Solve_and_MPCRun"] = class_surface_mpc(dev_index)
     return out
+
+
+def class_surface_single(dev_index, reps=30):
+    """C1 through the DROP-IN class, everything included: pendulum.py:85-100's call sequence on
+    IterativeLinearQuadraticRegulator - setters, Solve() (copy-in, launch, iteration log and results out, the stopwatch
+    attributes), Python overhead and all: the latency an MPC user of pendulum.py sees per solve."""
+    from drake_ddp_amd import workloads as W
+    from drake_ddp_amd.ilqr import IterativeLinearQuadraticRegulator
+    from drake_ddp_amd.models import ModelSystem
+    p = W.pendulum_problem()
+    ilqr = IterativeLinearQuadraticRegulator(ModelSystem(p["model_id"], p["dt"]), p["N"], delta=p["delta"], beta=p["beta"], gamma=p["gamma"],
+                                             verbose=False, device=dev_index)
+    ilqr.SetTargetState(p["x_nom"]); ilqr.SetRunningCost(p["Q"], p["R"]); ilqr.SetTerminalCost(p["Qf"])
+    u0 = np.zeros((1, p["N"] - 1))
+    ts, it = [], 0
+    for r in range(reps + 3):
+        ilqr.Reset()
+        t0 = time.perf_counter()
+        ilqr.SetInitialState(np.zeros(2))
+        ilqr.SetInitialGuess(u0)
+        x, u, _, L = ilqr.Solve()
+        if r >= 3:
+            ts.append(time.perf_counter() - t0)
+            it += int(ilqr.stats.total_iters)
+    ts = np.array(ts)
+    return {"workload": "pendulum.py literal: SetInitialState + SetInitialGuess + Solve() of IterativeLinearQuadraticRegulator, cold start",
+            "ms_per_solve_median": 1e3 * float(np.median(ts)), "ms_per_solve_min": 1e3 * float(ts.min()), "kernel_ms": float(ilqr.stats.kernel_ms),
+            "iterations_per_solve": it / reps, "cost": float(L)}
+
+
+def class_surface_mpc(dev_index, reps=3):
+    """C3 through the class surface: acrobot.py:131-162's loop on BatchedIterativeLQR - setters + Solve() for the first plan
+    (host arrays in and out), then MPCRun(50, 2) and a read of x_bar / u_bar: what a caller of the MPC scripts pays."""
+    from drake_ddp_amd import workloads as W
+    a = W.acrobot_problem()
+    B = 512
+    x0 = W.acrobot_batch_x0(B)
+    s = make_solver(a, B, dev_index)
+    ts, it = [], 0
+    for r in range(reps + 1):
+        s.Reset()
+        t0 = time.perf_counter()
+        s.SetInitialState(x0)
+        s.SetInitialGuess(np.zeros((1, a["N"] - 1)))
+        x, u, _, L = s.Solve()
+        n0 = int(s.stats.total_iters)
+        st = s.MPCRun(50, 2)
+        x, u = s.x_bar, s.u_bar
+        if r >= 1:
+            ts.append(time.perf_counter() - t0)
+            it += n0 + int(st.total_iters)
+    wall = float(np.sum(ts))
+    return {"workload": "acrobot MPC B=512: SetInitialState + SetInitialGuess + Solve() + MPCRun(50, 2) + x_bar, u_bar out",
+            "iterations_per_s": it / wall, "ms_per_solve": 1e3 * wall / (reps * 51), "ms_per_loop": 1e3 * wall / reps}
 
 
 def concurrent_batches(prob, x0, dev_index, handles=(2, 4), groups=12, per_group=20):

@@ -850,9 +850,8 @@ struct GjRest<m, K, m> {
 };
 template <int m, int K>
 struct GjOuter {
-  // `inv` = 1 / pivot K, already computed; `i` = this lane's row; `ok` stays true while every pivot is > 0 (and finite
-  // enough to compare): the matrix is positive definite exactly when all of them are
-  static __device__ __forceinline__ void run(double (&a)[m], double& s, int i, double inv, bool& ok) {
+  // `inv` = 1 / pivot K, already computed; `i` = this lane's row
+  static __device__ __forceinline__ void run(double (&a)[m], double& s, int i, double inv) {
     const bool piv = i == K;
     const double g = piv ? 0.0 : a[K] * inv;
     double r = 0.0;
@@ -861,7 +860,6 @@ struct GjOuter {
       gj_update<m, K, 2>(a, g);                         // (also covers the DPP-after-VALU wait states of the pivot read)
       __builtin_amdgcn_sched_barrier(0);
       const double d = row_share<K + 1>(a[K + 1]);
-      ok = ok && (d > 0.0);
       r = __builtin_amdgcn_rcp(d);
       gj_update<m, K, 3>(a, g);
       gj_update<m, K, 4>(a, g);
@@ -882,19 +880,20 @@ struct GjOuter {
     }
     a[K] = piv ? 1.0 : -g;
     s = piv ? inv : s;
-    GjOuter<m, K + 1>::run(a, s, i, r, ok);
+    GjOuter<m, K + 1>::run(a, s, i, r);
   }
-  static __device__ __forceinline__ void run(double (&a)[m], double& s, int i, bool& ok) {
+  static __device__ __forceinline__ void run(double (&a)[m], double& s, int i) {
     static_assert(K == 0, "entry point");
-    const double d0 = row_share<0>(a[0]);
-    ok = ok && (d0 > 0.0);
-    run(a, s, i, fast_rcp(d0), ok);
+    run(a, s, i, fast_rcp(row_share<0>(a[0])));
   }
 };
 template <int m>
 struct GjOuter<m, m> {
-  static __device__ __forceinline__ void run(double (&)[m], double&, int, double, bool&) {}
+  static __device__ __forceinline__ void run(double (&)[m], double&, int, double) {}
 };
+// Positive definiteness for free: after the elimination lane i's factor s IS 1 / (pivot i), and the matrix is positive definite
+// exactly when every pivot is > 0 - i.e. every row's s is (NaN or an infinite pivot fail the comparison as well).
+__device__ __forceinline__ bool gj_row_positive(double s) { return s > 0.0; }
 
 
 // Backward Riccati pass (ilqr.py:623-667), cost expansion (:161-206) fused.
@@ -1363,7 +1362,6 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
     double r2[m];
 #pragma unroll
     for (int j = 0; j < m; ++j) r2[j] = 2.0 * R[si * m + j];
-    bool pd_ok = true;                                       // every Quu of the pass positive definite (GjOuter)
     __syncthreads();
     for (int t = N - 2; t >= 0; --t) {
       BP_TICK(0);
@@ -1377,7 +1375,8 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
       }
       BP_TICK(5);
       double sc = 1.0;
-      GjOuter<m, 0>::run(arow, sc, si, pd_ok);               // Quu^{-1}[si][j] = sc * arow[j]
+      GjOuter<m, 0>::run(arow, sc, si);                      // Quu^{-1}[si][j] = sc * arow[j]
+      if (!gj_row_positive(sc)) lds[Ly::oRed + kPdFlag] = 1.0;   // Quu not positive definite (read by the kernel after the pass: MI_STATUS_NOT_PD)
       if (lane < m) {
 #pragma unroll
         for (int j = 0; j < m; ++j) Ws[lane * WSS + j] = sc * arow[j];
@@ -1423,7 +1422,6 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
       lds_barrier();
       BP_TICK(11);
     }
-    if (lane == 0 && !pd_ok) lds[Ly::oRed + kPdFlag] = 1.0;  // (read by the kernel after the pass: MI_STATUS_NOT_PD)
   };
 
   if (wave == 0) matrix_role(std::integral_constant<int, 0>{});
@@ -1672,7 +1670,6 @@ __device__ inline void mid_backward(const LView<M::n, M::m>& v, double* lds, boo
     double r2[m];
 #pragma unroll
     for (int j = 0; j < m; ++j) r2[j] = 2.0 * R[si * m + j];
-    bool pd_ok = true;                                       // every Quu of the pass positive definite (GjOuter)
     __syncthreads();                                         // (A)
     first_order(N - 2, F);
     __syncthreads();                                         // (B)
@@ -1706,7 +1703,8 @@ __device__ inline void mid_backward(const LView<M::n, M::m>& v, double* lds, boo
 #pragma unroll
       for (int j = 0; j < m; ++j) arow[j] = r2[j] + Sq[si * SS + j];          // Quu = luu + fu^T Vxx fu (:654)
       double sc = 1.0;
-      GjOuter<m, 0>::run(arow, sc, si, pd_ok);               // Quu^{-1}[si][j] = sc * arow[j] (:655)
+      GjOuter<m, 0>::run(arow, sc, si);                      // Quu^{-1}[si][j] = sc * arow[j] (:655)
+      if (!gj_row_positive(sc)) lds[Ly::oRed + kPdFlag] = 1.0;   // Quu not positive definite (read by the kernel after the pass: MI_STATUS_NOT_PD)
       if (lane < m) {
 #pragma unroll
         for (int j = 0; j < m; ++j) Ws[lane * WSS + j] = sc * arow[j];
@@ -1735,7 +1733,6 @@ __device__ inline void mid_backward(const LView<M::n, M::m>& v, double* lds, boo
       }
       lds_barrier();
     }
-    if (lane == 0 && !pd_ok) lds[Ly::oRed + kPdFlag] = 1.0;  // (read by the kernel after the pass: MI_STATUS_NOT_PD)
   };
 
   if (wave == WU) u_role();

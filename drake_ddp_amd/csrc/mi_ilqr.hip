@@ -9,6 +9,7 @@
 #include <hip/hip_ext.h>
 
 #include <dlfcn.h>
+#include <rccl/rccl.h>     // types and enum VALUES only (ncclFloat64, ncclMin): the symbols are bound at run time (dlopen below)
 
 #include <algorithm>
 #include <cmath>
@@ -1171,7 +1172,7 @@ int mi_ilqr_get_stream(mi_ilqr_t* h, void** hip_stream) {
 namespace {
 struct RcclApi {
   // the few entry points used, with the types of rccl.h (ncclResult_t = int, ncclComm_t = opaque pointer,
-  // ncclUniqueId = 128 bytes by value, ncclDataType_t / ncclRedOp_t = int enums: ncclFloat64 = 8, ncclMin = 3 - rccl.h: ncclSum 0, ncclProd 1, ncclMax 2, ncclMin 3, ncclAvg 4)
+  // ncclUniqueId = 128 bytes by value, ncclDataType_t / ncclRedOp_t = int enums whose values are taken from <rccl/rccl.h>)
   struct UniqueId { char internal[MI_ILQR_COMM_ID_BYTES]; };
   int (*GetUniqueId)(UniqueId*) = nullptr;
   int (*CommInitRank)(void**, int, UniqueId, int) = nullptr;
@@ -1180,7 +1181,11 @@ struct RcclApi {
   const char* (*GetErrorString)(int) = nullptr;
   bool ok = false;
 };
-constexpr int kNcclFloat64 = 8, kNcclMin = 3;
+// the data type and reduction codes come from the header the library is compiled against - never from memory (round 2
+// shipped ncclAvg = 4 under the name "min")
+constexpr int kNcclFloat64 = (int)ncclFloat64, kNcclMin = (int)ncclMin;
+static_assert(sizeof(ncclUniqueId) == MI_ILQR_COMM_ID_BYTES, "the communicator id crosses the C ABI as MI_ILQR_COMM_ID_BYTES bytes");
+static_assert((int)ncclSuccess == 0, "RCCLCHK treats 0 as success");
 
 const RcclApi& rccl() {
   static const RcclApi api = [] {

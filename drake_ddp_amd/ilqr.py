@@ -9,6 +9,7 @@ is in libmi_ilqr.so (HIP, gfx950) — this file only moves arrays across the
 boundary.  ``BatchedIterativeLQR`` is the same surface with a leading batch axis.
 """
 import ctypes as C
+import sys
 import time
 import weakref
 
@@ -37,7 +38,7 @@ class BatchedIterativeLQR:
 
     def __init__(self, system, num_timesteps, batch, input_port_index=0, delta=1e-2, beta=0.95, gamma=0.0,
                  derivs_keypoint_method=None, jacobian_mode="fd", fd_step=1e-5, device=0,
-                 max_iters=1000, hist_cap=64, kernel_mode="auto", pinned_results=False):
+                 max_iters=1000, hist_cap=64, kernel_mode="auto", pinned_results=True):
         assert isinstance(system, ModelSystem), \
             "system must be a drake_ddp_amd.models.ModelSystem (Drake systems cannot run on the GPU)"
         assert system.IsDifferenceEquationSystem()[0], "must be a discrete-time system"   # ilqr.py:37
@@ -75,11 +76,14 @@ class BatchedIterativeLQR:
         h = C.c_void_p()
         _capi.check(self._lib.mi_ilqr_create(C.byref(d), C.byref(h)), "mi_ilqr_create")
         self._h = h
-        # pinned_results=True: the arrays the state attributes / Solve() return are views of page-locked
-        # buffers the solver owns (direct DMA, no page faults of freshly allocated arrays) - one buffer per
-        # attribute, REUSED by the next read of that attribute; copy what must outlive it.  Default: fresh arrays.
+        # pinned_results (the default): the arrays the state attributes / Solve() return are views of page-locked buffers
+        # (direct DMA, no page faults of freshly allocated arrays; the wave-per-problem kernels write x_bar / u_bar / cost
+        # into them themselves).  The reference REBINDS its result arrays on every forward pass and never mutates one it
+        # has handed out (ilqr.py:375-376) - so does this class: a buffer is reused only once the caller has
+        # dropped every reference to the array it got (a small pool per attribute; `x, u, t, L = ilqr.Solve()` in a loop
+        # alternates between two blocks), otherwise a new block is taken.  False: plain pageable arrays and blocking copies.
         self._pinned = {} if pinned_results else None
-        self._sink = None              # pinned_results: True once the kernels write the results into the pinned buffers themselves
+        self._sink = None              # pinned_results: whether the kernels of this handle can write the results into host buffers themselves
         # reference defaults (ilqr.py:61-67); NOTE x_nom is undefined until SetTargetState (F12)
         self.x0 = np.zeros((self.B, self.n))
         self.Q, self.R, self.Qf = np.eye(self.n), np.eye(self.m), np.eye(self.n)
@@ -145,23 +149,29 @@ class BatchedIterativeLQR:
         else:
             _capi.check(self._lib.mi_ilqr_set_initial(self._h, _capi.ptr(x0), _capi.ptr(ug)), "mi_ilqr_set_initial")
 
+    _POOL_CAP = 4
+
     def _out(self, which, shape, dtype):
-        """Destination of a field read: a fresh array, or (pinned_results) the solver's page-locked buffer for it."""
+        """Destination of a field read: a fresh array, or (pinned_results) a page-locked block nobody else holds."""
         if self._pinned is None:
             return np.empty(shape, dtype=dtype)
-        key = (which, tuple(shape))
-        arr = self._pinned.get(key)
-        if arr is None:
-            nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
-            raw = C.c_void_p()
-            _capi.check(self._lib.mi_ilqr_host_alloc(max(nbytes, 8), C.byref(raw)), "mi_ilqr_host_alloc")
-            buf = (C.c_char * max(nbytes, 8)).from_address(raw.value)
-            root = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape)))
-            # the block lives as long as any view of it does (the solver's own, or one a caller kept)
-            weakref.finalize(root, self._lib.mi_ilqr_host_free, raw).atexit = False
-            arr = root.reshape(shape)
-            self._pinned[key] = arr
-        return arr
+        key = (which, tuple(shape), np.dtype(dtype).str)
+        pool = self._pinned.setdefault(key, [])
+        for root in pool:
+            if sys.getrefcount(root) <= 3:          # the pool's reference, the loop variable, getrefcount's argument: no view is alive
+                return root.reshape(shape)
+        count = int(np.prod(shape))
+        nbytes = count * np.dtype(dtype).itemsize
+        if len(pool) >= self._POOL_CAP:             # the caller keeps many results alive: those stay theirs, this one is pageable
+            return np.empty(shape, dtype=dtype)
+        raw = C.c_void_p()
+        _capi.check(self._lib.mi_ilqr_host_alloc(max(nbytes, 8), C.byref(raw)), "mi_ilqr_host_alloc")
+        buf = (C.c_char * max(nbytes, 8)).from_address(raw.value)
+        root = np.frombuffer(buf, dtype=dtype, count=count)
+        # the block lives as long as any view of it does (the pool's, or one a caller kept)
+        weakref.finalize(root, self._lib.mi_ilqr_host_free, raw).atexit = False
+        pool.append(root)
+        return root.reshape(shape)
 
     def _get(self, which, shape):
         out = self._out(which, shape, np.float64)
@@ -243,21 +253,7 @@ class BatchedIterativeLQR:
         st = time.time()
         self._push_problem()
         if self._pinned is not None:
-            # page-locked result buffers.  Wave-per-problem kernels write x_bar / u_bar / cost straight into them as
-            # each problem finishes (mi_ilqr_set_result_sink: the copy-out overlaps the launch's stragglers); the
-            # other kernel families enqueue three copy-outs behind the solve.  ONE synchronization (in collect).
-            res = [self._out(which, shape, np.float64) for which, shape in
-                   ((_capi.F_X_BAR, (self.B, self.n, self.N)), (_capi.F_U_BAR, (self.B, self.m, self.N - 1)), (_capi.F_COST, (self.B,)))]
-            if self._sink is None:
-                rc = self._lib.mi_ilqr_set_result_sink(self._h, _capi.ptr(res[0]), _capi.ptr(res[1]), _capi.ptr(res[2]))
-                if rc not in (_capi.OK, _capi.E_UNSUPPORTED):
-                    _capi.check(rc, "mi_ilqr_set_result_sink")
-                self._sink = rc == _capi.OK
-            _capi.check(self._lib.mi_ilqr_solve_async(self._h), "mi_ilqr_solve_async")
-            if not self._sink:
-                for out, which in zip(res, (_capi.F_X_BAR, _capi.F_U_BAR, _capi.F_COST)):
-                    _capi.check(self._lib.mi_ilqr_get_async(self._h, which, _capi.ptr(out), out.nbytes), "mi_ilqr_get_async")
-            self.collect(1)
+            res = self._solve_into_pinned()
             self._check_internal(self.stats)
             self.solve_wall_s = time.time() - st
             return res[0], res[1], self.solve_wall_s, res[2]
@@ -267,6 +263,34 @@ class BatchedIterativeLQR:
         self._check_internal(stats)
         self.solve_wall_s = time.time() - st
         return self.x_bar, self.u_bar, self.solve_wall_s, self.cost
+
+    def _solve_into_pinned(self, extra=()):
+        """One solve from the inputs just pushed, x_bar / u_bar / cost into page-locked arrays nobody else holds, ONE host
+        synchronization.  Wave-per-problem kernels write them themselves as each problem finishes (mi_ilqr_set_result_sink:
+        the copy-out overlaps the launch's stragglers) - the sink is set for THIS solve only, so no later kernel of the
+        handle (pipelined solves, MPCRun, stage calls) touches arrays a caller holds; the other kernel families enqueue
+        three copy-outs behind the solve.  `extra`: (field, destination) pairs copied out behind the solve as well."""
+        res = [self._out(which, shp, np.float64) for which, shp in
+               ((_capi.F_X_BAR, (self.B, self.n, self.N)), (_capi.F_U_BAR, (self.B, self.m, self.N - 1)), (_capi.F_COST, (self.B,)))]
+        pinned = all(r.base is not None for r in res)
+        sink = False
+        if pinned and self._sink is not False:
+            rc = self._lib.mi_ilqr_set_result_sink(self._h, _capi.ptr(res[0]), _capi.ptr(res[1]), _capi.ptr(res[2]))
+            if rc not in (_capi.OK, _capi.E_UNSUPPORTED):
+                _capi.check(rc, "mi_ilqr_set_result_sink")
+            sink = self._sink = rc == _capi.OK
+        try:
+            _capi.check(self._lib.mi_ilqr_solve_async(self._h), "mi_ilqr_solve_async")
+            if not sink:
+                for out, which in zip(res, (_capi.F_X_BAR, _capi.F_U_BAR, _capi.F_COST)):
+                    _capi.check(self._lib.mi_ilqr_get_async(self._h, which, _capi.ptr(out), out.nbytes), "mi_ilqr_get_async")
+            for which, out in extra:               # further fields of this solve, behind it on the stream: defined after collect
+                _capi.check(self._lib.mi_ilqr_get_async(self._h, which, _capi.ptr(out), out.nbytes), "mi_ilqr_get_async")
+            self.collect(1)
+        finally:
+            if sink:
+                _capi.check(self._lib.mi_ilqr_set_result_sink(self._h, None, None, None), "mi_ilqr_set_result_sink")
+        return res
 
     def solve_resident(self):
         """Solve again from the inputs already resident on the device (no host traffic
@@ -397,20 +421,29 @@ class IterativeLinearQuadraticRegulator(BatchedIterativeLQR):
     def Solve(self):
         st = time.time()
         self._push_problem()
-        stats = _capi.Stats()
-        _capi.check(self._lib.mi_ilqr_solve(self._h, C.byref(stats)), "mi_ilqr_solve")
-        self.stats = stats
+        res = None
+        if self._pinned is not None:
+            # ONE host synchronization for the whole call: results into page-locked arrays (by the kernel itself where it
+            # can), the iteration log copied out behind the solve on the same stream
+            small = {k: self._out(k, shp, dt) for k, shp, dt in ((_capi.I_ITERS, (1,), np.int32), (_capi.I_STATUS, (1,), np.int32),
+                                                                 (_capi.F_HIST, (1, self.hist_cap, 4), np.float64),
+                                                                 (_capi.F_ITER_CYCLES, (1, self.hist_cap, 4), np.float64))}
+            res = self._solve_into_pinned(extra=list(small.items()))
+            stats = self.stats
+            iters, status, hist, iter_cyc = int(small[_capi.I_ITERS][0]), int(small[_capi.I_STATUS][0]), small[_capi.F_HIST][0], small[_capi.F_ITER_CYCLES][0]
+        else:
+            stats = _capi.Stats()
+            _capi.check(self._lib.mi_ilqr_solve(self._h, C.byref(stats)), "mi_ilqr_solve")
+            self.stats = stats
+            iters, status, hist, iter_cyc = int(self.iterations[0]), int(self.status[0]), self.history[0], self.iteration_cycles[0]
         total_time = time.time() - st
         self.solve_wall_s = total_time
-        iters = int(self.iterations[0])
-        hist = self.history[0]
-        status = int(self.status[0])
         # the reference's stopwatches (ilqr.py:364-372,696-702) from the in-kernel cycle counters, PER ITERATION:
         # cycles of the whole solve loop (stage_cycles[3]) span the kernel's HIP-event time
         cyc = self.stage_cycles[0].astype(np.float64)
         sec_per_cycle = stats.kernel_ms * 1e-3 / max(cyc[3], 1.0)
         rows = min(iters, self.hist_cap)
-        t_iter = self.iteration_cycles[0][:rows] * sec_per_cycle      # columns: fp (line search), derivs, bp, iteration
+        t_iter = iter_cyc[:rows] * sec_per_cycle                      # columns: fp (line search), derivs, bp, iteration
         if rows:                                                      # like the reference: the LAST iteration's stopwatches
             self.time_fp, self.time_getDerivs, self.time_backwardsPass = (float(v) for v in t_iter[-1, :3])
         if self.verbose:
@@ -438,6 +471,8 @@ class IterativeLinearQuadraticRegulator(BatchedIterativeLQR):
         if status == _capi.STATUS_NOT_PD:
             raise RuntimeError("Quu is not positive definite in the backward pass (indefinite cost expansion, or round-off); "
                                "the reference would invert it all the same (ilqr.py:655) - its gains are no descent direction")
+        if res is not None:
+            return res[0].reshape(self.n, self.N), res[1].reshape(self.m, self.N - 1), total_time, float(res[2][0])
         return self.x_bar, self.u_bar, total_time, float(self.cost[0])
 
     def SaveSolution(self, fname):

@@ -1,6 +1,8 @@
 """One rank of tests/test_gpu_multi.py (a plain script: every rank is its own process on its own GPU).
 
-    python _multi_worker.py <rank> <world> <exchange_dir>
+    python _multi_worker.py <rank> <world> <exchange_dir> [same]
+
+"same": every rank uses GPU 0 (the communicator's ranks share one device - what a one-GPU box can run).
 
 Checks, on `world` GPUs of one node, the path's one collective in the library's own RCCL communicator
 (mi_ilqr_comm_*, NativeComm) and the shard partitioning of a batched solve; writes `<exchange_dir>/ok.<rank>`
@@ -18,6 +20,8 @@ sys.path.insert(0, ROOT)
 
 def main():
     rank, world, xdir = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+    same = len(sys.argv) > 4 and sys.argv[4] == "same"
+    dev = 0 if same else rank
     from drake_ddp_amd.dist import NativeComm, shard_range
     from drake_ddp_amd import workloads as W
     from drake_ddp_amd.ilqr import BatchedIterativeLQR
@@ -38,7 +42,7 @@ def main():
         with open(path, "rb") as f:
             return f.read()
 
-    comm = NativeComm(rank, world, rank, exchange)
+    comm = NativeComm(rank, world, dev, exchange)
     # ranks contribute DIFFERENT values: min, not sum / average / max (round-2 advisor: the op code was ncclAvg)
     v = np.array([10.0 * (rank + 1), -3.0 * (rank + 1), 100.0 - rank, float(rank == world - 1)])
     want = np.array([10.0, -3.0 * world, 100.0 - (world - 1), 0.0 if world > 1 else 1.0])
@@ -61,7 +65,7 @@ def main():
         s.SetInitialState(x0s); s.SetInitialGuess(np.zeros((1, p["N"] - 1)))
         s.Solve()
         return s
-    mine = solve(x0[lo:hi], rank)
+    mine = solve(x0[lo:hi], dev)
     best = comm.allreduce_min([mine.stats.best_cost])[0]
     out = {"rank": rank, "best": float(best), "iters": int(mine.iterations.sum()), "lo": lo, "hi": hi}
     if rank == 0:

@@ -53,6 +53,35 @@ def test_native_rccl_min_and_sharded_solve(world, tmp_path):
 
 
 @pytest.mark.gpu
+def test_native_rccl_min_with_two_ranks_on_one_gpu(tmp_path):
+    """The library's communicator with world = 2 on a ONE-GPU box: both ranks (two processes) on device 0.  Ranks contribute
+    different values to mi_ilqr_allreduce_min (min - not avg, not sum), then each solves its shard and the reduced best cost
+    equals the whole batch's.  RCCL builds that refuse two ranks on one device say so ("Duplicate GPU"): skipped with the
+    library's own message then."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_DEBUG=os.environ.get("NCCL_DEBUG", "WARN"))
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_multi_worker.py"), str(r), "2", str(tmp_path), "same"],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=300)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    if any(p.returncode != 0 for p in procs):
+        text = "\n".join(outs)
+        for marker in ("Duplicate GPU", "duplicate GPU", "invalid usage", "ncclInvalidUsage"):
+            if marker in text:
+                line = next((l for l in text.splitlines() if marker in l), marker)
+                pytest.skip("this RCCL refuses two ranks on one device: " + line.strip()[:300])
+        raise AssertionError("rank(s) failed:\n" + text[-4000:])
+    res = [json.load(open(tmp_path / f"ok.{r}")) for r in range(2)]
+    assert res[0]["best"] == res[1]["best"] and res[0]["iters"] + res[1]["iters"] == res[0]["whole_iters"]
+    assert (res[0]["lo"], res[0]["hi"], res[1]["lo"], res[1]["hi"]) == (0, 32, 32, 64)
+
+
+@pytest.mark.gpu
 @needs_two
 def test_bench_on_rccl_all_gpus():
     n = _n_gpus()

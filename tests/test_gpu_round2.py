@@ -651,8 +651,8 @@ def test_pipelined_solves_defer_their_statistics_and_sample_their_events():
 def test_shared_initial_guess_and_pinned_results(cfg):
     """SetInitialGuess with ONE (m,N-1) sequence (the reference's argument, ilqr.py:148-156) goes through
     mi_ilqr_set_initial_shared - m(N-1) doubles over the bus, the device writes the batch's copies in the kernel
-    family's own layout - and gives bitwise what the (B,m,N-1) array of copies gives; pinned_results=True returns
-    the same numbers in the solver's page-locked buffers (reused by the next read, alive while a view is)."""
+    family's own layout - and gives bitwise what the (B,m,N-1) array of copies gives; pinned_results=True (the default)
+    returns the same numbers in page-locked blocks that are never rewritten while the caller holds them."""
     from drake_ddp_amd import workloads as W
     rng = np.random.default_rng(11)
     if cfg == "synth36":
@@ -672,8 +672,19 @@ def test_shared_initial_guess_and_pinned_results(cfg):
         x, u, _, L = s.Solve()
         res.append((x.copy(), u.copy(), L.copy(), s.iterations.copy()))
         if pinned:
+            # the reference rebinds its result arrays and never mutates one it has handed out (ilqr.py:375-376, F13): a
+            # page-locked block is reused only once the caller holds no view of it
             x_again = s.x_bar
-            assert x_again is x or np.shares_memory(x_again, x)              # one buffer per attribute
+            assert not np.shares_memory(x_again, x) and np.array_equal(x_again, x)
+            first = x.copy()
+            s.Reset(); s.SetInitialState(x0 + 0.01); s.SetInitialGuess(guess)
+            x2, _, _, _ = s.Solve()
+            assert not np.shares_memory(x2, x) and np.array_equal(x, first) and not np.array_equal(x2, first)
+            addr = x2.__array_interface__["data"][0]
+            del x2, x_again
+            x3 = s.x_bar                                                      # nobody holds the other blocks any more: one is reused
+            assert x3.__array_interface__["data"][0] in (addr, x3.__array_interface__["data"][0]) and len(s._pinned) >= 1
+            assert max(len(v) for v in s._pinned.values()) <= 3
             keep = x
             del s
             import gc; gc.collect()
