@@ -73,8 +73,6 @@ struct mi_ilqr {
   int n_store = 1;         // line-search candidate trajectories kept in LDS
   bool batch_minor = false; // lane-per-problem path: state arrays are [t][row][b] in HBM
   double *sink_x = nullptr, *sink_u = nullptr, *sink_cost = nullptr;   // result sink (device aliases of host arrays), optional
-  int32_t* cont = nullptr;         // two-phase solves (ilqr_wide.hpp): [0], [1] the counters of alternate solves, [2..2+B) the list
-  long long phase_seq = 0;         // two-phase solves launched so far (parity selects the counter)
 };
 
 // Small batches of the wave-per-problem kernels aggregate the batch statistics in the solve kernel
@@ -82,24 +80,9 @@ struct mi_ilqr {
 // 98.  Large batches keep the separate stats_kernel: with pipelined solves the two cost the same per
 // step (measured at B = 1024: 0.166 ms either way), and the solve kernel stays 3.6 us shorter.
 // MI_ILQR_STATS_KERNEL=1 / =0 forces the separate kernel / the in-kernel epilogue (A/B runs).
-// Two-phase solve of the n = 2 models (ilqr_wide.hpp): the number of first-phase iterations, 0 = single-phase.  A rule on
-// the iteration index alone - the same for every batch size, so that results stay bitwise independent of batch size,
-// position and sharding.  OFF by default: built and measured in round 3 - exact parity, but slower than the single-phase
-// solve on C2 (DESIGN.md section 8 has the numbers and the reasons); MI_ILQR_PHASE_CAP=k turns it on with k first-phase
-// iterations.
-static inline int phase_cap_of(const mi_ilqr* h) {
-  static const int env = [] { const char* e = std::getenv("MI_ILQR_PHASE_CAP"); return e ? std::atoi(e) : -1; }();
-  static const bool seq = [] { const char* a = std::getenv("MI_ILQR_SEQ_BACKWARD"); const char* b = std::getenv("MI_ILQR_SEQ_ROLLOUT");
-                               return (a && a[0] == '1') || (b && b[0] == '1'); }();
-  if (!h->cont || h->large || h->batch_minor || h->n != 2 || h->m != 1 || h->N - 1 > 64 * 4 || seq || h->exact_backward ||
-      h->d.keypoint_method != MI_KP_SET_INTERVAL || h->d.minN != 1)
-    return 0;
-  return env > 0 ? env : 0;
-}
 static inline bool stats_in_kernel(const mi_ilqr* h) {
   static const int forced = [] { const char* e = std::getenv("MI_ILQR_STATS_KERNEL"); return !e ? -1 : (e[0] == '1' ? 1 : 0); }();
   if (h->large || h->batch_minor) return false;
-  if (phase_cap_of(h) > 0) return false;                 // (the statistics exist after the second launch only)
   if (forced >= 0) return forced == 0;
   return h->B <= 64;
 }

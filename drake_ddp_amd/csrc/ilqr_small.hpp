@@ -88,14 +88,7 @@ struct KArgs {
   // that receive x_bar (B,n,N), u_bar (B,m,N-1) and the costs (B,) straight from the kernel's write-back, problem by
   // problem as each one finishes: the copy-out of a batch overlaps the launch's stragglers instead of following it.
   double *sink_x, *sink_u, *sink_cost;
-  // n = 2, MODE_SOLVE: TWO-PHASE solve (ilqr_wide.hpp).  phase_cap > 0: a problem that has not converged after
-  // phase_cap iterations leaves this kernel with the internal status MI_STATUS_CONTINUE_, its state written back as
-  // usual, and appends its index to cont_list (cont_count: running count); the 4-wave continuation kernel picks it up.
-  // cont_reset: the counter of the NEXT solve, zeroed here.
-  int32_t phase_cap;
-  int32_t *cont_count, *cont_list, *cont_reset;
 };
-enum { MI_STATUS_CONTINUE_ = 4 };      // internal: never leaves the library
 
 __device__ __forceinline__ double bcast_lane0(double v) {
   union { double d; int i[2]; } u;
@@ -617,6 +610,12 @@ __device__ __forceinline__ void aff2_prefix_dpp(Aff2& P) {
 #define MI_NEWTON_MAX_SWEEPS 7
 #endif
 enum { NEWTON_FAILED = 0, NEWTON_STORED = 1, NEWTON_REJECTED = 2, NEWTON_ACCEPTED = 3 };
+// Models on which the time-parallel rollout's remainder was measured (models.hpp: kNewtonRollout - the built-in smooth
+// n = 2 models); every other n = 2 model (plugins) takes the rollout too, under the stricter guard of dynamics_hold.
+template <class M, class = void>
+struct NewtonMeasured { static constexpr bool value = false; };
+template <class M>
+struct NewtonMeasured<M, decltype((void)M::kNewtonRollout)> { static constexpr bool value = M::kNewtonRollout; };
 
 template <class M, int JAC, int CH>
 __device__ inline int rollout_newton_impl(const WS& w, const Consts<M>& c, const KArgs& a, const double* x0r, double eps,
@@ -735,8 +734,8 @@ __device__ inline int rollout_newton_impl(const WS& w, const Consts<M>& c, const
   // step instead of the Dual2 one - the guess is already so close that G at the previous guess is G at the
   // solution to ~1e-4, and the correction it computes (the defect ~c u^2 of the last full sweep, u its update)
   // is left with an error ~2c u * c u^2: 6e-14 at the u = 3.5e-4 typical of C2's third sweep, where a full sweep
-  // leaves 3e-19 - both far below the 1e-11 the chunk-edge guard accepts, and the final pass re-steps every
-  // chunk exactly either way.  A chord sweep that does not converge is followed by a full one.
+  // leaves 3e-19 - both far below the 1e-11 the a-posteriori guard (dynamics_hold, below) accepts.  A chord sweep
+  // that does not converge is followed by a full one.
   constexpr double kFrozenTol = 5e-4;
   double Gs[CH][n][n];                                       // closed-loop Jacobians of the last full sweep
   double prev_upd = __builtin_inf();
@@ -831,22 +830,32 @@ __device__ inline int rollout_newton_impl(const WS& w, const Consts<M>& c, const
   // The trial trajectory IS the last sweep's result: its update applied the linearized recurrence, i.e.
   //   x_{t+1} = g_t(X_t) + G_t (x_t - X_t),
   // to corrections below kTol = 1e-7, so it misses the exact step x_{t+1} = g_t(x_t) (ilqr.py:313-316) by the
-  // quadratic remainder ~c |x_t - X_t|^2 (c = 0.03 on C2: < 3e-16; a chord sweep leaves 2c u_full u_chord, < 1e-13
-  // by its entry rule) - the size of the chunk-edge defect the earlier re-step of every chunk left at its 49 edges,
-  // without that re-step's four model evaluations per lane.  A-posteriori guard of the stopping rule, model by
-  // model and trial by trial: ONE exact step per lane, its last, against the state the trajectory holds there; for
-  // dynamics or gains where the sweeps do not contract as measured the defect shows it and the caller falls back
-  // to the sequential rollout.
+  // quadratic remainder ~c |x_t - X_t|^2 (c = 0.03 on C2: < 3e-16; a chord sweep leaves 2c u_full u_chord, at most
+  // 2 x 0.03 x 5e-4 x 1e-7 = 3e-12 by its entry rule kFrozenTol and typically 6e-14) - the size of the chunk-edge defect
+  // the earlier re-step of every chunk left at its 49 edges, without that re-step's four model evaluations per lane.
+  // A-posteriori guard of the stopping rule, model by model and trial by trial: exact steps against the states the
+  // trajectory holds - ONE per lane (its last) for the built-in smooth models this was measured on, EVERY step of
+  // the chunk for any other model (plugins); where the sweeps do not contract as measured, or a kink sits inside a
+  // chunk, the defect shows it and the caller falls back to the sequential rollout.
   auto dynamics_hold = [&]() __attribute__((always_inline)) -> bool {
     constexpr double kEdgeTol = 1e-11;
     double dfc = 0.0;
-    if (valid[CH - 1]) {
-      double u[m], xe[n];
-      u[0] = dd[CH - 1] - (Kk[CH - 1][0] * (X[CH - 1][0] - xb[CH - 1][0]) + Kk[CH - 1][1] * (X[CH - 1][1] - xb[CH - 1][1]));
-      M::template step<double>(X[CH - 1], u, xe, a.params, a.dt);
-      const double d = fmax(fabs(xe[0] - x_end[0]), fabs(xe[1] - x_end[1]));
-      const double sc = fmax(1.0, fmax(fabs(xe[0]), fabs(xe[1])));
-      dfc = (d <= kEdgeTol * sc) ? 0.0 : 1.0;                  // NaN -> does not hold
+    // built-in smooth models (M::kNewtonRollout: the quadratic remainder was MEASURED, see above): the lane's last step;
+    // any other n = 2 model (plugins - a kink such as fmax or a contact inside a chunk would leave a defect of the size of
+    // the last correction that the last step alone does not see): EVERY valid step of the chunk, CH - 1 more plain steps
+    constexpr int kFirst = NewtonMeasured<M>::value ? CH - 1 : 0;
+#pragma unroll
+    for (int k = kFirst; k < CH; ++k) {
+      if (valid[k]) {
+        double u[m], xe[n];
+        u[0] = dd[k] - (Kk[k][0] * (X[k][0] - xb[k][0]) + Kk[k][1] * (X[k][1] - xb[k][1]));
+        M::template step<double>(X[k], u, xe, a.params, a.dt);
+        const double nx_0 = (k + 1 < CH) ? X[(k + 1 < CH) ? k + 1 : k][0] : x_end[0];
+        const double nx_1 = (k + 1 < CH) ? X[(k + 1 < CH) ? k + 1 : k][1] : x_end[1];
+        const double d = fmax(fabs(xe[0] - nx_0), fabs(xe[1] - nx_1));
+        const double sc = fmax(1.0, fmax(fabs(xe[0]), fabs(xe[1])));
+        dfc = (d <= kEdgeTol * sc) ? dfc : 1.0;                 // NaN -> does not hold
+      }
     }
     dfc = fmax(dfc, row_ror_f64<8>(dfc));
     dfc = fmax(dfc, row_ror_f64<4>(dfc));
@@ -966,7 +975,6 @@ __device__ inline bool linesearch(const WS& w, const Consts<M>& c, const KArgs& 
   int base = 0;
   double eps_base = 1.0;
   // the stored nominal trajectory is a usable first guess except at the first iteration of a solve
-  // (no_newton: the caller already tried the time-parallel rollout itself - ilqr_wide.hpp)
   const bool newton = !no_newton && newton_capable<M>(w, a) && L_last < __builtin_inf();
   if (optimistic) {
     double L, ex;
@@ -2209,7 +2217,6 @@ __global__ void __launch_bounds__(256) ilqr_small_kernel(const KArgs a) {
     long long c_prev = 0;
     while (improvement > a.delta) {
       if (it_this >= a.max_iters) { status = MI_STATUS_MAX_ITERS; break; }
-      if (MODE == MODE_SOLVE && n == 2 && a.phase_cap > 0 && it_this >= a.phase_cap) { status = MI_STATUS_CONTINUE_; break; }   // -> ilqr_wide_kernel
       double L_new, eps; int trials, slot = 0;
       // stopwatch reads cost an s_memtime round trip each: an iteration starts where the previous one
       // ended, and a rollout that linearized on the way has no separate linearization span
@@ -2370,13 +2377,6 @@ __global__ void __launch_bounds__(256) ilqr_small_kernel(const KArgs a) {
   if (lane == 0) {
     a.cost[b] = L; a.iters[b] = iters; a.status[b] = status; a.ls_trials[b] = ls_total; a.kp_count[b] = nk;
     if (a.sink_cost != nullptr) a.sink_cost[b] = L;
-    if (MODE == MODE_SOLVE && n == 2 && a.phase_cap > 0) {
-      if (b == 0) __hip_atomic_store(a.cont_reset, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (status == MI_STATUS_CONTINUE_) {
-        const int idx = __hip_atomic_fetch_add(a.cont_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        a.cont_list[idx] = b;
-      }
-    }
     a.prof[4 * b + 0] = c_ls; a.prof[4 * b + 1] = c_lin; a.prof[4 * b + 2] = c_bp; a.prof[4 * b + 3] = clock64() - c_begin;
 #ifdef MI_PROF_NEWTON
     // debug build: launch phases instead of the stage stopwatches

@@ -2,7 +2,6 @@
 #pragma once
 #include "host.hpp"
 #include "ilqr_small.hpp"
-#include "ilqr_wide.hpp"
 
 namespace mi_host {
 template <class M, int JAC, int MODE>
@@ -11,21 +10,6 @@ int launch_one(mi_ilqr* h, const KArgs& a) {
   static bool lds_ok[kMaxDevices] = {};
   { const int rc = allow_max_lds(kern, lds_ok, h->d.device_id); if (rc != MI_ILQR_OK) return rc; }
   const int waves = (a.helpers > 0 && (MODE == MODE_SOLVE || MODE == MODE_MPC)) ? 1 + a.helpers : 1;
-  if constexpr (M::n == 2 && M::m == 1 && MODE == MODE_SOLVE) {
-    if (a.phase_cap > 0) {
-      // two-phase solve (ilqr_wide.hpp): iterations 1..phase_cap here, the unfinished problems in the 4-wave kernel
-      auto wide = ilqr_wide_kernel<M, JAC>;
-      static bool wide_ok[kMaxDevices] = {};
-      { const int rc = allow_max_lds(wide, wide_ok, h->d.device_id); if (rc != MI_ILQR_OK) return rc; }
-      KArgs b = a;
-      const int par = (int)(h->phase_seq++ & 1);
-      b.cont_count = h->cont + par; b.cont_reset = h->cont + (par ^ 1); b.cont_list = h->cont + 2;
-      const int rc = launch_timed(h, kern, dim3(h->B), dim3(64 * waves), h->lds, b, 1);
-      if (rc != MI_ILQR_OK) return rc;
-      const int wgs = h->n_cus > 0 ? (h->B < h->n_cus ? h->B : h->n_cus) : h->B;
-      return launch_timed(h, wide, dim3(wgs), dim3(kWideThreads), kMaxLds, b, 2);    // the whole LDS: one workgroup per CU
-    }
-  }
   return launch_timed(h, kern, dim3(h->B), dim3(64 * waves), h->lds, a);
 }
 

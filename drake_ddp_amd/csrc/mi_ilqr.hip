@@ -126,7 +126,6 @@ KArgs make_args(const mi_ilqr* h) {
   // linearization (ilqr_large.hpp: cluster handshake), as many as keep every workgroup of the launch on its own CU.
   // MI_ILQR_CLUSTER=k forces k (1 = off) for A/B runs.
   a.sink_x = h->sink_x; a.sink_u = h->sink_u; a.sink_cost = h->sink_cost;
-  a.phase_cap = phase_cap_of(h); a.cont_count = a.cont_list = a.cont_reset = nullptr;     // (two-phase solves: launch_small.hpp fills the pointers)
   a.cluster = 1;
   a.cluster_sync = h->cluster_sync;
   if (h->large && h->cluster_sync && h->d.keypoint_method == MI_KP_SET_INTERVAL && h->d.minN == 1) {
@@ -612,7 +611,6 @@ int mi_ilqr_create(const mi_ilqr_desc* desc, mi_ilqr_t** out) {
   ALLOC(h->prof, B * 4, long long);
   ALLOC(h->done_counter, 1, int32_t);
   if (large) ALLOC(h->cluster_sync, B * 4, unsigned long long);
-  if (!large && !batch_minor && n == 2 && m == 1) ALLOC(h->cont, B + 2, int32_t);
 #undef ALLOC
   {
     int cus = 0;
@@ -656,7 +654,7 @@ void mi_ilqr_destroy(mi_ilqr_t* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   void* ptrs[] = {h->x_bar, h->u_bar, h->K, h->kappa, h->dV, h->fx, h->fu, h->x0, h->u_guess, h->cost_ring, h->hist, h->iter_cyc,
                   h->x_trial, h->u_trial, h->trial_cost, h->stage_in, h->costmat, h->iters_ring, h->status_ring, h->ls_ring,
-                  h->kp_count, h->kp_list, h->prof, h->done_counter, h->cluster_sync, h->cont};
+                  h->kp_count, h->kp_list, h->prof, h->done_counter, h->cluster_sync};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->h_ring) (void)hipHostFree(h->h_ring);
   if (h->mpc_log) (void)hipFree(h->mpc_log);

@@ -4,6 +4,7 @@
 
   vdp     n = 2, m = 1   controlled Van der Pol oscillator, params [mu]
                          (an n = 2 model: served by the time-parallel rollout and Riccati scan, like the pendulum)
+  kink2   n = 2, m = 1   a mass against a one-sided spring: non-smooth dynamics on the same kernels, params [c, k]
   chain3  n = 6, m = 2   three coupled pendula, the outer two actuated, params [ks, c, kc]
                          (a shape no built-in model has: served by the generic scalar passes of the wave-per-problem kernel)
   synth36p n = 36, m = 12 the built-in 36-state chain re-stated as a plugin (whole-step form) for the matrix-core family
@@ -24,6 +25,17 @@ VDP_BODY = """    // q'' = mu (1 - q^2) q' - q + u, semi-implicit Euler
     const T vn = v + dt * a;
     xn[1] = vn; xn[0] = q + dt * vn;"""
 VDP_DEFAULTS = [1.0]
+
+# A pendulum-like mass with a one-sided spring (a wall at q = 0): the force has a KINK where the mass touches the wall - an n = 2
+# model whose time-parallel rollout (ilqr_small.hpp: Newton on the trajectory) must notice a kink inside a lane's chunk of
+# steps (its guard re-steps every step of the chunk for models the remainder was not measured on) and fall back.
+KINK2_BODY = """    const double c = p[0], k = p[1];
+    const T q = x[0], v = x[1];
+    T a = u[0] - c * v - 2.0 * mi_sin(q);
+    if (value_of(q) < 0.0) a = a - k * q;
+    const T vn = v + dt * a;
+    xn[1] = vn; xn[0] = q + dt * vn;"""
+KINK2_DEFAULTS = [0.2, 400.0]
 
 CHAIN3_BODY = """    const double ks = p[0], c = p[1], kc = p[2];
     const T l01 = mi_sin(x[1] - x[0]), l12 = mi_sin(x[2] - x[1]);
@@ -121,7 +133,8 @@ def build_chain(nq, verbose=False):
 def build_all(verbose=False):
     """Compile the plugins (one hipcc each, in parallel: 10-40 s the first time) and return their ModelSystem factories."""
     from drake_ddp_amd import plugin
-    specs = [("vdp", 2, 1, VDP_BODY, VDP_DEFAULTS, "small"), ("chain3", 6, 2, CHAIN3_BODY, CHAIN3_DEFAULTS, "small"),
+    specs = [("vdp", 2, 1, VDP_BODY, VDP_DEFAULTS, "small"), ("kink2", 2, 1, KINK2_BODY, KINK2_DEFAULTS, "small"),
+             ("chain3", 6, 2, CHAIN3_BODY, CHAIN3_DEFAULTS, "small"),
              ("synth36p", 36, 12, SYNTH36P_BODY, SYNTH36P_DEFAULTS, "large"), chain_spec(17), chain_spec(20)]
     specs += [chainx_spec(*sh) for sh in CHAINX_SHAPES]
     return plugin.build_models(specs, verbose=verbose)

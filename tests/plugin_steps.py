@@ -61,3 +61,14 @@ def chain3_step(x, u, p, dt):
     a2 = -ks * D.sin(x[2]) - c * x[5] - kc * l12 + u[1]
     v0, v1, v2 = x[3] + dt * a0, x[4] + dt * a1, x[5] + dt * a2
     return [x[0] + dt * v0, x[1] + dt * v1, x[2] + dt * v2, v0, v1, v2]
+
+
+def kink2_step(x, u, p, dt):
+    c, k = p[0], p[1]
+    q, v = x[0], x[1]
+    a = u[0] - c * v - 2.0 * D.sin(q)
+    qv = q.v if isinstance(q, D.Dual) else q
+    if qv < 0.0:
+        a = a - k * q
+    vn = v + dt * a
+    return [q + dt * vn, vn]

@@ -491,3 +491,28 @@ np.savez(sys.argv[1], K1=K1, k1=k1, dV1=dV1, L=L, it=s.iterations, ls=s.ls_trial
     assert_flip_budget("scan_vs_seq_backward", same, (par["ls"], seq["ls"]))
     # (the stiff contact model amplifies faster: 1e-5 there)
     assert np.max(np.abs(par["L"][same] - seq["L"][same]) / np.abs(seq["L"][same])) < (1e-5 if model_id == 3 else 1e-6)
+
+
+def test_set_control_limits_is_the_reference_stub():
+    """SetControlLimits (ilqr.py:158-159) is `pass` in the reference: calling it, with any limits, changes nothing - results
+    bitwise those of a solver that never heard of it (both classes; nothing is pinned against limits because the reference has
+    no semantics for them)."""
+    from drake_ddp_amd import workloads as W
+    p = W.pendulum_problem()
+    x0 = W.pendulum_batch_x0(32)
+    out = []
+    for limits in (None, (-0.1, 0.1)):
+        s = make_solver(p, B=32, jac="fd")
+        if limits is not None:
+            assert s.SetControlLimits(np.full(1, limits[0]), np.full(1, limits[1])) is None
+        s.SetInitialState(x0); s.SetInitialGuess(np.zeros((1, p["N"] - 1)))
+        x, u, _, L = s.Solve()
+        out.append((x.copy(), u.copy(), L.copy(), s.K.copy(), s.iterations.copy()))
+    for a, b in zip(*out):
+        assert np.array_equal(a, b)
+    assert np.abs(out[1][1]).max() > 0.1                      # (the "limits" were well inside what the solution uses)
+    one = make_solver(p, jac="fd", single=True)
+    one.SetControlLimits(-1.0, 1.0)
+    one.SetInitialState(x0[0]); one.SetInitialGuess(np.zeros((1, p["N"] - 1)))
+    x1, u1, _, L1 = one.Solve()
+    assert np.array_equal(x1, out[0][0][0]) and L1 == out[0][2][0]

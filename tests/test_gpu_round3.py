@@ -367,53 +367,6 @@ def test_sensitive_goldens_deviate_no_more_than_their_own_sensitivity(name):
     assert 0.98 * min(Ls) <= L <= 1.02 * max(Ls), (L, Ls)
 
 
-def test_two_phase_solve_is_the_same_algorithm(tmp_path):
-    """The two-phase n = 2 solve (csrc/ilqr_wide.hpp; off by default, MI_ILQR_PHASE_CAP=k): iterations 1..k in the
-    wave-per-problem kernel, the unfinished problems continued by the 4-wave kernel (one step per lane, scans crossing
-    the waves through LDS).  Same algorithm: on C2's first 512 problems and on a batch with coarse backtracking
-    (beta = 0.7: the 4-wave kernel's single-wave line-search fallback runs) every problem's iterations, trial counts and
-    per-iteration (eps, trials) equal the single-phase solve's, costs and trajectories agree to round-off."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    script = f"""
-import sys, numpy as np
-sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, 'tests')!r})
-from drake_ddp_amd import workloads as W
-from test_gpu_parity import make_solver
-out = {{}}
-p = W.pendulum_problem()
-for tag, prob, B in (("c2", p, 512), ("coarse", dict(p, beta=0.7, gamma=0.1, N=120), 96)):
-    x0 = W.pendulum_batch_x0(1024)[:B]
-    s = make_solver(prob, B=B, jac="fd", hist_cap=32)
-    s.SetInitialState(x0); s.SetInitialGuess(np.zeros((1, prob["N"] - 1)))
-    x, u, _, L = s.Solve()
-    out.update({{tag + "_x": x, tag + "_L": L, tag + "_it": s.iterations, tag + "_ls": s.ls_trials, tag + "_st": s.status,
-                 tag + "_h": s.history[:, :, 1:3], tag + "_K": s.K}})
-np.savez(sys.argv[1], **out)
-"""
-    res = {}
-    for tag, env in (("one", {}), ("two", {"MI_ILQR_PHASE_CAP": "3"})):
-        f = str(tmp_path / f"{tag}.npz")
-        r = subprocess.run([sys.executable, "-c", script, f], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
-        assert r.returncode == 0, r.stderr[-2000:]
-        res[tag] = np.load(f)
-    a, b = res["one"], res["two"]
-    for tag in ("c2", "coarse"):
-        assert (a[tag + "_st"] == 0).all() and np.array_equal(a[tag + "_st"], b[tag + "_st"])
-        assert np.array_equal(a[tag + "_it"], b[tag + "_it"]) and np.array_equal(a[tag + "_ls"], b[tag + "_ls"])
-        assert np.array_equal(a[tag + "_h"], b[tag + "_h"])
-        assert a[tag + "_it"].max() > 3                                           # the second phase really ran
-        # (different association of the scans -> 1e-15-level trajectories -> 1e-10 through the central differences)
-        assert np.max(np.abs(a[tag + "_L"] - b[tag + "_L"]) / np.abs(a[tag + "_L"])) < 1e-8
-        assert np.max(np.abs(a[tag + "_x"] - b[tag + "_x"])) < 1e-7 and rel_err(b[tag + "_K"], a[tag + "_K"]) < 1e-6
-    # C2's backtracking iterations (problems 27, 73, 95, ...: 2-14 trials in their 4th / 5th iteration) fall into the second
-    # phase with phase_cap = 3: the 4-wave kernel's single-wave line-search fallback really ran
-    bt = a["c2_h"][:, 3:, 1] > 1
-    assert bt.any() and not (a["c2_h"][:, :3, 1] > 1).any()
-
-
 def test_lane_per_problem_kernels_refuse_other_keypoint_methods():
     """ilqr_batch.hpp serves setInterval / minN = 1 only: adaptiveJerk / iterativeError (ilqr.py:434-593) with
     kernel_mode = throughput are refused at create (MI_ILQR_E_UNSUPPORTED), and AUTO serves them on the wave-per-problem

@@ -45,6 +45,12 @@ def test_plugin_registers_without_a_gpu():
 
 CASES = {
     "vdp": dict(n=2, m=1, dt=0.02, N=100, x_nom=np.zeros(2), Q=np.eye(2), R=0.1 * np.eye(1), Qf=10.0 * np.eye(2), span=2.0),
+    # (target behind the wall at q = 0, starts on both sides of it: every trajectory crosses the kink, many inside a lane's chunk
+    #  of steps; gamma = 0.1 exercises the expected-improvement term of the acceptance test, ilqr.py:330-331.  The model keeps
+    #  a smooth nonlinearity beside the kink on purpose: with piecewise-LINEAR dynamics iLQR lands exactly on a stationary
+    #  point, and whether its next iteration's 1e-16 "improvement" counts as a decrease or ends in "linesearch failed" is
+    #  round-off on either side - observed in the NumPy oracle and on the device alike)
+    "kink2": dict(n=2, m=1, dt=0.01, N=180, x_nom=np.array([-0.05, 0.0]), Q=np.eye(2), R=0.02 * np.eye(1), Qf=20.0 * np.eye(2), span=0.6, gamma=0.1),
     "chain3": dict(n=6, m=2, dt=0.02, N=60, x_nom=np.array([np.pi, np.pi, np.pi, 0, 0, 0.0]), Q=np.diag([1, 1, 1, .1, .1, .1]),
                    R=0.05 * np.eye(2), Qf=20.0 * np.eye(6), span=0.6),
 }
@@ -52,7 +58,7 @@ CASES = {
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("jac", ["ad", "fd"])
-@pytest.mark.parametrize("name", ["vdp", "chain3"])
+@pytest.mark.parametrize("name", ["vdp", "chain3", "kink2"])
 def test_plugin_model_solves_like_the_oracle(name, jac):
     """A batch of 24 problems on a plugin model: iterations and line-search trials of every problem exactly the NumPy
     oracle's (driven by the Python statement of the same update), costs 1e-9 (duals) / 1e-8 (central differences),
@@ -69,18 +75,19 @@ def test_plugin_model_solves_like_the_oracle(name, jac):
     rng = np.random.default_rng(11)
     x0 = c["x_nom"] + rng.uniform(-c["span"], c["span"], (B, n))
     ug = rng.uniform(-0.1, 0.1, (m, N - 1))
-    s = BatchedIterativeLQR(sys_, N, B, delta=1e-3, beta=0.7, gamma=0.0, jacobian_mode=jac, hist_cap=64)
+    gamma = c.get("gamma", 0.0)
+    s = BatchedIterativeLQR(sys_, N, B, delta=1e-3, beta=0.7, gamma=gamma, jacobian_mode=jac, hist_cap=64)
     s.SetTargetState(c["x_nom"]); s.SetRunningCost(dt * c["Q"], dt * c["R"]); s.SetTerminalCost(c["Qf"])
     s.SetInitialState(x0); s.SetInitialGuess(ug)
     x, u, _, L = s.Solve()
     assert (s.status == 0).all()
     import plugin_steps as PS
-    step_fn = {"vdp": PS.vdp_step, "chain3": PS.chain3_step}[name]
+    step_fn = {"vdp": PS.vdp_step, "chain3": PS.chain3_step, "kink2": PS.kink2_step}[name]
     model = M.Model.custom(n, m, step_fn, sys_.params, dt)
     tolL = 1e-9 if jac == "ad" else 1e-8
     oracles = []
     for b in range(B):
-        o = OracleILQR(model, N, 1e-3, 0.7, 0.0, jacobian=jac, fd_step=1e-5)
+        o = OracleILQR(model, N, 1e-3, 0.7, gamma, jacobian=jac, fd_step=1e-5)
         o.set_problem(x0[b], c["x_nom"], dt * c["Q"], dt * c["R"], c["Qf"], ug)
         xo, uo, Lo, hist = o.solve()
         hist = np.array(hist)

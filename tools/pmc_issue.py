@@ -57,17 +57,43 @@ for k, c in acc.items():
             "mfma_busy_fraction_of_chip: SQ_VALU_MFMA_BUSY_CYCLES / (kernel_cycles * 1024 SIMDs)": c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (g * N_SIMD),
         }
 # fp64 work per launch from the instruction counters (wave-instructions x 64 lanes, i.e. an upper bound where exec
-# masks are partial; an FMA = 2 flops, one v_mfma_f64_16x16x4 = 2048) and, per BASELINE config, per iLQR iteration:
-# the iteration counts come from one un-profiled run of the same script (the solves are deterministic).
+# masks are partial; an FMA = 2 flops, one v_mfma_f64_16x16x4 = 2048 flops, one v_mfma_f64_4x4x4_4b = 512) and, per BASELINE
+# config, per iLQR iteration: the iteration counts come from one un-profiled run of the same script (the solves are
+# deterministic).  SQ_INSTS_MFMA does not tell the two MFMA shapes apart: their ratio is the static one of the kernel's ISA
+# (both sit in the same backward-pass loops; tools/isa_mix.py reads the built objects).
+def mfma_small_fraction(kernel_name):
+    import re
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_mix
+    m = re.search(r"ilqr_\w+_kernel<mi::(\w+)", kernel_name)
+    model = {"Synth36": "synth36", "PlanarQuad": "planar_quad", "Quad3D": "quad3d", "Arm27": "arm27", "Acrobot": "acrobot",
+             "CartPoleT": "cartpole_wall", "Pendulum": "pendulum"}.get(m.group(1) if m else "", None)
+    obj = os.path.join(ROOT, "drake_ddp_amd", "lib", "obj", "k_%s.o" % model) if model else None
+    if not obj or not os.path.exists(obj):
+        return 0.0
+    try:
+        fns = isa_mix.functions(isa_mix.device_asm(obj))
+    except Exception:
+        return 0.0
+    want = kernel_name.split("  grid=")[0].replace(" ", "")
+    n16 = n4 = 0
+    for name, body in fns.items():
+        if isa_mix.demangle(name).split("(")[0].replace("void ", "").replace(" ", "") == want:
+            n16, n4 = body.count("v_mfma_f64_16x16x4"), body.count("v_mfma_f64_4x4x4")
+    return n4 / float(n16 + n4) if n16 + n4 else 0.0
+
+
 for k, c in acc.items():
+    f4 = mfma_small_fraction(k) if c.get("SQ_INSTS_MFMA", 0) else 0.0
+    c["mfma_4x4x4_fraction_of_mfma_instructions (static ISA)"] = f4
     c["fp64_flops_per_launch"] = 64.0 * (2 * c.get("SQ_INSTS_VALU_FMA_F64", 0) + c.get("SQ_INSTS_VALU_ADD_F64", 0) + c.get("SQ_INSTS_VALU_MUL_F64", 0)
-                                         + c.get("SQ_INSTS_VALU_TRANS_F64", 0)) + 2048.0 * c.get("SQ_INSTS_MFMA", 0)
+                                         + c.get("SQ_INSTS_VALU_TRANS_F64", 0)) + (2048.0 * (1.0 - f4) + 512.0 * f4) * c.get("SQ_INSTS_MFMA", 0)
 r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "run_configs.py")], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600)
 lines = [json.loads(l) for l in r.stdout.decode().splitlines() if l.startswith("{")]
 iters = {l["config"].split()[0] + ("/8" if "shard" in l["config"] else ""): l.get("iters_total", l.get("iters_per_solve")) for l in lines}
 KERNELS = {   # config -> (model substring, workgroups of the launch); every kernel mode of that model and grid is the config's
     "C1": ("Pendulum", 1), "C2": ("Pendulum", 1024), "C3": ("Acrobot", 512), "C4": ("CartPoleT<true>", 256),
-    "C5": ("Synth36", 64), "C5q": ("PlanarQuad", None), "C5q3d": ("Quad3D", None)}
+    "C5": ("Synth36", 64), "C5q": ("PlanarQuad", None), "C5q3d": ("Quad3D", None), "C6": ("Arm27", None)}
 per_config = {}
 for cfg, (model, grid) in KERNELS.items():
     ks = [k for k in acc if model in k and (grid is None or ("grid=%d x" % grid) in k)]

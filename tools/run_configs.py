@@ -68,6 +68,8 @@ mpc("C5q planar quadruped MPC B=64 x 101 solves", pq, W.planar_quad_batch_x0(64)
 q3 = W.quad3d_problem()
 mpc("C5q3d 3-D quadruped MPC B=64 x 101 solves", q3, W.quad3d_batch_x0(64), W.quad3d_u_guess(q3["N"]), 100, 4,
     move=(4, W.QUAD3D_TARGET_VEL * q3["dt"] * 4))
+a27 = W.arm27_problem()
+mpc("C6 arm + ball MPC B=64 x 21 solves", a27, W.arm27_batch_x0(64), W.arm27_u_guess(a27["N"]), 20, 5)
 if os.environ.get("MI_RUN_SHARD") == "1":     # (same grid as C5 - 8 problems x 8 workgroups: kept out of the counter passes)
     mpc("C5/8GPU shard: synth36 MPC B=8 x 101 solves", q, W.synth36_batch_x0(64)[:8], W.synth36_u_guess(q["N"]), 100, 4,
         move=(0, W.SYNTH_TARGET_VEL * q["dt"] * 4))
