@@ -736,7 +736,10 @@ __device__ inline int rollout_newton_impl(const WS& w, const Consts<M>& c, const
   // is left with an error ~2c u * c u^2: 6e-14 at the u = 3.5e-4 typical of C2's third sweep, where a full sweep
   // leaves 3e-19 - both far below the 1e-11 the a-posteriori guard (dynamics_hold, below) accepts.  A chord sweep
   // that does not converge is followed by a full one.
-  constexpr double kFrozenTol = 5e-4;
+#ifndef MI_NEWTON_FROZEN_TOL
+#define MI_NEWTON_FROZEN_TOL 5e-4
+#endif
+  constexpr double kFrozenTol = MI_NEWTON_FROZEN_TOL;
   double Gs[CH][n][n];                                       // closed-loop Jacobians of the last full sweep
   double prev_upd = __builtin_inf();
   bool have_g = false, last_frozen = false;
@@ -744,6 +747,19 @@ __device__ inline int rollout_newton_impl(const WS& w, const Consts<M>& c, const
   for (int sweep = 0; sweep < kMaxSweeps && !converged; ++sweep) {
 #ifdef MI_PROF_NEWTON
     ++nsw;
+#endif
+#ifdef MI_NEWTON_RELOAD
+    // A/B variant (tools/isa_mix.py): the loop-invariant nominal data of the lane's steps is read from
+    // LDS again in every sweep instead of being held in registers across the loop - 20 LDS reads for a loop without
+    // register parking in the accumulation file
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      const double* g = w.G + (valid[k] ? t0 + k : 0) * Ly::GS;
+#pragma unroll
+      for (int i = 0; i < n; ++i) { xb[k][i] = g[Ly::XB + i]; Kk[k][i] = g[Ly::KK + i]; }
+      dd[k] = g[Ly::UB] - eps * g[Ly::KAP];
+    }
 #endif
     const bool frozen = have_g && !last_frozen && prev_upd < kFrozenTol;      // wave-uniform
     // X_{t+1} of this lane's last step = the next lane's first guess
