@@ -93,6 +93,20 @@ __device__ __forceinline__ double fast_cos(double x) {
   return flip_sign_if_odd(sin_reduced(r), kn.lo);
 }
 
+// sin(x) or cos(x), chosen PER LANE, in one instruction stream: bitwise fast_sin(x) / fast_cos(x).  Both reduce x by
+// k * pi/2 (k = 2n for the sine: 2n * (pi1/2) = n * pi1 exactly; k = 2n - 1 for the cosine) and run the same kernel, so a
+// wave can evaluate sines on some lanes and cosines on others for the price of one of them.
+__device__ __forceinline__ double fast_sin_or_cos(double x, bool is_cos) {
+  const double ts = fma(x, fm::kInvPi, kRoundMagic);                 // fast_sin: the product rounded once, inside the fma
+  const double tc = fma(x, fm::kInvPi, 0.5) + kRoundMagic;           // fast_cos
+  const Rounded kn = round_magic(is_cos ? tc : ts);
+  const double k = fma(2.0, kn.n, is_cos ? -1.0 : 0.0);
+  double r = fma(-k, 0.5 * fm::kPi1, x);
+  r = fma(-k, 0.5 * fm::kPi2, r);
+  r = fma(-k, 0.5 * fm::kPi3, r);
+  return flip_sign_if_odd(sin_reduced(r), kn.lo);
+}
+
 // 1/x: hardware seed + two Newton steps (~1 ulp); no denormal/overflow rescaling.
 __device__ __forceinline__ double fast_rcp(double x) {
   double r = __builtin_amdgcn_rcp(x);

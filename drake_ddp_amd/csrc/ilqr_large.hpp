@@ -132,6 +132,13 @@ template <class M, class = void>
 struct IsWholeStepModel { static constexpr bool value = false; };
 template <class M>
 struct IsWholeStepModel<M, decltype((void)M::kWholeStep)> { static constexpr bool value = M::kWholeStep; };
+// Models whose step starts with the sines / cosines of kJoints independent angles (models.hpp: Arm27): the rollout evaluates
+// them on 2 kJoints lanes at once and every lane of the first 16-lane row runs the rest of the step (M::core) on the shared
+// values; lane 0 publishes the result.  Bitwise M::step.
+template <class M, class = void>
+struct IsTrigModel { static constexpr bool value = false; };
+template <class M>
+struct IsTrigModel<M, decltype((void)M::kTrigCooperative)> { static constexpr bool value = M::kTrigCooperative; };
 // Models that can declare a step infeasible (Drake's update throwing -> L = inf, ilqr.py:315-323).
 template <class M, class = void>
 struct CanFail { static constexpr bool value = false; };
@@ -167,6 +174,16 @@ struct ModelScalars {
     fd_h = a.fd_h; if constexpr (M::n_params > 4) asm volatile("" : "+s"(fd_h));
   }
 };
+
+// lane i's value -> S[i], lane 8 + i's -> C[i], in every lane of the 16-lane row (DPP row_share)
+template <int NJ, int I>
+__device__ __forceinline__ void trig_gather(double v, double (&S)[NJ], double (&C)[NJ]) {
+  if constexpr (I < NJ) {
+    S[I] = row_share<I>(v);
+    C[I] = row_share<8 + I>(v);
+    trig_gather<NJ, I + 1>(v, S, C);
+  }
+}
 
 // One line-search trial (ilqr.py:306-327).  Returns L on every thread; trajectory -> Xn/Un.
 // Per step: (1) 16 lanes per control row form K_t(x-x_bar) partial dots — K_t, x_bar_t,
@@ -343,6 +360,21 @@ __device__ inline double large_rollout(const LView<M::n, M::m>& v, double* lds, 
           for (int i = 0; i < 7; ++i) { xn_[i] = xt[i]; Xo[i] = xt[i]; }
 #pragma unroll
           for (int i = 19; i < 25; ++i) { xn_[i] = xt[i]; Xo[i] = xt[i]; bad = bad || M::infeasible_velocity(xt[i], prm); }
+        }
+        dyn_done = true;
+      }
+    } else if constexpr (IsTrigModel<M>::value) {
+      if (tid < 16) {
+        static_assert(M::kJoints <= 8, "sines on lanes 0.., cosines on lanes 8.. of a 16-lane row");
+        const int j = (tid & 7) < M::kJoints ? (tid & 7) : M::kJoints - 1;
+        const double sc_ = fast_sin_or_cos(xc[j], tid >= 8);
+        double S_[M::kJoints], C_[M::kJoints];
+        trig_gather<M::kJoints, 0>(sc_, S_, C_);
+        double xt[n];
+        M::template core<double>(S_, C_, xc, us, xt, prm, dt_);
+        if (tid == 0) {
+#pragma unroll
+          for (int i = 0; i < n; ++i) { xn_[i] = xt[i]; v.Xn[(size_t)(t + 1) * n + i] = xt[i]; }
         }
         dyn_done = true;
       }
@@ -1440,14 +1472,16 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
 //   x-wave w (w < RT):  T1[:, w] = Vxx F_t[:, w]            (accumulators)  | K[:, w] = Quu^{-1} Qux[:, w]  -> HBM        (:660)
 //                       Qxx[:, w] - lxx = F_t[:, x]^T T1[:, w]             | Vxx'[:, w] = Qxx[:, w] + 2Q - Qux^T K[:, w] -> LDS (:667)
 //                       Qux[:, w] = fu_t^T T1[:, w]  -> LDS                |
-//   u-wave:             T1u = Vxx fu_t,  Quu = 2R + fu_t^T T1u    (:654)   | kappa = Quu^{-1} Qu (:659), dV (:663),
-//                       Quu^{-1}: Gauss-Jordan, one row per lane (GjOuter) | Vx' = Qx - Qux^T kappa (:666); first-order column of
-//                       -> LDS                                             | step t-1: l + F_{t-1}^T Vx' (:651-652)
+//                                                                          | its share of Quu_{t-1}: fu_{t-1}^T Vxx' fu_{t-1} -> LDS
+//   u-wave:             Quu = 2R + the x-waves' shares            (:654)   | Vx' = Qx - Qux^T kappa (:666); first-order column of
+//                       Quu^{-1}: Gauss-Jordan, one row per lane (GjOuter) | step t-1: l + F_{t-1}^T Vx' (:651-652)
+//                       -> LDS; kappa = Quu^{-1} Qu (:659), dV (:663)      |
 //   pipeline wave:      (F_{t-3} in flight from HBM)                       | F_{t-2} -> the LDS buffer F_t leaves, fetch F_{t-3}
 //
 // The D layout of one 16x16x4 product is the B-operand layout of the next (large_backward: "Fused chain"), so T1, the H
-// column and K stay in registers; Vxx is read and written in full (no symmetry is assumed of it - every entry of Vxx' is
-// computed once, by the wave that owns its column, like the reference's dense update).  Two barriers per step.
+// column and K stay in registers; Vxx is read and written in full (every entry of Vxx' is computed once, by the wave that owns
+// its column, like the reference's dense update); only Quu is formed from the transposed column tiles (= the transpose of a
+// matrix that is symmetric up to round-off), which takes it off the step's critical path.  Two barriers per step.
 template <class M>
 __device__ inline void mid_backward(const LView<M::n, M::m>& v, double* lds, bool lx_ready = false) {
   constexpr int n = M::n, m = M::m, nm = n + m;
@@ -1476,8 +1510,8 @@ __device__ inline void mid_backward(const LView<M::n, M::m>& v, double* lds, boo
   double* Ws = QuxS + 16 * QS;       // [16][WSS] Quu^{-1} (rows / columns >= m zero)
   double* Kap = Ws + 16 * WSS;       // [16]      kappa_t
   double* Fo = Kap + 16;             // [FS]      first-order column: Qx (entries < n), Qu (entries UC..UC+m)
-  double* Sq = Fo + FS;              // [16][SS]  Quu - luu, from the accumulator layout to one row per lane
-  constexpr int kExch = 16 * QS + 16 * WSS + 16 + FS + 16 * SS;
+  double* Pq = Fo + FS;              // [RT][16][SS] the x-waves' shares of Quu - luu (accumulator layout -> one row per lane)
+  constexpr int kExch = 16 * QS + 16 * WSS + 16 + FS + RT * 16 * SS;
   static_assert(kExch <= Ly::NMP * Ly::TS, "the exchange buffers live in the H area");
   const d4_t zero4 = {0.0, 0.0, 0.0, 0.0};
   auto wave_lds_fence = [&]() __attribute__((always_inline)) {
@@ -1577,10 +1611,39 @@ __device__ inline void mid_backward(const LView<M::n, M::m>& v, double* lds, boo
         const int row = 16 * q + 4 * reg + lk;
         q2[q][reg] = (row < n && col_ok) ? 2.0 * Q[row * n + col] : 0.0;
       }
+    // This wave's share of the next Quu - luu = fu^T Vxx fu, from the column tile of Vxx it holds in the accumulator layout:
+    // read as an A operand that tile is the ROW tile of Vxx^T (large_backward: "Fused chain"), so
+    //   T1u[16W + r][a] = sum_k Vxx^T[16W + r][k] fu[k][a],   P_W = fu[16W.., :]^T T1u[16W.., :],   sum_W P_W = (fu^T Vxx fu)^T -
+    // the transpose of a matrix that is symmetric up to round-off.  Off the u-wave's critical path: it only adds the shares.
+    auto quu_share = [&](const d4_t (&vc)[RT], const double* Fb) __attribute__((always_inline)) {
+      double fun[KN];
+      const double* ub = Fb + lk * FS + UC + lr;             // B[k][c] = fu[k][c]; also A = fu^T: A[p][k] = fu[k][p]
+#pragma unroll
+      for (int ks = 0; ks < KN; ++ks) fun[ks] = ub[ks * 4 * FS];
+      d4_t tu = zero4;
+#pragma unroll
+      for (int ks = 0; ks < KN; ++ks) tu = __builtin_amdgcn_mfma_f64_16x16x4f64(vc[ks >> 2][ks & 3], fun[ks], tu, 0, 0, 0);
+      d4_t pw = zero4;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg)
+        if (4 * W_ + reg < KN) pw = __builtin_amdgcn_mfma_f64_16x16x4f64(fun[4 * W_ + reg], tu[reg], pw, 0, 0, 0);
+      double* pd = Pq + W_ * 16 * SS + lk * SS + lr;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) pd[4 * reg * SS] = pw[reg];
+    };
     __syncthreads();                                         // (A)
+    {
+      d4_t vterm[RT];                                        // the terminal Vxx = 2 Qf: this wave's column tile
+#pragma unroll
+      for (int q = 0; q < RT; ++q)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) vterm[q][reg] = col_ok ? Vxx[(16 * q + 4 * reg + lk) * VS + col] : 0.0;
+      quu_share(vterm, F);
+    }
     __syncthreads();                                         // (B)
     for (int t = N - 2; t >= 0; --t) {
       const double* Fc = F + ((N - 2 - t) & 1) * FB1;         // F_t
+      const double* Fn = F + ((N - 1 - t) & 1) * FB1;         // F_{t-1}, published a step ago
       // ---- T1[:, W] = Vxx F[:, W]
       double fb[KN];
       const double* b_base = Fc + lk * FS + col;
@@ -1635,6 +1698,7 @@ __device__ inline void mid_backward(const LView<M::n, M::m>& v, double* lds, boo
         for (int j = 0; j < MK; ++j) if (4 * j + lk < m) Kg[(4 * j + lk) * n] = kt[j];
       }
       // ---- Vxx'[:, W] = Qxx[:, W] - Qux^T K[:, W] (:667)
+      d4_t vnew[RT];
 #pragma unroll
       for (int q = 0; q < RT; ++q) {
         double qa[MK];
@@ -1648,9 +1712,13 @@ __device__ inline void mid_backward(const LView<M::n, M::m>& v, double* lds, boo
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
           const int row = 16 * q + 4 * reg + lk;
-          if (row < n && col_ok) Vxx[row * VS + col] = vq[reg];
+          const bool ok = row < n && col_ok;
+          if (ok) Vxx[row * VS + col] = vq[reg];
+          vq[reg] = ok ? vq[reg] : 0.0;                      // (pad rows / columns of Vxx are exact zeros)
         }
+        vnew[q] = vq;
       }
+      if (t > 0) quu_share(vnew, Fn);                        // this wave's share of the NEXT step's Quu
       lds_barrier();
     }
   };
@@ -1674,34 +1742,14 @@ __device__ inline void mid_backward(const LView<M::n, M::m>& v, double* lds, boo
     first_order(N - 2, F);
     __syncthreads();                                         // (B)
     for (int t = N - 2; t >= 0; --t) {
-      const double* Fc = F + ((N - 2 - t) & 1) * FB1;         // F_t
       const double* Fn = F + ((N - 1 - t) & 1) * FB1;         // F_{t-1}
-      // ---- Quu - luu = fu^T (Vxx fu)
-      double fu_[KN];
-      const double* ub = Fc + lk * FS + UC + lr;             // B[k][c] = fu[k][c]; also A = fu^T: A[p][k] = fu[k][p]
-#pragma unroll
-      for (int ks = 0; ks < KN; ++ks) fu_[ks] = ub[ks * 4 * FS];
-      d4_t accU[RT];
-#pragma unroll
-      for (int q = 0; q < RT; ++q) {
-        const double* ap = Vxx + (16 * q + lr) * VS + lk;
-        double va[KN];
-#pragma unroll
-        for (int ks = 0; ks < KN; ++ks) va[ks] = ap[4 * ks];
-        d4_t acc = zero4;
-#pragma unroll
-        for (int ks = 0; ks < KN; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[ks], fu_[ks], acc, 0, 0, 0);
-        accU[q] = acc;
-      }
-      d4_t quu = zero4;
-#pragma unroll
-      for (int ks = 0; ks < KN; ++ks) quu = __builtin_amdgcn_mfma_f64_16x16x4f64(fu_[ks], accU[ks >> 2][ks & 3], quu, 0, 0, 0);
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) Sq[(4 * reg + lk) * SS + lr] = quu[reg];
-      wave_lds_fence();
+      // ---- Quu = luu + the x-waves' shares of fu^T Vxx fu (:654)
       double arow[m];
+      {
+        const double* p0 = Pq + si * SS;
 #pragma unroll
-      for (int j = 0; j < m; ++j) arow[j] = r2[j] + Sq[si * SS + j];          // Quu = luu + fu^T Vxx fu (:654)
+        for (int j = 0; j < m; ++j) arow[j] = r2[j] + (RT == 2 ? p0[j] + p0[16 * SS + j] : p0[j]);
+      }
       double sc = 1.0;
       GjOuter<m, 0>::run(arow, sc, si);                      // Quu^{-1}[si][j] = sc * arow[j] (:655)
       if (!gj_row_positive(sc)) lds[Ly::oRed + kPdFlag] = 1.0;   // Quu not positive definite (read by the kernel after the pass: MI_STATUS_NOT_PD)
@@ -1709,8 +1757,7 @@ __device__ inline void mid_backward(const LView<M::n, M::m>& v, double* lds, boo
 #pragma unroll
         for (int j = 0; j < m; ++j) Ws[lane * WSS + j] = sc * arow[j];
       }
-      lds_barrier();
-      // ---- kappa = Quu^{-1} Qu (:659), dV = Qu^T kappa (:663), Vx' = Qx - Qux^T kappa (:666)
+      // ---- kappa = Quu^{-1} Qu (:659), dV = Qu^T kappa (:663): Qu is the first-order column this wave formed a step ago
       {
         double kp = 0.0;
 #pragma unroll
@@ -1720,7 +1767,8 @@ __device__ inline void mid_backward(const LView<M::n, M::m>& v, double* lds, boo
         if (lane < m) { Kap[lane] = kp; v.kap[(size_t)t * m + lane] = kp; }
         if (lane == 0) v.dV[t] = dv;
       }
-      wave_lds_fence();
+      lds_barrier();
+      // ---- Vx' = Qx - Qux^T kappa (:666)
       if (lane < n) {
         double s = Fo[lane];
 #pragma unroll

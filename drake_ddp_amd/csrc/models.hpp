@@ -485,8 +485,21 @@ struct Arm27 {
   __device__ static inline void cross(const T (&a)[3], const T (&b)[3], T (&o)[3]) {
     o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
   }
+  // The sines and cosines of the seven joint angles are the one part of a step that is independent per joint: the
+  // workgroup-per-problem rollout evaluates them on fourteen lanes at once (ilqr_large.hpp: kTrigCooperative; sines on lanes
+  // 0..6, cosines on lanes 8..14 of one instruction stream - fast_sin_or_cos, bitwise mi_sin / mi_cos) and hands them to
+  // core(); step() evaluates them one after the other.  Same bits either way.
+  static constexpr bool kTrigCooperative = true;
+  static constexpr int kJoints = 7;
   template <class T>
   __device__ static inline void step(const T* x, const T* u, T* xn, const double* p, double dt) {
+    T S[7], C[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) { S[i] = mi_sin(x[i]); C[i] = mi_cos(x[i]); }
+    core<T>(S, C, x, u, xn, p, dt);
+  }
+  template <class T>
+  __device__ static inline void core(const T (&S)[7], const T (&C)[7], const T* x, const T* u, T* xn, const double* p, double dt) {
     const double g = p[0], kc = p[1], sig = p[2], dn = p[3], mu = p[4], bj = p[5];
     const double mb = p[6], rb = p[7], re = p[8], m_el = p[9], m_hd = p[10];
     // ---- kinematics: hand and elbow points, joint axes and origins in the world frame
@@ -494,7 +507,7 @@ struct Arm27 {
     T pos[3] = {T(0.0), T(0.0), T(kH0)}, elbow[3], hand[3], axes[7][3], orgs[7][3];
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
-      const T s = mi_sin(x[i]), c = mi_cos(x[i]);
+      const T s = S[i], c = C[i];
       if (i % 2 == 0) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) { axes[i][k] = ez[k]; orgs[i][k] = pos[k]; }
