@@ -1804,8 +1804,13 @@ __device__ __forceinline__ void backward_pass(const LView<M::n, M::m>& v, double
   else large_backward<M>(v, lds, bp_acc, lx_ready);
 }
 
+#ifndef MI_MID_MINBLOCKS
+#define MI_MID_MINBLOCKS 1
+#endif
+template <class M>
+constexpr int kMinBlocks = LLay<M::n, M::m>::kMid ? MI_MID_MINBLOCKS : 1;
 template <class M, int JAC, int MODE>
-__global__ void __launch_bounds__(kLargeThreads) ilqr_large_kernel(const KArgs a) {
+__global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kernel(const KArgs a) {
   constexpr int n = M::n, m = M::m;
   using Ly = LLay<n, m>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
