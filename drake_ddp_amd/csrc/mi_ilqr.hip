@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -39,6 +40,7 @@ struct ModelInfo { int n, m, n_params; double defaults[MI_ILQR_MAX_PARAMS]; };
 // models registered at run time (mi_ilqr_register_model): id = MI_MODEL_PLUGIN_BASE + slot
 struct PluginSlot { ModelInfo info; mi_ilqr_model_plugin p; bool used = false; };
 PluginSlot g_plugins[MI_ILQR_MAX_PLUGINS];
+std::mutex g_plugins_mutex;
 const PluginSlot* plugin_of(int id) {
   const int s_ = id - MI_MODEL_PLUGIN_BASE;
   return (s_ >= 0 && s_ < MI_ILQR_MAX_PLUGINS && g_plugins[s_].used) ? &g_plugins[s_] : nullptr;
@@ -479,9 +481,9 @@ const char* mi_ilqr_strerror(int code) {
 
 int mi_ilqr_register_model(const mi_ilqr_model_plugin* p, int32_t* model_id_out) {
   if (!p || !model_id_out || !p->launch || !p->lds_bytes) return MI_ILQR_E_BAD_ARG;
-  if (p->abi_version != MI_ILQR_ABI_VERSION || p->kernel_args_bytes != (int32_t)sizeof(KArgs)) {
-    std::fprintf(stderr, "mi_ilqr_register_model: plugin built against other headers (ABI %d, %d-byte kernel arguments; the library: %d, %d)\n",
-                 p->abi_version, p->kernel_args_bytes, MI_ILQR_ABI_VERSION, (int)sizeof(KArgs));
+  if (p->abi_version != MI_ILQR_ABI_VERSION || p->kernel_args_bytes != (int32_t)sizeof(KArgs) || p->handle_bytes != (int32_t)sizeof(mi_ilqr)) {
+    std::fprintf(stderr, "mi_ilqr_register_model: plugin built against other headers (ABI %d, %d-byte kernel arguments, %d-byte handle; the library: %d, %d, %d)\n",
+                 p->abi_version, p->kernel_args_bytes, p->handle_bytes, MI_ILQR_ABI_VERSION, (int)sizeof(KArgs), (int)sizeof(mi_ilqr));
     return MI_ILQR_E_BAD_ARG;
   }
   if (p->n < 1 || p->m < 1 || p->n > kMaxStateDim || p->n_params < 0 || p->n_params > MI_ILQR_MAX_PARAMS) return MI_ILQR_E_BAD_SHAPE;
@@ -489,6 +491,7 @@ int mi_ilqr_register_model(const mi_ilqr_model_plugin* p, int32_t* model_id_out)
   // (mid_backward), 32 < n <= 40 with m % 4 == 0 and 2 m <= n (large_backward's wave roles)
   if (p->family == 0 ? p->m > 2
                      : (p->family != 1 || p->m > 16 || (p->n > 32 && (2 * p->m > p->n || p->m % 4 != 0)))) return MI_ILQR_E_UNSUPPORTED;
+  std::lock_guard<std::mutex> lock(g_plugins_mutex);                     // (slots are filled once and read lock-free afterwards: `used` is set last)
   for (int s_ = 0; s_ < MI_ILQR_MAX_PLUGINS; ++s_) {
     if (g_plugins[s_].used) continue;
     PluginSlot& ps = g_plugins[s_];

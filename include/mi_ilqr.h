@@ -176,7 +176,10 @@ int mi_ilqr_model_info(int model_id, int32_t* n, int32_t* m, int32_t* n_params, 
 enum { MI_MODEL_PLUGIN_BASE = 100, MI_ILQR_MAX_PLUGINS = 32 };
 typedef struct {
   int32_t abi_version;              /* MI_ILQR_ABI_VERSION of the headers the plugin was compiled against ... */
-  int32_t kernel_args_bytes;        /* ... and their sizeof(mi::KArgs): a plugin built from other headers is refused */
+  int32_t kernel_args_bytes;        /* ... their sizeof(mi::KArgs) ... */
+  int32_t handle_bytes;             /* ... and their sizeof(struct mi_ilqr) (the plugin's launch code reads the handle's stream,
+                                       events and LDS size): a plugin built from other headers is refused (ABI 6) */
+  int32_t reserved_;
   int32_t n, m, n_params, family;
   double default_params[MI_ILQR_MAX_PARAMS];
   int (*launch)(mi_ilqr_t* h, int mode, const void* kernel_args);   /* instantiates and launches the model's kernels */

@@ -261,6 +261,10 @@ def main():
     single_solve("arm27_solve_0", ca, P.arm27_start(), ua)
     single_solve("arm27_solve_1", ca, xa[1], ua)
     mpc("arm27_mpc_0", ca, xa[2], ua, resolves=2, replan=5)
+    # kinova_gen3.py:34-40's derivative interpolation on the same problem (adaptiveJerk with its literal minN = 5, maxN = 40,
+    # jerk threshold 1e-4 - dof = int(27 / 2) = 13 "velocity rows" x[13:26], ilqr.py:444,477-484 - and iterativeError, minN = 5)
+    single_solve("arm27_kp_adaptivejerk", ca, xa[3], ua, keypoint=("adaptiveJerk", 5, 40, 1e-4, 0.0))
+    single_solve("arm27_kp_iterativeerror", ca, xa[3], ua, keypoint=("iterativeError", 5, 0, 0.0, 1e-2))
 
 if __name__ == "__main__":
     main()

@@ -91,7 +91,8 @@ def test_c_oracle_planar_quadruped_vs_reference_golden(name):
 
 
 @pytest.mark.parametrize("name", ["pendulum_kp_setinterval5", "pendulum_kp_adaptivejerk", "pendulum_kp_iterativeerror",
-                                  "acrobot_kp_adaptivejerk", "acrobot_kp_iterativeerror"])
+                                  "acrobot_kp_adaptivejerk", "acrobot_kp_iterativeerror",
+                                  "arm27_kp_adaptivejerk", "arm27_kp_iterativeerror"])
 def test_c_oracle_keypoint_methods_vs_numpy_oracle_and_golden(name):
     """setInterval / adaptiveJerk / iterativeError (ilqr.py:417-593) in the C restatement: against the NumPy oracle with
     the same central differences (per-iteration trials, step sizes and key-point counts exact, the last key-point

@@ -152,6 +152,30 @@ def test_arm27_mpc_vs_reference_golden(device_loop):
     assert ex_ < max(1e-7, 5 * own_x) and eK < max(1e-6, 5 * own_K)
 
 
+@pytest.mark.parametrize("name", ["arm27_kp_adaptivejerk", "arm27_kp_iterativeerror"])
+def test_arm27_keypoint_methods_vs_reference_golden(name):
+    """kinova_gen3.py:34-40's derivative interpolation on the arm + ball problem, recorded from the reference: adaptiveJerk with
+    the script's literal parameters (minN = 5, maxN = 40, jerk threshold 1e-4; for n = 27 the reference's "velocity rows" are
+    x[13:26], dof = int(n / 2): ilqr.py:444,477-484) and iterativeError (minN = 5, threshold 1e-2).  Iterations, step sizes,
+    trial counts, percentage of derivatives per iteration and the last key-point list exact; interpolated fx / fu 1e-8; cost
+    1e-8 (the converged trajectory moves with the problem's own sensitivity: test_arm27_solve_vs_reference_golden)."""
+    from common import golden_keypoint
+    g, prob = load_golden(name)
+    s = make_solver(prob, keypoint=golden_keypoint(g), jac="ad", single=True, hist_cap=32)
+    s.SetInitialState(g["x0"])
+    s.SetInitialGuess(g["u_guess"])
+    x, u, _, L = s.Solve()
+    iters = int(s.iterations[0])
+    assert iters == len(g["hist"])
+    h = s.history[0][:iters]
+    assert np.array_equal(h[:, 1:3], g["hist"][:, 1:3]) and np.allclose(h[:, 3], g["hist"][:, 3], rtol=0, atol=1e-9)
+    nk = int(s.keypoint_count[0])
+    assert np.array_equal(s.keypoint_list[0][:nk], g["kp_last"]) and 5 < nk < 30
+    assert abs(L - g["L"]) <= 1e-8 * abs(g["L"]) and rel_err(h[:, 0], g["hist"][:, 0]) < 1e-8
+    assert rel_err(s.fx, g["fx"]) < 1e-7 and rel_err(s.fu, g["fu"]) < 1e-7
+    assert np.max(np.abs(x - g["x_bar"])) < 1e-6 and rel_err(s.K, g["K"]) < 1e-4
+
+
 @pytest.mark.parametrize("B", [1, 64])
 def test_arm27_batch_fd_vs_c_oracle(B):
     """B = 1 and B = 64 seeded problems (arm and ball moved), central differences on both sides, against the C oracle:

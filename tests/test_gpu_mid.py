@@ -35,7 +35,7 @@ def test_mid_family_registers_the_reviewed_shapes():
     plug.mi_plugin_describe(C.byref(good))
     mid = C.c_int32()
     for n, m, ok in ((12, 17, False), (36, 10, False), (36, 20, False), (41, 4, False)):
-        rec = plugin._Plugin(abi_version=good.abi_version, kernel_args_bytes=good.kernel_args_bytes, n=n, m=m, n_params=0, family=1, launch=1, lds_bytes=1)
+        rec = plugin._Plugin(abi_version=good.abi_version, kernel_args_bytes=good.kernel_args_bytes, handle_bytes=good.handle_bytes, n=n, m=m, n_params=0, family=1, launch=1, lds_bytes=1)
         rc = lib.mi_ilqr_register_model(C.byref(rec), C.byref(mid))
         assert rc in (_capi.E_UNSUPPORTED, _capi.E_BAD_SHAPE), (n, m, rc)
     assert plugin.resolve_family(27, 7, "auto") == "large" and plugin.resolve_family(4, 1, "auto") == "small"

@@ -14,7 +14,8 @@ SINGLE = ["pendulum_c1", "pendulum_kp_setinterval5", "pendulum_kp_adaptivejerk",
           "acrobot_kp_adaptivejerk", "acrobot_kp_iterativeerror",
           "cartpole_wall_literal_n100", "cartpole_wall_c4_0", "cartpole_plain",
           "quad_solve_0", "quad_infeasible_0", "quad_infeasible_1",
-          "quad3d_solve_0", "quad3d_solve_1", "quad3d_infeasible_0", "arm27_solve_0", "arm27_solve_1"]
+          "quad3d_solve_0", "quad3d_solve_1", "quad3d_infeasible_0", "arm27_solve_0", "arm27_solve_1",
+          "arm27_kp_adaptivejerk", "arm27_kp_iterativeerror"]
 
 
 @pytest.mark.parametrize("name", SINGLE)

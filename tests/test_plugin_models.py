@@ -35,10 +35,12 @@ def test_plugin_registers_without_a_gpu():
     plug.mi_plugin_describe(C.byref(good))
     assert good.abi_version == _capi.ABI_VERSION and good.kernel_args_bytes > 500
     mid = C.c_int32()
-    bad = plugin._Plugin(abi_version=good.abi_version, kernel_args_bytes=good.kernel_args_bytes, n=2, m=3, n_params=0, family=0, launch=1, lds_bytes=1)
+    bad = plugin._Plugin(abi_version=good.abi_version, kernel_args_bytes=good.kernel_args_bytes, handle_bytes=good.handle_bytes, n=2, m=3, n_params=0, family=0, launch=1, lds_bytes=1)
     assert lib.mi_ilqr_register_model(C.byref(bad), C.byref(mid)) == _capi.E_UNSUPPORTED     # m > 2 on the wave-per-problem family
-    stale = plugin._Plugin(abi_version=good.abi_version, kernel_args_bytes=good.kernel_args_bytes - 8, n=2, m=1, n_params=0, family=0, launch=1, lds_bytes=1)
+    stale = plugin._Plugin(abi_version=good.abi_version, kernel_args_bytes=good.kernel_args_bytes - 8, handle_bytes=good.handle_bytes, n=2, m=1, n_params=0, family=0, launch=1, lds_bytes=1)
     assert lib.mi_ilqr_register_model(C.byref(stale), C.byref(mid)) == _capi.E_BAD_ARG       # built against other headers
+    stale2 = plugin._Plugin(abi_version=good.abi_version, kernel_args_bytes=good.kernel_args_bytes, handle_bytes=good.handle_bytes + 8, n=2, m=1, n_params=0, family=0, launch=1, lds_bytes=1)
+    assert lib.mi_ilqr_register_model(C.byref(stale2), C.byref(mid)) == _capi.E_BAD_ARG      # ... with another handle layout
     src = plugin.source("vdp", 2, 1, PM.VDP_BODY, PM.VDP_DEFAULTS)
     assert "launch_small.hpp" in src and "mi_plugin_describe" in src and "PluginModel" in src
 
