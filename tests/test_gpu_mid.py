@@ -197,3 +197,46 @@ def test_mid_family_mpc_loop_and_keypoints(shape):
         nk = int(s.keypoint_count[b])
         assert len(hist) == s.iterations[b] and list(s.keypoint_list[b][:nk]) == list(o.keypoints), b
         assert abs(s.cost[b] - Lo) < 1e-9 * abs(Lo)
+
+
+@pytest.mark.gpu
+def test_mid_family_batch_position_and_size_invariance():
+    """Problems of a batch are independent (the sharding argument): a problem solved alone, in a batch of 5 and in a
+    batch of 70 at another position - and with ragged horizons around the F pipeline's start-up branches - gives bitwise the
+    same trajectory, gains and cost on the mid-size kernels (arm + ball, central differences; ragged N on a (12, 4) plugin)."""
+    import models as PM
+    from drake_ddp_amd import workloads as W
+    from drake_ddp_amd.ilqr import BatchedIterativeLQR
+    from drake_ddp_amd.models import ArmAndBall
+    p = W.arm27_problem()
+    x0 = W.arm27_batch_x0(70)
+
+    def solve(xs):
+        s = BatchedIterativeLQR(ArmAndBall(p["dt"]), p["N"], len(xs), delta=p["delta"], beta=p["beta"], gamma=p["gamma"], max_iters=6)
+        s.SetTargetState(p["x_nom"]); s.SetRunningCost(p["Q"], p["R"]); s.SetTerminalCost(p["Qf"])
+        s.SetInitialState(xs); s.SetInitialGuess(W.arm27_u_guess(p["N"]))
+        try:
+            s.Solve()
+        except RuntimeError:
+            pass
+        return s.x_bar.copy(), s.K.copy(), s.cost.copy(), s.iterations.copy()
+    whole = solve(x0)
+    for lo, hi in ((3, 4), (10, 15), (69, 70)):
+        part = solve(x0[lo:hi])
+        for a, b in zip(whole, part):
+            assert np.array_equal(a[lo:hi], b), (lo, hi)
+    assert (whole[3] == 6).all()
+    # ragged horizons on a plugin shape with one x-wave: N = 4 (the shortest the library accepts) .. 9
+    sys_ = PM.build_chainx(6, 4, 0)(0.02)
+    rng = np.random.default_rng(3)
+    xs = 0.3 * rng.standard_normal((4, 12))
+    for N in (4, 5, 6, 7, 8, 9):
+        outs = []
+        for B in (1, 4):
+            s = BatchedIterativeLQR(sys_, N, B, delta=1e-4, beta=0.6)
+            s.SetTargetState(np.zeros(12)); s.SetRunningCost(0.02 * np.eye(12), 0.001 * np.eye(4)); s.SetTerminalCost(3.0 * np.eye(12))
+            s.SetInitialState(xs[:B]); s.SetInitialGuess(np.zeros((4, N - 1)))
+            s.Solve()
+            outs.append((s.x_bar.copy(), s.K.copy(), s.cost.copy()))
+        for a, b in zip(*outs):
+            assert np.array_equal(a[:1], b[:1]), N
