@@ -16,7 +16,11 @@
 // (:300-337), lanes that have accepted / converged are masked while the wave finishes the
 // slowest of its 64 problems.  x_bar/u_bar are double-buffered with a per-lane parity, so
 // accepting a trial is a flip, not a copy.  Linearization (central FD, :233-272 replaced)
-// is fused into the backward sweep.  Key-point method: 'setInterval' with minN = 1.
+// is fused into the backward sweep when every step is a key-point ('setInterval' with minN = 1: KP = false).
+// The other key-point configurations (ilqr.py:417-621) run in the KP = true instantiation: every lane builds ITS OWN
+// key-point list (batch-minor integer scratch in HBM), evaluates the Jacobians at its key-points, interpolates in a
+// lock-step pass over time (coalesced stores; a lane fetches a segment's end matrix when it crosses a key-point) and the
+// backward sweep reads fx / fu back from HBM.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -31,7 +35,7 @@ namespace mi {
 // batch-minor addressing helpers: element (t, r) of an array with `rows` rows per time step
 __device__ __forceinline__ size_t bm(int t, int r, int rows, int B) { return ((size_t)t * rows + r) * B; }
 
-template <class M, int JAC>
+template <class M, int JAC, bool KP = false>
 __global__ void __launch_bounds__(64) ilqr_batch_kernel(const KArgs a) {
   constexpr int n = M::n, m = M::m, nc = n + m;
   const int b = blockIdx.x * 64 + threadIdx.x;
@@ -93,6 +97,7 @@ __global__ void __launch_bounds__(64) ilqr_batch_kernel(const KArgs a) {
   int cur = 0;                                  // which buffer holds x_bar/u_bar for this lane
   double L = __builtin_inf(), improvement = __builtin_inf();
   int iters = 0, ls_total = 0, status = MI_STATUS_CONVERGED;
+  int nk_lane = N - 1;                          // key-points of the lane's last linearization
   bool active = live;
   double* hist = a.hist + (size_t)bb * a.hist_cap * 4;
 
@@ -197,6 +202,205 @@ __global__ void __launch_bounds__(64) ilqr_batch_kernel(const KArgs a) {
         }
       }
       const double h = a.fd_h, inv2h = 1.0 / (2.0 * h);
+      // one column of [fx | fu] after the other at (xv, uv): central differences or forward-mode duals (ilqr.py:233-272)
+      auto jac_columns = [&](const double (&xv)[n], const double (&uv)[m], auto emit) __attribute__((always_inline)) {
+#pragma unroll
+        for (int col = 0; col < nc; ++col) {
+          double d[n];
+          if (JAC == MI_JAC_FD_CENTRAL) {
+            double xp[n], up[m], fp[n], fmv[n];
+#pragma unroll
+            for (int i = 0; i < n; ++i) xp[i] = (col == i) ? xv[i] + h : xv[i];
+#pragma unroll
+            for (int k = 0; k < m; ++k) up[k] = (col == n + k) ? uv[k] + h : uv[k];
+            M::template step<double>(xp, up, fp, a.params, a.dt);
+#pragma unroll
+            for (int i = 0; i < n; ++i) xp[i] = (col == i) ? xv[i] - h : xv[i];
+#pragma unroll
+            for (int k = 0; k < m; ++k) up[k] = (col == n + k) ? uv[k] - h : uv[k];
+            M::template step<double>(xp, up, fmv, a.params, a.dt);
+#pragma unroll
+            for (int i = 0; i < n; ++i) d[i] = (fp[i] - fmv[i]) * inv2h;
+          } else {
+            Dual1 xd[n], ud[m], fd[n];
+#pragma unroll
+            for (int i = 0; i < n; ++i) xd[i] = Dual1(xv[i], (col == i) ? 1.0 : 0.0);
+#pragma unroll
+            for (int k = 0; k < m; ++k) ud[k] = Dual1(uv[k], (col == n + k) ? 1.0 : 0.0);
+            M::template step<Dual1>(xd, ud, fd, a.params, a.dt);
+#pragma unroll
+            for (int i = 0; i < n; ++i) d[i] = fd[i].d;
+          }
+          emit(col, d);
+        }
+      };
+      if constexpr (KP) {
+        // ---- _get_derivatives (ilqr.py:380-415) per LANE: key-point list -> kpl[i] (batch-minor ints), Jacobians at the
+        //      key-points -> fx / fu, then interpolation.  Lanes walk in lock step and mask what is not theirs.
+        int* const kpl = a.bm_scratch + bb;                          // [i][b], i < N-1: the lane's key-points, ascending
+        int* const done = a.bm_scratch + (size_t)(N - 1) * B + bb;     // [t][b]: derivative evaluated at t (iterativeError)
+        int* binA = a.bm_scratch + (size_t)2 * (N - 1) * B + bb;       // [2 i + {0,1}][b]: the level's bins (s, e)
+        int* binB = a.bm_scratch + (size_t)4 * (N - 1) * B + bb;
+        const size_t Bz = (size_t)B;
+        // Jacobians at the lane's own time step tt (act: this lane takes part) -> fx / fu
+        auto eval_store = [&](int tt, bool act) __attribute__((always_inline)) {
+          if (!__any(act)) return;
+          const int tq = act ? tt : 0;
+          double xv[n], uv[m];
+#pragma unroll
+          for (int i = 0; i < n; ++i) xv[i] = xb[bm(tq, i, n, B)];
+#pragma unroll
+          for (int k = 0; k < m; ++k) uv[k] = ub[bm(tq, k, m, B)];
+          double* fo = act ? Fxp : sink;
+          double* go = act ? Fup : sink;
+          const size_t wz = act ? Bz : 0;
+          jac_columns(xv, uv, [&](int col, const double (&d)[n]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < n; ++i) {
+              if (col < n) fo[((size_t)tq * n * n + i * n + col) * wz] = d[i];
+              else go[((size_t)tq * n * m + i * m + (col - n)) * wz] = d[i];
+            }
+          });
+        };
+        int nk = 0;
+        if (a.kp_method == MI_KP_SET_INTERVAL) {
+          // ilqr.py:417-432: arange(0, N-1, minN), the LAST entry overwritten with N-2 - the same list in every lane
+          const int count = (N - 2) / a.minN + 1;
+          for (int i = 0; i < count; ++i) {
+            int tv = i * a.minN;
+            if (i == count - 1 && tv != N - 2) tv = N - 2;
+            if (ok) kpl[(size_t)i * Bz] = tv;
+            eval_store(tv, ok);
+          }
+          nk = count;
+        } else if (a.kp_method == MI_KP_ADAPTIVE_JERK) {
+          // ilqr.py:434-486: signed second difference of the "velocity rows" x[dof + i], dof = int(n / 2); a key-point when the
+          // counter has reached minN and a jerk exceeds the threshold, or when it reaches maxN; the last one overwritten with N-2
+          constexpr int dof = n / 2;
+          int since = 0, last = 0;
+          if (ok) kpl[0] = 0;
+          nk = 1;
+          double v0[dof > 0 ? dof : 1], v1[dof > 0 ? dof : 1];
+#pragma unroll
+          for (int i = 0; i < dof; ++i) { v0[i] = xb[bm(0, i + dof, n, B)]; v1[i] = xb[bm(N > 1 ? 1 : 0, i + dof, n, B)]; }
+          for (int t = 0; t < N - 3; ++t) {
+            bool trig = false;
+#pragma unroll
+            for (int i = 0; i < dof; ++i) {
+              const double v2 = xb[bm(t + 2, i + dof, n, B)];
+              const double jerk = (v2 - v1[i]) - (v1[i] - v0[i]);
+              trig = trig || (jerk > a.jerk_thr);
+              v0[i] = v1[i]; v1[i] = v2;
+            }
+            since += 1;
+            if (since >= a.minN && trig) { if (ok) kpl[(size_t)nk * Bz] = t; last = t; nk += 1; since = 0; }
+            if (since >= a.maxN) { if (ok) kpl[(size_t)nk * Bz] = t; last = t; nk += 1; since = 0; }
+          }
+          if (last != N - 2 && ok) kpl[(size_t)(nk - 1) * Bz] = N - 2;                       // :465-466
+          int nk_max = nk;                                                                   // (lanes differ: the wave runs the longest list)
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) { const int w_ = __shfl_xor(nk_max, o); nk_max = w_ > nk_max ? w_ : nk_max; }
+          for (int i = 0; i < nk_max; ++i) {
+            const bool act = ok && i < nk;
+            const int tv = act ? kpl[(size_t)i * Bz] : 0;
+            eval_store(tv, act);
+          }
+        } else {
+          // ilqr.py:488-593: level-synchronous bisection of [0, N-2]; a bin wider than minN is tested at its midpoint against the
+          // mean of its end matrices (fx only, divisor 2n) and split when the error exceeds the threshold; every index the test
+          // touches gets its exact Jacobians (memoized); the key-points are the indices that have them
+          for (int t = 0; t < N - 1; ++t) { if (ok) done[(size_t)t * Bz] = 0; }
+          int nb = 1;
+          if (ok) { binA[0] = 0; binA[Bz] = N - 2; }
+          bool level_active = ok;
+          while (__any(level_active)) {
+            int nb_max = level_active ? nb : 0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { const int w_ = __shfl_xor(nb_max, o); nb_max = w_ > nb_max ? w_ : nb_max; }
+            int nn = 0;
+            for (int i = 0; i < nb_max; ++i) {
+              const bool have = level_active && i < nb;
+              const int s_ = have ? binA[(size_t)(2 * i) * Bz] : 0, e_ = have ? binA[(size_t)(2 * i + 1) * Bz] : 0;
+              const bool big = have && (e_ - s_ > a.minN);
+              const int mid = (s_ + e_) / 2;
+              for (int q = 0; q < 3; ++q) {
+                const int idx = q == 0 ? s_ : (q == 1 ? mid : e_);
+                const bool need = big && done[(size_t)idx * Bz] == 0;
+                eval_store(idx, need);
+                if (need) done[(size_t)idx * Bz] = 1;
+              }
+              bool bad = false;
+              if (__any(big)) {
+                double sum = 0.0;
+#pragma unroll
+                for (int r = 0; r < n * n; ++r) {
+                  const double fe = Fxp[bm(e_, r, n * n, B)], fs = Fxp[bm(s_, r, n * n, B)], fmid = Fxp[bm(mid, r, n * n, B)];
+                  const double lin = (fe + fs) / 2.0;
+                  const double df = lin - fmid;
+                  sum += df * df;
+                }
+                bad = big && (sum / (2.0 * n)) > a.err_thr;
+              }
+              if (bad) {
+                binB[(size_t)(4 * nn) * Bz] = s_; binB[(size_t)(4 * nn + 1) * Bz] = mid;
+                binB[(size_t)(4 * nn + 2) * Bz] = mid; binB[(size_t)(4 * nn + 3) * Bz] = e_;
+                nn += 1;
+              }
+            }
+            if (level_active) {
+              if (nn == 0) level_active = false;
+              else { nb = 2 * nn; int* tmp = binA; binA = binB; binB = tmp; }
+            }
+          }
+          for (int t = 0; t < N - 1; ++t) {
+            if (ok && done[(size_t)t * Bz] != 0) { kpl[(size_t)nk * Bz] = t; nk += 1; }
+          }
+        }
+        // ---- interpolate_derivatives (ilqr.py:596-621): lock step over time, interior points only; a lane fetches its segment's
+        //      end matrices when it crosses a key-point
+        if (!(a.kp_method == MI_KP_SET_INTERVAL && a.minN == 1)) {
+          constexpr int cnt = n * n + n * m;
+          double fS[cnt], fE[cnt];
+          int seg = 0, s_ = 0, e_ = 0;
+          auto fetch = [&](double (&f)[cnt], int tt, bool act) __attribute__((always_inline)) {
+            const int tq = act ? tt : 0;
+#pragma unroll
+            for (int r = 0; r < n * n; ++r) f[r] = Fxp[bm(tq, r, n * n, B)];
+#pragma unroll
+            for (int r = 0; r < n * m; ++r) f[n * n + r] = Fup[bm(tq, r, n * m, B)];
+          };
+          const bool have_seg = ok && nk >= 2;
+          s_ = have_seg ? kpl[0] : 0;
+          e_ = have_seg ? kpl[Bz] : 0;
+          fetch(fS, s_, have_seg);
+          fetch(fE, e_, have_seg);
+          for (int t = 0; t < N - 1; ++t) {
+            bool adv = have_seg && t == e_ && seg + 2 < nk;                  // crossing into the next segment
+            if (__any(adv)) {
+              const int e2 = adv ? kpl[(size_t)(seg + 2) * Bz] : 0;
+              double fN[cnt];
+              fetch(fN, e2, adv);
+              if (adv) {
+#pragma unroll
+                for (int r = 0; r < cnt; ++r) { fS[r] = fE[r]; fE[r] = fN[r]; }
+                s_ = e_; e_ = e2; seg += 1;
+              }
+            }
+            const bool inner = have_seg && t > s_ && t < e_;
+            if (__any(inner)) {
+              const double len = (double)(e_ - s_), w_ = (double)(t - s_);
+              double* fo = inner ? Fxp : sink;
+              double* go = inner ? Fup : sink;
+              const size_t wz = inner ? Bz : 0;
+#pragma unroll
+              for (int r = 0; r < n * n; ++r) fo[((size_t)t * n * n + r) * wz] = fS[r] + (fE[r] - fS[r]) * w_ / len;
+#pragma unroll
+              for (int r = 0; r < n * m; ++r) go[((size_t)t * n * m + r) * wz] = fS[n * n + r] + (fE[n * n + r] - fS[n * n + r]) * w_ / len;
+            }
+          }
+        }
+        if (ok) { nk_lane = nk; }
+      }
       struct XU { double x[n], u[m]; };
       auto loadxu = [&](XU& r, int t) __attribute__((always_inline)) {
 #pragma unroll
@@ -208,40 +412,24 @@ __global__ void __launch_bounds__(64) ilqr_batch_kernel(const KArgs a) {
       loadxu(cu, N - 2);
       for (int t = N - 2; t >= 0; --t) {
         loadxu(nx, t > 0 ? t - 1 : 0);
-        // dynamics partials at (x_bar_t, u_bar_t)
+        // dynamics partials at (x_bar_t, u_bar_t): evaluated here (every step a key-point), or read back (key-point variant)
         double fx[n][n], fu[n][m];
-#pragma unroll
-        for (int col = 0; col < nc; ++col) {
-          double d[n];
-          if (JAC == MI_JAC_FD_CENTRAL) {
-            double xp[n], up[m], fp[n], fmv[n];
-#pragma unroll
-            for (int i = 0; i < n; ++i) xp[i] = (col == i) ? cu.x[i] + h : cu.x[i];
-#pragma unroll
-            for (int k = 0; k < m; ++k) up[k] = (col == n + k) ? cu.u[k] + h : cu.u[k];
-            M::template step<double>(xp, up, fp, a.params, a.dt);
-#pragma unroll
-            for (int i = 0; i < n; ++i) xp[i] = (col == i) ? cu.x[i] - h : cu.x[i];
-#pragma unroll
-            for (int k = 0; k < m; ++k) up[k] = (col == n + k) ? cu.u[k] - h : cu.u[k];
-            M::template step<double>(xp, up, fmv, a.params, a.dt);
-#pragma unroll
-            for (int i = 0; i < n; ++i) d[i] = (fp[i] - fmv[i]) * inv2h;
-          } else {
-            Dual1 xd[n], ud[m], fd[n];
-#pragma unroll
-            for (int i = 0; i < n; ++i) xd[i] = Dual1(cu.x[i], (col == i) ? 1.0 : 0.0);
-#pragma unroll
-            for (int k = 0; k < m; ++k) ud[k] = Dual1(cu.u[k], (col == n + k) ? 1.0 : 0.0);
-            M::template step<Dual1>(xd, ud, fd, a.params, a.dt);
-#pragma unroll
-            for (int i = 0; i < n; ++i) d[i] = fd[i].d;
-          }
+        if constexpr (KP) {
 #pragma unroll
           for (int i = 0; i < n; ++i) {
-            if (col < n) { fx[i][col] = d[i]; fxw[((size_t)t * n * n + i * n + col) * ws] = d[i]; }
-            else { fu[i][col - n] = d[i]; fuw[((size_t)t * n * m + i * m + (col - n)) * ws] = d[i]; }
+#pragma unroll
+            for (int j = 0; j < n; ++j) fx[i][j] = Fxp[bm(t, i * n + j, n * n, B)];
+#pragma unroll
+            for (int k = 0; k < m; ++k) fu[i][k] = Fup[bm(t, i * m + k, n * m, B)];
           }
+        } else {
+          jac_columns(cu.x, cu.u, [&](int col, const double (&d)[n]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < n; ++i) {
+              if (col < n) { fx[i][col] = d[i]; fxw[((size_t)t * n * n + i * n + col) * ws] = d[i]; }
+              else { fu[i][col - n] = d[i]; fuw[((size_t)t * n * m + i * m + (col - n)) * ws] = d[i]; }
+            }
+          });
         }
         // cost expansion + Riccati step (same arithmetic as backward_scalar)
         double Qx[n], Qu[m], Qxx[n][n], Quu[m][m], Qux[m][n], Am[n][n], Bm[m][n];
@@ -366,7 +554,7 @@ __global__ void __launch_bounds__(64) ilqr_batch_kernel(const KArgs a) {
     if (ok) {
       if (iters < a.hist_cap) {
         hist[4 * iters + 0] = L_new; hist[4 * iters + 1] = eps_acc;
-        hist[4 * iters + 2] = (double)trials; hist[4 * iters + 3] = 100.0;
+        hist[4 * iters + 2] = (double)trials; hist[4 * iters + 3] = KP ? (double)nk_lane / (double)(N - 1) * 100.0 : 100.0;
       }
       improvement = L - L_new;                                          // :706
       L = L_new;
@@ -385,7 +573,10 @@ __global__ void __launch_bounds__(64) ilqr_batch_kernel(const KArgs a) {
     }
   }
   if (live) {
-    a.cost[b] = L; a.iters[b] = iters; a.status[b] = status; a.ls_trials[b] = ls_total; a.kp_count[b] = N - 1;
+    a.cost[b] = L; a.iters[b] = iters; a.status[b] = status; a.ls_trials[b] = ls_total; a.kp_count[b] = KP ? nk_lane : N - 1;
+    if constexpr (KP) {
+      if (iters > 0) { for (int i = 0; i < nk_lane; ++i) a.kp_list[(size_t)b * (N - 1) + i] = a.bm_scratch[(size_t)i * B + b]; }
+    }
   }
 }
 

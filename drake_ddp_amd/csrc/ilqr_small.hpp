@@ -88,6 +88,9 @@ struct KArgs {
   // that receive x_bar (B,n,N), u_bar (B,m,N-1) and the costs (B,) straight from the kernel's write-back, problem by
   // problem as each one finishes: the copy-out of a batch overlaps the launch's stragglers instead of following it.
   double *sink_x, *sink_u, *sink_cost;
+  // lane-per-problem kernels with key-points (ilqr_batch.hpp, KP = true): 6 (N-1) x B ints, batch-minor - the lanes' key-point
+  // lists, "derivative evaluated" flags and the two bin buffers of the iterative-error bisection
+  int32_t* bm_scratch;
 };
 
 __device__ __forceinline__ double bcast_lane0(double v) {

@@ -5,7 +5,11 @@
 namespace mi_host {
 template <class M, int JAC>
 int launch_batch_one(mi_ilqr* h, const KArgs& a) {
-  auto kern = ilqr_batch_kernel<M, JAC>;
+  if (a.bm_scratch != nullptr) {                          // key-point configurations other than setInterval / 1
+    auto kern = ilqr_batch_kernel<M, JAC, true>;
+    return launch_timed(h, kern, dim3((h->B + 63) / 64), dim3(64), 0, a);
+  }
+  auto kern = ilqr_batch_kernel<M, JAC, false>;
   return launch_timed(h, kern, dim3((h->B + 63) / 64), dim3(64), 0, a);
 }
 

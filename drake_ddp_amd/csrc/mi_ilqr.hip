@@ -128,6 +128,7 @@ KArgs make_args(const mi_ilqr* h) {
   // linearization (ilqr_large.hpp: cluster handshake), as many as keep every workgroup of the launch on its own CU.
   // MI_ILQR_CLUSTER=k forces k (1 = off) for A/B runs.
   a.sink_x = h->sink_x; a.sink_u = h->sink_u; a.sink_cost = h->sink_cost;
+  a.bm_scratch = h->bm_scratch;
   a.cluster = 1;
   a.cluster_sync = h->cluster_sync;
   if (h->large && h->cluster_sync && h->d.keypoint_method == MI_KP_SET_INTERVAL && h->d.minN == 1) {
@@ -548,7 +549,8 @@ int mi_ilqr_create(const mi_ilqr_desc* desc, mi_ilqr_t** out) {
   bool batch_minor = false;
   if (desc->kernel_mode < MI_KERNEL_AUTO || desc->kernel_mode > MI_KERNEL_THROUGHPUT) return MI_ILQR_E_BAD_ARG;
   {
-    const bool can = !large && desc->keypoint_method == MI_KP_SET_INTERVAL && desc->minN == 1 && !plugin_of(desc->model_id);
+    // (every key-point configuration since round 4: the KP instantiation of the lane-per-problem kernels)
+    const bool can = !large && !plugin_of(desc->model_id);
     if (desc->kernel_mode == MI_KERNEL_THROUGHPUT && !can) return MI_ILQR_E_UNSUPPORTED;
     // n = 2 within the time-parallel passes' horizon: the wave-per-problem kernel is the faster one at
     // every batch size (B = 65536: 68 M vs 42 M it/s, profiles/r01n_c2_modes_batch_sweep.txt)
@@ -614,6 +616,7 @@ int mi_ilqr_create(const mi_ilqr_desc* desc, mi_ilqr_t** out) {
   ALLOC(h->prof, B * 4, long long);
   ALLOC(h->done_counter, 1, int32_t);
   if (large) ALLOC(h->cluster_sync, B * 4, unsigned long long);
+  if (batch_minor && !(desc->keypoint_method == MI_KP_SET_INTERVAL && desc->minN == 1)) ALLOC(h->bm_scratch, B * 6 * (N - 1), int32_t);
 #undef ALLOC
   {
     int cus = 0;
@@ -657,7 +660,7 @@ void mi_ilqr_destroy(mi_ilqr_t* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   void* ptrs[] = {h->x_bar, h->u_bar, h->K, h->kappa, h->dV, h->fx, h->fu, h->x0, h->u_guess, h->cost_ring, h->hist, h->iter_cyc,
                   h->x_trial, h->u_trial, h->trial_cost, h->stage_in, h->costmat, h->iters_ring, h->status_ring, h->ls_ring,
-                  h->kp_count, h->kp_list, h->prof, h->done_counter, h->cluster_sync};
+                  h->kp_count, h->kp_list, h->prof, h->done_counter, h->cluster_sync, h->bm_scratch};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->h_ring) (void)hipHostFree(h->h_ring);
   if (h->mpc_log) (void)hipFree(h->mpc_log);

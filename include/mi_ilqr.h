@@ -79,7 +79,8 @@ enum { MI_JAC_FD_CENTRAL = 0, MI_JAC_AUTODIFF = 1 };
 /* Which kernel family serves a small-state model (mi_ilqr_desc.kernel_mode):
  *   LATENCY    wave-per-problem, state in LDS: minimal time-to-solution, up to ~2k problems/GPU in flight;
  *   THROUGHPUT lane-per-problem, batch-minor state streamed through HBM: for tens of thousands of
- *              problems (setInterval/1 key-points; stage-level entries are not available);
+ *              problems (every key-point method - a key-point list per lane; stage-level entries are not
+ *              available; built-in models only);
  *   AUTO       THROUGHPUT when B >= 8192 and the configuration allows it - except n = 2 models with
  *              N <= 257, whose LATENCY kernel (rollout and Riccati sweep parallel in time) is the faster one
  *              at every batch size - else LATENCY. */

@@ -60,7 +60,8 @@ KP_CASES = {"setInterval": ("pendulum_kp_setinterval5", 0), "adaptiveJerk": ("pe
 
 
 @pytest.mark.parametrize("case", list(KP_CASES))
-def test_keypoint_methods_at_batch_scale_vs_c_oracle(case):
+@pytest.mark.parametrize("kernel_mode", ["auto", "throughput"])
+def test_keypoint_methods_at_batch_scale_vs_c_oracle(case, kernel_mode):
     """setInterval(5) / adaptiveJerk / iterativeError (ilqr.py:417-593) on 256 problems with the golden's own
     key-point configuration: per problem the iteration and trial counts, the key-point count of EVERY iteration
     (derivs '%' column, ilqr.py:406) and the integer key-point list of the last linearization are exactly the C
@@ -73,7 +74,7 @@ def test_keypoint_methods_at_batch_scale_vs_c_oracle(case):
     B = 256
     x0 = W.pendulum_batch_x0(1024)[:B] if model_id == 0 else W.acrobot_batch_x0(512)[:B]
     ug = np.zeros((1, prob["N"] - 1))
-    s = make_solver(prob, B=B, keypoint=kp, jac="fd", hist_cap=64)
+    s = make_solver(prob, B=B, keypoint=kp, jac="fd", hist_cap=64, kernel_mode=kernel_mode)
     s.SetInitialState(x0)
     s.SetInitialGuess(ug)
     x, u, _, L = s.Solve()
@@ -367,17 +368,20 @@ def test_sensitive_goldens_deviate_no_more_than_their_own_sensitivity(name):
     assert 0.98 * min(Ls) <= L <= 1.02 * max(Ls), (L, Ls)
 
 
-def test_lane_per_problem_kernels_refuse_other_keypoint_methods():
-    """ilqr_batch.hpp serves setInterval / minN = 1 only: adaptiveJerk / iterativeError (ilqr.py:434-593) with
-    kernel_mode = throughput are refused at create (MI_ILQR_E_UNSUPPORTED), and AUTO serves them on the wave-per-problem
-    kernels at any batch size."""
+def test_lane_per_problem_kernels_serve_every_keypoint_method():
+    """Until round 3 ilqr_batch.hpp served setInterval / minN = 1 only and refused the rest at create; since round 4 its
+    KP instantiation builds a key-point list per lane (ilqr.py:417-593), so kernel_mode = throughput takes every key-point
+    configuration of the built-in small models (the exact lists against the C oracle:
+    test_keypoint_methods_at_batch_scale_vs_c_oracle[*-throughput]).  Plugin models stay on the wave-per-problem kernels.
+    AUTO still serves the methods at any batch size."""
     from drake_ddp_amd import workloads as W, _capi
-    from drake_ddp_amd._capi import MiIlqrError
     a = W.acrobot_problem()
     for kp in (("adaptiveJerk", 2, 10, 1e-5, 0.0), ("iterativeError", 2, 0, 0.0, 1e-9), ("setInterval", 3, 0, 0.0, 0.0)):
-        with pytest.raises(MiIlqrError) as e:
-            make_solver(a, B=16, keypoint=kp, jac="fd", kernel_mode="throughput")
-        assert e.value.code == _capi.E_UNSUPPORTED
+        t = make_solver(a, B=16, keypoint=kp, jac="fd", kernel_mode="throughput")
+        t.SetInitialState(W.acrobot_batch_x0(512)[:16])
+        t.SetInitialGuess(np.zeros((1, a["N"] - 1)))
+        t.Solve()
+        assert (t.status == 0).all() and (t.keypoint_count < a["N"] - 1).all() and (t.keypoint_count >= 2).all(), kp
     s = make_solver(a, B=9000, keypoint=("adaptiveJerk", 2, 10, 1e-5, 0.0), jac="fd")        # AUTO at a large batch
     s.SetInitialState(np.tile(W.acrobot_batch_x0(512), (18, 1))[:9000])
     s.SetInitialGuess(np.zeros((1, a["N"] - 1)))
