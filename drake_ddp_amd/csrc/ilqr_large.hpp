@@ -242,7 +242,17 @@ __device__ inline double large_rollout(const LView<M::n, M::m>& v, double* lds, 
   const ModelScalars<M> ms(a);
   const double* prm = ms.p;
   const double dt_ = ms.dt;
-  if (tid < n) { xs[tid] = x0g[tid]; v.Xn[tid] = x0g[tid]; }
+  // Models whose whole state is advanced by ONE lane (whole-step plugins) or redundantly by every lane of a row (trig models):
+  // that lane carries x_t in registers from step to step (it does not read back what it has just published), and the
+  // trajectory goes to HBM from the lanes that form x_t - x_nom - one coalesced store instead of n scalar ones on the
+  // lane every other thread is waiting for.
+  constexpr bool kCarry = IsTrigModel<M>::value || IsWholeStepModel<M>::value;
+  if (tid < n) { xs[tid] = x0g[tid]; if constexpr (!kCarry) v.Xn[tid] = x0g[tid]; }
+  double xr[kCarry ? n : 1];
+  if constexpr (kCarry) {
+#pragma unroll
+    for (int i = 0; i < n; ++i) xr[i] = x0g[i];
+  }
   double acc = 0.0;                    // per-thread cost partial over all time steps
   bool bad = false;                    // this thread saw an infeasible step (models that can fail)
   // Operands of the control law (K_t row slice, x_bar_t slice, u_bar_t, kappa_t) come from
@@ -278,7 +288,11 @@ __device__ inline double large_rollout(const LView<M::n, M::m>& v, double* lds, 
       p = row16_sum(p);
       if (ul == 0) us[uk] = (f.ubk - eps * f.kpk) - p;
     }
-    if (drole) dxc[tid - 192] = xc[tid - 192] - xnr;
+    if (drole) {
+      const double xv_ = xc[tid - 192];
+      dxc[tid - 192] = xv_ - xnr;
+      if constexpr (kCarry) v.Xn[(size_t)t * n + (tid - 192)] = xv_;
+    }
     if (t + 2 < N - 1) prefetch(f, t + 2);       // this set is free again
     lds_barrier();
     // dynamics (ilqr.py:316); cost rows on the other waves (:325)
@@ -367,23 +381,28 @@ __device__ inline double large_rollout(const LView<M::n, M::m>& v, double* lds, 
       if (tid < 16) {
         static_assert(M::kJoints <= 8, "sines on lanes 0.., cosines on lanes 8.. of a 16-lane row");
         const int j = (tid & 7) < M::kJoints ? (tid & 7) : M::kJoints - 1;
-        const double sc_ = fast_sin_or_cos(xc[j], tid >= 8);
+        double xj_ = xr[0];                                // (joint angle j of the carried state: a select chain, no LDS round trip)
+#pragma unroll
+        for (int q_ = 1; q_ < M::kJoints; ++q_) xj_ = (j == q_) ? xr[q_] : xj_;
+        const double sc_ = fast_sin_or_cos(xj_, tid >= 8);
         double S_[M::kJoints], C_[M::kJoints];
         trig_gather<M::kJoints, 0>(sc_, S_, C_);
         double xt[n];
-        M::template core<double>(S_, C_, xc, us, xt, prm, dt_);
+        M::template core<double>(S_, C_, xr, us, xt, prm, dt_);
+#pragma unroll
+        for (int i = 0; i < n; ++i) xr[i] = xt[i];
         if (tid == 0) {
 #pragma unroll
-          for (int i = 0; i < n; ++i) { xn_[i] = xt[i]; v.Xn[(size_t)(t + 1) * n + i] = xt[i]; }
+          for (int i = 0; i < n; ++i) xn_[i] = xt[i];
         }
         dyn_done = true;
       }
     } else if constexpr (IsWholeStepModel<M>::value) {
       if (tid == 0) {                                      // (plugin models without cooperative hooks)
         double xt[n];
-        M::template step<double>(xc, us, xt, prm, dt_);
+        M::template step<double>(xr, us, xt, prm, dt_);
 #pragma unroll
-        for (int i = 0; i < n; ++i) { xn_[i] = xt[i]; v.Xn[(size_t)(t + 1) * n + i] = xt[i]; }
+        for (int i = 0; i < n; ++i) { xn_[i] = xt[i]; xr[i] = xt[i]; }
         dyn_done = true;
       }
     } else {
@@ -434,6 +453,7 @@ __device__ inline double large_rollout(const LView<M::n, M::m>& v, double* lds, 
     if (t + 1 < N - 1) one_step(pfB, t + 1);
   }
   xs = xc;                             // final state x_{N-1}
+  if constexpr (kCarry) { if (tid < n) v.Xn[(size_t)(N - 1) * n + tid] = xs[tid]; }
   if constexpr (kLx) {
     if (qrole && N >= 2) Lxu[(N - 2) * (n + m) + (tid - 64)] = 2.0 * (r1_prev + r2buf[((N - 2) & 1) * 64 + (tid - 64)]);
   }
@@ -473,6 +493,231 @@ __device__ inline bool large_linesearch(const LView<M::n, M::m>& v, double* lds,
     const double L = large_rollout<M>(v, lds, a, x0g, eps, ex);
     if ((L_last - L) > a.gamma * ex) { L_out = L; eps_out = eps; return true; }
     eps *= a.beta;
+    __syncthreads();
+  }
+  return false;
+}
+
+// ---- mid-size kernels: FOUR line-search candidates per pass ------------------------------------------------------
+// A rollout is a chain of N-1 dependent steps on a handful of lanes - the other lanes of the workgroup wait with it.
+// A problem that backtracks (the arm + ball: 2.4 trials per iteration) pays that chain once per trial.  mid_rollout4
+// walks the candidates eps, eps beta, eps beta^2, eps beta^3 through the SAME step loop: the control-law lanes form
+// four dot products instead of one (independent DPP reductions), the dynamics run on four lanes (whole-step models)
+// or four 16-lane rows (trig models) of wave 0 in one instruction stream, the cost rows accumulate four sums.  Per
+// candidate the arithmetic is large_rollout's, operation for operation - the same bits - and the search takes the
+// FIRST candidate in order that passes the test of ilqr.py:330, which is what the sequential search returns.
+constexpr int kSpec = 4;
+template <class M>
+constexpr bool kSpecRollout = LLay<M::n, M::m>::kMid && (IsTrigModel<M>::value || IsWholeStepModel<M>::value) && !CanFail<M>::value;
+// KArgs::spec_policy - 0: never; 1 (default): once the problem has backtracked in this launch (a problem that never
+// backtracks never pays for candidates it does not need; a rule on the problem's own history, so results do not depend
+// on the batch); 2: whenever there is a cost to beat.  MI_ILQR_SPEC=0|1|2 overrides (A/B runs, tests).
+
+template <class M>
+__device__ inline void mid_rollout4(const LView<M::n, M::m>& v, double* xsp, double* usp, size_t sx, size_t su, double* lds,
+                                    const KArgs& a, const double* x0g, const double (&eps4)[kSpec], double (&L4)[kSpec],
+                                    double& dvs_out) {
+  constexpr int n = M::n, m = M::m;
+  using Ly = LLay<n, m>;
+  constexpr int JR = (n + 15) / 16;
+  constexpr int XS = 34;               // candidate stride of the state buffers: the candidates' copies of an entry on different banks
+  const int tid = threadIdx.x, N = v.N;
+  // state (two buffers), controls and x - x_nom of the four candidates: the backward pass's H area is idle
+  double* xc = lds + Ly::oH;           // [4][XS] current
+  double* xn_ = xc + kSpec * XS;       // [4][XS] next
+  double* us4 = xn_ + kSpec * XS;      // [4][16]
+  double* dx4 = us4 + kSpec * 16;      // [4][32]
+  static_assert(n <= 32 && m <= 16 && 2 * kSpec * XS + kSpec * 48 <= Ly::NMP * Ly::TS, "candidate buffers inside H");
+  const double* xnom = lds + Ly::oXnom;
+  const bool urole = tid < m * 16;
+  const int uk = tid >> 4, ul = tid & 15;
+  const bool qrole = tid >= 64 && tid < 64 + n;
+  const bool q2role = tid >= 192 && tid < 192 + n;
+  constexpr int nh = n / 2;
+  const bool rrole = tid >= 128 && tid < 128 + m;
+  double qrow[n], rrow[m];
+  if (qrole || q2role) {
+    const int i = qrole ? tid - 64 : tid - 192;
+#pragma unroll
+    for (int j = 0; j < n; ++j) qrow[j] = lds[Ly::oQ + i * n + j];
+  }
+  if (rrole) {
+#pragma unroll
+    for (int j = 0; j < m; ++j) rrow[j] = lds[Ly::oR + (tid - 128) * m + j];
+  }
+  const bool drole = tid >= 192 && tid < 192 + n;
+  const double xnr = drole ? xnom[tid - 192] : 0.0;
+  const ModelScalars<M> ms(a);
+  const double* prm = ms.p;
+  const double dt_ = ms.dt;
+  auto Xo = [&](int c) __attribute__((always_inline)) { return c == 0 ? v.Xn : xsp + (size_t)(c - 1) * sx; };
+  auto Uo = [&](int c) __attribute__((always_inline)) { return c == 0 ? v.Un : usp + (size_t)(c - 1) * su; };
+  if (tid < n) {
+    const double x0v = x0g[tid];
+#pragma unroll
+    for (int c = 0; c < kSpec; ++c) xc[c * XS + tid] = x0v;
+  }
+  double xr[n];                                            // the dynamics lanes carry their candidate's state (large_rollout: kCarry)
+#pragma unroll
+  for (int i = 0; i < n; ++i) xr[i] = x0g[i];
+  double acc[kSpec] = {0.0, 0.0, 0.0, 0.0};
+  struct Pf { double kr[JR], xbr[JR], ubk, kpk; };
+  Pf pfA, pfB;
+  auto prefetch = [&](Pf& f, int t) __attribute__((always_inline)) {
+    if (urole) {
+      const double* Kr = v.K + ((size_t)t * m + uk) * n;
+      const double* xbt = v.X + (size_t)t * n;
+#pragma unroll
+      for (int q = 0; q < JR; ++q) {
+        const int j = ul + 16 * q;
+        f.kr[q] = (j < n) ? Kr[j] : 0.0;
+        f.xbr[q] = (j < n) ? xbt[j] : 0.0;
+      }
+      f.ubk = 0.0; f.kpk = 0.0;
+      if (ul == 0) { f.ubk = v.U[(size_t)t * m + uk]; f.kpk = v.kap[(size_t)t * m + uk]; }
+    }
+  };
+  auto one_step = [&](Pf& f, int t) __attribute__((always_inline)) {
+    if (urole) {                                           // u_t = u_bar_t - eps kappa_t - K_t (x_t - x_bar_t)   (ilqr.py:313)
+      double p[kSpec];
+#pragma unroll
+      for (int c = 0; c < kSpec; ++c) {
+        p[c] = 0.0;
+#pragma unroll
+        for (int q = 0; q < JR; ++q) {
+          const int j = ul + 16 * q;
+          if (j < n) p[c] += f.kr[q] * (xc[c * XS + j] - f.xbr[q]);
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < kSpec; ++c) p[c] = row16_sum(p[c]);
+      if (ul == 0) {
+#pragma unroll
+        for (int c = 0; c < kSpec; ++c) us4[c * 16 + uk] = (f.ubk - eps4[c] * f.kpk) - p[c];
+      }
+    }
+    if (drole) {
+#pragma unroll
+      for (int c = 0; c < kSpec; ++c) {
+        const double xv_ = xc[c * XS + tid - 192];
+        dx4[c * 32 + tid - 192] = xv_ - xnr;
+        Xo(c)[(size_t)t * n + (tid - 192)] = xv_;
+      }
+    }
+    if (t + 2 < N - 1) prefetch(f, t + 2);
+    lds_barrier();
+    if constexpr (IsTrigModel<M>::value) {
+      if (tid < 16 * kSpec) {                              // candidate c on the c-th 16-lane row of wave 0
+        const int c = tid >> 4, l = tid & 15;
+        const double* usc = us4 + c * 16;
+        const int j = (l & 7) < M::kJoints ? (l & 7) : M::kJoints - 1;
+        double xj_ = xr[0];
+#pragma unroll
+        for (int q_ = 1; q_ < M::kJoints; ++q_) xj_ = (j == q_) ? xr[q_] : xj_;
+        const double sc_ = fast_sin_or_cos(xj_, l >= 8);
+        double S_[M::kJoints], C_[M::kJoints];
+        trig_gather<M::kJoints, 0>(sc_, S_, C_);
+        double xt[n];
+        M::template core<double>(S_, C_, xr, usc, xt, prm, dt_);
+#pragma unroll
+        for (int i = 0; i < n; ++i) xr[i] = xt[i];
+        if (l == 0) {
+#pragma unroll
+          for (int i = 0; i < n; ++i) xn_[c * XS + i] = xt[i];
+        }
+      }
+    } else {
+      if (tid < kSpec) {                                   // whole-step models: candidate c on lane c
+        const int c = tid;
+        double xt[n];
+        M::template step<double>(xr, us4 + c * 16, xt, prm, dt_);
+#pragma unroll
+        for (int i = 0; i < n; ++i) { xn_[c * XS + i] = xt[i]; xr[i] = xt[i]; }
+      }
+    }
+    if (qrole) {                                           // (x - x_nom)^T Q (x - x_nom): row i, columns 0 .. n/2 - 1
+      const int i = tid - 64;
+#pragma unroll
+      for (int c = 0; c < kSpec; ++c) {
+        double r = 0.0;
+#pragma unroll
+        for (int j = 0; j < nh; ++j) r += qrow[j] * dx4[c * 32 + j];
+        acc[c] += dx4[c * 32 + i] * r;
+      }
+    } else if (q2role) {                                   // ... columns n/2 .. n - 1
+      const int i = tid - 192;
+#pragma unroll
+      for (int c = 0; c < kSpec; ++c) {
+        double r = 0.0;
+#pragma unroll
+        for (int j = nh; j < n; ++j) r += qrow[j] * dx4[c * 32 + j];
+        acc[c] += dx4[c * 32 + i] * r;
+      }
+    } else if (rrole) {
+      const int k = tid - 128;
+#pragma unroll
+      for (int c = 0; c < kSpec; ++c) {
+        double r = 0.0;
+#pragma unroll
+        for (int j = 0; j < m; ++j) r += rrow[j] * us4[c * 16 + j];
+        acc[c] += us4[c * 16 + k] * r;
+        Uo(c)[(size_t)t * m + k] = us4[c * 16 + k];
+      }
+    }
+    lds_barrier();
+    double* tmp_ = xc; xc = xn_; xn_ = tmp_;
+  };
+  prefetch(pfA, 0);
+  if (1 < N - 1) prefetch(pfB, 1);
+  __syncthreads();
+  for (int t = 0; t < N - 1; t += 2) {
+    one_step(pfA, t);
+    if (t + 1 < N - 1) one_step(pfB, t + 1);
+  }
+  if (tid < n) {
+#pragma unroll
+    for (int c = 0; c < kSpec; ++c) Xo(c)[(size_t)(N - 1) * n + tid] = xc[c * XS + tid];
+  }
+  if (qrole) {                                             // terminal cost (ilqr.py:327)
+    const int i = tid - 64;
+    const double* Qf = lds + Ly::oQf;
+#pragma unroll
+    for (int c = 0; c < kSpec; ++c) {
+      double r = 0.0;
+      for (int j = 0; j < n; ++j) r += Qf[i * n + j] * (xc[c * XS + j] - xnom[j]);
+      acc[c] += (xc[c * XS + i] - xnom[i]) * r;
+    }
+  }
+  double dvp = 0.0;
+  for (int t = tid; t < N - 1; t += kLargeThreads) dvp += v.dV[t];
+  double* red = lds + Ly::oRed;
+#pragma unroll
+  for (int c = 0; c < kSpec; ++c) L4[c] = block_sum(acc[c], red);
+  dvs_out = block_sum(dvp, red);
+}
+
+// The line search of ilqr.py:300-337, four candidates per pass; `win` = which candidate's buffers hold the accepted trial.
+template <class M>
+__device__ inline bool mid_linesearch4(const LView<M::n, M::m>& v, double* xsp, double* usp, size_t sx, size_t su, double* lds,
+                                       const KArgs& a, const double* x0g, double L_last, double& L_out, double& eps_out,
+                                       int& trials, int& win) {
+  double eps = 1.0;
+  trials = 0;
+  win = 0;
+  while (eps >= 1e-8) {
+    double e4[kSpec], L4[kSpec], dvs;
+    e4[0] = eps;
+#pragma unroll
+    for (int c = 1; c < kSpec; ++c) e4[c] = e4[c - 1] * a.beta;               // (the sequence eps *= beta produces, :335)
+    mid_rollout4<M>(v, xsp, usp, sx, su, lds, a, x0g, e4, L4, dvs);
+#pragma unroll
+    for (int c = 0; c < kSpec; ++c) {
+      if (!(e4[c] >= 1e-8)) return false;                                     // the search has run out of step sizes (:300)
+      trials += 1;
+      const double ex = -e4[c] * (1.0 - e4[c] / 2.0) * dvs;                   // :326
+      if ((L_last - L4[c]) > a.gamma * ex) { L_out = L4[c]; eps_out = e4[c]; win = c; return true; }
+    }
+    eps = e4[kSpec - 1] * a.beta;
     __syncthreads();
   }
   return false;
@@ -1534,20 +1779,35 @@ __device__ inline void mid_backward(const LView<M::n, M::m>& v, double* lds, boo
     Vx[tid] = s - qfn[tid];
   }
   // cost gradients for all steps (ilqr.py:180-181), unless the accepted trial's rollout left them (large_rollout)
+  // (a thread keeps ITS row of 2Q / 2R in registers and walks the time steps: kLargeThreads / (n + m) of them in flight)
   if (!lx_ready) {
-    for (int idx = tid; idx < (N - 1) * nm; idx += kLargeThreads) {
-      const int tt = idx / nm, pp = idx - tt * nm;
-      double s_;
+    constexpr int TG = kLargeThreads / nm;
+    const int pp = tid % nm, g0 = tid / nm;
+    if (g0 < TG) {
       if (pp < n) {
-        const double* xg = v.X + (size_t)tt * n;
-        s_ = -qn[pp];
-        for (int j = 0; j < n; ++j) s_ += (2.0 * Q[pp * n + j]) * xg[j];
+        double q2[n];
+#pragma unroll
+        for (int j = 0; j < n; ++j) q2[j] = 2.0 * Q[pp * n + j];
+        const double qnp = qn[pp];
+        for (int tt = g0; tt < N - 1; tt += TG) {
+          const double* xg = v.X + (size_t)tt * n;
+          double s_ = -qnp;
+#pragma unroll
+          for (int j = 0; j < n; ++j) s_ += q2[j] * xg[j];
+          Lxu[tt * nm + pp] = s_;
+        }
       } else {
-        const double* ug = v.U + (size_t)tt * m;
-        s_ = 0.0;
-        for (int j = 0; j < m; ++j) s_ += (2.0 * R[(pp - n) * m + j]) * ug[j];
+        double r2_[m];
+#pragma unroll
+        for (int j = 0; j < m; ++j) r2_[j] = 2.0 * R[(pp - n) * m + j];
+        for (int tt = g0; tt < N - 1; tt += TG) {
+          const double* ug = v.U + (size_t)tt * m;
+          double s_ = 0.0;
+#pragma unroll
+          for (int j = 0; j < m; ++j) s_ += r2_[j] * ug[j];
+          Lxu[tt * nm + pp] = s_;
+        }
       }
-      Lxu[idx] = s_;
     }
   }
   __syncthreads();                                           // (the rollout's scratch inside the T1 area is dead now)
@@ -2024,6 +2284,11 @@ __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kerne
   long long c_ls = 0, c_lin = 0, c_bp = 0;
   const long long c_begin = clock64();
   const int n_solves = (MODE == MODE_MPC) ? a.mpc_resolves : 1;
+  // mid-size kernels: the trial buffers of line-search candidates 1..3 (mid_rollout4), and whether this problem has backtracked
+  const size_t sx_ = (size_t)a.B * n * N, su_ = (size_t)a.B * m * (N - 1);
+  double* const xsp = kSpecRollout<M> ? a.x_spec + (size_t)b * n * N : nullptr;
+  double* const usp = kSpecRollout<M> ? a.u_spec + (size_t)b * m * (N - 1) : nullptr;
+  bool backtracked = false;
   for (int rs = 0; rs < n_solves; ++rs) {
     if (MODE == MODE_MPC) {
       // warm start (mini_cheetah.py:193-198): x0 <- x_bar[:, replan]; u_bar <- [u_bar[:, replan:], repeat(last)]
@@ -2069,20 +2334,34 @@ __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kerne
       if (it_this >= a.max_iters) { status = MI_STATUS_MAX_ITERS; break; }
       double L_new, eps; int trials;
       const long long c0 = clock64();
-      const bool ok = large_linesearch<M>(v, lds, a, x0g, L, L_new, eps, trials);
+      bool ok, used_spec = false;
+      int win = 0;
+      if constexpr (kSpecRollout<M>) {
+        if ((a.spec_policy == 2 || (a.spec_policy == 1 && backtracked)) && L < __builtin_inf()) {
+          used_spec = true;
+          ok = mid_linesearch4<M>(v, xsp, usp, sx_, su_, lds, a, x0g, L, L_new, eps, trials, win);
+        } else {
+          ok = large_linesearch<M>(v, lds, a, x0g, L, L_new, eps, trials);
+        }
+        backtracked = backtracked || trials > 1;
+      } else {
+        ok = large_linesearch<M>(v, lds, a, x0g, L, L_new, eps, trials);
+      }
       ls_total += trials;
       if (!ok) { status = MI_STATUS_LINESEARCH_FAILED; break; }
       __syncthreads();
       const long long c1 = clock64();
+      const double* const Xw = win == 0 ? v.Xn : xsp + (size_t)(win - 1) * sx_;      // the accepted trial
+      const double* const Uw = win == 0 ? v.Un : usp + (size_t)(win - 1) * su_;
       {                                                                              // :375-376 (+ the LDS copy the
         double* xs_ = lds + Ly::oT1;                                                 //  linearization reads)
         double* us_ = lds + Ly::oF;
         if (clustered) {                                                             // (the helpers read x_bar / u_bar: write-through)
-          for (int e = tid; e < n * N; e += kLargeThreads) { const double x_ = v.Xn[e]; st_shared<true>(v.X + e, x_); xs_[(e / n) * kXS + e % n] = x_; }
-          for (int e = tid; e < m * (N - 1); e += kLargeThreads) { const double u_ = v.Un[e]; st_shared<true>(v.U + e, u_); us_[(e / m) * kUS + e % m] = u_; }
+          for (int e = tid; e < n * N; e += kLargeThreads) { const double x_ = Xw[e]; st_shared<true>(v.X + e, x_); xs_[(e / n) * kXS + e % n] = x_; }
+          for (int e = tid; e < m * (N - 1); e += kLargeThreads) { const double u_ = Uw[e]; st_shared<true>(v.U + e, u_); us_[(e / m) * kUS + e % m] = u_; }
         } else {
-          for (int e = tid; e < n * N; e += kLargeThreads) { const double x_ = v.Xn[e]; v.X[e] = x_; if (lin_staged) xs_[(e / n) * kXS + e % n] = x_; }
-          for (int e = tid; e < m * (N - 1); e += kLargeThreads) { const double u_ = v.Un[e]; v.U[e] = u_; if (lin_staged) us_[(e / m) * kUS + e % m] = u_; }
+          for (int e = tid; e < n * N; e += kLargeThreads) { const double x_ = Xw[e]; v.X[e] = x_; if (lin_staged) xs_[(e / n) * kXS + e % n] = x_; }
+          for (int e = tid; e < m * (N - 1); e += kLargeThreads) { const double u_ = Uw[e]; v.U[e] = u_; if (lin_staged) us_[(e / m) * kUS + e % m] = u_; }
         }
       }
       __syncthreads();
@@ -2104,7 +2383,8 @@ __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kerne
         for (int q_ = 0; q_ < 16; ++q_) hp[q_] = (double)bpa[q_];
       }
 #else
-      if (MODE != MODE_FORWARD) { backward_pass<M>(v, lds, nullptr, kLxFromRollout<M>); __syncthreads(); }      // :697
+      // (a four-candidate pass leaves no cost gradients behind: the backward pass forms them itself)
+      if (MODE != MODE_FORWARD) { backward_pass<M>(v, lds, nullptr, kLxFromRollout<M> && !used_spec); __syncthreads(); }      // :697
 #endif
       const long long c3 = clock64();
       const bool not_pd = MODE != MODE_FORWARD && lds[Ly::oRed + kPdFlag] != 0.0;     // a Quu of this backward pass was not positive definite

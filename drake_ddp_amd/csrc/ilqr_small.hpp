@@ -91,6 +91,10 @@ struct KArgs {
   // lane-per-problem kernels with key-points (ilqr_batch.hpp, KP = true): 6 (N-1) x B ints, batch-minor - the lanes' key-point
   // lists, "derivative evaluated" flags and the two bin buffers of the iterative-error bisection
   int32_t* bm_scratch;
+  // mid-size workgroup-per-problem kernels (ilqr_large.hpp: mid_rollout4): trial trajectories of the line-search candidates
+  // rolled out beside the first, [3][B][N][n] and [3][B][N-1][m]
+  double *x_spec, *u_spec;
+  int spec_policy, pad_spec_;
 };
 
 __device__ __forceinline__ double bcast_lane0(double v) {

@@ -129,6 +129,9 @@ KArgs make_args(const mi_ilqr* h) {
   // MI_ILQR_CLUSTER=k forces k (1 = off) for A/B runs.
   a.sink_x = h->sink_x; a.sink_u = h->sink_u; a.sink_cost = h->sink_cost;
   a.bm_scratch = h->bm_scratch;
+  a.x_spec = h->x_spec; a.u_spec = h->u_spec;
+  static const int spec = [] { const char* e = std::getenv("MI_ILQR_SPEC"); return e ? std::atoi(e) : 1; }();
+  a.spec_policy = (h->x_spec && spec >= 0 && spec <= 2) ? spec : 0;
   a.cluster = 1;
   a.cluster_sync = h->cluster_sync;
   if (h->large && h->cluster_sync && h->d.keypoint_method == MI_KP_SET_INTERVAL && h->d.minN == 1) {
@@ -616,6 +619,10 @@ int mi_ilqr_create(const mi_ilqr_desc* desc, mi_ilqr_t** out) {
   ALLOC(h->prof, B * 4, long long);
   ALLOC(h->done_counter, 1, int32_t);
   if (large) ALLOC(h->cluster_sync, B * 4, unsigned long long);
+  if (large && n <= 32) {                                   // mid-size kernels: four line-search candidates per pass
+    ALLOC(h->x_spec, 3 * B * n * N, double);
+    ALLOC(h->u_spec, 3 * B * m * (N - 1), double);
+  }
   if (batch_minor && !(desc->keypoint_method == MI_KP_SET_INTERVAL && desc->minN == 1)) ALLOC(h->bm_scratch, B * 6 * (N - 1), int32_t);
 #undef ALLOC
   {
@@ -660,7 +667,7 @@ void mi_ilqr_destroy(mi_ilqr_t* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   void* ptrs[] = {h->x_bar, h->u_bar, h->K, h->kappa, h->dV, h->fx, h->fu, h->x0, h->u_guess, h->cost_ring, h->hist, h->iter_cyc,
                   h->x_trial, h->u_trial, h->trial_cost, h->stage_in, h->costmat, h->iters_ring, h->status_ring, h->ls_ring,
-                  h->kp_count, h->kp_list, h->prof, h->done_counter, h->cluster_sync, h->bm_scratch};
+                  h->kp_count, h->kp_list, h->prof, h->done_counter, h->cluster_sync, h->bm_scratch, h->x_spec, h->u_spec};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->h_ring) (void)hipHostFree(h->h_ring);
   if (h->mpc_log) (void)hipFree(h->mpc_log);

@@ -240,3 +240,58 @@ def test_mid_family_batch_position_and_size_invariance():
             outs.append((s.x_bar.copy(), s.K.copy(), s.cost.copy()))
         for a, b in zip(*outs):
             assert np.array_equal(a[:1], b[:1]), N
+
+
+@pytest.mark.gpu
+def test_four_candidate_line_search_is_the_sequential_one(tmp_path):
+    """mid_rollout4 walks four line-search candidates (eps, eps beta, eps beta^2, eps beta^3) through one step loop and the
+    search takes the first that passes (ilqr.py:330) - what the sequential search returns.  Against the same kernels with
+    the candidates one after the other (MI_ILQR_SPEC=0), and with four candidates from the first finite cost on (=2), on 96 arm +
+    ball problems (2.4 trials per iteration) and a plugin chain that backtracks with beta = 0.5: iterations, trials per
+    problem and the eps / trial count of EVERY iteration are identical; costs agree to round-off (the only arithmetic
+    difference: after a four-candidate pass the backward pass forms lx, lu from x_bar, u_bar instead of taking the rows
+    the rollout left - 2 Q x - 2 Q x_nom against 2 (Q (x - x_nom)))."""
+    import subprocess
+    script = f"""
+import sys, numpy as np
+sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'tests')!r}); sys.path.insert(0, {os.path.join(ROOT, 'examples', 'plugins')!r})
+from drake_ddp_amd import workloads as W
+from drake_ddp_amd.ilqr import BatchedIterativeLQR
+from test_gpu_parity import make_solver
+import models as PM
+p = W.arm27_problem()
+B = 96
+s = make_solver(p, B=B, jac='fd', hist_cap=64)
+s.SetInitialState(W.arm27_batch_x0(B)); s.SetInitialGuess(W.arm27_u_guess(p['N']))
+x, u, _, L = s.Solve()
+out = dict(L=L, it=s.iterations, ls=s.ls_trials, h=s.history[:, :, 1:3], x=x, st=s.status)
+n, m, N, dt = 12, 4, 40, 0.03
+sys_ = PM.build_chainx(6, 4, 0)(dt)
+c = BatchedIterativeLQR(sys_, N, 64, delta=1e-4, beta=0.5, jacobian_mode='ad', hist_cap=64)
+c.SetTargetState(np.concatenate([np.full(6, 2.5), np.zeros(6)])); c.SetRunningCost(dt * np.eye(n), dt * 1e-3 * np.eye(m)); c.SetTerminalCost(80.0 * np.eye(n))
+c.SetInitialState(np.random.default_rng(5).uniform(-1.5, 1.5, (64, n))); c.SetInitialGuess(np.zeros((m, N - 1)))
+try:
+    xc, uc, _, Lc = c.Solve()
+except RuntimeError:
+    xc, Lc = c.x_bar, c.cost
+out.update(cL=Lc, cit=c.iterations, cls=c.ls_trials, ch=c.history[:, :, 1:3], cst=c.status)
+np.savez(sys.argv[1], **out)
+"""
+    outs = {}
+    for pol in ("1", "0", "2"):
+        f = str(tmp_path / f"spec{pol}.npz")
+        r = subprocess.run([sys.executable, "-c", script, f], capture_output=True, text=True, timeout=600, env=dict(os.environ, MI_ILQR_SPEC=pol))
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[pol] = np.load(f)
+    ref = outs["0"]
+    print(f"arm + ball: {int(ref['ls'].sum())} trials in {int(ref['it'].sum())} iterations; chain: {int(ref['cls'].sum())} in {int(ref['cit'].sum())}, "
+          f"status {np.unique(ref['cst']).tolist()}")
+    assert ref["ls"].sum() > 1.5 * ref["it"].sum() and ref["cls"].sum() > 1.2 * ref["cit"].sum()      # (both cases do backtrack)
+    for pol in ("1", "2"):
+        o = outs[pol]
+        for k in ("it", "ls", "h", "st", "cit", "cls", "ch", "cst"):
+            assert np.array_equal(o[k], ref[k]), (pol, k)
+        ok = ref["cst"] == 0
+        dev = max(np.max(np.abs(o["L"] - ref["L"]) / np.abs(ref["L"])), np.max(np.abs(o["cL"][ok] - ref["cL"][ok]) / np.abs(ref["cL"][ok])))
+        print(f"  MI_ILQR_SPEC={pol}: every decision identical; largest relative cost difference {dev:.1e}")
+        assert dev < 1e-9
