@@ -115,5 +115,5 @@ def build_asan(verbose=False):
 if __name__ == "__main__":
     ex = ["-Rpass-analysis=kernel-resource-usage"] if "--resource-usage" in sys.argv else []
     build(force="--force" in sys.argv, extra=ex)
-    if "--asan" in sys.argv:
-        build_asan(verbose=True)
+    if "--asan" in sys.argv or os.path.exists(ASAN_LIB):      # (an existing sanitizer build follows the headers: a stale one refuses plugins)
+        build_asan(verbose="--asan" in sys.argv)

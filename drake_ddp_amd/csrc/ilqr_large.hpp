@@ -1022,16 +1022,22 @@ __device__ __forceinline__ void large_jac_at_legs(const LView<M::n, M::m>& v, co
   }
 }
 
-template <class M, int JAC>
-__device__ __forceinline__ void large_jac_at(const LView<M::n, M::m>& v, const KArgs& a, const int* list, int count) {
+// Dense models (whole-step plugins, the arm + ball): one (key-point, column) item per thread, the whole step evaluated at
+// the perturbed / seeded point.  Xsrc / Usrc: the nominal trajectory in HBM, or its LDS copy (row strides xstride / ustride);
+// first / cstride: this workgroup's share of the items when a cluster of workgroups linearizes one problem (chunks of 256
+// dealt round-robin; COH: write-through stores, read by another workgroup).
+template <class M, int JAC, bool COH = false>
+__device__ __forceinline__ void large_jac_at(const LView<M::n, M::m>& v, const KArgs& a, const int* list, int count,
+                                             const double* Xsrc, const double* Usrc, int xstride, int ustride,
+                                             int first = 0, int cstride = 1) {
   constexpr int n = M::n, m = M::m, nc = n + m;
   const ModelScalars<M> ms(a);
   const double h = ms.fd_h, inv2h = 1.0 / (2.0 * h);
-  for (int it = threadIdx.x; it < count * nc; it += kLargeThreads) {
+  for (int it = first * kLargeThreads + threadIdx.x; it < count * nc; it += cstride * kLargeThreads) {
     const int ki = it / nc, col = it - ki * nc;
     const int t = list[ki];
-    const double* xg = v.X + (size_t)t * n;
-    const double* ug = v.U + (size_t)t * m;
+    const double* xg = Xsrc + (size_t)t * xstride;
+    const double* ug = Usrc + (size_t)t * ustride;
     double d[n];
     if (JAC == MI_JAC_FD_CENTRAL) {
       double x[n], u[m], f[n];
@@ -1060,11 +1066,11 @@ __device__ __forceinline__ void large_jac_at(const LView<M::n, M::m>& v, const K
     if (col < n) {
       double* o = v.Fx + (size_t)t * n * n + col;
 #pragma unroll
-      for (int i = 0; i < n; ++i) o[i * n] = d[i];
+      for (int i = 0; i < n; ++i) st_shared<COH>(o + i * n, d[i]);
     } else {
       double* o = v.Fu + (size_t)t * n * m + (col - n);
 #pragma unroll
-      for (int i = 0; i < n; ++i) o[i * m] = d[i];
+      for (int i = 0; i < n; ++i) st_shared<COH>(o + i * m, d[i]);
     }
   }
 }
@@ -2130,8 +2136,7 @@ __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kerne
   // The sparse Jacobian code reads a handful of x/u entries per evaluation: it takes them from an
   // LDS copy of the nominal trajectory (the backward pass's T1|H and F areas are idle during the
   // linearization) instead of paying an L2 round trip per dependent access.
-  const bool lin_staged = (HasSparsity<M>::value || IsChainModel<M>::value || IsLegModel<M>::value) &&
-                          (size_t)(n + 1) * N <= (size_t)(Ly::NK + Ly::NMP) * Ly::TS && (size_t)(m + 1) * (N - 1) <= (size_t)Ly::NK * Ly::NMP;
+  const bool lin_staged = (size_t)(n + 1) * N <= (size_t)(Ly::NK + Ly::NMP) * Ly::TS && (size_t)(m + 1) * (N - 1) <= (size_t)Ly::NK * Ly::NMP;
   const double* lin_X = lin_staged ? lds + Ly::oT1 : v.X;
   const double* lin_U = lin_staged ? lds + Ly::oF : v.U;
   // Row strides of the LDS copy.  Chain models deal their items key-point fastest: the lanes of a wave read the
@@ -2143,7 +2148,7 @@ __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kerne
     if constexpr (HasSparsity<M>::value) large_jac_at_sparse<M, JAC>(v, a, list, count, lin_X, lin_U);
     else if constexpr (IsChainModel<M>::value) large_jac_at_tree<M, JAC>(v, a, list, count, lin_X, lin_U, lin_xs, lin_us, lds + Ly::doubles);   // (the cost-gradient area of the backward pass is idle here)
     else if constexpr (IsLegModel<M>::value) large_jac_at_legs<M, JAC>(v, a, list, count, lin_X, lin_U, lin_xs, lin_us);
-    else large_jac_at<M, JAC>(v, a, list, count);
+    else large_jac_at<M, JAC>(v, a, list, count, lin_X, lin_U, lin_xs, lin_us);
   };
   // ---- cluster handshake (G > 1; every step a key-point, models with an LDS-staged linearization) -------------
   // The linearization is the one stage of an iteration whose (step, column) items are independent, and with few
@@ -2157,8 +2162,7 @@ __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kerne
   // single-workgroup path - bitwise the same fx, fu).  Trajectory and Jacobians cross workgroups through global
   // memory under device-scope release / acquire fences.
   unsigned long long* csync = a.cluster_sync + (size_t)4 * b;
-  constexpr bool kClusterable = HasSparsity<M>::value || IsChainModel<M>::value || IsLegModel<M>::value;
-  const bool clustered = kClusterable && G > 1 && lin_staged && a.kp_method == MI_KP_SET_INTERVAL && a.minN == 1;
+  const bool clustered = G > 1 && lin_staged && a.kp_method == MI_KP_SET_INTERVAL && a.minN == 1;
   auto stage_trajectory = [&]() __attribute__((always_inline)) {          // helper: the leader's x_bar / u_bar -> LDS
     double* xs_ = lds + Ly::oT1;
     double* us_ = lds + Ly::oF;
@@ -2172,6 +2176,7 @@ __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kerne
     if constexpr (HasSparsity<M>::value) large_jac_at_sparse<M, JAC, COH>(v, a, acc.kp, N - 1, lin_X, lin_U, first, stride);
     else if constexpr (IsChainModel<M>::value) large_jac_at_tree<M, JAC, COH>(v, a, acc.kp, N - 1, lin_X, lin_U, lin_xs, lin_us, lds + Ly::doubles, first, stride);
     else if constexpr (IsLegModel<M>::value) large_jac_at_legs<M, JAC, COH>(v, a, acc.kp, N - 1, lin_X, lin_U, lin_xs, lin_us, first, stride);
+    else large_jac_at<M, JAC, COH>(v, a, acc.kp, N - 1, lin_X, lin_U, lin_xs, lin_us, first, stride);
   };
   constexpr long long kSpinCap = 1ll << 22;                 // x s_sleep(4) ~ 1 s: a lost partner ends the wait, not the device
   if (role > 0) {
