@@ -1734,7 +1734,7 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
 // its column, like the reference's dense update); only Quu is formed from the transposed column tiles (= the transpose of a
 // matrix that is symmetric up to round-off), which takes it off the step's critical path.  Two barriers per step.
 template <class M>
-__device__ inline void mid_backward(const LView<M::n, M::m>& v, double* lds, bool lx_ready = false) {
+__device__ inline void mid_backward(const LView<M::n, M::m>& v, double* lds, bool lx_ready = false, bool xu_staged = false) {
   constexpr int n = M::n, m = M::m, nm = n + m;
   using Ly = LLay<n, m>;
   static_assert(Ly::kMid && Ly::kSplit && m >= 1 && m <= 16, "mid-size family: n <= 32, m <= 16");
@@ -1785,8 +1785,11 @@ __device__ inline void mid_backward(const LView<M::n, M::m>& v, double* lds, boo
     Vx[tid] = s - qfn[tid];
   }
   // cost gradients for all steps (ilqr.py:180-181), unless the accepted trial's rollout left them (large_rollout)
-  // (a thread keeps ITS row of 2Q / 2R in registers and walks the time steps: kLargeThreads / (n + m) of them in flight)
+  // (a thread keeps ITS row of 2Q / 2R in registers and walks the time steps: kLargeThreads / (n + m) of them in flight;
+  //  xu_staged: the linearization's LDS copy of x_bar / u_bar - rows of n / m doubles in the T1 / F areas - is still there)
   if (!lx_ready) {
+    const double* const Xs_ = xu_staged ? lds + Ly::oT1 : v.X;
+    const double* const Us_ = xu_staged ? lds + Ly::oF : v.U;
     constexpr int TG = kLargeThreads / nm;
     const int pp = tid % nm, g0 = tid / nm;
     if (g0 < TG) {
@@ -1796,7 +1799,7 @@ __device__ inline void mid_backward(const LView<M::n, M::m>& v, double* lds, boo
         for (int j = 0; j < n; ++j) q2[j] = 2.0 * Q[pp * n + j];
         const double qnp = qn[pp];
         for (int tt = g0; tt < N - 1; tt += TG) {
-          const double* xg = v.X + (size_t)tt * n;
+          const double* xg = Xs_ + (size_t)tt * n;
           double s_ = -qnp;
 #pragma unroll
           for (int j = 0; j < n; ++j) s_ += q2[j] * xg[j];
@@ -1807,7 +1810,7 @@ __device__ inline void mid_backward(const LView<M::n, M::m>& v, double* lds, boo
 #pragma unroll
         for (int j = 0; j < m; ++j) r2_[j] = 2.0 * R[(pp - n) * m + j];
         for (int tt = g0; tt < N - 1; tt += TG) {
-          const double* ug = v.U + (size_t)tt * m;
+          const double* ug = Us_ + (size_t)tt * m;
           double s_ = 0.0;
 #pragma unroll
           for (int j = 0; j < m; ++j) s_ += r2_[j] * ug[j];
@@ -2065,8 +2068,8 @@ __device__ inline void mid_backward(const LView<M::n, M::m>& v, double* lds, boo
 
 // The backward pass of a model's size class.
 template <class M>
-__device__ __forceinline__ void backward_pass(const LView<M::n, M::m>& v, double* lds, long long* bp_acc, bool lx_ready) {
-  if constexpr (LLay<M::n, M::m>::kMid) mid_backward<M>(v, lds, lx_ready);
+__device__ __forceinline__ void backward_pass(const LView<M::n, M::m>& v, double* lds, long long* bp_acc, bool lx_ready, bool xu_staged = false) {
+  if constexpr (LLay<M::n, M::m>::kMid) mid_backward<M>(v, lds, lx_ready, xu_staged);
   else large_backward<M>(v, lds, bp_acc, lx_ready);
 }
 
@@ -2389,7 +2392,7 @@ __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kerne
       }
 #else
       // (a four-candidate pass leaves no cost gradients behind: the backward pass forms them itself)
-      if (MODE != MODE_FORWARD) { backward_pass<M>(v, lds, nullptr, kLxFromRollout<M> && !used_spec); __syncthreads(); }      // :697
+      if (MODE != MODE_FORWARD) { backward_pass<M>(v, lds, nullptr, kLxFromRollout<M> && !used_spec, lin_staged && !IsChainModel<M>::value); __syncthreads(); }      // :697
 #endif
       const long long c3 = clock64();
       const bool not_pd = MODE != MODE_FORWARD && lds[Ly::oRed + kPdFlag] != 0.0;     // a Quu of this backward pass was not positive definite

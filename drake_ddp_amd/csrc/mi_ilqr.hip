@@ -140,7 +140,16 @@ KArgs make_args(const mi_ilqr* h) {
     // a handshake costs ~40 k cycles when a few hundred workgroups fence at once: worth it for the articulated
     // model at any batch (its linearization is 450 k cycles), for the sparse chain model (75 k) only while the
     // launch stays small
-    if (forced <= 0 && h->d.model_id != MI_MODEL_PLANAR_QUAD && h->d.model_id != MI_MODEL_QUAD3D && h->B > 16) g = 1;
+    // (the arm + ball's dense linearization is 100 k: 38 k with a cluster of 8 at B = 1, 62 k with 4 at B = 64 where the
+    // helpers' Jacobians cost the backward pass 12 k in L2 misses - worth it up to there; plugin models: the library
+    // cannot know what their step costs - a cheap one loses to the handshake, so they are not clustered unless forced)
+    if (forced <= 0) {
+      const int id = h->d.model_id;
+      if (id == MI_MODEL_PLANAR_QUAD || id == MI_MODEL_QUAD3D) {}
+      else if (id == MI_MODEL_ARM27) { if (h->B > 64) g = 1; }
+      else if (plugin_of(id)) g = 1;
+      else if (h->B > 16) g = 1;
+    }
     if (g > 8) g = 8;
     if (g < 1) g = 1;
     a.cluster = g;

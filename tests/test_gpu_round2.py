@@ -556,13 +556,16 @@ def test_per_iteration_stopwatches_and_console_table(capsys):
 
 
 @pytest.mark.parametrize("cfg,B,forced", [("quad", 8, None), ("synth36", 8, None), ("quad", 64, "8"), ("quad", 3, "5"),
-                                          ("quad3d", 8, None), ("quad3d", 64, None), ("quad3d", 5, "3")])
+                                          ("quad3d", 8, None), ("quad3d", 64, None), ("quad3d", 5, "3"),
+                                          ("arm27", 1, None), ("arm27", 48, None), ("arm27", 7, "3"), ("chainx", 5, "4")])
 def test_cluster_linearization_is_bitwise_the_single_workgroup_one(cfg, B, forced, tmp_path):
     """With few problems per GPU the linearization of ONE problem is shared by a cluster of workgroups (leader +
     helpers, handshake through global memory, ilqr_large.hpp).  Every Jacobian entry is still computed by the
     same code on the same inputs, so everything the solve returns must be bitwise what a single workgroup per
     problem returns (MI_ILQR_CLUSTER=1) - including when the launch is oversubscribed (512 workgroups on 256 CUs:
-    helpers that are not resident are never waited for) and for cluster sizes that do not divide anything."""
+    helpers that are not resident are never waited for) and for cluster sizes that do not divide anything.  Since round 4
+    the dense (whole-step) linearization of the mid-size models is shared the same way: the arm + ball (by default up to
+    B = 64) and a plugin chain (forced: plugins are not clustered by default - the library cannot know what their step costs)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -577,10 +580,24 @@ if {cfg!r} == 'quad':
 elif {cfg!r} == 'quad3d':
     prob, x0, ug = W.quad3d_problem(target_vel=1.0), W.quad3d_batch_x0(64)[:{B}], W.quad3d_u_guess(40)
     step = np.zeros(37); step[4] = 1.0 * prob['dt'] * 4
+elif {cfg!r} == 'arm27':
+    prob, x0, ug = W.arm27_problem(), W.arm27_batch_x0(64)[:{B}], W.arm27_u_guess(50)
+    step = np.zeros(27); step[12] = 0.002
+elif {cfg!r} == 'chainx':
+    sys.path.insert(0, {os.path.join(root, 'examples', 'plugins')!r})
+    import models as PM
+    from drake_ddp_amd.ilqr import BatchedIterativeLQR
+    n, m, N, dt = 14, 7, 30, 0.02
+    step = np.zeros(n); step[0] = 0.01
 else:
     prob, x0, ug = W.synth36_problem(), W.synth36_batch_x0(64)[:{B}], W.synth36_u_guess(40)
     step = np.zeros(36); step[0] = W.SYNTH_TARGET_VEL * prob['dt'] * 4
-s = make_solver(prob, B={B}, jac='fd')
+if {cfg!r} == 'chainx':
+    s = BatchedIterativeLQR(PM.build_chainx(7, 7, 0)(dt), N, {B}, delta=1e-3, beta=0.7, jacobian_mode='fd')
+    s.SetTargetState(np.zeros(n)); s.SetRunningCost(dt * np.eye(n), dt * 0.05 * np.eye(m)); s.SetTerminalCost(5.0 * np.eye(n))
+    x0, ug = 0.4 * np.random.default_rng(2).standard_normal(({B}, n)), np.zeros((m, N - 1))
+else:
+    s = make_solver(prob, B={B}, jac='fd')
 s.SetInitialState(x0); s.SetInitialGuess(ug)
 x, u, _, L = s.Solve()
 fx0, it0 = s.fx.copy(), s.iterations.copy()
