@@ -246,8 +246,9 @@ __device__ inline double large_rollout(const LView<M::n, M::m>& v, double* lds, 
   // that lane carries x_t in registers from step to step (it does not read back what it has just published), and the
   // trajectory goes to HBM from the lanes that form x_t - x_nom - one coalesced store instead of n scalar ones on the
   // lane every other thread is waiting for.
+  // (every model: x_t goes to HBM from the x - x_nom lanes, the dynamics lanes only publish to LDS)
   constexpr bool kCarry = IsTrigModel<M>::value || IsWholeStepModel<M>::value;
-  if (tid < n) { xs[tid] = x0g[tid]; if constexpr (!kCarry) v.Xn[tid] = x0g[tid]; }
+  if (tid < n) xs[tid] = x0g[tid];
   double xr[kCarry ? n : 1];
   if constexpr (kCarry) {
 #pragma unroll
@@ -291,7 +292,7 @@ __device__ inline double large_rollout(const LView<M::n, M::m>& v, double* lds, 
     if (drole) {
       const double xv_ = xc[tid - 192];
       dxc[tid - 192] = xv_ - xnr;
-      if constexpr (kCarry) v.Xn[(size_t)t * n + (tid - 192)] = xv_;
+      v.Xn[(size_t)t * n + (tid - 192)] = xv_;
     }
     if (t + 2 < N - 1) prefetch(f, t + 2);       // this set is free again
     lds_barrier();
@@ -326,7 +327,6 @@ __device__ inline double large_rollout(const LView<M::n, M::m>& v, double* lds, 
             const double vn_ = xc[M::nq + i] + dt_ * q3[b_];
             const double qn_ = xc[i] + dt_ * vn_;
             xn_[i] = qn_; xn_[M::nq + i] = vn_;
-            v.Xn[(size_t)(t + 1) * n + i] = qn_; v.Xn[(size_t)(t + 1) * n + M::nq + i] = vn_;
             bad = bad || M::infeasible_velocity(vn_, prm);
           }
         }
@@ -335,7 +335,6 @@ __device__ inline double large_rollout(const LView<M::n, M::m>& v, double* lds, 
           const double vn_ = xc[M::nq + tid] + dt_ * acc_;
           const double qn_ = xc[tid] + dt_ * vn_;
           xn_[tid] = qn_; xn_[M::nq + tid] = vn_;
-          v.Xn[(size_t)(t + 1) * n + tid] = qn_; v.Xn[(size_t)(t + 1) * n + M::nq + tid] = vn_;
           bad = bad || M::infeasible_velocity(vn_, prm);
         }
         dyn_done = true;
@@ -357,7 +356,6 @@ __device__ inline double large_rollout(const LView<M::n, M::m>& v, double* lds, 
         for (int i = 0; i < 3; ++i) { Fw[i] = row16_sum(keep * lo.fw[i]); Tq[i] = row16_sum(keep * lo.tq[i]); }
         double xt[n];
         M::template trunk<double>(xc, Fw, Tq, xt, prm, dt_);
-        double* Xo = v.Xn + (size_t)(t + 1) * n;
         if (tid < M::kLegs) {
 #pragma unroll
           for (int i = 0; i < 3; ++i) {
@@ -365,15 +363,14 @@ __device__ inline double large_rollout(const LView<M::n, M::m>& v, double* lds, 
             const double jdn = xc[25 + j] + dt_ * lo.ja[i];
             const double jn = xc[7 + j] + dt_ * jdn;
             xn_[25 + j] = jdn; xn_[7 + j] = jn;
-            Xo[25 + j] = jdn; Xo[7 + j] = jn;
             bad = bad || M::infeasible_velocity(jdn, prm);
           }
         }
         if (tid == 0) {
 #pragma unroll
-          for (int i = 0; i < 7; ++i) { xn_[i] = xt[i]; Xo[i] = xt[i]; }
+          for (int i = 0; i < 7; ++i) xn_[i] = xt[i];
 #pragma unroll
-          for (int i = 19; i < 25; ++i) { xn_[i] = xt[i]; Xo[i] = xt[i]; bad = bad || M::infeasible_velocity(xt[i], prm); }
+          for (int i = 19; i < 25; ++i) { xn_[i] = xt[i]; bad = bad || M::infeasible_velocity(xt[i], prm); }
         }
         dyn_done = true;
       }
@@ -410,8 +407,6 @@ __device__ inline double large_rollout(const LView<M::n, M::m>& v, double* lds, 
         double qn_ = 0.0, vn_ = 0.0;
         M::template dof<double>(tid, xc, us, qn_, vn_, prm, dt_);
         xn_[tid] = qn_; xn_[M::nq + tid] = vn_;
-        v.Xn[(size_t)(t + 1) * n + tid] = qn_;
-        v.Xn[(size_t)(t + 1) * n + M::nq + tid] = vn_;
         dyn_done = true;
       }
     }
@@ -453,7 +448,7 @@ __device__ inline double large_rollout(const LView<M::n, M::m>& v, double* lds, 
     if (t + 1 < N - 1) one_step(pfB, t + 1);
   }
   xs = xc;                             // final state x_{N-1}
-  if constexpr (kCarry) { if (tid < n) v.Xn[(size_t)(N - 1) * n + tid] = xs[tid]; }
+  if (tid < n) v.Xn[(size_t)(N - 1) * n + tid] = xs[tid];
   if constexpr (kLx) {
     if (qrole && N >= 2) Lxu[(N - 2) * (n + m) + (tid - 64)] = 2.0 * (r1_prev + r2buf[((N - 2) & 1) * 64 + (tid - 64)]);
   }

@@ -628,9 +628,15 @@ int mi_ilqr_create(const mi_ilqr_desc* desc, mi_ilqr_t** out) {
   ALLOC(h->prof, B * 4, long long);
   ALLOC(h->done_counter, 1, int32_t);
   if (large) ALLOC(h->cluster_sync, B * 4, unsigned long long);
-  if (large && n <= 32) {                                   // mid-size kernels: four line-search candidates per pass
-    ALLOC(h->x_spec, 3 * B * n * N, double);
-    ALLOC(h->u_spec, 3 * B * m * (N - 1), double);
+  if (large && n <= 32) {
+    // mid-size kernels: four line-search candidates per pass - an optimization, so a batch too large for three more
+    // trial buffers simply searches one candidate at a time (make_args: spec_policy = 0 without them)
+    const size_t xb = 3 * B * n * N * sizeof(double), ub = 3 * B * m * (N - 1) * sizeof(double);
+    if (hipMalloc(reinterpret_cast<void**>(&h->x_spec), xb) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&h->u_spec), ub) != hipSuccess) {
+      (void)hipGetLastError();
+      if (h->x_spec) (void)hipFree(h->x_spec);
+      h->x_spec = nullptr; h->u_spec = nullptr;
+    }
   }
   if (batch_minor && !(desc->keypoint_method == MI_KP_SET_INTERVAL && desc->minN == 1)) ALLOC(h->bm_scratch, B * 6 * (N - 1), int32_t);
 #undef ALLOC
