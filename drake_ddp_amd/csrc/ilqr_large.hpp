@@ -50,7 +50,9 @@ struct LLay {
   // of 48 doubles keeps the four rows of a k-step on disjoint banks for the 64-bit reads (32 would put them on the same).
   static constexpr bool kMid = n <= 32;
   static constexpr int NMPc = ((nm + 15) / 16) * 16;
-  static constexpr bool kSplit = kMid || !(NMPc - 16 <= n && n % 4 == 0);
+  // (COMPACT only when x's tail and u fill the last tile exactly - (36, 12), (40, 8): with pad columns behind u, Quu would not
+  //  end at the tile's corner, which the solver wave's row mapping relies on; (36, 4), (36, 8), (40, 4) take the split layout)
+  static constexpr bool kSplit = kMid || !(NMPc - 16 <= n && n % 4 == 0 && nm == NMPc);
   static constexpr int UC = kSplit ? NP : n;               // column of u_0
   static constexpr int NMP = kMid ? 48 : (kSplit ? NP + ((m + 15) / 16) * 16 : NMPc);
   static constexpr int TS = NMP + 4;                       // row stride of T1 / H: whole tiles + the Vx/first-order column
@@ -1359,7 +1361,7 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
   constexpr int QO = UC - 16 * (CT - 1);                      // Quu's offset inside that tile
   static_assert(QO % 4 == 0, "the rows of Qux are whole result registers");
   constexpr int R0 = QO / 4, MK = m / 4;
-  constexpr int QS = NP, WSS = 13, PS = 16 * SS;              // row strides (QS = 48: the four rows of a k-step on disjoint banks)
+  constexpr int QS = NP, WSS = m <= 12 ? 13 : 17, PS = 16 * SS;   // row strides (QS = 48: the four rows of a k-step on disjoint banks; WSS odd, > m)
   constexpr int FB1 = Ly::oT1 - Ly::oF;                       // F_t lives in buffer (N - 2 - t) & 1; the second buffer is the T1 area
   double* QuxS = H;                                           // [m][QS]   Qux_t, exchanged between the waves
   double* Ws = QuxS + m * QS;                                 // [16][WSS] Quu^{-1}, rows >= m zero (an A operand)

@@ -500,6 +500,7 @@ int mi_ilqr_register_model(const mi_ilqr_model_plugin* p, int32_t* model_id_out)
     return MI_ILQR_E_BAD_ARG;
   }
   if (p->n < 1 || p->m < 1 || p->n > kMaxStateDim || p->n_params < 0 || p->n_params > MI_ILQR_MAX_PARAMS) return MI_ILQR_E_BAD_SHAPE;
+  if (p->m_user < 0 || p->m_user > p->m) return MI_ILQR_E_BAD_SHAPE;     // (0: no padding controls)
   // family 0: wave-per-problem kernels (m <= 2); family 1: workgroup-per-problem kernels - n <= 32 with any m <= 16
   // (mid_backward), 32 < n <= 40 with m % 4 == 0 and 2 m <= n (large_backward's wave roles)
   if (p->family == 0 ? p->m > 2

@@ -48,6 +48,10 @@ class BatchedIterativeLQR:
         self.B = int(batch)
         self.delta, self.beta, self.gamma = delta, beta, gamma
         self.n, self.m = system.n, system.m
+        # device-side number of controls: more than m when the model carries padding controls (n > 32 with m % 4 != 0 on the
+        # workgroup-per-problem kernels, plugin.device_controls).  Everything a caller passes or receives has m controls;
+        # R gets a unit block, guesses zeros, results are cut back - the padding's gains and inputs are exact zeros.
+        self._md = int(getattr(system, "m_dev", system.m))
         # ilqr.py:97-100: default = derivatives at every time step
         if derivs_keypoint_method is None:
             derivs_keypoint_method = utils_derivs_interpolation.derivs_interpolation('setInterval', 1, 0, 0, 0)
@@ -55,7 +59,7 @@ class BatchedIterativeLQR:
         if derivs_keypoint_method.keypoint_method not in _KP_IDS:
             raise Exception('unknown interpolation method')                               # ilqr.py:404
         d = _capi.Desc()
-        d.n, d.m, d.N, d.B = self.n, self.m, self.N, self.B
+        d.n, d.m, d.N, d.B = self.n, self._md, self.N, self.B
         d.model_id = system.model_id
         d.n_params = system.params.size
         for i, v in enumerate(system.params):
@@ -124,7 +128,7 @@ class BatchedIterativeLQR:
     # ------------------------------------------------------------- boundary traffic
     def _push_problem(self):
         x_nom = self.x_nom             # AttributeError if SetTargetState was never called, as in the reference
-        Q, R, Qf = (_capi.as_f64(a) for a in (self.Q, self.R, self.Qf))
+        Q, R, Qf = (_capi.as_f64(a) for a in (self.Q, self._pad_u(self.R, (0, 1), diag=1.0), self.Qf))
         xn = _capi.as_f64(x_nom, (self.n,))
         _capi.check(self._lib.mi_ilqr_set_cost(self._h, _capi.ptr(Q), _capi.ptr(R), _capi.ptr(Qf), _capi.ptr(xn)),
                     "mi_ilqr_set_cost")
@@ -140,9 +144,9 @@ class BatchedIterativeLQR:
                 raise AssertionError(f"initial guess must be (m,N-1) or (B,m,N-1), got {ug.shape}")
             shared = ug.ndim == 2 or (ug.shape[0] == 1 and self.B > 1)
             if shared:
-                ug = np.ascontiguousarray(ug.reshape(self.m, self.N - 1))
+                ug = np.ascontiguousarray(self._pad_u(ug.reshape(self.m, self.N - 1), (0,)))
             else:
-                ug = np.ascontiguousarray(np.broadcast_to(ug, (self.B, self.m, self.N - 1)))
+                ug = np.ascontiguousarray(self._pad_u(np.broadcast_to(ug, (self.B, self.m, self.N - 1)), (1,)))
             self._u_guess = None       # u_bar is rebound by the forward pass (ilqr.py:375)
         if shared:
             _capi.check(self._lib.mi_ilqr_set_initial_shared(self._h, _capi.ptr(x0), _capi.ptr(ug)), "mi_ilqr_set_initial_shared")
@@ -173,10 +177,40 @@ class BatchedIterativeLQR:
         pool.append(root)
         return root.reshape(shape)
 
-    def _get(self, which, shape):
-        out = self._out(which, shape, np.float64)
-        _capi.check(self._lib.mi_ilqr_get(self._h, which, _capi.ptr(out), out.nbytes), "mi_ilqr_get")
+    # axis (from the end) along which a field carries the controls
+    _U_AXIS = {_capi.F_U_BAR: -2, _capi.F_KAPPA: -2, _capi.F_U_TRIAL: -2, _capi.F_K: -3, _capi.F_FU: -2}
+
+    def _pad_u(self, a, axes, diag=0.0):
+        """`a` with its control axes grown from m to the device's count (zeros; `diag` on the new diagonal of a square block)."""
+        if self._md == self.m:
+            return a
+        a = np.asarray(a, dtype=np.float64)
+        shape = list(a.shape)
+        for ax in axes:
+            shape[ax] = self._md
+        out = np.zeros(shape)
+        out[tuple(slice(0, self.m) if i in [ax % a.ndim for ax in axes] else slice(None) for i in range(a.ndim))] = a
+        if diag and len(axes) == 2:
+            for k in range(self.m, self._md):
+                out[k, k] = diag
         return out
+
+    def _dev_shape(self, which, shape):
+        if self._md == self.m or which not in self._U_AXIS:
+            return tuple(shape), None
+        ax = len(shape) + self._U_AXIS[which]
+        dev = list(shape)
+        dev[ax] = self._md
+        return tuple(dev), ax
+
+    def _cut_u(self, out, ax):
+        return out if ax is None else out[tuple(slice(0, self.m) if i == ax else slice(None) for i in range(out.ndim))]
+
+    def _get(self, which, shape):
+        dev, ax = self._dev_shape(which, shape)
+        out = self._out(which, dev, np.float64)
+        _capi.check(self._lib.mi_ilqr_get(self._h, which, _capi.ptr(out), out.nbytes), "mi_ilqr_get")
+        return self._cut_u(out, ax)
 
     def _get_int(self, which, shape):
         out = self._out(which, shape, np.int32)
@@ -184,6 +218,9 @@ class BatchedIterativeLQR:
         return out
 
     def _set(self, which, arr, shape):
+        dev, ax = self._dev_shape(which, shape)
+        if ax is not None:
+            arr, shape = self._pad_u(np.asarray(arr, dtype=np.float64).reshape(shape), (ax,)), dev
         arr = _capi.as_f64(arr, shape)
         _capi.check(self._lib.mi_ilqr_set(self._h, which, _capi.ptr(arr), arr.nbytes), "mi_ilqr_set")
 
@@ -271,7 +308,7 @@ class BatchedIterativeLQR:
         handle (pipelined solves, MPCRun, stage calls) touches arrays a caller holds; the other kernel families enqueue
         three copy-outs behind the solve.  `extra`: (field, destination) pairs copied out behind the solve as well."""
         res = [self._out(which, shp, np.float64) for which, shp in
-               ((_capi.F_X_BAR, (self.B, self.n, self.N)), (_capi.F_U_BAR, (self.B, self.m, self.N - 1)), (_capi.F_COST, (self.B,)))]
+               ((_capi.F_X_BAR, (self.B, self.n, self.N)), (_capi.F_U_BAR, (self.B, self._md, self.N - 1)), (_capi.F_COST, (self.B,)))]
         pinned = all(r.base is not None for r in res)
         sink = False
         if pinned and self._sink is not False:
@@ -290,6 +327,8 @@ class BatchedIterativeLQR:
         finally:
             if sink:
                 _capi.check(self._lib.mi_ilqr_set_result_sink(self._h, None, None, None), "mi_ilqr_set_result_sink")
+        if self._md != self.m:
+            res[1] = res[1][:, :self.m, :]
         return res
 
     def solve_resident(self):
@@ -472,7 +511,7 @@ class IterativeLinearQuadraticRegulator(BatchedIterativeLQR):
             raise RuntimeError("Quu is not positive definite in the backward pass (indefinite cost expansion, or round-off); "
                                "the reference would invert it all the same (ilqr.py:655) - its gains are no descent direction")
         if res is not None:
-            return res[0].reshape(self.n, self.N), res[1].reshape(self.m, self.N - 1), total_time, float(res[2][0])
+            return res[0].reshape(self.n, self.N), res[1][0], total_time, float(res[2][0])
         return self.x_bar, self.u_bar, total_time, float(self.cost[0])
 
     def SaveSolution(self, fname):

@@ -51,10 +51,13 @@ class ModelSystem:
             raise ValueError("too many model parameters")
 
     @classmethod
-    def registered(cls, model_id, n, m, dt, params):
-        """A model registered at run time (drake_ddp_amd/plugin.py, mi_ilqr_register_model)."""
+    def registered(cls, model_id, n, m, dt, params, m_user=0):
+        """A model registered at run time (drake_ddp_amd/plugin.py, mi_ilqr_register_model).  m_user: the model's own number
+        of controls when the device model carries padding controls (plugin.device_controls): `m` is what callers see,
+        `m_dev` what the device arrays are sized with."""
         s = cls.__new__(cls)
-        s.model_id, s.n, s.m, s.dt = int(model_id), int(n), int(m), float(dt)
+        s.model_id, s.n, s.m, s.dt = int(model_id), int(n), int(m_user) if m_user else int(m), float(dt)
+        s.m_dev = int(m)
         s.params = np.array(params, dtype=np.float64)
         if s.params.size > _capi.MAX_PARAMS:
             raise ValueError("too many model parameters")

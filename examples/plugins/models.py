@@ -121,6 +121,15 @@ def build_chainx(nq, m, ne=0, verbose=False):
 CHAINX_SHAPES = [(6, 4, 0), (7, 7, 0), (10, 7, 7), (16, 16, 0), (4, 4, 1), (3, 3, 1), (8, 1, 0)]
 
 
+# n > 32 with a number of controls that is not a multiple of 4: the plugin pads the device model's controls (plugin.device_controls),
+# the classes of drake_ddp_amd/ilqr.py hide it: (n, m) = (36, 7) -> 8 device controls, (37, 3) -> 4
+PADDED_SHAPES = [(18, 7, 0), (16, 3, 5)]
+# 32 < n <= 40 with m in {4, 8, 16}: every layout class of the n > 32 backward pass other than the bench's (36, 12) - x's tail and
+# u sharing a tile exactly ((40, 8)), a tile of its own for u because they would not fill one ((36, 4), (36, 8), (40, 4)) or
+# because n % 4 != 0 ((35, 4), (38, 8), (39, 12)), and sixteen pivots ((33, 16), (36, 16), (40, 16))
+LARGE_SHAPES = [(18, 4, 0), (18, 8, 0), (20, 4, 0), (20, 8, 0), (17, 4, 1), (19, 8, 0), (19, 12, 1), (16, 16, 1), (18, 16, 0), (20, 16, 0)]
+
+
 def chain_spec(nq):
     return ("chain%d" % nq, 2 * nq, 12, chain_body(nq), CHAIN_DEFAULTS, "large")
 
@@ -136,7 +145,7 @@ def build_all(verbose=False):
     specs = [("vdp", 2, 1, VDP_BODY, VDP_DEFAULTS, "small"), ("kink2", 2, 1, KINK2_BODY, KINK2_DEFAULTS, "small"),
              ("chain3", 6, 2, CHAIN3_BODY, CHAIN3_DEFAULTS, "small"),
              ("synth36p", 36, 12, SYNTH36P_BODY, SYNTH36P_DEFAULTS, "large"), chain_spec(17), chain_spec(20)]
-    specs += [chainx_spec(*sh) for sh in CHAINX_SHAPES]
+    specs += [chainx_spec(*sh) for sh in CHAINX_SHAPES + PADDED_SHAPES + LARGE_SHAPES]
     return plugin.build_models(specs, verbose=verbose)
 
 

@@ -172,7 +172,11 @@ int mi_ilqr_model_info(int model_id, int32_t* n, int32_t* m, int32_t* n_params, 
  *   family 1: workgroup-per-problem kernels - n <= 32 with ANY m <= 16 (one or two 16-row tiles: the shapes of a quadrotor
  *             (12, 4), a 7-joint arm (14, 7), kinova_gen3.py's arm + free body (27, 7)), or 32 < n <= 40 with m <= 16,
  *             m % 4 == 0, 2 m <= n; dynamics as `step` per Jacobian column and a one-lane step in the rollout unless the
- *             model provides the cooperative hooks of csrc/models.hpp.
+ *             model provides the cooperative hooks of csrc/models.hpp.  A model with 32 < n <= 40 and another number of
+ *             controls declares m as the next multiple of 4 and ignores the extra ones; with any positive cost on them
+ *             (R block-diagonal) and a zero initial guess their gains, feed-forward terms and values stay EXACT zeros
+ *             (zero columns of fu, zero rows of Qux) and every other result is what the unpadded problem gives.  The
+ *             Python mirror does this by itself (drake_ddp_amd/plugin.py pads, drake_ddp_amd/ilqr.py hides it).
  * Plugin models are served by these two families only (no lane-per-problem THROUGHPUT kernels). */
 enum { MI_MODEL_PLUGIN_BASE = 100, MI_ILQR_MAX_PLUGINS = 32 };
 typedef struct {
@@ -180,7 +184,8 @@ typedef struct {
   int32_t kernel_args_bytes;        /* ... their sizeof(mi::KArgs) ... */
   int32_t handle_bytes;             /* ... and their sizeof(struct mi_ilqr) (the plugin's launch code reads the handle's stream,
                                        events and LDS size): a plugin built from other headers is refused (ABI 6) */
-  int32_t reserved_;
+  int32_t m_user;                   /* 0, or the number of controls the model's step READS when that is fewer than m: controls
+                                       m_user .. m-1 are padding (see family 1 above); informational - hosts size their arrays with m */
   int32_t n, m, n_params, family;
   double default_params[MI_ILQR_MAX_PARAMS];
   int (*launch)(mi_ilqr_t* h, int mode, const void* kernel_args);   /* instantiates and launches the model's kernels */

@@ -23,7 +23,7 @@ def test_mid_family_registers_the_reviewed_shapes():
     import ctypes as C
     import models as PM
     from drake_ddp_amd import _capi, plugin
-    assert PM.CHAINX_SHAPES == SHAPES
+    assert PM.CHAINX_SHAPES == SHAPES and PM.PADDED_SHAPES == PADDED and PM.LARGE_SHAPES == LARGE
     make = PM.build_all()
     for nq, m, ne in SHAPES:
         s = make["chainx_%d_%d_%d" % (nq, m, ne)](0.01)
@@ -95,12 +95,23 @@ def test_mid_backward_pass_on_random_inputs(shape):
     print(f"mid backward {IDS[SHAPES.index(shape)]}: worst relative error vs extended precision {worst:.2e} (NumPy fp64 oracle: {worst_ref:.2e}; max cond(Quu) {worst_cond:.1e})")
 
 
+PADDED = [(18, 7, 0), (16, 3, 5)]       # n = 36, m = 7 and n = 37, m = 3: the n > 32 kernels with padded controls
+# n > 32 with m = 4, 8, 16 (examples/plugins/models.py: LARGE_SHAPES).  Until round 4 only m = 12 had ever run on these kernels,
+# and (36, 4), (36, 8), (40, 4) - pad columns behind u inside the shared tile - and every m = 16 (row stride of Quu^{-1}'s
+# exchange buffer) returned WRONG gains without any error; found by the sweep of all 32 (n, m) in 33..40 x {4, 8, 12, 16}.
+LARGE = [(18, 4, 0), (18, 8, 0), (20, 4, 0), (20, 8, 0), (17, 4, 1), (19, 8, 0), (19, 12, 1), (16, 16, 1), (18, 16, 0), (20, 16, 0)]
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", SHAPES, ids=IDS)
+@pytest.mark.parametrize("shape", SHAPES + PADDED + LARGE, ids=IDS + ["n36_m7_padded", "n37_m3_padded"] + ["n%d_m%d" % (2 * a + c, b) for a, b, c in LARGE])
 def test_mid_family_solves_like_the_oracle(shape):
     """End to end on a plugin model of the shape: forward-mode duals after two iterations (round-off level: x_bar 1e-11,
     K / kappa 1e-10) and at convergence (iterations, step sizes and trial counts exact, cost 1e-10); central differences
-    at convergence (counts exact, cost 1e-8, trajectories 1e-6: SURVEY 8(c))."""
+    at convergence (counts exact, cost 1e-8, trajectories 1e-6: SURVEY 8(c)).
+    The two PADDED shapes close the last hole in n <= 40: above 32 states the matrix-core backward pass wants m % 4 == 0, so
+    the plugin's device model carries one padding control that its step never reads (8 for 7, 4 for 3) and the class pads R
+    with a unit block and the guess with zeros - the padding's gains, feed-forward terms and inputs are exact zeros and what
+    the caller sees has m controls: compared here with the NumPy oracle of the UNPADDED problem."""
     import models as PM
     import plugin_steps as PS
     from drake_ddp_amd.ilqr import BatchedIterativeLQR
@@ -110,6 +121,7 @@ def test_mid_family_solves_like_the_oracle(shape):
     n = 2 * nq + ne
     dt, N, B = 0.02, 24, 3
     sys_ = PM.build_chainx(nq, m, ne)(dt)
+    assert (sys_.n, sys_.m) == (n, m) and sys_.m_dev == (m if shape not in PADDED else 4 * ((m + 3) // 4))
     rng = np.random.default_rng(n * 17 + m)
     x_nom = np.zeros(n)
     x0 = 0.4 * rng.standard_normal((B, n))
@@ -133,6 +145,7 @@ def test_mid_family_solves_like_the_oracle(shape):
             hist = np.array(hist)
             assert s.iterations[b] == len(hist) and np.array_equal(s.history[b][:len(hist), 1:3], hist[:, 1:3]), (jac, cap, b)
             sc = lambda a_: max(1.0, float(np.max(np.abs(a_))))
+            assert s.u_bar.shape == (B, m, N - 1) and s.K.shape == (B, m, n, N - 1) and s.fu.shape == (B, n, m, N - 1)
             if cap == 2:
                 assert np.max(np.abs(s.x_bar[b] - xo)) < 1e-11 * sc(xo) and np.max(np.abs(s.K[b] - o.K)) < 1e-10 * sc(o.K)
                 assert np.max(np.abs(s.kappa[b] - o.kappa)) < 1e-10 * sc(o.kappa)
@@ -145,7 +158,7 @@ def test_mid_family_solves_like_the_oracle(shape):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", [(6, 4, 0), (10, 7, 7)], ids=["n12_m4", "n27_m7"])
+@pytest.mark.parametrize("shape", [(6, 4, 0), (10, 7, 7), (18, 7, 0)], ids=["n12_m4", "n27_m7", "n36_m7_padded"])
 def test_mid_family_mpc_loop_and_keypoints(shape):
     """The receding-horizon loop on the device (mi_ilqr_mpc_run: stale-gain first rollouts) and the key-point
     methods (shared code of the workgroup-per-problem kernels) on mid-size shapes: per-re-solve iteration counts exact,
