@@ -543,7 +543,7 @@ int mi_ilqr_create(const mi_ilqr_desc* desc, mi_ilqr_t** out) {
   const ModelInfo* info = model_info(desc->model_id);
   if (!info) return MI_ILQR_E_BAD_ARG;
   if (desc->n != info->n || desc->m != info->m) return MI_ILQR_E_BAD_SHAPE;
-  if (desc->N < 4 || desc->B < 1) return MI_ILQR_E_BAD_SHAPE;
+  if (desc->N < 2 || desc->B < 1) return MI_ILQR_E_BAD_SHAPE;
   if (desc->keypoint_method < MI_KP_SET_INTERVAL || desc->keypoint_method > MI_KP_ITERATIVE_ERROR) return MI_ILQR_E_BAD_METHOD;
   if (desc->minN < 1) return MI_ILQR_E_BAD_ARG;
   if (desc->jacobian_mode != MI_JAC_FD_CENTRAL && desc->jacobian_mode != MI_JAC_AUTODIFF) return MI_ILQR_E_BAD_ARG;

@@ -563,3 +563,34 @@ def test_set_control_limits_is_the_reference_stub():
     one.SetInitialState(x0[0]); one.SetInitialGuess(np.zeros((1, p["N"] - 1)))
     x1, u1, _, L1 = one.Solve()
     assert np.array_equal(x1, out[0][0][0]) and L1 == out[0][2][0]
+
+
+@pytest.mark.parametrize("N", [2, 3])
+def test_shortest_horizons_vs_c_oracle(N):
+    """The reference takes any num_timesteps >= 2 (ilqr.py:51); until round 4 mi_ilqr_create refused N < 4 without a
+    reason.  One and two control steps on every kernel family (wave-per-problem, lane-per-problem, mid-size and n = 36
+    workgroup-per-problem) against the C oracle: costs to round-off and the same trajectories.  (The iteration / trial COUNTS
+    are not compared: a one-step problem is solved by its first iteration and every later cost comparison, L_last - L > 0 with
+    gamma = 0, is a tie decided by the last bit - the reference's own line search is a coin flip there.)"""
+    from drake_ddp_amd import workloads as W
+    from oracle import c_oracle, models_np as M
+    B = 70
+    for name, prob, x0, m, modes in (("pendulum", W.pendulum_problem(), W.pendulum_batch_x0(128)[:B], 1, ("auto", "throughput")),
+                                     ("acrobot", W.acrobot_problem(), W.acrobot_batch_x0(128)[:B], 1, ("auto", "throughput")),
+                                     ("cart-pole + wall", W.cartpole_wall_problem(), W.cartpole_wall_batch_x0(128)[:B], 1, ("auto",)),
+                                     ("36-state chain", W.synth36_problem(), W.synth36_batch_x0(B), 12, ("auto",)),
+                                     ("arm + ball", W.arm27_problem(), W.arm27_batch_x0(B), 7, ("auto",))):
+        p = dict(prob, N=N)
+        ug = 0.1 * np.random.default_rng(1).standard_normal((B, m, N - 1))
+        r = c_oracle.solve_batch(M.Model(p["model_id"], p["dt"]), p, x0, ug)
+        for mode in modes:
+            s = make_solver(p, B=B, jac="fd", kernel_mode=mode)
+            s.SetInitialState(x0); s.SetInitialGuess(ug)
+            try:
+                s.Solve()
+            except RuntimeError:                         # (a line search that ran out of step sizes on a tie)
+                pass
+            rel = np.abs(s.cost - r["cost"]) / np.abs(r["cost"])
+            xe = np.abs(s.x_bar - r["x_bar"]).max()
+            print(f"N = {N} {name} ({mode}): cost {rel.max():.1e}, x {xe:.1e}")
+            assert np.isfinite(s.x_bar).all() and rel.max() < 1e-11 and xe < 2e-5
