@@ -633,3 +633,50 @@ def test_longest_horizons_of_the_workgroup_kernels_vs_c_oracle():
         with pytest.raises(MiIlqrError) as e:
             make_solver(dict(prob, N=N + 1), B=B, jac="fd")
         assert e.value.code == _capi.E_UNSUPPORTED
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
+def test_randomized_configs_of_the_workgroup_kernels_vs_c_oracle(seed):
+    """test_randomized_configs_vs_c_oracle for the workgroup-per-problem families: random horizon (5 .. 60), beta (0.3 .. 0.85),
+    gamma (0, 0.1, 0.3: the expected-improvement side of the test of ilqr.py:330, also inside the four-candidate passes of
+    the mid-size kernels), random positive weights, on the arm + ball (backtracks), the 36-state chain and the 3-D quadruped.
+    Decisions (status, iterations, trials) against the C oracle with at most the flips the oracle shows against itself (x0 one
+    ulp away) + 1; costs of the agreeing problems within 10 x its own deviation (at least 1e-8)."""
+    from drake_ddp_amd import workloads as W
+    from oracle import c_oracle, models_np as M
+    rng = np.random.default_rng(500 + seed)
+    name = ["arm", "arm", "synth36", "quad3d", "arm", "synth36"][seed]
+    base, x0f, ugf = {"arm": (W.arm27_problem(), W.arm27_batch_x0, W.arm27_u_guess), "synth36": (W.synth36_problem(), W.synth36_batch_x0, W.synth36_u_guess),
+                      "quad3d": (W.quad3d_problem(), W.quad3d_batch_x0, W.quad3d_u_guess)}[name]
+    n, m = base["Q"].shape[0], base["R"].shape[0]
+    N = int(rng.integers(5, 61))
+    B = int(rng.integers(3, 40))
+    def scale(M_):                                   # D M D with a random positive diagonal D: symmetric, as definite as M
+        d_ = np.sqrt(10.0 ** rng.uniform(-0.5, 0.5, M_.shape[0]))
+        return M_ * d_[:, None] * d_[None, :]
+    prob = dict(base, N=N, Q=scale(base["Q"]), R=scale(base["R"]), Qf=scale(base["Qf"]),
+                beta=float(rng.choice([0.3, 0.5, 0.7, 0.85])), gamma=float(rng.choice([0.0, 0.1, 0.3])))
+    x0, ug = x0f(B), ugf(N)
+    s = make_solver(prob, B=B, jac="fd", hist_cap=8)
+    s.SetInitialState(x0); s.SetInitialGuess(ug)
+    try:
+        s.Solve()
+    except RuntimeError:
+        pass
+    model = M.Model(prob["model_id"], prob["dt"])
+    r = c_oracle.solve_batch(model, prob, x0, ug)
+    same = (s.status == r["status"]) & (s.iterations == r["iters"]) & (s.ls_trials == r["ls"])
+    flips, own = 0, 0.0
+    for d in (np.inf, -np.inf):
+        xq = x0.copy()
+        xq[:, 0] = np.nextafter(xq[:, 0], d)
+        rq = c_oracle.solve_batch(model, prob, xq, ug)
+        keep = (rq["iters"] == r["iters"]) & (rq["ls"] == r["ls"]) & (rq["status"] == r["status"])
+        flips = max(flips, int((~keep).sum()))
+        if keep.any():
+            own = max(own, float((np.abs(rq["cost"] - r["cost"]) / np.abs(r["cost"]))[keep].max()))
+    rel = np.abs(s.cost - r["cost"]) / np.abs(r["cost"])
+    print(f"{name} N = {N} B = {B} beta {prob['beta']} gamma {prob['gamma']}: {int(r['ls'].sum())} trials in {int(r['iters'].sum())} iterations, statuses {np.unique(r['status']).tolist()}; "
+          f"{int((~same).sum())} problems decide differently (the oracle against itself: {flips}); cost {rel[same].max() if same.any() else 0:.1e} (own {own:.1e})")
+    assert int((~same).sum()) <= flips + 1
+    assert same.any() and rel[same].max() <= max(1e-8, 10 * own)
