@@ -680,3 +680,37 @@ def test_randomized_configs_of_the_workgroup_kernels_vs_c_oracle(seed):
           f"{int((~same).sum())} problems decide differently (the oracle against itself: {flips}); cost {rel[same].max() if same.any() else 0:.1e} (own {own:.1e})")
     assert int((~same).sum()) <= flips + 1
     assert same.any() and rel[same].max() <= max(1e-8, 10 * own)
+
+
+def test_a_poisoned_problem_fails_alone():
+    """NaN in one problem's x0: the reference's line search would run out of step sizes on it (every cost comparison with NaN
+    is false, ilqr.py:330-337) - status LINESEARCH_FAILED for that problem, no hang, and its batch neighbours come out
+    bitwise as from a clean batch, on every kernel family.  An infinite initial guess fails the same way; NaN cost matrices
+    are refused by the workgroup-per-problem families at set_cost and fail every problem's first search elsewhere."""
+    from drake_ddp_amd import workloads as W, _capi
+    for name, prob, x0, ug, kw in (("pendulum", W.pendulum_problem(), W.pendulum_batch_x0(70), np.zeros((1, 199)), {}),
+                                   ("pendulum, lane per problem", W.pendulum_problem(), W.pendulum_batch_x0(70), np.zeros((1, 199)), {"kernel_mode": "throughput"}),
+                                   ("cart-pole + wall", W.cartpole_wall_problem(), W.cartpole_wall_batch_x0(70), np.zeros((1, 199)), {}),
+                                   ("36-state chain", W.synth36_problem(), W.synth36_batch_x0(9), W.synth36_u_guess(40), {}),
+                                   ("3-D quadruped", W.quad3d_problem(), W.quad3d_batch_x0(9), W.quad3d_u_guess(40), {}),
+                                   ("arm + ball", W.arm27_problem(), W.arm27_batch_x0(9), W.arm27_u_guess(50), {})):
+        B = len(x0)
+        clean = make_solver(prob, B=B, jac="fd", **kw)
+        clean.SetInitialState(x0); clean.SetInitialGuess(ug)
+        xc, uc, _, Lc = clean.Solve()
+        bad = x0.copy()
+        bad[3, 0] = np.nan
+        s = make_solver(prob, B=B, jac="fd", **kw)
+        s.SetInitialState(bad); s.SetInitialGuess(ug)
+        x, u, _, L = s.Solve()
+        others = np.arange(B) != 3
+        assert s.status[3] == _capi.STATUS_LINESEARCH_FAILED and (s.status[others] == clean.status[others]).all(), name
+        assert np.array_equal(x[others], xc[others]) and np.array_equal(u[others], uc[others]) and np.array_equal(L[others], Lc[others]), name
+        assert np.array_equal(s.iterations[others], clean.iterations[others]), name
+        g = np.broadcast_to(np.asarray(ug, dtype=float), (B,) + np.asarray(ug).shape[-2:]).copy()
+        g[5, 0, 0] = np.inf
+        t = make_solver(prob, B=B, jac="fd", **kw)
+        t.SetInitialState(x0); t.SetInitialGuess(g)
+        t.Solve()
+        assert t.status[5] == _capi.STATUS_LINESEARCH_FAILED and (np.delete(t.status, 5) == np.delete(clean.status, 5)).all(), name
+        print(f"{name}: the poisoned problem stops with status 2, the other {B - 1} are bitwise the clean batch's")
