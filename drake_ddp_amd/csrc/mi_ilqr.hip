@@ -1003,11 +1003,30 @@ int mi_ilqr_mpc_shift(mi_ilqr_t* h, int32_t replan_steps) {
   return MI_ILQR_OK;
 }
 
+// host-loop form of the receding-horizon loop: the record the single-launch kernels write themselves (x0 | cost | iterations)
+__global__ void __launch_bounds__(256) mpc_log_fill_kernel(const double* __restrict__ x0, const double* __restrict__ cost,
+                                                           const int32_t* __restrict__ iters, double* __restrict__ log, int B, int n,
+                                                           int resolves, int r) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  double* lg = log + ((size_t)b * resolves + r) * (n + 2);
+  for (int i = 0; i < n; ++i) lg[i] = x0[(size_t)b * n + i];
+  lg[n] = cost[b];
+  lg[n + 1] = (double)iters[b];
+}
+
 int mi_ilqr_mpc_run(mi_ilqr_t* h, int32_t num_resolves, int32_t replan_steps, const double* target_step, mi_ilqr_stats* stats) {
   if (!h) return MI_ILQR_E_BAD_ARG;
   if (num_resolves < 1 || replan_steps < 1 || replan_steps >= h->N - 1) return MI_ILQR_E_BAD_ARG;
   HIPCHK(hipSetDevice(h->d.device_id));
   int rc;
+  if (h->mpc_log_resolves < num_resolves) {
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->mpc_log) HIPCHK(hipFree(h->mpc_log));
+    h->mpc_log = nullptr;
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&h->mpc_log), (size_t)h->B * num_resolves * (h->n + 2) * 8));
+    h->mpc_log_resolves = num_resolves;
+  }
   const bool large_on_device = h->large && (size_t)h->m * (h->N - 1) <= 8 * (size_t)kLargeThreads;
   if ((h->large && !large_on_device) || h->batch_minor || (!h->large && (h->N > 512 || h->n > 8))) {
     // lane-per-problem path (and horizons the in-kernel shift does not cover): loop shift + solve on the host
@@ -1024,24 +1043,21 @@ int mi_ilqr_mpc_run(mi_ilqr_t* h, int32_t num_resolves, int32_t replan_steps, co
       }
       mi_ilqr_stats st;
       if ((rc = mi_ilqr_solve(h, &st)) != MI_ILQR_OK) return rc;
+      hipLaunchKernelGGL(mpc_log_fill_kernel, dim3((h->B + 255) / 256), dim3(256), 0, h->stream, h->x0, h->cost, h->iters, h->mpc_log,
+                         h->B, h->n, num_resolves, r);
+      HIPCHK(hipGetLastError());
       acc.total_iters += st.total_iters; acc.total_ls_trials += st.total_ls_trials; acc.kernel_ms += st.kernel_ms;
       acc.algorithmic_bytes += st.algorithmic_bytes;
       acc.n_converged = st.n_converged; acc.n_max_iters = st.n_max_iters; acc.n_ls_failed = st.n_ls_failed; acc.n_internal = st.n_internal; acc.n_not_pd = st.n_not_pd;
       if (st.max_iters_seen > acc.max_iters_seen) acc.max_iters_seen = st.max_iters_seen;
       acc.best_cost = st.best_cost; acc.best_index = st.best_index;
     }
+    h->mpc_resolves = num_resolves; h->mpc_replan = replan_steps;
     if (stats) *stats = acc;
     return MI_ILQR_OK;
   }
   if ((rc = materialize_zero_state(h)) != MI_ILQR_OK) return rc;
   if ((rc = materialize_u(h)) != MI_ILQR_OK) return rc;
-  if (h->mpc_log_resolves < num_resolves) {
-    HIPCHK(hipStreamSynchronize(h->stream));
-    if (h->mpc_log) HIPCHK(hipFree(h->mpc_log));
-    h->mpc_log = nullptr;
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(&h->mpc_log), (size_t)h->B * num_resolves * (h->n + 2) * 8));
-    h->mpc_log_resolves = num_resolves;
-  }
   h->mpc_resolves = num_resolves; h->mpc_replan = replan_steps;
   for (int i = 0; i < kMaxStateDim; ++i) h->mpc_target_step[i] = (target_step && i < h->n) ? target_step[i] : 0.0;
   rc = launch(h, MODE_MPC);

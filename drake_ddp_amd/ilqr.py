@@ -379,7 +379,7 @@ class BatchedIterativeLQR:
 
     @property
     def mpc_log(self):
-        """(B, num_resolves, n+2): x0 of each re-solve | cost | iterations (single-launch paths)."""
+        """(B, num_resolves, n+2): x0 of each re-solve | cost | iterations (written by the single-launch kernels, or after each re-solve of the host loop)."""
         out = np.empty((self.B, self._mpc_resolves, self.n + 2), dtype=np.float64)
         _capi.check(self._lib.mi_ilqr_get_mpc_log(self._h, _capi.ptr(out), out.nbytes), "mi_ilqr_get_mpc_log")
         return out

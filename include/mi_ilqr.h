@@ -271,7 +271,7 @@ int mi_ilqr_mpc_shift(mi_ilqr_t* h, int32_t replan_steps);
  * Limits of the single-launch form: wave-per-problem kernels N <= 512 (the in-kernel shift holds eight
  * controls per lane), workgroup-per-problem kernel m*(N-1) <= 2048.  Beyond them, and for the
  * lane-per-problem "throughput" kernels, the same loop runs as shift + solve launches from the host:
- * same results, no log (mi_ilqr_get_mpc_log then returns MI_ILQR_E_BAD_ARG). */
+ * same results, same log (filled after each re-solve). */
 int mi_ilqr_mpc_run(mi_ilqr_t* h, int32_t num_resolves, int32_t replan_steps, const double* target_step, mi_ilqr_stats* stats);
 int mi_ilqr_get_mpc_log(mi_ilqr_t* h, double* dst, size_t bytes);
 

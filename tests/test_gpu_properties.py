@@ -714,3 +714,41 @@ def test_a_poisoned_problem_fails_alone():
         t.Solve()
         assert t.status[5] == _capi.STATUS_LINESEARCH_FAILED and (np.delete(t.status, 5) == np.delete(clean.status, 5)).all(), name
         print(f"{name}: the poisoned problem stops with status 2, the other {B - 1} are bitwise the clean batch's")
+
+
+@pytest.mark.parametrize("replan", ["1", "N-2"])
+def test_mpc_loop_replan_extremes_vs_c_oracle(replan):
+    """The receding-horizon loop (acrobot.py:145-155) with the shortest and the longest shift the reference's warm start allows
+    - one step, and N - 2 steps (all but one control of the new guess is the repeated last one) - three re-solves, on the
+    wave-per-problem (pendulum), lane-per-problem (acrobot, host loop), n = 36 and mid-size workgroup kernels: per-re-solve
+    iteration counts and x0's against oracle_mpc_batch; a shift of N - 1 is refused."""
+    from drake_ddp_amd import workloads as W, _capi
+    from drake_ddp_amd._capi import MiIlqrError
+    from oracle import c_oracle, models_np as M
+    for name, prob, x0, ug, kw in (("pendulum", dict(W.pendulum_problem(), N=60), W.pendulum_batch_x0(40), np.zeros((1, 59)), {}),
+                                   ("acrobot, lane per problem", W.acrobot_problem(), W.acrobot_batch_x0(70), np.zeros((1, 39)), {"kernel_mode": "throughput"}),
+                                   ("36-state chain", W.synth36_problem(), W.synth36_batch_x0(6), W.synth36_u_guess(40), {}),
+                                   ("arm + ball", dict(W.arm27_problem(), N=20), W.arm27_batch_x0(6), W.arm27_u_guess(20), {})):
+        N, n = prob["N"], prob["Q"].shape[0]
+        r_ = 1 if replan == "1" else N - 2
+        s = make_solver(prob, B=len(x0), jac="fd", **kw)
+        s.SetInitialState(x0); s.SetInitialGuess(ug)
+        s.Solve()
+        first_it = s.iterations.copy()
+        try:
+            s.MPCRun(3, r_)
+        except RuntimeError:
+            pass
+        log = s.mpc_log
+        r = c_oracle.mpc_batch(M.Model(prob["model_id"], prob["dt"]), prob, x0, ug, 3, r_)
+        assert np.array_equal(first_it, r["first"][:, 1].astype(int)), name
+        same = (log[:, :, -1] == r["log"][:, :, -1]).all(axis=1)
+        relL = np.abs(log[:, :, -2] - r["log"][:, :, -2]) / np.abs(r["log"][:, :, -2])
+        dx = np.abs(log[:, :, :n] - r["log"][:, :, :n]).max()
+        print(f"{name} replan {r_}: {int(same.sum())}/{len(x0)} problems with the oracle's iteration counts in every re-solve, costs {relL[same].max():.1e}, x0 of the re-solves {dx:.1e}")
+        # (a shift of N - 2 steps applies gains far from where they were computed, SURVEY F10: round-off grows by the re-solve -
+        #  5e-9, 1e-8, 4e-6 on the pendulum - while every count stays the oracle's)
+        assert same.mean() >= 0.9 and relL[same].max() < (1e-6 if r_ == 1 else 1e-4) and np.abs(log[same][:, :, :n] - r["log"][same][:, :, :n]).max() < 1e-4
+        with pytest.raises(MiIlqrError) as e:
+            s.MPCRun(1, N - 1)
+        assert e.value.code == _capi.E_BAD_ARG
