@@ -752,3 +752,58 @@ def test_mpc_loop_replan_extremes_vs_c_oracle(replan):
         with pytest.raises(MiIlqrError) as e:
             s.MPCRun(1, N - 1)
         assert e.value.code == _capi.E_BAD_ARG
+
+
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_randomized_keypoint_configs_vs_c_oracle(seed):
+    """The three key-point methods (ilqr.py:417-593) with random minN / maxN / thresholds on every kernel family - wave per
+    problem, lane per problem (per-lane lists), mid-size and n = 36 workgroup kernels: statuses, iterations, trials, the
+    key-point count of every iteration and the last key-point list against the C oracle.  A jerk or an interpolation error within
+    round-off of its threshold may fall on the other side (libm against the device's sin / cos): at most two problems of a case
+    may differ from the oracle, every other one is exact."""
+    from drake_ddp_amd import workloads as W
+    from oracle import c_oracle, models_np as M
+    rng = np.random.default_rng(900 + seed)
+    name, prob, x0f, ugf, kw = [("pendulum", W.pendulum_problem(), lambda B: W.pendulum_batch_x0(128)[:B], lambda N: np.zeros((1, N - 1)), {}),
+                                ("acrobot, lane per problem", W.acrobot_problem(), lambda B: W.acrobot_batch_x0(128)[:B], lambda N: np.zeros((1, N - 1)), {"kernel_mode": "throughput"}),
+                                ("arm + ball", W.arm27_problem(), W.arm27_batch_x0, W.arm27_u_guess, {}),
+                                ("36-state chain", W.synth36_problem(), W.synth36_batch_x0, W.synth36_u_guess, {}),
+                                ("acrobot", W.acrobot_problem(), lambda B: W.acrobot_batch_x0(128)[:B], lambda N: np.zeros((1, N - 1)), {}),
+                                ("pendulum, lane per problem", W.pendulum_problem(), lambda B: W.pendulum_batch_x0(128)[:B], lambda N: np.zeros((1, N - 1)), {"kernel_mode": "throughput"}),
+                                ("arm + ball", W.arm27_problem(), W.arm27_batch_x0, W.arm27_u_guess, {}),
+                                ("3-D quadruped", W.quad3d_problem(), W.quad3d_batch_x0, W.quad3d_u_guess, {})][seed]
+    method = ["adaptiveJerk", "iterativeError", "iterativeError", "adaptiveJerk", "setInterval", "adaptiveJerk", "setInterval", "iterativeError"][seed]
+    N = int(rng.integers(12, 70)) if prob["Q"].shape[0] > 4 else int(rng.integers(30, 200))
+    minN = int(rng.integers(1, 6))
+    kp = (method, minN, minN + int(rng.integers(1, 12)), float(10.0 ** rng.uniform(-6, -3)), float(10.0 ** rng.uniform(-9, -5)))
+    B = 24 if prob["Q"].shape[0] > 4 else 70
+    p = dict(prob, N=N)
+    x0, ug = x0f(B), ugf(N)
+    s = make_solver(p, B=B, keypoint=kp, jac="fd", hist_cap=64, **kw)
+    s.SetInitialState(x0); s.SetInitialGuess(ug)
+    try:
+        s.Solve()
+    except RuntimeError:
+        pass
+    r = c_oracle.solve_batch(M.Model(p["model_id"], p["dt"]), p, x0, ug, keypoint=kp, hist_cap=64)
+    h, nk, kl = s.history, s.keypoint_count, s.keypoint_list
+    exact = np.zeros(B, bool)
+    for b in range(B):
+        it = min(int(r["iters"][b]), 64)
+        exact[b] = (s.status[b] == r["status"][b] and s.iterations[b] == r["iters"][b] and s.ls_trials[b] == r["ls"][b]
+                    and np.array_equal(np.round(h[b, :it, 3] * (N - 1) / 100.0), r["hist"][b, :it, 3])
+                    and nk[b] == r["kp_count"][b] and np.array_equal(kl[b][:nk[b]], r["kp_list"][b][:nk[b]]))
+    # (long stiff solves - the plain cart-pole over 190 steps - amplify round-off by the iteration: the yardstick is again the
+    #  oracle against itself with x0 one ulp away)
+    flips = 0
+    if (~exact).sum() > 2:
+        for d in (np.inf, -np.inf):
+            xq = x0.copy()
+            xq[:, 1] = np.nextafter(xq[:, 1], d)
+            rq = c_oracle.solve_batch(M.Model(p["model_id"], p["dt"]), p, xq, ug, keypoint=kp, hist_cap=64)
+            flips = max(flips, int(((rq["iters"] != r["iters"]) | (rq["ls"] != r["ls"]) | (rq["kp_count"] != r["kp_count"])).sum()))
+    print(f"{name} N = {N} {kp}: {int(exact.sum())}/{B} problems exact (statuses {np.unique(r['status']).tolist()}, key-points {r['kp_count'].min()}..{r['kp_count'].max()} of {N - 1})"
+          + (f"; the oracle against itself, x0 one ulp away: {flips} problems differ" if flips else ""))
+    assert (~exact).sum() <= 2 + flips
+    ok = exact & (r["status"] == 0)
+    assert ok.any() and (np.abs(s.cost - r["cost"]) / np.abs(r["cost"]))[ok].max() < 1e-6
