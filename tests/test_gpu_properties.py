@@ -807,3 +807,24 @@ def test_randomized_keypoint_configs_vs_c_oracle(seed):
     assert (~exact).sum() <= 2 + flips
     ok = exact & (r["status"] == 0)
     assert ok.any() and (np.abs(s.cost - r["cost"]) / np.abs(r["cost"]))[ok].max() < 1e-6
+
+
+@pytest.mark.parametrize("fd_step", [1e-4, 1e-6])
+def test_other_difference_steps_vs_c_oracle(fd_step):
+    """The central-difference step is a constructor option (default 1e-5, BASELINE's north_star); with 1e-4 and 1e-6 on every
+    kernel family the decisions are the C oracle's with the same step, costs to 1e-7."""
+    from drake_ddp_amd import workloads as W
+    from oracle import c_oracle, models_np as M
+    for name, prob, x0, ug, kw in (("pendulum", W.pendulum_problem(), W.pendulum_batch_x0(70), np.zeros((1, 199)), {}),
+                                   ("acrobot, lane per problem", W.acrobot_problem(), W.acrobot_batch_x0(70), np.zeros((1, 39)), {"kernel_mode": "throughput"}),
+                                   ("36-state chain", W.synth36_problem(), W.synth36_batch_x0(8), W.synth36_u_guess(40), {}),
+                                   ("3-D quadruped", W.quad3d_problem(), W.quad3d_batch_x0(8), W.quad3d_u_guess(40), {}),
+                                   ("arm + ball", W.arm27_problem(), W.arm27_batch_x0(8), W.arm27_u_guess(50), {})):
+        s = make_solver(prob, B=len(x0), jac="fd", fd_step=fd_step, **kw)
+        s.SetInitialState(x0); s.SetInitialGuess(ug)
+        s.Solve()
+        r = c_oracle.solve_batch(M.Model(prob["model_id"], prob["dt"]), prob, x0, ug, fd_h=fd_step)
+        same = (s.status == r["status"]) & (s.iterations == r["iters"]) & (s.ls_trials == r["ls"])
+        rel = np.abs(s.cost - r["cost"]) / np.abs(r["cost"])
+        print(f"{name} h = {fd_step:g}: {int(same.sum())}/{len(x0)} with the oracle's decisions, costs {rel[same].max():.1e}")
+        assert same.sum() >= len(x0) - 1 and rel[same].max() < 1e-7
