@@ -43,7 +43,7 @@ make = plugin.build_models([spec(*sh) for sh in shapes], verbose=False)
 bad = 0
 for nq, m, ne, fam in shapes:
     n = 2 * nq + ne
-    dt, B = 0.02, 2
+    dt, B = 0.02, int(os.environ.get("SWEEP_B", "2"))
     sys_ = make["chainx_%d_%d_%d_%s" % (nq, m, ne, fam)](dt)
     model = M.Model.custom(n, m, PS.chainx_step(nq, m, ne), sys_.params, dt)
     for N in [int(v) for v in os.environ.get("SWEEP_N", "24,4").split(",")]:
