@@ -248,6 +248,29 @@ def arm27_u_guess(N):
     return np.repeat(u[:, None], N - 1, axis=1)
 
 
+# panda_fr3.py:20-58 switches between scenarios that differ in start pose, ball target and initial guess only.  "side" is the one
+# above (kinova_gen3.py's); "forward": the hand 1 cm behind the ball on the -x side (inverse kinematics of the build's arm with
+# the base yaw at 0), target 0.2 m along +x, gravity compensation at that pose + J^T (5 N along +x) as the guess.  ("lift"
+# needs the reference's whole-arm hydroelastic wrap: a single point contact cannot carry the ball.)
+_A27_Q_FORWARD = np.array([0.0, 0.52920677, 0.0, 2.20419733, 0.0, -0.1334041, 0.0])
+_A27_U_GRAV_FORWARD = np.array([0.0, -5.53319785, 0.0, -1.78905756, 0.0, -0.82333227, 0.0])
+_A27_JT_X_FORWARD = np.array([0.0, -0.17396357, 0.0, -0.53651085, 0.0, -0.25198002, 0.0])     # J^T e_x at that pose
+
+
+def arm27_scenario(name, N=50):
+    """(problem, x0, u_guess) of a panda_fr3.py scenario on the arm + ball model: "side" or "forward"."""
+    prob = arm27_problem(N)
+    if name == "side":
+        return prob, arm27_start(), arm27_u_guess(N)
+    if name != "forward":
+        raise RuntimeError("Unknown scenario %s" % name)          # panda_fr3.py:47 ("lift": see above)
+    x0 = np.concatenate([_A27_Q_FORWARD, [1.0, 0.0, 0.0, 0.0, 0.6, 0.0, _A27_BALL_Z], np.zeros(13)])
+    x_nom = x0.copy()
+    x_nom[11] += 0.2
+    u = _A27_U_GRAV_FORWARD + 5.0 * _A27_JT_X_FORWARD
+    return dict(prob, x_nom=x_nom), x0, np.repeat(u[:, None], N - 1, axis=1)
+
+
 def mpc_shift(x, u, replan):
     """Warm start of the MPC loop (acrobot.py:147-152, mini_cheetah.py:193-198):
     drop the first `replan` controls, repeat the last one; restart at x[:, replan].

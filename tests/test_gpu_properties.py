@@ -181,7 +181,8 @@ def test_c3_c4_c5_configs_converge_at_full_size():
 
 
 @pytest.mark.parametrize("script", ["swingup_pendulum.py", "mpc_acrobot.py", "wall_cartpole.py", "mpc_many_legs.py",
-                                    "mpc_planar_quadruped.py", "mpc_mini_cheetah_3d.py", "arm_reach.py", "swingup_cartpole.py"])
+                                    "mpc_planar_quadruped.py", "mpc_mini_cheetah_3d.py", "arm_reach.py", "swingup_cartpole.py",
+                                    "arm_push_scenarios.py"])
 def test_example_scripts_run(script):
     import subprocess
     import sys
