@@ -72,12 +72,31 @@ __host__ __device__ constexpr size_t large_lds_bytes(int N) {
   return (LLay<n, m>::doubles + (size_t)N * (n + m)) * 8 + (size_t)7 * N * 4 + 16;
 }
 
+// Horizons whose cost gradients do not fit next to the fixed block any more (N > 148 for (36, 12), > 319 for (27, 7)): the
+// gradients go to HBM (KArgs::lxu) and LDS keeps the fixed block + the key-point scratch - a slower backward step (one L2 read
+// of lx_t | lu_t per step on the wave that forms the first-order column), but no horizon limit short of 160 KB of integers.
+template <int n, int m>
+__host__ __device__ constexpr size_t large_lds_bytes_hbm(int N) {
+  return (size_t)LLay<n, m>::doubles * 8 + (size_t)7 * N * 4 + 16;
+}
+
 // Per-problem views of the time-major HBM arrays.
 template <int n, int m>
 struct LView {
   double *X, *U, *K, *kap, *dV, *Fx, *Fu, *Xn, *Un;
+  double* LxG;      // the cost gradients [N-1][n+m] in HBM (long horizons), or nullptr: in LDS behind the fixed block
   int N;
 };
+
+// lx_t | lu_t: LDS (the address space stays known to the compiler) or HBM, chosen per launch
+template <class V>
+__device__ __forceinline__ void lxu_store(const V& v, double* lds_area, int idx, double val) {
+  if (v.LxG) v.LxG[idx] = val; else lds_area[idx] = val;
+}
+template <class V>
+__device__ __forceinline__ double lxu_load(const V& v, const double* lds_area, int idx) {
+  return v.LxG ? v.LxG[idx] : lds_area[idx];
+}
 
 template <int n_, int m_>
 struct LargeAcc {
@@ -420,7 +439,7 @@ __device__ inline double large_rollout(const LView<M::n, M::m>& v, double* lds, 
       for (int j = 0; j < nh; ++j) r += qrow[j] * dxc[j];
       acc += dxc[i] * r;
       if constexpr (kLx) {
-        if (t > 0) Lxu[(t - 1) * (n + m) + i] = 2.0 * (r1_prev + r2buf[((t - 1) & 1) * 64 + i]);
+        if (t > 0) lxu_store(v, Lxu, (t - 1) * (n + m) + i, 2.0 * (r1_prev + r2buf[((t - 1) & 1) * 64 + i]));
         r1_prev = r;
       }
     } else if (q2role) {                                 // ... and columns n/2..n-1, on the wave that has nothing else to do here
@@ -436,7 +455,7 @@ __device__ inline double large_rollout(const LView<M::n, M::m>& v, double* lds, 
 #pragma unroll
       for (int j = 0; j < m; ++j) r += rrow[j] * us[j];
       acc += us[k] * r;
-      if constexpr (kLx) Lxu[t * (n + m) + n + k] = 2.0 * r;
+      if constexpr (kLx) lxu_store(v, Lxu, t * (n + m) + n + k, 2.0 * r);
       v.Un[(size_t)t * m + k] = us[k];
     }
     lds_barrier();
@@ -452,7 +471,7 @@ __device__ inline double large_rollout(const LView<M::n, M::m>& v, double* lds, 
   xs = xc;                             // final state x_{N-1}
   if (tid < n) v.Xn[(size_t)(N - 1) * n + tid] = xs[tid];
   if constexpr (kLx) {
-    if (qrole && N >= 2) Lxu[(N - 2) * (n + m) + (tid - 64)] = 2.0 * (r1_prev + r2buf[((N - 2) & 1) * 64 + (tid - 64)]);
+    if (qrole && N >= 2) lxu_store(v, Lxu, (N - 2) * (n + m) + (tid - 64), 2.0 * (r1_prev + r2buf[((N - 2) & 1) * 64 + (tid - 64)]));
   }
   if (qrole) {                         // terminal cost (ilqr.py:327)
     const int i = tid - 64;
@@ -1270,7 +1289,7 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
           const int tt = 16 * q + lk + 4 * reg;
-          if (tt < N - 1 && pp < n) Lxu[tt * nm + pp] = acc[reg];
+          if (tt < N - 1 && pp < n) lxu_store(v, Lxu, tt * nm + pp, acc[reg]);
         }
       }
       for (int idx = tid; idx < (N - 1) * m; idx += kLargeThreads) {
@@ -1278,7 +1297,7 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
         double s_ = 0.0;
 #pragma unroll
         for (int j = 0; j < m; ++j) s_ += (2.0 * R[a_ * m + j]) * Us_[tt * m + j];
-        Lxu[tt * nm + n + a_] = s_;
+        lxu_store(v, Lxu, tt * nm + n + a_, s_);
       }
      }
     } else {
@@ -1294,7 +1313,7 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
           s_ = 0.0;
           for (int j = 0; j < m; ++j) s_ += (2.0 * R[(pp - n) * m + j]) * ug[j];
         }
-        Lxu[idx] = s_;
+        lxu_store(v, Lxu, idx, s_);
       }
     }
     if (wave == 0) BP_TICK(6);
@@ -1614,7 +1633,7 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
     // first-order column of step ts: l_{x,u} + F^T Vx (:651-652); F_ts (buffer Fb) and Vx are in LDS
     auto first_order = [&](int ts, const double* Fb) __attribute__((always_inline)) {
       if (lane < nm) {
-        double s = Lxu[ts * nm + lane];
+        double s = lxu_load(v, Lxu, ts * nm + lane);
         const int hp = lane < n ? lane : UC + (lane - n);    // this entry's column of F
         // chunks of the contraction (rows >= n: zeros), software-pipelined: the next chunk's LDS reads are in flight
         // while this chunk's multiply-adds run - one exposed LDS latency per call instead of one per chunk
@@ -1800,7 +1819,7 @@ __device__ inline void mid_backward(const LView<M::n, M::m>& v, double* lds, boo
           double s_ = -qnp;
 #pragma unroll
           for (int j = 0; j < n; ++j) s_ += q2[j] * xg[j];
-          Lxu[tt * nm + pp] = s_;
+          lxu_store(v, Lxu, tt * nm + pp, s_);
         }
       } else {
         double r2_[m];
@@ -1811,7 +1830,7 @@ __device__ inline void mid_backward(const LView<M::n, M::m>& v, double* lds, boo
           double s_ = 0.0;
 #pragma unroll
           for (int j = 0; j < m; ++j) s_ += r2_[j] * ug[j];
-          Lxu[tt * nm + pp] = s_;
+          lxu_store(v, Lxu, tt * nm + pp, s_);
         }
       }
     }
@@ -1993,7 +2012,7 @@ __device__ inline void mid_backward(const LView<M::n, M::m>& v, double* lds, boo
   auto u_role = [&]() __attribute__((always_inline)) {
     auto first_order = [&](int ts, const double* Fb) __attribute__((always_inline)) {   // l_{x,u} + F^T Vx (:651-652)
       if (lane < nm) {
-        double s = Lxu[ts * nm + lane];
+        double s = lxu_load(v, Lxu, ts * nm + lane);
         const int hp = lane < n ? lane : UC + (lane - n);    // this entry's column of F
 #pragma unroll
         for (int k = 0; k < NK; ++k) s += Fb[k * FS + hp] * Vx[k];
@@ -2081,7 +2100,7 @@ __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kerne
   using Ly = LLay<n, m>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* lds = reinterpret_cast<double*>(smem);
-  int* ilds = reinterpret_cast<int*>(lds + Ly::doubles + (size_t)a.N * (n + m));
+  int* ilds = reinterpret_cast<int*>(lds + Ly::doubles + (a.lxu ? (size_t)0 : (size_t)a.N * (n + m)));
   // `cluster` workgroups per problem (MODE_SOLVE / MODE_MPC): workgroup 0 of a cluster is the leader and runs the
   // solve, the others only help with its linearizations (cluster handshake below)
   const int G = ((MODE == MODE_SOLVE || MODE == MODE_MPC) && a.cluster > 1) ? a.cluster : 1;
@@ -2097,6 +2116,7 @@ __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kerne
   v.Fu = a.fu + (size_t)b * n * m * (N - 1);
   v.Xn = a.x_trial + (size_t)b * n * N;
   v.Un = a.u_trial + (size_t)b * m * (N - 1);
+  v.LxG = a.lxu ? a.lxu + (size_t)b * (N - 1) * (n + m) : nullptr;
   LargeAcc<n, m> acc;
   acc.X = v.X; acc.Fx = v.Fx; acc.Fu = v.Fu; acc.N = N;
   acc.kp = ilds; acc.aux = ilds + N; acc.need = ilds + 2 * N; acc.binA = ilds + 3 * N; acc.binB = ilds + 5 * N;

@@ -95,6 +95,8 @@ struct KArgs {
   // rolled out beside the first, [3][B][N][n] and [3][B][N-1][m]
   double *x_spec, *u_spec;
   int spec_policy, pad_spec_;
+  // workgroup-per-problem kernels, long horizons: the cost gradients [B][N-1][n+m] in HBM instead of LDS (ilqr_large.hpp)
+  double* lxu;
 };
 
 __device__ __forceinline__ double bcast_lane0(double v) {

@@ -84,6 +84,18 @@ size_t large_lds(int model_id, int N) {
   }
 }
 
+// LDS of the workgroup-per-problem kernels with the cost gradients in HBM (long horizons); 0: not available for the model
+// (the planar quadruped's linearization keeps a per-key-point cache in the gradients' LDS area)
+size_t large_lds_hbm(int model_id, int N) {
+  if (const PluginSlot* ps = plugin_of(model_id)) return ps->p.family == 1 ? ps->p.lds_bytes(N, -1) : 0;
+  switch (model_id) {
+    case MI_MODEL_SYNTH36: return large_lds_bytes_hbm<Synth36::n, Synth36::m>(N);
+    case MI_MODEL_QUAD3D: return large_lds_bytes_hbm<Quad3D::n, Quad3D::m>(N);
+    case MI_MODEL_ARM27: return large_lds_bytes_hbm<Arm27::n, Arm27::m>(N);
+    default: return 0;
+  }
+}
+
 KArgs make_args(const mi_ilqr* h) {
   KArgs a;
   std::memset(&a, 0, sizeof(a));
@@ -130,6 +142,7 @@ KArgs make_args(const mi_ilqr* h) {
   a.sink_x = h->sink_x; a.sink_u = h->sink_u; a.sink_cost = h->sink_cost;
   a.bm_scratch = h->bm_scratch;
   a.x_spec = h->x_spec; a.u_spec = h->u_spec;
+  a.lxu = h->lxu;
   static const int spec = [] { const char* e = std::getenv("MI_ILQR_SPEC"); return e ? std::atoi(e) : 1; }();
   a.spec_policy = (h->x_spec && spec >= 0 && spec <= 2) ? spec : 0;
   a.cluster = 1;
@@ -574,6 +587,12 @@ int mi_ilqr_create(const mi_ilqr_desc* desc, mi_ilqr_t** out) {
     // served by the HBM-streaming kernel, which has no such limit
     if (!batch_minor && lds > kMaxLds && can && desc->kernel_mode == MI_KERNEL_AUTO) batch_minor = true;
   }
+  bool lxu_hbm = false;
+  if (!batch_minor && lds > kMaxLds && large) {
+    // the horizon's cost gradients do not fit beside the fixed block: keep them in HBM (ilqr_large.hpp: large_lds_bytes_hbm)
+    const size_t l = large_lds_hbm(desc->model_id, desc->N);
+    if (l != 0 && l <= kMaxLds) { lds = l; lxu_hbm = true; }
+  }
   if (!batch_minor && lds > kMaxLds) return MI_ILQR_E_UNSUPPORTED;
   if (batch_minor) lds = 0;
   if (!large && !batch_minor && desc->beta <= 0.75) {
@@ -629,6 +648,7 @@ int mi_ilqr_create(const mi_ilqr_desc* desc, mi_ilqr_t** out) {
   ALLOC(h->prof, B * 4, long long);
   ALLOC(h->done_counter, 1, int32_t);
   if (large) ALLOC(h->cluster_sync, B * 4, unsigned long long);
+  if (lxu_hbm) ALLOC(h->lxu, B * (N - 1) * (n + m), double);
   if (large && n <= 32) {
     // mid-size kernels: four line-search candidates per pass - an optimization, so a batch too large for three more
     // trial buffers simply searches one candidate at a time (make_args: spec_policy = 0 without them)
@@ -683,7 +703,7 @@ void mi_ilqr_destroy(mi_ilqr_t* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   void* ptrs[] = {h->x_bar, h->u_bar, h->K, h->kappa, h->dV, h->fx, h->fu, h->x0, h->u_guess, h->cost_ring, h->hist, h->iter_cyc,
                   h->x_trial, h->u_trial, h->trial_cost, h->stage_in, h->costmat, h->iters_ring, h->status_ring, h->ls_ring,
-                  h->kp_count, h->kp_list, h->prof, h->done_counter, h->cluster_sync, h->bm_scratch, h->x_spec, h->u_spec};
+                  h->kp_count, h->kp_list, h->prof, h->done_counter, h->cluster_sync, h->bm_scratch, h->x_spec, h->u_spec, h->lxu};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h->h_ring) (void)hipHostFree(h->h_ring);
   if (h->mpc_log) (void)hipFree(h->mpc_log);

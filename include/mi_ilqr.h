@@ -189,7 +189,8 @@ typedef struct {
   int32_t n, m, n_params, family;
   double default_params[MI_ILQR_MAX_PARAMS];
   int (*launch)(mi_ilqr_t* h, int mode, const void* kernel_args);   /* instantiates and launches the model's kernels */
-  size_t (*lds_bytes)(int32_t N, int32_t n_store);                  /* dynamic LDS of one problem */
+  size_t (*lds_bytes)(int32_t N, int32_t n_store);                  /* dynamic LDS of one problem (family 1: n_store < 0 asks for the
+                                                                       size with the horizon's cost gradients kept in HBM) */
 } mi_ilqr_model_plugin;
 int mi_ilqr_register_model(const mi_ilqr_model_plugin* plugin, int32_t* model_id_out);
 
