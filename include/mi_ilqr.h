@@ -178,7 +178,7 @@ int mi_ilqr_model_info(int model_id, int32_t* n, int32_t* m, int32_t* n_params, 
  *             (zero columns of fu, zero rows of Qux) and every other result is what the unpadded problem gives.  The
  *             Python mirror does this by itself (drake_ddp_amd/plugin.py pads, drake_ddp_amd/ilqr.py hides it).
  * Plugin models are served by these two families only (no lane-per-problem THROUGHPUT kernels). */
-enum { MI_MODEL_PLUGIN_BASE = 100, MI_ILQR_MAX_PLUGINS = 32 };
+enum { MI_MODEL_PLUGIN_BASE = 100, MI_ILQR_MAX_PLUGINS = 256 };
 typedef struct {
   int32_t abi_version;              /* MI_ILQR_ABI_VERSION of the headers the plugin was compiled against ... */
   int32_t kernel_args_bytes;        /* ... their sizeof(mi::KArgs) ... */

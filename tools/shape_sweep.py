@@ -32,7 +32,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "build":
     with concurrent.futures.ThreadPoolExecutor(os.cpu_count() or 4) as ex:
         list(ex.map(lambda sp: plugin.compile_model(*sp), [spec(*sh) for sh in shapes]))
     sys.exit(0)
-if len(sys.argv) == 1:                                   # the registry holds 32 models per process: chunks of 24 in child processes
+if len(sys.argv) == 1:                                   # chunks of 24 in child processes (one hipModule set per chunk keeps the process small)
     import subprocess
     rc = 0
     for c in range((len(shapes) + 23) // 24):
