@@ -109,6 +109,7 @@ using namespace mi;
   } while (0)
 
 constexpr size_t kMaxLds = 160 * 1024;
+constexpr int kMaxBatchPluginN = 6;      // family-0 plugin models up to this n also get the lane-per-problem kernels
 
 // The dynamic-LDS ceiling of a kernel is raised once per (kernel, device), to the hardware maximum - not
 // on every launch.

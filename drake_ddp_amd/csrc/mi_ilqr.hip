@@ -182,7 +182,10 @@ int launch(mi_ilqr* h, int mode) {
   h->u_zero = false;
   const KArgs a = make_args(h);
   int rc;
-  if (h->batch_minor) return launch_batch_minor(h, mode, a);
+  if (h->batch_minor) {
+    if (const PluginSlot* ps = plugin_of(h->d.model_id)) return ps->p.launch(h, mode, &a);   // (family-0 plugins carry the lane-per-problem kernels too)
+    return launch_batch_minor(h, mode, a);
+  }
   switch (h->d.model_id) {
     case MI_MODEL_PENDULUM: rc = launch_pendulum(h, mode, a); break;
     case MI_MODEL_ACROBOT: rc = launch_acrobot(h, mode, a); break;
@@ -576,7 +579,10 @@ int mi_ilqr_create(const mi_ilqr_desc* desc, mi_ilqr_t** out) {
   if (desc->kernel_mode < MI_KERNEL_AUTO || desc->kernel_mode > MI_KERNEL_THROUGHPUT) return MI_ILQR_E_BAD_ARG;
   {
     // (every key-point configuration since round 4: the KP instantiation of the lane-per-problem kernels)
-    const bool can = !large && !plugin_of(desc->model_id);
+    // plugin models: family 0 with n <= 6 (their units instantiate the lane-per-problem kernels as well - per-lane register
+    // arrays of n x n doubles set the limit)
+    const PluginSlot* const plug = plugin_of(desc->model_id);
+    const bool can = !large && (!plug || (plug->p.family == 0 && plug->p.n <= kMaxBatchPluginN));
     if (desc->kernel_mode == MI_KERNEL_THROUGHPUT && !can) return MI_ILQR_E_UNSUPPORTED;
     // n = 2 within the time-parallel passes' horizon: the wave-per-problem kernel is the faster one at
     // every batch size (B = 65536: 68 M vs 42 M it/s, profiles/r01n_c2_modes_batch_sweep.txt)

@@ -80,7 +80,7 @@ enum { MI_JAC_FD_CENTRAL = 0, MI_JAC_AUTODIFF = 1 };
  *   LATENCY    wave-per-problem, state in LDS: minimal time-to-solution, up to ~2k problems/GPU in flight;
  *   THROUGHPUT lane-per-problem, batch-minor state streamed through HBM: for tens of thousands of
  *              problems (every key-point method - a key-point list per lane; stage-level entries are not
- *              available; built-in models only);
+ *              available; built-in models and family-0 plugins with n <= 6);
  *   AUTO       THROUGHPUT when B >= 8192 and the configuration allows it - except n = 2 models with
  *              N <= 257, whose LATENCY kernel (rollout and Riccati sweep parallel in time) is the faster one
  *              at every batch size - else LATENCY. */
@@ -177,7 +177,8 @@ int mi_ilqr_model_info(int model_id, int32_t* n, int32_t* m, int32_t* n_params, 
  *             (R block-diagonal) and a zero initial guess their gains, feed-forward terms and values stay EXACT zeros
  *             (zero columns of fu, zero rows of Qux) and every other result is what the unpadded problem gives.  The
  *             Python mirror does this by itself (drake_ddp_amd/plugin.py pads, drake_ddp_amd/ilqr.py hides it).
- * Plugin models are served by these two families only (no lane-per-problem THROUGHPUT kernels). */
+ * Family-0 plugins with n <= 6 also carry the lane-per-problem THROUGHPUT kernels (kernel_mode, batches >= 8192 and
+ * horizons beyond LDS under AUTO, like the built-in small models); other plugins are served by their family only. */
 enum { MI_MODEL_PLUGIN_BASE = 100, MI_ILQR_MAX_PLUGINS = 256 };
 typedef struct {
   int32_t abi_version;              /* MI_ILQR_ABI_VERSION of the headers the plugin was compiled against ... */

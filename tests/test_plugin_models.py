@@ -181,3 +181,54 @@ def test_matrix_core_family_at_other_state_dimensions(nq):
                 assert np.max(np.abs(s.kappa[b] - o.kappa)) < 1e-10 * sc(o.kappa)
             else:
                 assert s.status[b] == 0 and abs(s.cost[b] - Lo) < 1e-10 * abs(Lo)
+
+
+@pytest.mark.gpu
+def test_family0_plugins_on_the_lane_per_problem_kernels():
+    """Family-0 plugin units (n <= 6) instantiate the lane-per-problem "throughput" kernels as well: kernel_mode = throughput,
+    and - under AUTO - horizons whose state does not fit LDS (N = 900 for the n = 6, m = 2 chain: refused until round 4).
+    Against the wave-per-problem kernels of the same plugin (decisions identical, costs to 1e-9) and the NumPy oracle; with a
+    key-point method and through the receding-horizon loop (host-loop form) as well."""
+    import models as PM
+    import plugin_steps as PS
+    from drake_ddp_amd import utils_derivs_interpolation as U
+    from drake_ddp_amd.ilqr import BatchedIterativeLQR
+    from oracle import models_np as M
+    from oracle.ilqr_np import OracleILQR
+    make = PM.build_all()
+    rng = np.random.default_rng(4)
+    for name, n, m, step, N in (("vdp", 2, 1, PS.vdp_step, 80), ("chain3", 6, 2, PS.chain3_step, 50)):
+        dt, B = 0.02, 70
+        sys_ = make[name](dt)
+        x0 = rng.uniform(-1.0, 1.0, (B, n)); ug = np.zeros((m, N - 1))
+        Q, R, Qf = dt * np.eye(n), dt * 0.1 * np.eye(m), 10.0 * np.eye(n)
+        out = {}
+        for mode in ("latency", "throughput"):
+            for kp in (None, U.derivs_interpolation("adaptiveJerk", 2, 8, 1e-4, 0.0)):
+                s = BatchedIterativeLQR(sys_, N, B, delta=1e-3, beta=0.7, jacobian_mode="fd", kernel_mode=mode, derivs_keypoint_method=kp)
+                s.SetTargetState(np.zeros(n)); s.SetRunningCost(Q, R); s.SetTerminalCost(Qf)
+                s.SetInitialState(x0); s.SetInitialGuess(ug)
+                s.Solve()
+                out[mode, kp is None] = (s.iterations.copy(), s.ls_trials.copy(), s.cost.copy(), s.keypoint_count.copy())
+                if mode == "throughput" and kp is None:
+                    s.MPCRun(3, 2)
+                    assert (s.status == 0).all() and s.mpc_log.shape == (B, 3, n + 2)
+        for plain in (True, False):
+            a, b = out["latency", plain], out["throughput", plain]
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[3], b[3]), (name, plain)
+            assert np.max(np.abs(a[2] - b[2]) / np.abs(a[2])) < 1e-9
+        o = OracleILQR(M.Model.custom(n, m, step, sys_.params, dt), N, 1e-3, 0.7, 0.0, jacobian="fd", fd_step=1e-5)
+        o.set_problem(x0[0], np.zeros(n), Q, R, Qf, ug)
+        xo, uo, Lo, hist = o.solve()
+        assert out["throughput", True][0][0] == len(hist) and abs(out["throughput", True][2][0] - Lo) < 1e-8 * abs(Lo)
+    # a horizon beyond LDS: AUTO takes the streaming kernels
+    n, m, N, dt, B = 6, 2, 900, 0.01, 5
+    s = BatchedIterativeLQR(make["chain3"](dt), N, B, delta=1e-3, beta=0.7, jacobian_mode="fd")
+    s.SetTargetState(np.zeros(n)); s.SetRunningCost(dt * np.eye(n), dt * 0.1 * np.eye(m)); s.SetTerminalCost(10.0 * np.eye(n))
+    x0 = rng.uniform(-0.5, 0.5, (B, n))
+    s.SetInitialState(x0); s.SetInitialGuess(np.zeros((m, N - 1)))
+    s.Solve()
+    o = OracleILQR(M.Model.custom(n, m, PS.chain3_step, make["chain3"](dt).params, dt), N, 1e-3, 0.7, 0.0, jacobian="fd", fd_step=1e-5)
+    o.set_problem(x0[1], np.zeros(n), dt * np.eye(n), dt * 0.1 * np.eye(m), 10.0 * np.eye(n), np.zeros((m, N - 1)))
+    xo, uo, Lo, hist = o.solve()
+    assert (s.status == 0).all() and s.iterations[1] == len(hist) and abs(s.cost[1] - Lo) < 1e-7 * abs(Lo)
