@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MI_ILQR_LIB") or os.path.join(_HERE, "lib", "libmi_ilqr.so")
 
 MAX_PARAMS = 16
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 # enums (include/mi_ilqr.h)
 OK, E_BAD_SHAPE, E_BAD_METHOD, E_LINESEARCH, E_HIP, E_NO_DEVICE, E_BAD_ARG, E_UNSUPPORTED, E_RCCL = 0, -1, -2, -3, -4, -5, -6, -7, -8
@@ -49,6 +49,7 @@ class Desc(C.Structure):
         ("jerk_threshold", C.c_double), ("iterative_error_threshold", C.c_double),
         ("jacobian_mode", C.c_int32), ("fd_step", C.c_double),
         ("max_iters", C.c_int32), ("hist_cap", C.c_int32), ("device_id", C.c_int32), ("kernel_mode", C.c_int32),
+        ("on_indefinite", C.c_int32),
     ]
 
 

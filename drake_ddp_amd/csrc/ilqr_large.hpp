@@ -89,13 +89,18 @@ struct LView {
 };
 
 // lx_t | lu_t: LDS (the address space stays known to the compiler) or HBM, chosen per launch
+// (the HBM side as relaxed device-scope atomics: plain accesses let the compiler fold the two branches into ONE access through a
+//  selected flat pointer - slower for the LDS case, and the address-space cast it needs trips an instruction-selection error
+//  of this hipcc on some instantiations: "V_CMP_NE_U32 0, $src_shared_base")
 template <class V>
 __device__ __forceinline__ void lxu_store(const V& v, double* lds_area, int idx, double val) {
-  if (v.LxG) v.LxG[idx] = val; else lds_area[idx] = val;
+  if (v.LxG) __hip_atomic_store(v.LxG + idx, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else lds_area[idx] = val;
 }
 template <class V>
 __device__ __forceinline__ double lxu_load(const V& v, const double* lds_area, int idx) {
-  return v.LxG ? v.LxG[idx] : lds_area[idx];
+  if (v.LxG) return __hip_atomic_load(v.LxG + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return lds_area[idx];
 }
 
 template <int n_, int m_>
@@ -2166,7 +2171,11 @@ __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kerne
   const int lin_xs = lin_staged ? kXS : n, lin_us = lin_staged ? kUS : m;
   auto jac = [&](const int* list, int count) __attribute__((always_inline)) {
     if constexpr (HasSparsity<M>::value) large_jac_at_sparse<M, JAC>(v, a, list, count, lin_X, lin_U);
-    else if constexpr (IsChainModel<M>::value) large_jac_at_tree<M, JAC>(v, a, list, count, lin_X, lin_U, lin_xs, lin_us, lds + Ly::doubles);   // (the cost-gradient area of the backward pass is idle here)
+    else if constexpr (IsChainModel<M>::value) {
+      // the per-key-point cache lives where the backward pass keeps its cost gradients (idle here): LDS, or - long horizons - HBM
+      if (v.LxG) large_jac_at_tree<M, JAC>(v, a, list, count, lin_X, lin_U, lin_xs, lin_us, v.LxG);
+      else large_jac_at_tree<M, JAC>(v, a, list, count, lin_X, lin_U, lin_xs, lin_us, lds + Ly::doubles);
+    }
     else if constexpr (IsLegModel<M>::value) large_jac_at_legs<M, JAC>(v, a, list, count, lin_X, lin_U, lin_xs, lin_us);
     else large_jac_at<M, JAC>(v, a, list, count, lin_X, lin_U, lin_xs, lin_us);
   };
@@ -2424,7 +2433,7 @@ __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kerne
       L = L_new;
       it_this += 1;
       if (MODE == MODE_FORWARD) break;
-      if (not_pd) { status = MI_STATUS_NOT_PD; break; }      // the gains of that pass are not to be used
+      if (not_pd && !a.pd_continue) { status = MI_STATUS_NOT_PD; break; }      // the gains of that pass are not to be used (unless asked to: on_indefinite)
     }
     iters += it_this;
     if (MODE == MODE_MPC) {

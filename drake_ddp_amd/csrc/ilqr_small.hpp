@@ -97,6 +97,7 @@ struct KArgs {
   int spec_policy, pad_spec_;
   // workgroup-per-problem kernels, long horizons: the cost gradients [B][N-1][n+m] in HBM instead of LDS (ilqr_large.hpp)
   double* lxu;
+  int pd_continue, pad_pd_;       // mi_ilqr_desc.on_indefinite
 };
 
 __device__ __forceinline__ double bcast_lane0(double v) {

@@ -84,12 +84,12 @@ size_t large_lds(int model_id, int N) {
   }
 }
 
-// LDS of the workgroup-per-problem kernels with the cost gradients in HBM (long horizons); 0: not available for the model
-// (the planar quadruped's linearization keeps a per-key-point cache in the gradients' LDS area)
+// LDS of the workgroup-per-problem kernels with the cost gradients in HBM (long horizons)
 size_t large_lds_hbm(int model_id, int N) {
   if (const PluginSlot* ps = plugin_of(model_id)) return ps->p.family == 1 ? ps->p.lds_bytes(N, -1) : 0;
   switch (model_id) {
     case MI_MODEL_SYNTH36: return large_lds_bytes_hbm<Synth36::n, Synth36::m>(N);
+    case MI_MODEL_PLANAR_QUAD: return large_lds_bytes_hbm<PlanarQuad::n, PlanarQuad::m>(N);
     case MI_MODEL_QUAD3D: return large_lds_bytes_hbm<Quad3D::n, Quad3D::m>(N);
     case MI_MODEL_ARM27: return large_lds_bytes_hbm<Arm27::n, Arm27::m>(N);
     default: return 0;
@@ -143,6 +143,7 @@ KArgs make_args(const mi_ilqr* h) {
   a.bm_scratch = h->bm_scratch;
   a.x_spec = h->x_spec; a.u_spec = h->u_spec;
   a.lxu = h->lxu;
+  a.pd_continue = h->d.on_indefinite == 1 ? 1 : 0;
   static const int spec = [] { const char* e = std::getenv("MI_ILQR_SPEC"); return e ? std::atoi(e) : 1; }();
   a.spec_policy = (h->x_spec && spec >= 0 && spec <= 2) ? spec : 0;
   a.cluster = 1;
@@ -577,6 +578,7 @@ int mi_ilqr_create(const mi_ilqr_desc* desc, mi_ilqr_t** out) {
   if (lds == 0) return MI_ILQR_E_UNSUPPORTED;
   bool batch_minor = false;
   if (desc->kernel_mode < MI_KERNEL_AUTO || desc->kernel_mode > MI_KERNEL_THROUGHPUT) return MI_ILQR_E_BAD_ARG;
+  if (desc->on_indefinite != 0 && desc->on_indefinite != 1) return MI_ILQR_E_BAD_ARG;
   {
     // (every key-point configuration since round 4: the KP instantiation of the lane-per-problem kernels)
     // plugin models: family 0 with n <= 6 (their units instantiate the lane-per-problem kernels as well - per-lane register

@@ -38,7 +38,7 @@ class BatchedIterativeLQR:
 
     def __init__(self, system, num_timesteps, batch, input_port_index=0, delta=1e-2, beta=0.95, gamma=0.0,
                  derivs_keypoint_method=None, jacobian_mode="fd", fd_step=1e-5, device=0,
-                 max_iters=1000, hist_cap=64, kernel_mode="auto", pinned_results=True):
+                 max_iters=1000, hist_cap=64, kernel_mode="auto", pinned_results=True, on_indefinite="stop"):
         assert isinstance(system, ModelSystem), \
             "system must be a drake_ddp_amd.models.ModelSystem (Drake systems cannot run on the GPU)"
         assert system.IsDifferenceEquationSystem()[0], "must be a discrete-time system"   # ilqr.py:37
@@ -75,6 +75,9 @@ class BatchedIterativeLQR:
         d.max_iters, d.hist_cap, d.device_id = int(max_iters), int(hist_cap), int(device)
         d.kernel_mode = {"auto": _capi.KERNEL_AUTO, "latency": _capi.KERNEL_LATENCY,
                          "throughput": _capi.KERNEL_THROUGHPUT}[kernel_mode]
+        # a Quu that is not positive definite (workgroup-per-problem kernels): "stop" the problem with STATUS_NOT_PD, or "continue"
+        # with whatever inverse comes out, which is what the reference's np.linalg.inv does (ilqr.py:655)
+        d.on_indefinite = {"stop": 0, "continue": 1}[on_indefinite]
         self._desc = d
         self.hist_cap = int(hist_cap)
         h = C.c_void_p()

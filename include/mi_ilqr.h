@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MI_ILQR_ABI_VERSION 6
+#define MI_ILQR_ABI_VERSION 7   /* 7: mi_ilqr_desc.on_indefinite, mi_ilqr_model_plugin.m_user, 256 plugin slots */
 #define MI_ILQR_MAX_PARAMS 16
 
 /* Error codes (0 = OK).  The Python wrapper maps them onto the exception types
@@ -138,6 +138,11 @@ typedef struct {
   int32_t hist_cap;                          /* per-problem iteration rows kept; <=0 -> 64 */
   int32_t device_id;                         /* HIP device ordinal */
   int32_t kernel_mode;                       /* MI_KERNEL_AUTO / _LATENCY / _THROUGHPUT */
+  int32_t on_indefinite;                     /* workgroup-per-problem kernels, a Quu that is not positive definite in a backward pass:
+                                                0 = stop that problem with MI_STATUS_NOT_PD (default); 1 = carry on with the inverse the
+                                                elimination returns, as the reference does with np.linalg.inv (ilqr.py:655) - long,
+                                                stiff horizons on which round-off makes Quu indefinite while the line search still
+                                                finds its way (the wave- and lane-per-problem kernels always behave like 1) */
 } mi_ilqr_desc;
 
 typedef struct {

@@ -151,3 +151,44 @@ def test_solve_stops_with_not_pd_instead_of_silent_garbage():
     t.SetInitialState(W.arm27_start()[None]); t.SetInitialGuess(W.arm27_u_guess(prob["N"]))
     with pytest.raises(Exception, match="not supported"):
         t.Solve()
+
+
+def test_riccati_error_growth_with_the_horizon_and_on_indefinite():
+    """What a LONG horizon does to the backward pass of a stiff contact model (the planar quadruped, dt = 1.5e-3): cond(Quu) stays
+    ~2e3, but the recursion amplifies round-off ~10 x every dozen steps - against the extended-precision pass the fp64 reference
+    is at 1e-8 (N = 40), 1e-5 (80), 0.2 (110) and the device at 1e-10, 1e-6, 1e-3: the device keeps one to two more digits for
+    as long as anybody has any.  Past that (N = 148) round-off makes a Quu indefinite: the reference inverts it all the same
+    (ilqr.py:655) and carries on; the device stops the problem with MI_STATUS_NOT_PD by default and carries on like the reference
+    with on_indefinite = "continue" (mi_ilqr_desc.on_indefinite) - never an error, never a hang."""
+    from drake_ddp_amd import _capi, workloads as W
+    got = {}
+    for N in (40, 80, 110):
+        p = dict(W.planar_quad_problem(), dt=1.5e-3, N=N)
+        x0, ug = W.planar_quad_batch_x0(1), W.planar_quad_u_guess(N)
+        s = make_solver(p, B=1, jac="fd")
+        s.SetInitialState(x0); s.SetInitialGuess(ug)
+        s.stage_forward(np.inf); s.stage_linearize()
+        xb, ub, fx, fu = s.x_bar[0], s.u_bar[0], s.fx[0], s.fu[0]
+        s.stage_backward()
+        o = make_oracle(p)
+        o.set_problem(x0[0], p["x_nom"], p["Q"], p["R"], p["Qf"], ub)
+        o.x_bar, o.u_bar, o.fx, o.fu = xb.copy(), ub.copy(), fx.copy(), fu.copy()
+        o.backward()
+        e_dev, e_ref, cond = backward_errors((s.K[0], s.kappa[0], s.dV_coeff[0]), o)
+        got[N] = (e_dev, e_ref)
+        print(f"N = {N}: device {e_dev:.1e}, NumPy fp64 {e_ref:.1e} from the extended-precision pass; max cond(Quu) {cond:.1e}")
+        assert int(s.status[0]) == 0 and e_dev < max(1e-9, 2 * e_ref)
+    assert got[110][1] > 1e3 * got[40][1]                               # (the growth is the recursion's, not the elimination's)
+    p = dict(W.planar_quad_problem(), dt=1.5e-3, N=148)
+    x0, ug = W.planar_quad_batch_x0(4), W.planar_quad_u_guess(148)
+    stop = make_solver(p, B=4, jac="fd")
+    stop.SetInitialState(x0); stop.SetInitialGuess(ug)
+    with pytest.raises(RuntimeError, match="not positive definite"):
+        stop.Solve()
+    assert (stop.status == _capi.STATUS_NOT_PD).all()
+    go = make_solver(p, B=4, jac="fd", on_indefinite="continue")
+    go.SetInitialState(x0); go.SetInitialGuess(ug)
+    go.Solve()
+    print(f"N = 148: default -> status {stop.status.tolist()} after {stop.iterations.tolist()} iterations; on_indefinite = continue -> status {go.status.tolist()}, "
+          f"{go.iterations.tolist()} iterations, costs {np.round(go.cost, 3).tolist()} (first rollout: {np.round(stop.history[:, 0, 0], 3).tolist()})")
+    assert (go.status != _capi.STATUS_NOT_PD).all() and np.isfinite(go.cost).all() and (go.cost <= stop.history[:, 0, 0]).all()

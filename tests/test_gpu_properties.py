@@ -602,14 +602,18 @@ def test_longest_horizons_of_the_workgroup_kernels_vs_c_oracle():
     horizon that still fits: N = 148 for (36, 12), 96 for (37, 12), 319 for the arm + ball's (27, 7).  At
     those horizons (three times the reference scripts' 40 - 50 steps) and at twice to three times that - where the gradients
     move to HBM (large_lds_bytes_hbm: refused at create until round 4) - against the C oracle, costs within 10 x the oracle's
-    own one-ulp sensitivity.  The planar quadruped (its linearization keeps a cache in that LDS area) is still refused beyond
-    its limit: MI_ILQR_E_UNSUPPORTED at create, never a launch failure."""
+    own one-ulp sensitivity.  What still bounds the horizon is the key-point code's integer scratch: MI_ILQR_E_UNSUPPORTED at
+    create, never a launch failure."""
     from drake_ddp_amd import workloads as W, _capi
     from drake_ddp_amd._capi import MiIlqrError
     from oracle import c_oracle, models_np as M
     B = 6
     for name, prob, x0, ugf, horizons in (("36-state chain", W.synth36_problem(), W.synth36_batch_x0(B), W.synth36_u_guess, (148, 149, 400)),
                                           ("3-D quadruped", W.quad3d_problem(), W.quad3d_batch_x0(B), W.quad3d_u_guess, (96, 97, 200)),
+                                          ("planar quadruped", dict(W.planar_quad_problem(), dt=2e-4), W.planar_quad_batch_x0(B), W.planar_quad_u_guess, (148, 149, 260)),
+                                          # (a short step: with dt = 4e-3 the standing guess falls within 148 steps, and with 1.5e-3 the Riccati recursion through
+                                          #  this stiff contact model amplifies round-off by ~10 x every 12 steps - DESIGN section 8 - so that beyond N ~ 110
+                                          #  neither the device nor the fp64 reference has a digit left)
                                           ("arm + ball", W.arm27_problem(), W.arm27_batch_x0(B), W.arm27_u_guess, (319, 320, 420))):
         for N in horizons:
             p = dict(prob, N=N)
@@ -632,12 +636,12 @@ def test_longest_horizons_of_the_workgroup_kernels_vs_c_oracle():
                 keep = (rq["iters"] == r["iters"]) & (rq["ls"] == r["ls"])
                 flips = max(flips, int((~keep).sum()))
                 own = max(own, float((np.abs(rq["cost"] - r["cost"]) / np.abs(r["cost"]))[keep].max()) if keep.any() else 0.0)
-            worst = float(rel[same].max()) if same.any() else 0.0
+            fin = np.isfinite(r["cost"])                      # (a quadruped that falls within a long horizon: L = inf on both sides)
+            worst = float(rel[same & fin].max()) if (same & fin).any() else 0.0
             print(f"{name} N = {N}: same decisions {int(same.sum())}/{B} (the oracle against itself: {B - flips}/{B}), cost {worst:.1e} (its own one-ulp sensitivity {own:.1e})")
-            assert (~same).sum() <= flips and worst < max(1e-7, 10 * own) and np.isfinite(s.cost).all()
-    q = W.planar_quad_problem()
-    with pytest.raises(MiIlqrError) as e:
-        make_solver(dict(q, N=149), B=B, jac="fd")
+            assert (~same).sum() <= flips and worst < max(1e-7, 10 * own) and np.array_equal(np.isfinite(s.cost)[same], fin[same])
+    with pytest.raises(MiIlqrError) as e:                   # (what still bounds the horizon: the key-point code's integers in LDS)
+        make_solver(dict(W.synth36_problem(), N=20000), B=B, jac="fd")
     assert e.value.code == _capi.E_UNSUPPORTED
 
 
