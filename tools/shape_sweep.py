@@ -69,5 +69,48 @@ for nq, m, ne, fam in shapes:
             bad += not ok
             if not ok or (N == 24 and jac == "ad"):
                 print(f"{fam:5s} n={n:2d} m={m:2d} N={N:2d} {jac}: {'ok ' if ok else 'BAD'} x {ex:.1e} K {ek:.1e} kappa {ekap:.1e}", flush=True)
+if os.environ.get("SWEEP_MPC"):
+    # converged solve + two receding-horizon re-solves (device loop) + an adaptive-jerk key-point solve, per shape
+    from drake_ddp_amd import utils_derivs_interpolation as U
+    from drake_ddp_amd.workloads import mpc_shift
+    from oracle.ilqr_np import KeypointCfg
+    for nq, m, ne, fam in shapes:
+        n = 2 * nq + ne
+        dt, B, N = 0.02, 2, 16
+        sys_ = make["chainx_%d_%d_%d_%s" % (nq, m, ne, fam)](dt)
+        model = M.Model.custom(n, m, PS.chainx_step(nq, m, ne), sys_.params, dt)
+        rng = np.random.default_rng(n * 31 + m)
+        x_nom = np.zeros(n); x0 = 0.3 * rng.standard_normal((B, n)); ug = 0.1 * rng.standard_normal((m, N - 1))
+        Q, R, Qf = dt * np.eye(n), dt * 0.05 * np.eye(m), 5.0 * np.eye(n)
+        s = BatchedIterativeLQR(sys_, N, B, delta=1e-3, beta=0.6, gamma=0.0, jacobian_mode="ad")
+        s.SetTargetState(x_nom); s.SetRunningCost(Q, R); s.SetTerminalCost(Qf); s.SetInitialState(x0); s.SetInitialGuess(ug)
+        s.Solve(); it0 = s.iterations.copy()
+        s.MPCRun(2, 3); log = s.mpc_log
+        o = OracleILQR(model, N, 1e-3, 0.6, 0.0, jacobian="ad")
+        o.set_problem(x0[1], x_nom, Q, R, Qf, ug); xo, uo, Lo, hist = o.solve()
+        ok = len(hist) == it0[1]
+        for r_ in range(2):
+            x0r, ugr = mpc_shift(xo, uo, 3)
+            o.set_problem(x0r, x_nom, Q, R, Qf, ugr); xo, uo, Lo, hist = o.solve()
+            ok = ok and log[1, r_, -1] == len(hist) and abs(log[1, r_, -2] - Lo) < 1e-8 * abs(Lo)
+        kp = ("adaptiveJerk", 2, 5, 1e-3, 0.0)
+        s2 = BatchedIterativeLQR(sys_, N, B, delta=1e-3, beta=0.6, gamma=0.0, jacobian_mode="ad", derivs_keypoint_method=U.derivs_interpolation(*kp))
+        s2.SetTargetState(x_nom); s2.SetRunningCost(Q, R); s2.SetTerminalCost(Qf); s2.SetInitialState(x0); s2.SetInitialGuess(ug)
+        s2.Solve()
+        o2 = OracleILQR(model, N, 1e-3, 0.6, 0.0, keypoint=KeypointCfg(*kp), jacobian="ad")
+        o2.set_problem(x0[1], x_nom, Q, R, Qf, ug)
+        nk = int(s2.keypoint_count[1])
+        try:
+            xo2, uo2, Lo2, hist2 = o2.solve()
+            ok2 = len(hist2) == s2.iterations[1] and list(s2.keypoint_list[1][:nk]) == list(o2.keypoints) and abs(s2.cost[1] - Lo2) < 1e-8 * abs(Lo2)
+        except Exception:                      # (interpolated Jacobians: the reference's line search may run out of step sizes, ilqr.py:337)
+            # ... or, at the optimum, tie on the last bit of L_last - L > 0: the device then either fails the same way or accepts a
+            # step of ~1e-8 that changes nothing and converges
+            h2 = s2.history[1]
+            it2 = int(s2.iterations[1])
+            ok2 = int(s2.status[1]) == 2 or (it2 >= 2 and abs(h2[it2 - 1, 0] - h2[it2 - 2, 0]) <= 1e-9 * abs(h2[it2 - 1, 0]))
+        bad += (not ok) + (not ok2)
+        if not (ok and ok2):
+            print(f"{fam:5s} n={n:2d} m={m:2d}: MPC {'ok' if ok else 'BAD'} key-points {'ok' if ok2 else 'BAD'}", flush=True)
 print("shapes", len(shapes), "bad", bad)
 sys.exit(1 if bad else 0)
