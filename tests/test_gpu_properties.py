@@ -838,3 +838,34 @@ def test_other_difference_steps_vs_c_oracle(fd_step):
         rel = np.abs(s.cost - r["cost"]) / np.abs(r["cost"])
         print(f"{name} h = {fd_step:g}: {int(same.sum())}/{len(x0)} with the oracle's decisions, costs {rel[same].max():.1e}")
         assert same.sum() >= len(x0) - 1 and rel[same].max() < 1e-7
+
+
+def test_other_model_parameters_vs_c_oracle():
+    """Every built-in model with its physical parameters scaled by random factors in [0.8, 1.25] (masses, lengths, damping,
+    contact stiffness ...: mi_ilqr_desc.model_params, the `params` argument of drake_ddp_amd.models): decisions against the C
+    oracle run with the same parameters, costs to 1e-7."""
+    from drake_ddp_amd import workloads as W
+    from oracle import c_oracle, models_np as M
+    rng = np.random.default_rng(77)
+    for name, prob, x0, ug, kw in (("pendulum", W.pendulum_problem(), W.pendulum_batch_x0(70), np.zeros((1, 199)), {}),
+                                   ("acrobot", W.acrobot_problem(), W.acrobot_batch_x0(70), np.zeros((1, 39)), {}),
+                                   ("acrobot, lane per problem", W.acrobot_problem(), W.acrobot_batch_x0(70), np.zeros((1, 39)), {"kernel_mode": "throughput"}),
+                                   ("cart-pole + wall", dict(W.cartpole_wall_problem(), N=60), W.cartpole_wall_batch_x0(70), np.zeros((1, 59)), {}),
+                                   ("36-state chain", W.synth36_problem(), W.synth36_batch_x0(8), W.synth36_u_guess(40), {}),
+                                   ("3-D quadruped", W.quad3d_problem(), W.quad3d_batch_x0(8), W.quad3d_u_guess(40), {}),
+                                   ("arm + ball", W.arm27_problem(), W.arm27_batch_x0(8), W.arm27_u_guess(50), {})):
+        base = M.Model(prob["model_id"], prob["dt"]).params
+        params = base * rng.uniform(0.8, 1.25, base.size)
+        p = dict(prob, params=params)
+        s = make_solver(p, B=len(x0), jac="fd", **kw)
+        s.SetInitialState(x0); s.SetInitialGuess(ug)
+        try:
+            s.Solve()
+        except RuntimeError:
+            pass
+        r = c_oracle.solve_batch(M.Model(prob["model_id"], prob["dt"], params), p, x0, ug)
+        same = (s.status == r["status"]) & (s.iterations == r["iters"]) & (s.ls_trials == r["ls"])
+        fin = same & np.isfinite(r["cost"])
+        rel = (np.abs(s.cost - r["cost"]) / np.abs(r["cost"]))[fin]
+        print(f"{name}: {int(same.sum())}/{len(x0)} with the oracle's decisions (statuses {np.unique(r['status']).tolist()}), costs {rel.max() if rel.size else 0:.1e}")
+        assert same.sum() >= len(x0) - 1 and (rel.size == 0 or rel.max() < 1e-7)
