@@ -869,3 +869,34 @@ def test_other_model_parameters_vs_c_oracle():
         rel = (np.abs(s.cost - r["cost"]) / np.abs(r["cost"]))[fin]
         print(f"{name}: {int(same.sum())}/{len(x0)} with the oracle's decisions (statuses {np.unique(r['status']).tolist()}), costs {rel.max() if rel.size else 0:.1e}")
         assert same.sum() >= len(x0) - 1 and (rel.size == 0 or rel.max() < 1e-7)
+
+
+def test_pipelined_cold_and_warm_solves_on_every_kernel_family():
+    """mi_ilqr_solve_async on the workgroup-per-problem (mid-size with its four-candidate passes, n = 36) and lane-per-problem
+    kernels: a cold / warm / warm / cold sequence enqueued back to back returns, solve by solve, the statistics of the same
+    sequence run with a collect after each - warm re-solves start from the persistent gains and take fewer
+    iterations, a cold one repeats the first."""
+    from drake_ddp_amd import workloads as W
+    for name, prob, x0, ug, kw in (("arm + ball", W.arm27_problem(), W.arm27_batch_x0(24), W.arm27_u_guess(50), {}),
+                                   ("36-state chain", W.synth36_problem(), W.synth36_batch_x0(24), W.synth36_u_guess(40), {}),
+                                   ("acrobot, lane per problem", W.acrobot_problem(), W.acrobot_batch_x0(200), np.zeros((1, 39)), {"kernel_mode": "throughput"})):
+        s = make_solver(prob, B=len(x0), jac="fd", **kw)
+        s.SetInitialState(x0); s.SetInitialGuess(ug)
+        s.Solve()
+        ref = []
+        for cold in (True, False, False, True):
+            if cold:
+                s.rearm(cold=True)
+            s.solve_resident_async()
+            st = s.collect(1)[0]
+            ref.append((st.total_iters, st.total_ls_trials, st.n_converged, st.best_cost, st.best_index, s.iterations.copy(), s.cost.copy()))
+        assert ref[0][:5] == ref[3][:5] and ref[1][0] < ref[0][0], name
+        for cold in (True, False, False, True):
+            if cold:
+                s.rearm(cold=True)
+            s.solve_resident_async()
+        got = s.collect(4)
+        for g, r in zip(got, ref):
+            assert (g.total_iters, g.total_ls_trials, g.n_converged, g.best_cost, g.best_index) == r[:5], name
+        assert np.array_equal(s.iterations, ref[3][5]) and np.array_equal(s.cost, ref[3][6])
+        print(f"{name}: iterations of the cold / warm / warm / cold solves {[r[0] for r in ref]}")
