@@ -1636,9 +1636,11 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
   // ------------------------------------------------------------------------------------------------------------
   auto solver_role = [&]() __attribute__((always_inline)) {
     // first-order column of step ts: l_{x,u} + F^T Vx (:651-652); F_ts (buffer Fb) and Vx are in LDS
-    auto first_order = [&](int ts, const double* Fb) __attribute__((always_inline)) {
+    // (s0 = l_{x,u} of that step, fetched by the caller at the TOP of the step: an LDS read, or - long horizons - an L2 read
+    //  whose latency then hides behind the elimination)
+    auto first_order = [&](double s0, const double* Fb) __attribute__((always_inline)) {
       if (lane < nm) {
-        double s = lxu_load(v, Lxu, ts * nm + lane);
+        double s = s0;
         const int hp = lane < n ? lane : UC + (lane - n);    // this entry's column of F
         // chunks of the contraction (rows >= n: zeros), software-pipelined: the next chunk's LDS reads are in flight
         // while this chunk's multiply-adds run - one exposed LDS latency per call instead of one per chunk
@@ -1660,7 +1662,7 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
         Fo[hp] = s;
       }
     };
-    first_order(N - 2, F);
+    first_order(lane < nm ? lxu_load(v, Lxu, (N - 2) * nm + lane) : 0.0, F);
     // this lane's row of luu = 2R (lanes >= m of each 16-lane row shadow the last row)
     const int si = lr < m ? lr : m - 1;
     double r2[m];
@@ -1671,6 +1673,7 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
       BP_TICK(0);
       const double* Fc = F + ((N - 2 - t) & 1) * FB1;         // F_t
       const double* Fn = F + ((N - 1 - t) & 1) * FB1;         // F_{t-1}
+      const double lx_next = (t > 0 && lane < nm) ? lxu_load(v, Lxu, (t - 1) * nm + lane) : 0.0;
       double arow[m];
       {
         const double* p0 = Pq + (QO + si) * SS + QO;
@@ -1720,7 +1723,7 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
       BP_TICK(10);
       if (t > 0) {
         wave_lds_fence();
-        first_order(t - 1, Fn);                              // the next step's, from the Vx' just formed
+        first_order(lx_next, Fn);                            // the next step's, from the Vx' just formed
       }
       BP_TICK(7);
       lds_barrier();
@@ -2015,6 +2018,8 @@ __device__ inline void mid_backward(const LView<M::n, M::m>& v, double* lds, boo
 
   // u-wave: Quu and its inverse, the first-order terms
   auto u_role = [&]() __attribute__((always_inline)) {
+    // (the gradient is read HERE, not at the top of the step as in large_backward: measured on the mid-size kernels the early
+    //  read costs the u-wave's elimination more than it saves - (12, 4): 2.46 k -> 2.59 k cycles per step)
     auto first_order = [&](int ts, const double* Fb) __attribute__((always_inline)) {   // l_{x,u} + F^T Vx (:651-652)
       if (lane < nm) {
         double s = lxu_load(v, Lxu, ts * nm + lane);
