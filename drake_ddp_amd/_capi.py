@@ -27,7 +27,7 @@ F_X_BAR, F_U_BAR, F_K, F_KAPPA, F_DV, F_FX, F_FU, F_COST, F_X0, F_HIST, F_X_TRIA
 I_ITERS, I_STATUS, I_LS_TRIALS, I_KP_COUNT, I_KP_LIST = 100, 101, 102, 103, 104
 
 EXPORTS = [
-    "mi_ilqr_abi_version", "mi_ilqr_strerror", "mi_ilqr_model_info", "mi_ilqr_register_model", "mi_ilqr_create", "mi_ilqr_destroy",
+    "mi_ilqr_abi_version", "mi_ilqr_struct_sizes", "mi_ilqr_strerror", "mi_ilqr_model_info", "mi_ilqr_register_model", "mi_ilqr_create", "mi_ilqr_destroy",
     "mi_ilqr_set_cost", "mi_ilqr_set_initial", "mi_ilqr_set_initial_shared", "mi_ilqr_host_alloc", "mi_ilqr_host_free", "mi_ilqr_set_result_sink", "mi_ilqr_reset", "mi_ilqr_rearm_initial_guess",
     "mi_ilqr_solve", "mi_ilqr_solve_async", "mi_ilqr_collect_stats", "mi_ilqr_collect_stats_n",
     "mi_ilqr_rollout", "mi_ilqr_forward", "mi_ilqr_linearize", "mi_ilqr_backward", "mi_ilqr_mpc_shift",
@@ -125,6 +125,13 @@ def load():
     lib.mi_ilqr_allreduce_min_wait.argtypes = [H, C.c_void_p, C.c_int32]
     if lib.mi_ilqr_abi_version() != ABI_VERSION:
         raise ImportError("libmi_ilqr.so ABI version mismatch")
+    # this module restates mi_ilqr_desc / mi_ilqr_stats with ctypes: their sizes must be the library's
+    d_, s_ = C.c_int32(), C.c_int32()
+    lib.mi_ilqr_struct_sizes.restype = None
+    lib.mi_ilqr_struct_sizes(C.byref(d_), C.byref(s_), None)
+    if (d_.value, s_.value) != (C.sizeof(Desc), C.sizeof(Stats)):
+        raise ImportError(f"libmi_ilqr.so struct layout mismatch: desc {d_.value} / stats {s_.value} bytes in the library, "
+                          f"{C.sizeof(Desc)} / {C.sizeof(Stats)} here")
     _lib = lib
     return lib
 

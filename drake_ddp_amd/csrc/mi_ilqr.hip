@@ -493,6 +493,11 @@ double bytes_per_iteration(int n, int m, int N, int ls) {
 extern "C" {
 
 int mi_ilqr_abi_version(void) { return MI_ILQR_ABI_VERSION; }
+void mi_ilqr_struct_sizes(int32_t* desc_bytes, int32_t* stats_bytes, int32_t* plugin_bytes) {
+  if (desc_bytes) *desc_bytes = (int32_t)sizeof(mi_ilqr_desc);
+  if (stats_bytes) *stats_bytes = (int32_t)sizeof(mi_ilqr_stats);
+  if (plugin_bytes) *plugin_bytes = (int32_t)sizeof(mi_ilqr_model_plugin);
+}
 
 const char* mi_ilqr_strerror(int code) {
   switch (code) {

@@ -161,6 +161,10 @@ typedef struct {
 } mi_ilqr_stats;
 
 int mi_ilqr_abi_version(void);
+/* sizeof(mi_ilqr_desc), sizeof(mi_ilqr_stats), sizeof(mi_ilqr_model_plugin) as the LIBRARY was compiled: a binding that restates the
+ * structs in its own language (ctypes, cgo, JNI) compares them with its own at load time - a field added on one side only
+ * would otherwise shift every later field silently.  Any pointer may be NULL. */
+void mi_ilqr_struct_sizes(int32_t* desc_bytes, int32_t* stats_bytes, int32_t* plugin_bytes);
 const char* mi_ilqr_strerror(int code);
 
 /* Model registry: dimensions and default parameters of a model id. */
