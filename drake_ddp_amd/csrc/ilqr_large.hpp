@@ -1334,30 +1334,54 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
   // 16-byte pairs into registers three steps ahead and published to one of two LDS buffers two steps ahead, always in
   // the second half of a step - the three matrix-core waves only touch global memory to store K.
   // (16-byte pairs where the rows allow it - n, m even; single doubles otherwise, e.g. n = 37)
-  constexpr int W = (n % 2 == 0 && m % 2 == 0 && FS % 2 == 0 && Ly::oF % 2 == 0 && Ly::oT1 % 2 == 0) ? 2 : 1;
-  constexpr int PFX = n * n / W, PFU = n * m / W;                       // pairs (or single doubles)
+  // fx and fu have their own width: with an odd n (37) the rows of fx do not hold whole pairs, but HBM still delivers
+  // pairs - 16-byte loads that may straddle two rows, stored as two doubles (kSplitX) - and fu (m even) keeps whole pairs:
+  // half the load instructions of the single-double form on the wave that binds the second half-step of n = 37.
+  constexpr bool kEvenBase = FS % 2 == 0 && Ly::oF % 2 == 0 && Ly::oT1 % 2 == 0;
+  constexpr int WX = (n % 2 == 0 && kEvenBase) ? 2 : 1;                  // doubles per LDS store of fx
+  constexpr int WU = (m % 2 == 0 && UC % 2 == 0 && kEvenBase) ? 2 : 1;   // ... of fu
+  constexpr bool kSplitX = WX == 1 && n * n >= 2;                        // fx: pair loads, two single stores
+  constexpr int PFX = kSplitX ? (n * n + 1) / 2 : n * n / WX, PFU = n * m / WU;
   constexpr int NFX = (PFX + 63) / 64, NFU = (PFU + 63) / 64;
   typedef double d2_t __attribute__((ext_vector_type(2)));
-  using fw_t = std::conditional_t<W == 2, d2_t, double>;
-  fw_t frx[NFX], fru[NFU];
-  int fx_off[NFX], fu_off[NFU];                                          // LDS offsets (doubles) of this lane's pairs
+  using fx_t = std::conditional_t<(WX == 2 || kSplitX), d2_t, double>;
+  using fu_t = std::conditional_t<WU == 2, d2_t, double>;
+  fx_t frx[NFX];
+  fu_t fru[NFU];
+  int fx_src[kSplitX ? NFX : 1], fx_off[NFX], fx_off1[kSplitX ? NFX : 1], fu_off[NFU];   // (split: first element in HBM;) LDS offsets (doubles)
 #pragma unroll
-  for (int r = 0; r < NFX; ++r) { int e = W * (lane + 64 * r); e = e < n * n ? e : n * n - W; fx_off[r] = (e / n) * FS + (e % n); }
+  for (int r = 0; r < NFX; ++r) {
+    int e = (kSplitX ? 2 : WX) * (lane + 64 * r);
+    if constexpr (kSplitX) {
+      e = e < n * n - 1 ? e : n * n - 2;                                 // (the last pair overlaps its neighbour: same values stored twice)
+      fx_src[r] = e;
+      fx_off1[r] = ((e + 1) / n) * FS + ((e + 1) % n);
+    } else {
+      e = e < n * n ? e : n * n - WX;
+    }
+    fx_off[r] = (e / n) * FS + (e % n);
+  }
 #pragma unroll
-  for (int r = 0; r < NFU; ++r) { int e = W * (lane + 64 * r); e = e < n * m ? e : n * m - W; fu_off[r] = (e / m) * FS + UC + (e % m); }
+  for (int r = 0; r < NFU; ++r) { int e = WU * (lane + 64 * r); e = e < n * m ? e : n * m - WU; fu_off[r] = (e / m) * FS + UC + (e % m); }
   auto fetch = [&](int t) __attribute__((always_inline)) {
-    const fw_t* fxg = reinterpret_cast<const fw_t*>(v.Fx + (size_t)t * n * n);
-    const fw_t* fug = reinterpret_cast<const fw_t*>(v.Fu + (size_t)t * n * m);
+    const double* fxg = v.Fx + (size_t)t * n * n;
+    const fu_t* fug = reinterpret_cast<const fu_t*>(v.Fu + (size_t)t * n * m);
 #pragma unroll
-    for (int r = 0; r < NFX; ++r) { const int pi = lane + 64 * r; frx[r] = fxg[pi < PFX ? pi : PFX - 1]; }
+    for (int r = 0; r < NFX; ++r) {
+      if constexpr (kSplitX) __builtin_memcpy(&frx[r], fxg + fx_src[r], 16);   // (8-byte aligned: an unaligned 16-byte load)
+      else { const int pi = lane + 64 * r; frx[r] = reinterpret_cast<const fx_t*>(fxg)[pi < PFX ? pi : PFX - 1]; }
+    }
 #pragma unroll
     for (int r = 0; r < NFU; ++r) { const int pi = lane + 64 * r; fru[r] = fug[pi < PFU ? pi : PFU - 1]; }
   };
   auto publish = [&](double* Fb) __attribute__((always_inline)) {       // clamped duplicates rewrite the last pair with itself
 #pragma unroll
-    for (int r = 0; r < NFX; ++r) *reinterpret_cast<fw_t*>(Fb + fx_off[r]) = frx[r];
+    for (int r = 0; r < NFX; ++r) {
+      if constexpr (kSplitX) { Fb[fx_off[r]] = frx[r][0]; Fb[fx_off1[r]] = frx[r][1]; }
+      else *reinterpret_cast<fx_t*>(Fb + fx_off[r]) = frx[r];
+    }
 #pragma unroll
-    for (int r = 0; r < NFU; ++r) *reinterpret_cast<fw_t*>(Fb + fu_off[r]) = fru[r];
+    for (int r = 0; r < NFU; ++r) *reinterpret_cast<fu_t*>(Fb + fu_off[r]) = fru[r];
   };
   // =====================================================================================================
   // Fused chain.  The D (result) layout of one 16x16x4 product IS the B-operand layout of the next: lane
