@@ -124,3 +124,13 @@ def test_mpc_shift_matches_reference_callers():
     ref_guess = np.block([u[:, replan:], np.repeat(last_u[np.newaxis].T, replan, axis=1)])
     x0, ug = mpc_shift(x, u, replan)
     assert np.array_equal(ug, ref_guess) and np.array_equal(x0, x[:, replan])
+
+
+def test_struct_sizes_match_the_ctypes_mirror(lib):
+    """mi_ilqr_struct_sizes: the library's sizeof(mi_ilqr_desc / _stats / _model_plugin) against the ctypes restatements of
+    drake_ddp_amd/_capi.py and plugin.py - a field added on one side only must fail at load time, not shift fields silently."""
+    from drake_ddp_amd import _capi, plugin
+    d, s, p = C.c_int32(), C.c_int32(), C.c_int32()
+    lib.mi_ilqr_struct_sizes(C.byref(d), C.byref(s), C.byref(p))
+    assert (d.value, s.value, p.value) == (C.sizeof(_capi.Desc), C.sizeof(_capi.Stats), C.sizeof(plugin._Plugin))
+    lib.mi_ilqr_struct_sizes(None, None, None)            # (any pointer may be NULL)
