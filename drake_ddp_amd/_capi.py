@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MI_ILQR_LIB") or os.path.join(_HERE, "lib", "libmi_ilqr.so")
 
 MAX_PARAMS = 16
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 # enums (include/mi_ilqr.h)
 OK, E_BAD_SHAPE, E_BAD_METHOD, E_LINESEARCH, E_HIP, E_NO_DEVICE, E_BAD_ARG, E_UNSUPPORTED, E_RCCL = 0, -1, -2, -3, -4, -5, -6, -7, -8
@@ -23,6 +23,7 @@ JAC_FD_CENTRAL, JAC_AUTODIFF = 0, 1
 KERNEL_AUTO, KERNEL_LATENCY, KERNEL_THROUGHPUT = 0, 1, 2
 STATUS_CONVERGED, STATUS_MAX_ITERS, STATUS_LINESEARCH_FAILED, STATUS_INTERNAL = 0, 1, 2, 3
 STATUS_NOT_PD = 5
+STATUS_FLAG_INDEFINITE = 16     # OR-ed onto the outcome: on_indefinite="continue" inverted a Quu that is not positive definite
 F_X_BAR, F_U_BAR, F_K, F_KAPPA, F_DV, F_FX, F_FU, F_COST, F_X0, F_HIST, F_X_TRIAL, F_U_TRIAL, F_TRIAL_COST, F_ITER_CYCLES = range(14)
 I_ITERS, I_STATUS, I_LS_TRIALS, I_KP_COUNT, I_KP_LIST = 100, 101, 102, 103, 104
 

@@ -62,6 +62,7 @@ struct mi_ilqr {
   bool u_pending = false;  // SetInitialGuess input waiting in u_guess
   bool u_zero = false;     // u_bar is to read as all zero (after reset, until a guess is set or re-armed): ilqr.py:71
   int exact_backward = 0;  // cost matrices the fast backward forms do not cover (asymmetric / indefinite): reference recursion
+  int cost_asym = 0;       // workgroup-per-problem kernels, n <= 32: Q, R or Qf is not symmetric (mid_backward then uses no symmetry at all)
   std::vector<double> h_costmat;   // host mirror of costmat (Q | R | Qf | x_nom)
   bool costmat_synced = false;     // the device copy equals the mirror
   unsigned long long* cluster_sync = nullptr;   // workgroup-per-problem kernels: 4 handshake words per problem

@@ -86,6 +86,8 @@ struct LView {
   double *X, *U, *K, *kap, *dV, *Fx, *Fu, *Xn, *Un;
   double* LxG;      // the cost gradients [N-1][n+m] in HBM (long horizons), or nullptr: in LDS behind the fixed block
   int N;
+  int pd_continue;  // a Quu that is not positive definite: 1 = invert it with partial pivoting and carry on like np.linalg.inv (ilqr.py:655)
+  int asym;         // Q, R or Qf is not symmetric (mid-size kernels only): the reference's recursion without any use of symmetry
 };
 
 // lx_t | lu_t: LDS (the address space stays known to the compiler) or HBM, chosen per launch
@@ -1199,6 +1201,94 @@ struct GjOuter<m, m> {
 // exactly when every pivot is > 0 - i.e. every row's s is (NaN or an infinite pivot fail the comparison as well).
 __device__ __forceinline__ bool gj_row_positive(double s) { return s > 0.0; }
 
+// Inverse of a Quu that is NOT positive definite, the way np.linalg.inv computes it (ilqr.py:655: the reference inverts whatever
+// comes out and carries on): LAPACK's getrf + getri - LU with partial pivoting (row exchanges), inv(U), then inv(A) from
+// inv(A) L = inv(U), then the exchanges undone on the columns.  (A Gauss-Jordan sweep with the same pivoting was the first
+// version: measurably less accurate than LU once cond(Quu) passes 1e5 - 3e-8 against the oracle's 2e-11 on the (27, 7) plugin
+// with asymmetric costs.)  The COLD path of the backward passes: entered only after the unpivoted elimination above has met
+// a non-positive pivot AND the caller asked to continue (mi_ilqr_desc.on_indefinite = 1) - a positive definite Quu never pays
+// for it.  It therefore works in LDS, not in registers, in plain run-time loops: a few dozen instructions and a handful of
+// registers inside kernels that have none to spare (a register formulation - rows exchanged between lanes with ds_bpermute -
+// cost the solve kernels up to 70 more spilled scalars and 80 B more scratch per lane on the paths that never run it; this one
+// is within +-10 of the build without it).  W[i * ws + j], i, j < m: Quu on entry, its inverse on exit.  One wave; lane i < m
+// owns row i (eliminations, triangular solves) or column i (row exchanges).  Ties take the lowest row like idamax; a NaN
+// candidate wins (the result is NaN like the reference's).  ~m^2 dependent LDS round trips.
+template <int m>
+__device__ __forceinline__ void quu_inverse_pivoted(double* W, int ws, int lane) {
+  static_assert(m <= 16, "one row per lane of a 16-lane row; the permutation packs 4 bits per step");
+  auto fence = [&]() __attribute__((always_inline)) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+  };
+  const bool on = lane < m;
+  const int i = on ? lane : 0;
+  unsigned long long perm = 0ull;
+  // ---- getrf: P A = L U in place (unit lower L below the diagonal)
+#pragma unroll 1
+  for (int k = 0; k < m; ++k) {
+    fence();
+    double best = (on && lane >= k) ? fabs(W[i * ws + k]) : -1.0;
+    best = best == best ? best : __builtin_inf();
+    int idx = lane;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+      const double ob = __shfl_xor(best, o, 16);
+      const int oi = __shfl_xor(idx, o, 16);
+      const bool take = ob > best || (ob == best && oi < idx);
+      best = take ? ob : best;
+      idx = take ? oi : idx;
+    }
+    const int p = __builtin_amdgcn_readfirstlane(idx);
+    perm |= (unsigned long long)p << (4 * k);
+    if (p != k) {                                            // rows k and p change places (lane i: column i)
+      const double t1 = W[k * ws + i], t2 = W[p * ws + i];
+      fence();
+      if (on) { W[k * ws + i] = t2; W[p * ws + i] = t1; }
+      fence();
+    }
+    if (on && i > k) {                                       // lane i: row i
+      const double l = W[i * ws + k] * (1.0 / W[k * ws + k]);
+      W[i * ws + k] = l;
+#pragma unroll 1
+      for (int j = k + 1; j < m; ++j) W[i * ws + j] = fma(-l, W[k * ws + j], W[i * ws + j]);
+    }
+  }
+  // ---- trtri: inv(U) over U, column by column (lane i: entry (i, j), from its own row of inv(U) and column j of U)
+#pragma unroll 1
+  for (int j = 0; j < m; ++j) {
+    fence();
+    const double ujj = 1.0 / W[j * ws + j];
+    double acc = 0.0;
+    if (on && i < j) {
+#pragma unroll 1
+      for (int k = i; k < j; ++k) acc = fma(W[i * ws + k], W[k * ws + j], acc);
+    }
+    fence();
+    if (on && i < j) W[i * ws + j] = -acc * ujj;
+    if (on && i == j) W[i * ws + j] = ujj;
+  }
+  // ---- getri: inv(A) L = inv(U), columns from the last to the first (lane i: entry (i, j))
+#pragma unroll 1
+  for (int j = m - 2; j >= 0; --j) {
+    fence();
+    double acc = 0.0;
+    if (on) {
+#pragma unroll 1
+      for (int k = j + 1; k < m; ++k) acc = fma(W[i * ws + k], W[k * ws + j], acc);
+    }
+    const double base = (on && i <= j) ? W[i * ws + j] : 0.0;
+    fence();
+    if (on) W[i * ws + j] = base - acc;
+  }
+  fence();
+#pragma unroll 1
+  for (int k = m - 1; k >= 0; --k) {                         // the row exchanges, undone as column exchanges of the inverse (own row only)
+    const int p = (int)((perm >> (4 * k)) & 15ull);
+    if (p != k && on) { const double t1 = W[i * ws + k]; W[i * ws + k] = W[i * ws + p]; W[i * ws + p] = t1; }
+  }
+  fence();
+}
 
 // Backward Riccati pass (ilqr.py:623-667), cost expansion (:161-206) fused.
 //
@@ -1594,7 +1684,17 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
       double wa[MK], qux[MK], qa[RT][MK], fu_[KN];
       d4_t cm;
 #pragma unroll
-      for (int j = 0; j < MK; ++j) { wa[j] = Ws[lr * WSS + 4 * j + lk]; qux[j] = QuxS[(4 * j + lk) * QS + col]; }
+      for (int j = 0; j < MK; ++j) {
+        // Quu^{-1} enters K as an EXACTLY symmetric matrix: its upper triangle, mirrored.  The elimination's W is symmetric only to
+        // eps * cond(Quu), and this pass uses Vxx' both as computed and transposed (a wave's column tile is its row tile too): with a
+        // nearly singular Quu that asymmetry - fed back through -Qux^T K into Vxx' - grows ~1.5 x per step and takes K, kappa with it
+        // (planar quadruped, dt = 1.5e-3, N = 148: kappa_0 1.4e3 against 2.5 in extended precision, and a line search that then
+        // fails where the reference's succeeds; with a symmetric W the pass stays on the extended-precision gains there - K_0 within
+        // 0.2 where the fp64 reference is off by 16 x: tools/diag/n148_continue.py).  Same three LDS reads, another address.
+        const int k_ = 4 * j + lk;
+        wa[j] = Ws[lr < m ? (lr <= k_ ? lr * WSS + k_ : k_ * WSS + lr) : lr * WSS + k_];
+        qux[j] = QuxS[(4 * j + lk) * QS + col];
+      }
 #pragma unroll
       for (int q = 0; q < LT; ++q)
 #pragma unroll
@@ -1708,6 +1808,17 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
       double sc = 1.0;
       GjOuter<m, 0>::run(arow, sc, si);                      // Quu^{-1}[si][j] = sc * arow[j]
       if (!gj_row_positive(sc)) lds[Ly::oRed + kPdFlag] = 1.0;   // Quu not positive definite (read by the kernel after the pass: MI_STATUS_NOT_PD)
+      if (v.pd_continue && __any(!gj_row_positive(sc))) {    // cold path: the reference's inverse of an indefinite Quu
+        const double* p0 = Pq + (QO + si) * SS + QO;
+        if (lane < m) {
+#pragma unroll
+          for (int j = 0; j < m; ++j) Ws[lane * WSS + j] = r2[j] + ((p0[j] + p0[PS + j]) + p0[2 * PS + j]);
+        }
+        quu_inverse_pivoted<m>(Ws, WSS, lane);
+#pragma unroll
+        for (int j = 0; j < m; ++j) arow[j] = Ws[si * WSS + j];
+        sc = 1.0;
+      }
       if (lane < m) {
 #pragma unroll
         for (int j = 0; j < m; ++j) Ws[lane * WSS + j] = sc * arow[j];
@@ -1810,7 +1921,8 @@ __device__ inline void mid_backward(const LView<M::n, M::m>& v, double* lds, boo
   double* Kap = Ws + 16 * WSS;       // [16]      kappa_t
   double* Fo = Kap + 16;             // [FS]      first-order column: Qx (entries < n), Qu (entries UC..UC+m)
   double* Pq = Fo + FS;              // [RT][16][SS] the x-waves' shares of Quu - luu (accumulator layout -> one row per lane)
-  constexpr int kExch = 16 * QS + 16 * WSS + 16 + FS + RT * 16 * SS;
+  double* KapT = Pq + RT * 16 * SS;  // [16]      Quu^{-T} Qu (cost matrices that are not symmetric: Vx' = Qx - Qux^T Quu^{-T} Qu, :666)
+  constexpr int kExch = 16 * QS + 16 * WSS + 16 + FS + RT * 16 * SS + 16;
   static_assert(kExch <= Ly::NMP * Ly::TS, "the exchange buffers live in the H area");
   const d4_t zero4 = {0.0, 0.0, 0.0, 0.0};
   auto wave_lds_fence = [&]() __attribute__((always_inline)) {
@@ -2005,7 +2117,10 @@ __device__ inline void mid_backward(const LView<M::n, M::m>& v, double* lds, boo
       // ---- K[:, W] = Quu^{-1} Qux[:, W] (:660)
       double wa[MK];
 #pragma unroll
-      for (int j = 0; j < MK; ++j) wa[j] = Ws[lr * WSS + 4 * j + lk];
+      for (int j = 0; j < MK; ++j) {                         // symmetric costs: W's upper triangle, mirrored (large_backward, same place)
+        const int k_ = 4 * j + lk;
+        wa[j] = Ws[(v.asym || lr <= k_) ? lr * WSS + k_ : k_ * WSS + lr];
+      }
       d4_t kt = zero4;
 #pragma unroll
       for (int j = 0; j < MK; ++j) kt = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[j], hu[j], kt, 0, 0, 0);
@@ -2064,14 +2179,36 @@ __device__ inline void mid_backward(const LView<M::n, M::m>& v, double* lds, boo
       const double* Fn = F + ((N - 1 - t) & 1) * FB1;         // F_{t-1}
       // ---- Quu = luu + the x-waves' shares of fu^T Vxx fu (:654)
       double arow[m];
-      {
-        const double* p0 = Pq + si * SS;
+      // (the shares add up to the TRANSPOSE of fu^T Vxx fu - x_role - which only matters when the cost matrices are not symmetric)
+      auto load_quu = [&](double (&ar)[m]) __attribute__((always_inline)) {
+        if (v.asym) {
+          const double* p0 = Pq + si;
 #pragma unroll
-        for (int j = 0; j < m; ++j) arow[j] = r2[j] + (RT == 2 ? p0[j] + p0[16 * SS + j] : p0[j]);
-      }
+          for (int j = 0; j < m; ++j) ar[j] = r2[j] + (RT == 2 ? p0[j * SS] + p0[(16 + j) * SS] : p0[j * SS]);
+        } else {
+          const double* p0 = Pq + si * SS;
+#pragma unroll
+          for (int j = 0; j < m; ++j) ar[j] = r2[j] + (RT == 2 ? p0[j] + p0[16 * SS + j] : p0[j]);
+        }
+      };
+      load_quu(arow);
       double sc = 1.0;
       GjOuter<m, 0>::run(arow, sc, si);                      // Quu^{-1}[si][j] = sc * arow[j] (:655)
       if (!gj_row_positive(sc)) lds[Ly::oRed + kPdFlag] = 1.0;   // Quu not positive definite (read by the kernel after the pass: MI_STATUS_NOT_PD)
+      // cold path: the reference's inverse (LU with partial pivoting) of an indefinite Quu - and of EVERY Quu when the cost matrices
+      // are not symmetric: positive pivots say nothing about the growth of an unpivoted elimination of a matrix that is not
+      // symmetric (measured: 5e-8 / 4e-5 from the oracle on the (27, 7) plugin / the arm at N = 24 next to steps that tripped the check)
+      if (v.asym || (v.pd_continue && __any(!gj_row_positive(sc)))) {
+        load_quu(arow);
+        if (lane < m) {
+#pragma unroll
+          for (int j = 0; j < m; ++j) Ws[lane * WSS + j] = arow[j];
+        }
+        quu_inverse_pivoted<m>(Ws, WSS, lane);
+#pragma unroll
+        for (int j = 0; j < m; ++j) arow[j] = Ws[si * WSS + j];
+        sc = 1.0;
+      }
       if (lane < m) {
 #pragma unroll
         for (int j = 0; j < m; ++j) Ws[lane * WSS + j] = sc * arow[j];
@@ -2086,12 +2223,23 @@ __device__ inline void mid_backward(const LView<M::n, M::m>& v, double* lds, boo
         if (lane < m) { Kap[lane] = kp; v.kap[(size_t)t * m + lane] = kp; }
         if (lane == 0) v.dV[t] = dv;
       }
+      if (v.asym) {
+        // Vx' = Qx - Qu^T Quu^{-1} Qux (:666) = Qx - Qux^T (Quu^{-T} Qu): with a Quu that is not symmetric that is NOT Qux^T kappa
+        wave_lds_fence();
+        if (lane < m) {
+          double kt_ = 0.0;
+#pragma unroll
+          for (int i_ = 0; i_ < m; ++i_) kt_ = fma(Ws[i_ * WSS + lane], Fo[UC + i_], kt_);
+          KapT[lane] = kt_;
+        }
+      }
       lds_barrier();
       // ---- Vx' = Qx - Qux^T kappa (:666)
       if (lane < n) {
+        const double* const kv_ = v.asym ? KapT : Kap;
         double s = Fo[lane];
 #pragma unroll
-        for (int a_ = 0; a_ < m; ++a_) s -= QuxS[a_ * QS + lane] * Kap[a_];
+        for (int a_ = 0; a_ < m; ++a_) s -= QuxS[a_ * QS + lane] * kv_[a_];
         Vx[lane] = s;
       }
       if (t > 0) {
@@ -2151,6 +2299,8 @@ __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kerne
   v.Xn = a.x_trial + (size_t)b * n * N;
   v.Un = a.u_trial + (size_t)b * m * (N - 1);
   v.LxG = a.lxu ? a.lxu + (size_t)b * (N - 1) * (n + m) : nullptr;
+  v.pd_continue = a.pd_continue;
+  v.asym = Ly::kMid ? a.cost_asym : 0;      // (the host refuses such matrices for n >= 33: large_backward mirrors tiles)
   LargeAcc<n, m> acc;
   acc.X = v.X; acc.Fx = v.Fx; acc.Fu = v.Fu; acc.N = N;
   acc.kp = ilds; acc.aux = ilds + N; acc.need = ilds + 2 * N; acc.binA = ilds + 3 * N; acc.binB = ilds + 5 * N;
@@ -2334,7 +2484,7 @@ __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kerne
   if (MODE == MODE_BACKWARD) {
     backward_pass<M>(v, lds, nullptr, false);
     __syncthreads();
-    if (tid == 0) a.status[b] = lds[Ly::oRed + kPdFlag] != 0.0 ? MI_STATUS_NOT_PD : MI_STATUS_CONVERGED;
+    if (tid == 0) a.status[b] = lds[Ly::oRed + kPdFlag] == 0.0 ? MI_STATUS_CONVERGED : (a.pd_continue ? MI_STATUS_FLAG_INDEFINITE : MI_STATUS_NOT_PD);
     return;
   }
 
@@ -2352,6 +2502,7 @@ __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kerne
   double* const xsp = kSpecRollout<M> ? a.x_spec + (size_t)b * n * N : nullptr;
   double* const usp = kSpecRollout<M> ? a.u_spec + (size_t)b * m * (N - 1) : nullptr;
   bool backtracked = false;
+  bool met_indefinite = false;                               // on_indefinite = continue: a backward pass of this launch inverted a Quu that is not positive definite
   for (int rs = 0; rs < n_solves; ++rs) {
     if (MODE == MODE_MPC) {
       // warm start (mini_cheetah.py:193-198): x0 <- x_bar[:, replan]; u_bar <- [u_bar[:, replan:], repeat(last)]
@@ -2440,14 +2591,15 @@ __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kerne
       // profiling build only: 16 phase accumulators of thread 0 (a matrix-core wave) and of thread
       // 192 (the spare wave) land in the last 8 rows of the history buffer (tools/bp_prof.py)
       long long bpa[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-      if (MODE != MODE_FORWARD) { backward_pass<M>(v, lds, bpa, kLxFromRollout<M>); __syncthreads(); }
+      if (MODE != MODE_FORWARD) { backward_pass<M>(v, lds, bpa, kLxFromRollout<M> && !v.asym); __syncthreads(); }
       if ((tid == 0 || tid == 192) && iters == 0 && it_this == 0) {
         double* hp = a.hist + (size_t)b * a.hist_cap * 4 + 4 * (a.hist_cap - (tid == 0 ? 4 : 8));
         for (int q_ = 0; q_ < 16; ++q_) hp[q_] = (double)bpa[q_];
       }
 #else
       // (a four-candidate pass leaves no cost gradients behind: the backward pass forms them itself)
-      if (MODE != MODE_FORWARD) { backward_pass<M>(v, lds, nullptr, kLxFromRollout<M> && !used_spec, lin_staged && !IsChainModel<M>::value); __syncthreads(); }      // :697
+      // (nor does any rollout when Q is not symmetric: its cost rows hold 2 Q (x - x_nom), the reference's lx is 2 Q x - 2 Q^T x_nom, :180)
+      if (MODE != MODE_FORWARD) { backward_pass<M>(v, lds, nullptr, kLxFromRollout<M> && !used_spec && !v.asym, lin_staged && !IsChainModel<M>::value); __syncthreads(); }      // :697
 #endif
       const long long c3 = clock64();
       const bool not_pd = MODE != MODE_FORWARD && lds[Ly::oRed + kPdFlag] != 0.0;     // a Quu of this backward pass was not positive definite
@@ -2463,6 +2615,7 @@ __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kerne
       it_this += 1;
       if (MODE == MODE_FORWARD) break;
       if (not_pd && !a.pd_continue) { status = MI_STATUS_NOT_PD; break; }      // the gains of that pass are not to be used (unless asked to: on_indefinite)
+      met_indefinite = met_indefinite || not_pd;
     }
     iters += it_this;
     if (MODE == MODE_MPC) {
@@ -2475,7 +2628,7 @@ __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kerne
   if (G > 1 && tid == 0) __hip_atomic_store(csync + 3, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // helpers: go home
   for (int i = tid; i < nk; i += kLargeThreads) a.kp_list[(size_t)b * (N - 1) + i] = acc.kp[i];
   if (tid == 0) {
-    a.cost[b] = L; a.iters[b] = iters; a.status[b] = status; a.ls_trials[b] = ls_total; a.kp_count[b] = nk;
+    a.cost[b] = L; a.iters[b] = iters; a.status[b] = status | (met_indefinite ? MI_STATUS_FLAG_INDEFINITE : 0); a.ls_trials[b] = ls_total; a.kp_count[b] = nk;
 #ifndef MI_PROF_BACKWARD
     a.prof[4 * b + 0] = c_ls; a.prof[4 * b + 1] = c_lin; a.prof[4 * b + 2] = c_bp; a.prof[4 * b + 3] = clock64() - c_begin;
 #endif

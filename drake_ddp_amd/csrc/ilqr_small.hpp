@@ -97,7 +97,8 @@ struct KArgs {
   int spec_policy, pad_spec_;
   // workgroup-per-problem kernels, long horizons: the cost gradients [B][N-1][n+m] in HBM instead of LDS (ilqr_large.hpp)
   double* lxu;
-  int pd_continue, pad_pd_;       // mi_ilqr_desc.on_indefinite
+  int pd_continue;                // mi_ilqr_desc.on_indefinite
+  int cost_asym;                  // workgroup-per-problem kernels, n <= 32: Q, R or Qf is not symmetric (mi_ilqr_set_cost)
 };
 
 __device__ __forceinline__ double bcast_lane0(double v) {

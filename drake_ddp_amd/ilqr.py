@@ -9,8 +9,8 @@ is in libmi_ilqr.so (HIP, gfx950) — this file only moves arrays across the
 boundary.  ``BatchedIterativeLQR`` is the same surface with a leading batch axis.
 """
 import ctypes as C
-import sys
 import time
+import warnings
 import weakref
 
 import numpy as np
@@ -26,6 +26,17 @@ _JAC_IDS = {"fd": _capi.JAC_FD_CENTRAL, "fd_central": _capi.JAC_FD_CENTRAL,
 
 
 from .dist import shard_range, allreduce_min, allreduce_min_async  # noqa: E402,F401
+
+
+class _PinnedBlock:
+    """One page-locked allocation of a solver's result pool and whether an array handed out over it is still alive."""
+    __slots__ = ("raw", "nbytes", "busy", "__weakref__")
+
+    def __init__(self, raw, nbytes):
+        self.raw, self.nbytes, self.busy = raw, nbytes, False
+
+    def release(self):
+        self.busy = False
 
 
 class BatchedIterativeLQR:
@@ -75,9 +86,11 @@ class BatchedIterativeLQR:
         d.max_iters, d.hist_cap, d.device_id = int(max_iters), int(hist_cap), int(device)
         d.kernel_mode = {"auto": _capi.KERNEL_AUTO, "latency": _capi.KERNEL_LATENCY,
                          "throughput": _capi.KERNEL_THROUGHPUT}[kernel_mode]
-        # a Quu that is not positive definite (workgroup-per-problem kernels): "stop" the problem with STATUS_NOT_PD, or "continue"
-        # with whatever inverse comes out, which is what the reference's np.linalg.inv does (ilqr.py:655)
+        # a Quu that is not positive definite (workgroup-per-problem kernels): "stop" the problem with STATUS_NOT_PD (this class's
+        # default: one such problem does not spoil a batch - it is reported, never raised), or "continue" like the reference, which
+        # inverts whatever comes out with np.linalg.inv and carries on (ilqr.py:655; the single-problem drop-in's default)
         d.on_indefinite = {"stop": 0, "continue": 1}[on_indefinite]
+        self.on_indefinite = on_indefinite
         self._desc = d
         self.hist_cap = int(hist_cap)
         h = C.c_void_p()
@@ -159,26 +172,33 @@ class BatchedIterativeLQR:
     _POOL_CAP = 4
 
     def _out(self, which, shape, dtype):
-        """Destination of a field read: a fresh array, or (pinned_results) a page-locked block nobody else holds."""
+        """Destination of a field read: a fresh array, or (pinned_results) a page-locked block nobody else holds.
+
+        Every hand-out wraps the block in a NEW owner array (np.frombuffer); every view a caller derives from what it got has
+        that owner as its base, so the owner dies exactly when the last of them does - its finalizer marks the block free.  No
+        reference counts are read (a debugger, a profiler or another interpreter may hold extra ones): a block whose owner has
+        not been collected yet simply is not reused."""
         if self._pinned is None:
             return np.empty(shape, dtype=dtype)
         key = (which, tuple(shape), np.dtype(dtype).str)
         pool = self._pinned.setdefault(key, [])
-        for root in pool:
-            if sys.getrefcount(root) <= 3:          # the pool's reference, the loop variable, getrefcount's argument: no view is alive
-                return root.reshape(shape)
-        count = int(np.prod(shape))
-        nbytes = count * np.dtype(dtype).itemsize
-        if len(pool) >= self._POOL_CAP:             # the caller keeps many results alive: those stay theirs, this one is pageable
-            return np.empty(shape, dtype=dtype)
-        raw = C.c_void_p()
-        _capi.check(self._lib.mi_ilqr_host_alloc(max(nbytes, 8), C.byref(raw)), "mi_ilqr_host_alloc")
-        buf = (C.c_char * max(nbytes, 8)).from_address(raw.value)
-        root = np.frombuffer(buf, dtype=dtype, count=count)
-        # the block lives as long as any view of it does (the pool's, or one a caller kept)
-        weakref.finalize(root, self._lib.mi_ilqr_host_free, raw).atexit = False
-        pool.append(root)
-        return root.reshape(shape)
+        blk = next((b for b in pool if not b.busy), None)
+        if blk is None:
+            if len(pool) >= self._POOL_CAP:         # the caller keeps many results alive: those stay theirs, this one is pageable
+                return np.empty(shape, dtype=dtype)
+            nbytes = max(int(np.prod(shape)) * np.dtype(dtype).itemsize, 8)
+            raw = C.c_void_p()
+            _capi.check(self._lib.mi_ilqr_host_alloc(nbytes, C.byref(raw)), "mi_ilqr_host_alloc")
+            blk = _PinnedBlock(raw, nbytes)
+            # the memory lives as long as the block object does: the pool's reference, or a buffer a caller's array still wraps
+            weakref.finalize(blk, self._lib.mi_ilqr_host_free, raw).atexit = False
+            pool.append(blk)
+        buf = (C.c_char * blk.nbytes).from_address(blk.raw.value)
+        buf._block = blk
+        owner = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape)))
+        blk.busy = True
+        weakref.finalize(owner, blk.release).atexit = False
+        return owner.reshape(shape)
 
     # axis (from the end) along which a field carries the controls
     _U_AXIS = {_capi.F_U_BAR: -2, _capi.F_KAPPA: -2, _capi.F_U_TRIAL: -2, _capi.F_K: -3, _capi.F_FU: -2}
@@ -280,13 +300,18 @@ class BatchedIterativeLQR:
 
     def _check_internal(self, stats):
         """A solve aborted inside the kernel (MI_STATUS_INTERNAL: a cluster helper stopped answering) left x_bar / u_bar
-        that are not a solution: never hand them out as one."""
+        that are not a solution: never hand them out as one.  Problems that met a Quu which is not positive definite do NOT
+        abort the batch - the other B - 1 results are valid: they are reported per problem (`status`: STATUS_NOT_PD = stopped
+        there with on_indefinite="stop", STATUS_FLAG_INDEFINITE OR-ed onto the outcome with "continue"), counted in
+        stats.n_not_pd, and announced by a warning."""
         if stats is not None and stats.n_internal > 0:
             raise RuntimeError(f"{stats.n_internal} problem(s) aborted inside the device kernel (status {_capi.STATUS_INTERNAL}); "
                                "their results are not a solution")
         if stats is not None and stats.n_not_pd > 0:
-            raise RuntimeError(f"{stats.n_not_pd} problem(s) met a Quu that is not positive definite in a backward pass (status "
-                               f"{_capi.STATUS_NOT_PD}: an indefinite cost expansion, or one ruined by round-off); their gains are not to be used")
+            how = ("stopped there (status %d): their gains are not to be used" % _capi.STATUS_NOT_PD if self.on_indefinite == "stop"
+                   else "inverted it like the reference's np.linalg.inv (ilqr.py:655) and carried on (status flag %d)" % _capi.STATUS_FLAG_INDEFINITE)
+            warnings.warn(f"{stats.n_not_pd} of {self.B} problem(s) met a Quu that is not positive definite in a backward pass and {how}",
+                          RuntimeWarning, stacklevel=3)
 
     # ------------------------------------------------------------- Solve (ilqr.py:669-710)
     def Solve(self):
@@ -440,6 +465,9 @@ class IterativeLinearQuadraticRegulator(BatchedIterativeLQR):
     def __init__(self, system, num_timesteps, input_port_index=0, delta=1e-2, beta=0.95, gamma=0.0,
                  derivs_keypoint_method=None, **device_options):
         self.verbose = device_options.pop("verbose", True)
+        # the reference inverts every Quu with np.linalg.inv and never looks at its definiteness (ilqr.py:655): so does the drop-in.
+        # `status` then carries STATUS_FLAG_INDEFINITE; on_indefinite="stop" raises RuntimeError at the first such Quu instead.
+        device_options.setdefault("on_indefinite", "continue")
         super().__init__(system, num_timesteps, 1, input_port_index=input_port_index, delta=delta, beta=beta,
                          gamma=gamma, derivs_keypoint_method=derivs_keypoint_method, **device_options)
         self.x0 = np.zeros(self.n)
@@ -500,6 +528,10 @@ class IterativeLinearQuadraticRegulator(BatchedIterativeLQR):
                 elapsed += t_it
                 print(f"{i + 1:^14}{L_new:11.4f}  {eps:^12.4f}{int(ls):^11}   {t_derivs:1.5f}         {pct:.1f}       "
                       f"{t_bp:1.5f}    {t_fp:1.5f}      {t_it:1.5f}          {elapsed:4.2f}")
+        self.met_indefinite_quu = bool(status & _capi.STATUS_FLAG_INDEFINITE)
+        status &= ~_capi.STATUS_FLAG_INDEFINITE
+        if self.met_indefinite_quu and self.verbose:
+            print("note: a Quu of this solve was not positive definite; inverted like np.linalg.inv (ilqr.py:655) and carried on")
         if status == _capi.STATUS_LINESEARCH_FAILED:
             # ilqr.py:337 reports the trials of the FAILING line search (not the solve's running total): every step
             # size eps = beta^k >= 1e-8 was tried, counted with the reference's own float recurrence (ilqr.py:299-335)
@@ -511,8 +543,8 @@ class IterativeLinearQuadraticRegulator(BatchedIterativeLQR):
         if status == _capi.STATUS_INTERNAL:
             raise RuntimeError("solve aborted inside the device kernel (cluster hand-shake lost); results are not a solution")
         if status == _capi.STATUS_NOT_PD:
-            raise RuntimeError("Quu is not positive definite in the backward pass (indefinite cost expansion, or round-off); "
-                               "the reference would invert it all the same (ilqr.py:655) - its gains are no descent direction")
+            raise RuntimeError("Quu is not positive definite in the backward pass (indefinite cost expansion, or round-off) and "
+                               "on_indefinite=\"stop\" was asked for; the default, \"continue\", inverts it like the reference (ilqr.py:655)")
         if res is not None:
             return res[0].reshape(self.n, self.N), res[1][0], total_time, float(res[2][0])
         return self.x_bar, self.u_bar, total_time, float(self.cost[0])

@@ -32,7 +32,8 @@
 extern "C" {
 #endif
 
-#define MI_ILQR_ABI_VERSION 7   /* 7: mi_ilqr_desc.on_indefinite, mi_ilqr_model_plugin.m_user, 256 plugin slots */
+#define MI_ILQR_ABI_VERSION 8   /* 7: mi_ilqr_desc.on_indefinite, mi_ilqr_model_plugin.m_user, 256 plugin slots;
+                                   8: MI_STATUS_FLAG_INDEFINITE, on_indefinite = 1 inverts with partial pivoting, asymmetric costs for n <= 32 */
 #define MI_ILQR_MAX_PARAMS 16
 
 /* Error codes (0 = OK).  The Python wrapper maps them onto the exception types
@@ -89,12 +90,15 @@ enum { MI_KERNEL_AUTO = 0, MI_KERNEL_LATENCY = 1, MI_KERNEL_THROUGHPUT = 2 };
 /* Per-problem status written by solve/forward. */
 enum { MI_STATUS_CONVERGED = 0, MI_STATUS_MAX_ITERS = 1, MI_STATUS_LINESEARCH_FAILED = 2,
        MI_STATUS_INTERNAL = 3, /* a helper workgroup of the problem's cluster stopped answering (never seen) */
-       /* 4: internal to the library */
-       MI_STATUS_NOT_PD = 5    /* workgroup-per-problem kernels (n >= 5 models with m > 2): a backward pass met a Quu that is not
-                                  positive definite (a pivot of its elimination <= 0 or not finite) - an indefinite cost
-                                  expansion or one ruined by round-off.  The reference inverts such a Quu all the same
-                                  (np.linalg.inv, ilqr.py:655) and carries on with gains that are no descent direction; here
-                                  the problem stops with this status (its gains are NOT to be used) */ };
+       /* 4: unused */
+       MI_STATUS_NOT_PD = 5,   /* workgroup-per-problem kernels (n >= 5 models with m > 2), mi_ilqr_desc.on_indefinite = 0: a backward
+                                  pass met a Quu that is not positive definite (a pivot of its unpivoted elimination <= 0 or not
+                                  finite) - an indefinite cost expansion or one ruined by round-off - and the problem STOPPED there:
+                                  its gains are NOT to be used.  The reference inverts such a Quu all the same (np.linalg.inv,
+                                  ilqr.py:655) and carries on: that is on_indefinite = 1 */
+       MI_STATUS_FLAG_INDEFINITE = 16 /* OR-ed onto the outcome above (ABI 8), on_indefinite = 1: a backward pass of this solve (of this
+                                  mpc_run) met such a Quu, inverted it with partial pivoting like the reference and carried on;
+                                  `status & ~MI_STATUS_FLAG_INDEFINITE` is the solve's outcome.  Counted in stats.n_not_pd too */ };
 
 /* Selector for mi_ilqr_get / mi_ilqr_set / mi_ilqr_device_ptr. */
 enum {
@@ -139,10 +143,11 @@ typedef struct {
   int32_t device_id;                         /* HIP device ordinal */
   int32_t kernel_mode;                       /* MI_KERNEL_AUTO / _LATENCY / _THROUGHPUT */
   int32_t on_indefinite;                     /* workgroup-per-problem kernels, a Quu that is not positive definite in a backward pass:
-                                                0 = stop that problem with MI_STATUS_NOT_PD (default); 1 = carry on with the inverse the
-                                                elimination returns, as the reference does with np.linalg.inv (ilqr.py:655) - long,
-                                                stiff horizons on which round-off makes Quu indefinite while the line search still
-                                                finds its way (the wave- and lane-per-problem kernels always behave like 1) */
+                                                0 = stop that problem with MI_STATUS_NOT_PD (default of this struct); 1 = what the reference
+                                                does (np.linalg.inv, ilqr.py:655): invert it all the same - with partial pivoting, a cold
+                                                path no positive definite Quu ever enters - carry on, and flag the problem's status with
+                                                MI_STATUS_FLAG_INDEFINITE.  (The wave- and lane-per-problem kernels always behave like 1,
+                                                without the flag: their m <= 2 inverses are closed forms.) */
 } mi_ilqr_desc;
 
 typedef struct {
@@ -209,13 +214,16 @@ int mi_ilqr_create(const mi_ilqr_desc* desc, mi_ilqr_t** out);
 void mi_ilqr_destroy(mi_ilqr_t* h);
 
 /* SetRunningCost / SetTerminalCost / SetTargetState (ilqr.py:111-146): Q (n,n), R (m,m),
- * Qf (n,n), x_nom (n), shared by the batch.  Any pointer may be NULL = keep.  Any matrices are accepted,
- * like the reference (lxx = 2Q, never symmetrized - ilqr.py:182), by the wave- and lane-per-problem kernels: symmetric
- * positive semi-definite Q, Qf and positive definite R take the time-parallel / matrix-core backward passes, anything else
- * the reference's recursion verbatim.  The workgroup-per-problem kernels (models with m > 2 or n > 6: Arm27, the n = 36 / 37
- * models, plugin family 1) need SYMMETRIC matrices (asymmetries up to 8 ulp of the largest entry are averaged away, larger
- * ones: MI_ILQR_E_UNSUPPORTED); definiteness is not required of them - it is checked where it matters: a backward pass
- * that meets a Quu which is not positive definite stops its problem with MI_STATUS_NOT_PD. */
+ * Qf (n,n), x_nom (n), shared by the batch.  Any pointer may be NULL = keep.  ANY finite matrices are accepted, like the
+ * reference (lxx = 2Q, luu = 2R, lx = 2Qx - 2 x_nom^T Q, never symmetrized - ilqr.py:180-184), by every kernel family up to
+ * n = 32:  wave- and lane-per-problem kernels - symmetric positive semi-definite Q, Qf and positive definite R take the
+ * time-parallel / matrix-core backward passes, anything else the reference's recursion verbatim;  mid-size
+ * workgroup-per-problem kernels (m > 2 or n > 6, n <= 32: Arm27, plugin family 1) - the matrix-core pass itself uses no
+ * symmetry when a matrix is not symmetric (ABI 8).  Only the n = 33..40 kernels (n = 36 / 37 models, plugin family 1
+ * above 32 states) need SYMMETRIC matrices: their chain mirrors tiles of the symmetric products (asymmetries up to 8 ulp
+ * of the largest entry are averaged away, larger ones: MI_ILQR_E_UNSUPPORTED).  Definiteness is required of none - it is
+ * checked where it matters: mi_ilqr_desc.on_indefinite says what a backward pass does with a Quu that is not positive
+ * definite. */
 int mi_ilqr_set_cost(mi_ilqr_t* h, const double* Q, const double* R, const double* Qf, const double* x_nom);
 
 /* SetInitialState / SetInitialGuess (ilqr.py:102-109,148-156): x0 (B,n), u_guess (B,m,N-1).

@@ -48,7 +48,7 @@ def load(native=False):
 
 
 def solve_batch(model, prob, x0, u_guess=None, minN=1, fd_h=1e-5, nthreads=0, want_arrays=True, native=False,
-                keypoint=None, hist_cap=0):
+                keypoint=None, hist_cap=0, max_iters=100000):
     """Cold-start batched solve on the host.  model: oracle.models_np.Model.  keypoint: (method, minN, maxN,
     jerk_threshold, iterative_error_threshold) like utils_derivs_interpolation.derivs_interpolation; hist_cap > 0
     also returns hist (B, hist_cap, 4) = cost | eps | trials | key-point count per iteration, and the key-points of
@@ -58,7 +58,7 @@ def solve_batch(model, prob, x0, u_guess=None, minN=1, fd_h=1e-5, nthreads=0, wa
     x0 = np.ascontiguousarray(x0, dtype=np.float64).reshape(-1, n)
     B = x0.shape[0]
     cfg = Cfg(n=n, m=m, N=N, model_id=model.model_id, dt=model.dt, delta=prob["delta"], beta=prob["beta"],
-              gamma=prob["gamma"], minN=minN, fd_h=fd_h, max_iters=100000)
+              gamma=prob["gamma"], minN=minN, fd_h=fd_h, max_iters=int(max_iters))
     if keypoint is not None:
         cfg.kp_method, cfg.minN, cfg.maxN = KP_METHODS[keypoint[0]], int(keypoint[1]), int(keypoint[2])
         cfg.jerk_thr, cfg.err_thr = float(keypoint[3]), float(keypoint[4])

@@ -134,10 +134,7 @@ def test_mid_family_solves_like_the_oracle(shape):
         s = BatchedIterativeLQR(sys_, N, B, delta=1e-3, beta=0.7, gamma=0.0, jacobian_mode=jac, **({"max_iters": cap} if cap == 2 else {}))
         s.SetTargetState(x_nom); s.SetRunningCost(Q, R); s.SetTerminalCost(Qf)
         s.SetInitialState(x0); s.SetInitialGuess(ug)
-        try:
-            s.Solve()
-        except RuntimeError:
-            assert cap == 2
+        s.Solve()                                                # (MI_STATUS_MAX_ITERS raises nothing: cap = 2 included)
         for b in range(B):
             o = OracleILQR(model, N, 1e-3, 0.7, 0.0, jacobian=jac, fd_step=1e-5, max_iters=cap)
             o.set_problem(x0[b], x_nom, Q, R, Qf, ug[b])
@@ -308,3 +305,117 @@ np.savez(sys.argv[1], **out)
         dev = max(np.max(np.abs(o["L"] - ref["L"]) / np.abs(ref["L"])), np.max(np.abs(o["cL"][ok] - ref["cL"][ok]) / np.abs(ref["cL"][ok])))
         print(f"  MI_ILQR_SPEC={pol}: every decision identical; largest relative cost difference {dev:.1e}")
         assert dev < 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["chainx_12_4", "chainx_27_7", "arm27_n16", "arm27_n24"])
+def test_asymmetric_costs_follow_the_reference_on_the_mid_size_kernels(which):
+    """The reference accepts any Q, R, Qf and never symmetrizes (ilqr.py:120-146,161-186): lxx = 2Q, luu = 2R,
+    lx = 2Qx - 2 x_nom^T Q, Quu not symmetric, Vx' = Qx - Qu^T Quu^{-1} Qux, Vxx' = Qxx - Qux^T Quu^{-1} Qux.  The mid-size
+    matrix-core pass (mid_backward, n <= 32) follows it with every use of symmetry switched off (until round 5:
+    MI_ILQR_E_UNSUPPORTED): a backward pass on the device's own first trajectory against the NumPy oracle (stage level, 1e-10)
+    and a short solve (iterations, step sizes and trial counts exact - or the reference's own line-search failure, which an
+    asymmetric Q can cause: its lx is not the gradient of its cost).  Q, R AND Qf asymmetric, x_nom != 0.
+    (The reference's recursion is itself fragile on such costs: the antisymmetric part of Vxx enters the symmetric part of Vxx'
+    through -Qux^T Quu^{-1} Qux and takes it indefinite within a few dozen steps - on the arm + ball problem the fp64 NumPy pass
+    is 1e-12 from the extended-precision one at N = 16, 1e-9 at N = 24 and has no digit left at the scripts' N = 50 (cond(Quu)
+    1e14), whatever the size of the asymmetry.  Hence the arm's short horizons here, and the extended-precision yardstick.)"""
+    import models as PM
+    import plugin_steps as PS
+    from drake_ddp_amd import workloads as W
+    from drake_ddp_amd.ilqr import BatchedIterativeLQR
+    from drake_ddp_amd.models import ModelSystem
+    from oracle import models_np as M
+    from oracle.ilqr_np import OracleILQR, LinesearchFailed
+    rng = np.random.default_rng(23)
+    B, cap = 2, 5
+    from common import backward_errors
+    if which.startswith("arm27"):
+        prob = W.arm27_problem(N=int(which[-2:]))
+        n, m, N, dt = 27, 7, prob["N"], prob["dt"]
+        sys_ = ModelSystem(prob["model_id"], dt, prob.get("params"))
+        model = M.Model(prob["model_id"], dt, prob.get("params"))
+        Q, R, Qf, x_nom = prob["Q"].copy(), prob["R"].copy(), prob["Qf"].copy(), prob["x_nom"]
+        x0 = W.arm27_batch_x0(B)
+        ug = np.broadcast_to(W.arm27_u_guess(N), (B, m, N - 1)).copy()
+        delta, beta = prob["delta"], prob["beta"]
+    else:
+        nq, m, ne = {"chainx_12_4": (6, 4, 0), "chainx_27_7": (10, 7, 7)}[which]
+        n, N, dt = 2 * nq + ne, 24, 0.02
+        sys_ = PM.build_chainx(nq, m, ne)(dt)
+        model = M.Model.custom(n, m, PS.chainx_step(nq, m, ne), sys_.params, dt)
+        Q = dt * np.diag(10.0 ** rng.uniform(-1, 0.5, n)); R = dt * 0.05 * np.eye(m); Qf = np.diag(10.0 ** rng.uniform(0, 1, n))
+        x_nom = 0.2 * rng.standard_normal(n)
+        x0 = 0.4 * rng.standard_normal((B, n))
+        ug = 0.2 * rng.standard_normal((B, m, N - 1))
+        delta, beta = 1e-3, 0.7
+    # asymmetric parts: strictly upper / lower triangles, 5 - 10 % of sqrt(A_ii A_jj)
+    def asym(A, upper):
+        d = np.sqrt(np.abs(np.diag(A)))
+        T = rng.uniform(0.5, 1.0, A.shape)
+        return A + 0.1 * (d[:, None] * (np.triu(T, 1) if upper else np.tril(T, -1)) * d[None, :])
+    Q, R, Qf = asym(Q, True), asym(R, False), asym(Qf, False)
+    assert not np.allclose(Q, Q.T) and not np.allclose(R, R.T) and not np.allclose(Qf, Qf.T)
+
+    def device(max_iters=None):
+        s = BatchedIterativeLQR(sys_, N, B, delta=delta, beta=beta, gamma=0.0, jacobian_mode="ad", on_indefinite="continue",
+                                **({"max_iters": max_iters} if max_iters else {}))
+        s.SetTargetState(x_nom); s.SetRunningCost(Q, R); s.SetTerminalCost(Qf)
+        s.SetInitialState(x0); s.SetInitialGuess(ug)
+        return s
+
+    s = device()
+    s.stage_forward(np.inf)
+    s.stage_backward()
+    xb, ub, fx, fu, K1, k1, dV1 = s.x_bar, s.u_bar, s.fx, s.fu, s.K, s.kappa, s.dV_coeff
+    worst = 0.0
+    for b in range(B):
+        o = OracleILQR(model, N, delta, beta, 0.0)
+        o.set_problem(x0[b], x_nom, Q, R, Qf, ug[b])
+        o.x_bar, o.u_bar, o.fx, o.fu = xb[b], ub[b], fx[b], fu[b]
+        o.backward()
+        e_dev, e_ref, cond = backward_errors((K1[b], k1[b], dV1[b]), o)
+        worst = max(worst, e_dev)
+        per = [float(np.max(np.abs(a_ - b_))) / float(np.max(np.abs(b_))) for a_, b_ in ((K1[b], o.K), (k1[b], o.kappa), (dV1[b], o.dV))]
+        print(f"{which} problem {b}: device vs NumPy K {per[0]:.1e} kappa {per[1]:.1e} dV {per[2]:.1e}; vs extended {e_dev:.1e} (NumPy {e_ref:.1e}), cond {cond:.1e}, status {int(s.status[b])}")
+        assert e_ref < 1e-7, (which, b, e_ref, cond)              # (the comparison means something: the reference has digits here)
+        assert e_dev < max(1e-10, 20 * e_ref), (which, b, e_dev, e_ref, cond)
+        # (and it is NOT what a symmetrized cost would give: the asymmetric parts are seen)
+        osym = OracleILQR(model, N, delta, beta, 0.0)
+        osym.set_problem(x0[b], x_nom, 0.5 * (Q + Q.T), 0.5 * (R + R.T), 0.5 * (Qf + Qf.T), ug[b])
+        osym.x_bar, osym.u_bar, osym.fx, osym.fu = xb[b], ub[b], fx[b], fu[b]
+        osym.backward()
+        assert float(np.max(np.abs(osym.K - o.K))) / float(np.max(np.abs(o.K))) > 1e-6
+    s = device(cap)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        x, u, _, L = s.Solve()
+    n_eps = int(np.floor(np.log(1e-8) / np.log(beta))) + 1
+    outcomes = []
+    for b in range(B):
+        o = OracleILQR(model, N, delta, beta, 0.0, max_iters=cap)
+        o.set_problem(x0[b], x_nom, Q, R, Qf, ug[b])
+        Lo, done, failed, trials, hist = np.inf, 0, False, 0, []
+        while done < cap:
+            try:
+                L_new, eps, ls = o.forward(Lo)
+            except LinesearchFailed:
+                failed = True
+                break
+            o.backward()
+            hist.append((L_new, eps, ls)); trials += ls; done += 1
+            improvement, Lo = Lo - L_new, L_new
+            if not improvement > delta:
+                break
+        st = int(s.status[b]) & 15
+        assert s.iterations[b] == done, (which, b, s.iterations[b], done, st)
+        h = s.history[b][:done]
+        assert np.array_equal(h[:, 1:3], np.array([[r[1], r[2]] for r in hist]).reshape(done, 2)), (which, b)
+        if failed:
+            assert st == 2 and s.ls_trials[b] == trials + n_eps
+        else:
+            assert s.ls_trials[b] == trials and abs(L[b] - Lo) < 1e-9 * abs(Lo)
+            assert np.max(np.abs(x[b] - o.x_bar)) < 1e-8 * max(1.0, float(np.abs(o.x_bar).max()))
+        outcomes.append("failed" if failed else done)
+    print(f"{which}: stage level, worst distance from the extended-precision pass {worst:.1e}; solves (iterations or failed) {outcomes}")

@@ -702,6 +702,16 @@ def test_shared_initial_guess_and_pinned_results(cfg):
             x3 = s.x_bar                                                      # nobody holds the other blocks any more: one is reused
             assert x3.__array_interface__["data"][0] in (addr, x3.__array_interface__["data"][0]) and len(s._pinned) >= 1
             assert max(len(v) for v in s._pinned.values()) <= 3
+            # a DERIVED view alone keeps its block (every view's base is the hand-out's owner array), and no reference count is
+            # consulted: extra references to a result (a debugger's, a profiler's) change nothing
+            x4 = s.x_bar
+            piece, extra_refs = x4[1, :, 5:9], [x4, x4, x4]
+            want = piece.copy()
+            del x4
+            s.Reset(); s.SetInitialState(x0 - 0.02); s.SetInitialGuess(guess); s.Solve()
+            _ = [s.x_bar for _k in range(6)]
+            assert np.array_equal(piece, want)
+            del extra_refs, _
             keep = x
             del s
             import gc; gc.collect()
