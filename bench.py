@@ -558,7 +558,7 @@ def main():
     # MI_BENCH_NATIVE_RCCL=1: the collective goes through the library's own RCCL communicator
     # (mi_ilqr_allreduce_min_start/_wait, the C caller's path) instead of torch.distributed
     native = None
-    if world > 1 and backend == "nccl" and os.environ.get("MI_BENCH_NATIVE_RCCL") == "1":
+    if world > 1 and os.environ.get("MI_BENCH_NATIVE_RCCL") == "1":     # (any torch backend: it only ships the communicator's id)
         from drake_ddp_amd.dist import NativeComm
         native = NativeComm.from_torch(dev_index)
     RING = 32      # solves the library lets us keep in flight (per-launch events + statistics records)

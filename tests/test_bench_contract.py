@@ -76,3 +76,60 @@ def test_bench_line_carries_every_config_and_the_boundary():
     assert d["clock_ramp_steps"] >= 0 and "order" in d and "kernel_ms_source" in rf
     cb = d["concurrent_batches"]["runs"]
     assert [r_["handles"] for r_ in cb] == [2, 4] and all(r_["iterations_per_s"] > 0.8 * d["value"] for r_ in cb)
+
+
+_ONE_RANK = {}
+
+
+def _one_rank_configs():
+    """The single-rank run with every config (cached for the sharded runs to be compared with)."""
+    if "d" not in _ONE_RANK:
+        r = _run(["--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
+        assert r.returncode == 0, r.stderr[-3000:]
+        _ONE_RANK["d"] = _json_line(r.stdout)
+    return _ONE_RANK["d"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_sharded_configs_do_exactly_the_whole_batchs_work(world):
+    """`bench.py --gpus N` WITH every config (C1, C3 ... C6 through run_config's shard path: C3 at 512 / N problems per rank, C5 at
+    64 / N, C1's single problem on rank 0 alone), N ranks over gloo sharing this box's GPU - the form of the run the driver's
+    8-GPU node executes over RCCL.  Problems are independent and every kernel's result is independent of its batch,
+    so the ranks together must do EXACTLY the single-rank run's work: the same iterations per config (rank-summed), every problem
+    converged, batch_per_gpu = ceil(B / N); the line says how many ranks and which collective."""
+    one = _one_rank_configs()
+    r = _run(["--gpus", str(world), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], env={"MI_BENCH_BACKEND": "gloo"}, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == world and d["scaling"] == "weak" and d["config"]["global_batch"] == 1024 * world
+    assert d["config"]["parallelism"] == f"batch-shard x{world}" and "all_reduce(MIN)" in d["config"]["collective"]
+    ref = {c["name"]: c for c in one["configs"]}
+    names = [c["name"] for c in d["configs"]]
+    assert [n[:3].strip() for n in names] == ["C1", "C3", "C4", "C5", "C5q", "C5q", "C6"], names     # (the B = 8 shard line is a 1-rank entry)
+    for c in d["configs"]:
+        o = ref[c["name"]]
+        assert c["batch"] == o["batch"] and c["batch_per_gpu"] == -(-c["batch"] // world), c["name"]
+        assert c["iterations"] == o["iterations"], (c["name"], c["iterations"], o["iterations"])
+        assert c["converged"] == o["converged"] and (c["converged"] == c["batch"] or c["name"].startswith("C4")), (c["name"], c["converged"], o["converged"])
+        assert c["max_iterations_per_problem"] == o["max_iterations_per_problem"]
+        assert c["iterations_per_s"] > 0 and c["ms_per_solve"] > 0
+    assert d["boundary_inclusive"] is not None and d["concurrent_batches"] is None
+    # headline: weak scaling, rank 0 solves its 1024-problem block of the 1024 N drawn with one seed (another draw than the single-rank batch)
+    assert abs(d["iterations_per_step_rank0"] - one["iterations_per_step_rank0"]) < 0.05 * one["iterations_per_step_rank0"] and d["converged_rank0"] == 1024
+
+
+@pytest.mark.gpu
+def test_bench_native_rccl_communicator_two_ranks():
+    """MI_BENCH_NATIVE_RCCL=1: the best-cost reduction through the LIBRARY's communicator (mi_ilqr_comm_create over librccl, the C
+    caller's path), the ranks and the 128-byte id shipped by torch.distributed.  With two GPUs it runs; on a one-GPU box RCCL
+    refuses two ranks on one device - the run must then stop with the library's own message, not hang or fall back."""
+    import torch
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-configs"],
+             env={"MI_BENCH_BACKEND": "gloo", "MI_BENCH_NATIVE_RCCL": "1"}, timeout=600)
+    if torch.cuda.device_count() >= 2:
+        assert r.returncode == 0, r.stderr[-3000:]
+        assert "mi_ilqr_allreduce_min_start" in _json_line(r.stdout)["config"]["collective"]
+    else:
+        assert r.returncode != 0
+        assert "ncclCommInitRank failed" in r.stderr and "mi_ilqr_comm_create" in r.stderr, r.stderr[-3000:]
