@@ -359,9 +359,49 @@ def all_configs(rk, dev_index):
                           "1 + 20 re-solves x batch 64, device loop, mid-size kernels", a27,
                           W.arm27_batch_x0(64), W.arm27_u_guess(a27["N"]), reps=2, mpc=(20, 5, None)))
     if rk.world == 1:
+        out.append(throughput_entry(dev_index))
         out.append(run_config(rk, dev_index, "C5 shard of an 8-GPU run: batch 8 on this GPU", q,
                               W.synth36_batch_x0(64)[:8], W.synth36_u_guess(q["N"]), reps=2,
                               mpc=(100, 4, (0, W.SYNTH_TARGET_VEL * q["dt"] * 4))))
+    return out
+
+
+def throughput_entry(dev_index, B=262144, reps=5):
+    """The lane-per-problem ("throughput") kernels - the one family that STREAMS its state through HBM (ilqr_batch.hpp): acrobot
+    n = 4, m = 1, N = 40, B problems, cold-start batched solves from resident inputs.  `roofline.traffic`: HBM bytes per launch
+    from the committed FETCH_SIZE / WRITE_SIZE passes of the same workload (tools/pmc_throughput.py; the counters calibrated on an
+    8 B / lane stream: FETCH_SIZE counts half of the bytes read, WRITE_SIZE all of the bytes written)."""
+    from drake_ddp_amd import workloads as W
+    a = W.acrobot_problem()
+    s = make_solver(a, B, dev_index, kernel_mode="throughput")
+    s.SetInitialState(np.tile(W.acrobot_batch_x0(512), (B // 512, 1)))
+    s.SetInitialGuess(np.zeros((1, a["N"] - 1)))
+    s._push_problem()
+    s.rearm(cold=True); s.solve_resident()
+    t0 = time.perf_counter()
+    it = kms = ab = 0.0
+    for _ in range(reps):
+        s.rearm(cold=True)
+        st = s.solve_resident()
+        it += st.total_iters; kms += st.kernel_ms; ab += st.algorithmic_bytes
+    wall = time.perf_counter() - t0
+    traffic = src = None
+    path = os.path.join(ROOT, "profiles", "r05_pmc_throughput.json")
+    if os.path.exists(path):
+        for r in json.load(open(path))["runs"]:
+            if r["B"] == B and r["kp"] == "none":
+                traffic, src = r["hbm_bytes_per_launch"], "committed profiles/r05_pmc_throughput.json (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE, calibrated on tools/ubench/stream8)"
+    k_s = kms / reps * 1e-3
+    achieved = ab / reps / k_s / 1e9
+    out = {"name": f"throughput: acrobot N=40, batch {B}, lane-per-problem kernels (state streamed through HBM), cold-start solves",
+           "batch": B, "batch_per_gpu": B, "n": 4, "m": 1, "N": a["N"], "solves": reps, "iterations": it / reps, "iterations_per_s": it / wall,
+           "ms_per_solve": 1e3 * wall / reps, "kernel_ms_per_solve": kms / reps, "max_iterations_per_problem": int(st.max_iters_seen),
+           "converged": int(st.n_converged), "algorithmic_GBps_per_gpu": achieved, "hbm_frac": achieved / HBM_PEAK_GBS,
+           "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                        "traffic": traffic, "traffic_source": src, "kernel": "ilqr_batch_kernel<Acrobot,FD,KP=false>", "kernel_ms": kms / reps,
+                        "hbm_traffic_frac": (traffic / k_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                        "note": "algorithmic bytes exceed the real traffic: the linearization is fused into the backward sweep (fx, fu never written or re-read)"}}
+    del s
     return out
 
 
@@ -697,6 +737,8 @@ def main():
                          "kernel_ms_source": f"HIP events carried by {n_timed} of the {args.steps} timed launches (one in {TIME_EVERY})",
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "hbm_traffic_frac": (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                         "limiter": "fp64 issue latency, NOT HBM: `bound`/`frac` are SURVEY 8(d)'s algorithmic-bytes accounting; the state is LDS-resident, the real "
+                                    "HBM traffic is `hbm_traffic_frac` of the peak and what binds is `roofline_compute` (fp64 issued / fp64 peak at one wave per SIMD)",
                          "note": "issue-latency-bound: one wave per problem, rollout and Riccati sweep as time-parallel scans; state is LDS-resident, the launch lasts as long as its slowest problem"},
         }
         out["roofline_compute"] = compute
