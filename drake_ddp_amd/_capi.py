@@ -26,10 +26,11 @@ STATUS_NOT_PD = 5
 STATUS_FLAG_INDEFINITE = 16     # OR-ed onto the outcome: on_indefinite="continue" inverted a Quu that is not positive definite
 F_X_BAR, F_U_BAR, F_K, F_KAPPA, F_DV, F_FX, F_FU, F_COST, F_X0, F_HIST, F_X_TRIAL, F_U_TRIAL, F_TRIAL_COST, F_ITER_CYCLES = range(14)
 I_ITERS, I_STATUS, I_LS_TRIALS, I_KP_COUNT, I_KP_LIST = 100, 101, 102, 103, 104
+I64_STAGE_CYCLES = 200
 
 EXPORTS = [
     "mi_ilqr_abi_version", "mi_ilqr_struct_sizes", "mi_ilqr_strerror", "mi_ilqr_model_info", "mi_ilqr_register_model", "mi_ilqr_create", "mi_ilqr_destroy",
-    "mi_ilqr_set_cost", "mi_ilqr_set_initial", "mi_ilqr_set_initial_shared", "mi_ilqr_host_alloc", "mi_ilqr_host_free", "mi_ilqr_set_result_sink", "mi_ilqr_reset", "mi_ilqr_rearm_initial_guess",
+    "mi_ilqr_set_cost", "mi_ilqr_set_initial", "mi_ilqr_set_initial_shared", "mi_ilqr_host_alloc", "mi_ilqr_host_free", "mi_ilqr_set_result_sink", "mi_ilqr_solve_into", "mi_ilqr_reset", "mi_ilqr_rearm_initial_guess",
     "mi_ilqr_solve", "mi_ilqr_solve_async", "mi_ilqr_collect_stats", "mi_ilqr_collect_stats_n",
     "mi_ilqr_rollout", "mi_ilqr_forward", "mi_ilqr_linearize", "mi_ilqr_backward", "mi_ilqr_mpc_shift",
     "mi_ilqr_mpc_run", "mi_ilqr_get_mpc_log",
@@ -101,6 +102,8 @@ def load():
     lib.mi_ilqr_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
     lib.mi_ilqr_host_free.argtypes = [C.c_void_p]
     lib.mi_ilqr_set_result_sink.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.mi_ilqr_solve_into.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.POINTER(Stats), C.POINTER(C.c_int32)]
     lib.mi_ilqr_mpc_shift.argtypes = [H, C.c_int32]
     lib.mi_ilqr_mpc_run.argtypes = [H, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(Stats)]
     lib.mi_ilqr_get_mpc_log.argtypes = [H, C.c_void_p, C.c_size_t]
@@ -157,4 +160,5 @@ def as_f64(a, shape=None):
 
 
 def ptr(a):
-    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+    """Address of an array's first element (an int: ctypes takes it for a c_void_p argument), None for None."""
+    return a.__array_interface__["data"][0] if a is not None else None

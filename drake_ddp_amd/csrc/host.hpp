@@ -62,6 +62,13 @@ struct mi_ilqr {
   bool u_pending = false;  // SetInitialGuess input waiting in u_guess
   bool u_zero = false;     // u_bar is to read as all zero (after reset, until a guess is set or re-armed): ilqr.py:71
   int exact_backward = 0;  // cost matrices the fast backward forms do not cover (asymmetric / indefinite): reference recursion
+  // tiny batches (B <= 4): the per-solve records - iteration log, stopwatches, iterations, status - live in page-locked host memory the
+  // kernels write directly (hist, iter_cyc, prof, iters_ring, status_ring point into it): mi_ilqr_solve_into reads them with a memcpy
+  // after the solve's one synchronization instead of five device-to-host copies queued behind the kernel (~5 us each)
+  char* host_records = nullptr;       // host address of the block (hipHostMalloc, mapped)
+  char* host_records_dev = nullptr;   // the same block as the device sees it
+  size_t host_records_bytes = 0;
+  bool host_inputs = false;           // x0 and u_guess live in the block too (B <= 4, wave-per-problem kernels)
   int cost_asym = 0;       // workgroup-per-problem kernels, n <= 32: Q, R or Qf is not symmetric (mid_backward then uses no symmetry at all)
   std::vector<double> h_costmat;   // host mirror of costmat (Q | R | Qf | x_nom)
   bool costmat_synced = false;     // the device copy equals the mirror

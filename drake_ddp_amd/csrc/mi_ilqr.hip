@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -38,12 +39,15 @@ namespace {
 struct ModelInfo { int n, m, n_params; double defaults[MI_ILQR_MAX_PARAMS]; };
 
 // models registered at run time (mi_ilqr_register_model): id = MI_MODEL_PLUGIN_BASE + slot
-struct PluginSlot { ModelInfo info; mi_ilqr_model_plugin p; bool used = false; };
+// Registrations take the mutex; a slot is filled once and read lock-free afterwards: `used` is published LAST with release
+// ordering and read with acquire ordering, so a thread that sees it set also sees the slot's contents (a create or a launch on
+// one thread may race a registration on another).
+struct PluginSlot { ModelInfo info; mi_ilqr_model_plugin p; std::atomic<bool> used{false}; };
 PluginSlot g_plugins[MI_ILQR_MAX_PLUGINS];
 std::mutex g_plugins_mutex;
 const PluginSlot* plugin_of(int id) {
   const int s_ = id - MI_MODEL_PLUGIN_BASE;
-  return (s_ >= 0 && s_ < MI_ILQR_MAX_PLUGINS && g_plugins[s_].used) ? &g_plugins[s_] : nullptr;
+  return (s_ >= 0 && s_ < MI_ILQR_MAX_PLUGINS && g_plugins[s_].used.load(std::memory_order_acquire)) ? &g_plugins[s_] : nullptr;
 }
 
 const ModelInfo* model_info(int id) {
@@ -233,7 +237,7 @@ int materialize_u(mi_ilqr* h) {
   if (h->u_zero && !h->u_pending) HIPCHK(hipMemsetAsync(h->u_bar, 0, (size_t)h->B * h->m * (h->N - 1) * 8, h->stream));
   h->u_zero = false;
   if (!h->u_pending) return MI_ILQR_OK;
-  HIPCHK(hipMemcpyAsync(h->u_bar, h->u_guess, (size_t)h->B * h->m * (h->N - 1) * 8, hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->u_bar, h->u_guess, (size_t)h->B * h->m * (h->N - 1) * 8, h->host_inputs ? hipMemcpyDefault : hipMemcpyDeviceToDevice, h->stream));
   h->u_pending = false;
   return MI_ILQR_OK;
 }
@@ -486,6 +490,7 @@ Field field_of(mi_ilqr* h, int which) {
     case MI_I_LS_TRIALS: return {h->ls_trials, B * 4, true};
     case MI_I_KP_COUNT: return {h->kp_count, B * 4, true};
     case MI_I_KP_LIST: return {h->kp_list, B * (N - 1) * 4, true};
+    case MI_I64_STAGE_CYCLES: return {h->prof, B * 4 * 8, true};
   }
   return {nullptr, 0, false};
 }
@@ -540,14 +545,14 @@ int mi_ilqr_register_model(const mi_ilqr_model_plugin* p, int32_t* model_id_out)
   // (mid_backward), 32 < n <= 40 with m % 4 == 0 and 2 m <= n (large_backward's wave roles)
   if (p->family == 0 ? p->m > 2
                      : (p->family != 1 || p->m > 16 || (p->n > 32 && (2 * p->m > p->n || p->m % 4 != 0)))) return MI_ILQR_E_UNSUPPORTED;
-  std::lock_guard<std::mutex> lock(g_plugins_mutex);                     // (slots are filled once and read lock-free afterwards: `used` is set last)
+  std::lock_guard<std::mutex> lock(g_plugins_mutex);                     // (readers: plugin_of, lock-free)
   for (int s_ = 0; s_ < MI_ILQR_MAX_PLUGINS; ++s_) {
-    if (g_plugins[s_].used) continue;
+    if (g_plugins[s_].used.load(std::memory_order_relaxed)) continue;
     PluginSlot& ps = g_plugins[s_];
     ps.p = *p;
     ps.info.n = p->n; ps.info.m = p->m; ps.info.n_params = p->n_params;
     for (int i = 0; i < MI_ILQR_MAX_PARAMS; ++i) ps.info.defaults[i] = p->default_params[i];
-    ps.used = true;
+    ps.used.store(true, std::memory_order_release);
     *model_id_out = MI_MODEL_PLUGIN_BASE + s_;
     return MI_ILQR_OK;
   }
@@ -656,22 +661,47 @@ int mi_ilqr_create(const mi_ilqr_desc* desc, mi_ilqr_t** out) {
   ALLOC(h->dV, B * (N - 1), double);
   ALLOC(h->fx, B * n * n * (N - 1), double);
   ALLOC(h->fu, B * n * m * (N - 1), double);
-  ALLOC(h->x0, B * n, double);
-  ALLOC(h->u_guess, B * m * (N - 1), double);
+  const bool host_rec = B <= 4;              // (host.hpp: host_records)
+  const bool host_in = host_rec && !large && !batch_minor;   // ... and the inputs x0, u_guess (wave-per-problem kernels: the boundary's layout)
+  if (!host_in) {
+    ALLOC(h->x0, B * n, double);
+    ALLOC(h->u_guess, B * m * (N - 1), double);
+  }
   ALLOC(h->cost_ring, B * mi_ilqr::kStatsRing, double);
-  ALLOC(h->hist, B * (size_t)h->d.hist_cap * 4, double);
-  ALLOC(h->iter_cyc, B * (size_t)h->d.hist_cap * 4, double);
+  if (host_rec) {
+    auto up = [](size_t v) { return (v + 63) & ~(size_t)63; };
+    const size_t s_hist = up(B * (size_t)h->d.hist_cap * 4 * 8), s_prof = up(B * 4 * 8), s_ring = up(B * mi_ilqr::kStatsRing * 4);
+    const size_t s_x0 = host_in ? up(B * n * 8) : 0, s_ug = host_in ? up(B * m * (N - 1) * 8) : 0;
+    h->host_records_bytes = 2 * s_hist + s_prof + 2 * s_ring + s_x0 + s_ug;
+    void* dv = nullptr;
+    if (hipHostMalloc(reinterpret_cast<void**>(&h->host_records), h->host_records_bytes, hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer(&dv, h->host_records, 0) != hipSuccess) { mi_ilqr_destroy(h); return MI_ILQR_E_HIP; }
+    std::memset(h->host_records, 0, h->host_records_bytes);
+    h->host_records_dev = static_cast<char*>(dv);
+    char* q = h->host_records_dev;
+    h->hist = reinterpret_cast<double*>(q); q += s_hist;
+    h->iter_cyc = reinterpret_cast<double*>(q); q += s_hist;
+    h->prof = reinterpret_cast<long long*>(q); q += s_prof;
+    h->iters_ring = reinterpret_cast<int32_t*>(q); q += s_ring;
+    h->status_ring = reinterpret_cast<int32_t*>(q); q += s_ring;
+    if (host_in) { h->x0 = reinterpret_cast<double*>(q); q += s_x0; h->u_guess = reinterpret_cast<double*>(q); h->host_inputs = true; }
+  } else {
+    ALLOC(h->hist, B * (size_t)h->d.hist_cap * 4, double);
+    ALLOC(h->iter_cyc, B * (size_t)h->d.hist_cap * 4, double);
+  }
   ALLOC(h->x_trial, B * n * N, double);
   ALLOC(h->u_trial, B * m * (N - 1), double);
   ALLOC(h->trial_cost, B * 2, double);
   ALLOC(h->stage_in, B, double);
   ALLOC(h->costmat, 2 * n * n + m * m + n, double);
-  ALLOC(h->iters_ring, B * mi_ilqr::kStatsRing, int32_t);
-  ALLOC(h->status_ring, B * mi_ilqr::kStatsRing, int32_t);
+  if (!host_rec) {
+    ALLOC(h->iters_ring, B * mi_ilqr::kStatsRing, int32_t);
+    ALLOC(h->status_ring, B * mi_ilqr::kStatsRing, int32_t);
+    ALLOC(h->prof, B * 4, long long);
+  }
   ALLOC(h->ls_ring, B * mi_ilqr::kStatsRing, int32_t);
   ALLOC(h->kp_count, B, int32_t);
   ALLOC(h->kp_list, B * (N - 1), int32_t);
-  ALLOC(h->prof, B * 4, long long);
   ALLOC(h->done_counter, 1, int32_t);
   if (large) ALLOC(h->cluster_sync, B * 4, unsigned long long);
   if (lxu_hbm) ALLOC(h->lxu, B * (N - 1) * (n + m), double);
@@ -727,6 +757,11 @@ void mi_ilqr_destroy(mi_ilqr_t* h) {
   if (!h) return;
   (void)hipSetDevice(h->d.device_id);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->host_records) {                               // (the five record buffers point into this block)
+    (void)hipHostFree(h->host_records);
+    h->hist = h->iter_cyc = nullptr; h->prof = nullptr; h->iters_ring = h->status_ring = nullptr;
+    if (h->host_inputs) h->x0 = h->u_guess = nullptr;
+  }
   void* ptrs[] = {h->x_bar, h->u_bar, h->K, h->kappa, h->dV, h->fx, h->fu, h->x0, h->u_guess, h->cost_ring, h->hist, h->iter_cyc,
                   h->x_trial, h->u_trial, h->trial_cost, h->stage_in, h->costmat, h->iters_ring, h->status_ring, h->ls_ring,
                   h->kp_count, h->kp_list, h->prof, h->done_counter, h->cluster_sync, h->bm_scratch, h->x_spec, h->u_spec, h->lxu};
@@ -840,9 +875,29 @@ int mi_ilqr_set_cost(mi_ilqr_t* h, const double* Q, const double* R, const doubl
   return rc;
 }
 
+// tiny batches of the wave-per-problem kernels keep x0 / u_guess in page-locked host memory the kernels read directly (host.hpp:
+// host_inputs): setting them is a memcpy once nothing on the stream can still be reading the old values - no copy engine, no
+// broadcast kernel in front of the solve (C1: two ~5 us copies + one launch off the critical path of every Solve())
+static int host_inputs_write(mi_ilqr* h, const double* x0, const double* u_guess, bool shared) {
+  const hipError_t q = hipStreamQuery(h->stream);
+  if (q == hipErrorNotReady) HIPCHK(hipStreamSynchronize(h->stream));
+  else if (q != hipSuccess) return MI_ILQR_E_HIP;
+  char* const base = h->host_records;
+  if (x0) std::memcpy(base + (reinterpret_cast<char*>(h->x0) - h->host_records_dev), x0, (size_t)h->B * h->n * 8);
+  if (u_guess) {
+    const size_t one = (size_t)h->m * (h->N - 1) * 8;
+    char* dst = base + (reinterpret_cast<char*>(h->u_guess) - h->host_records_dev);
+    for (int b = 0; b < h->B; ++b) std::memcpy(dst + b * one, reinterpret_cast<const char*>(u_guess) + (shared ? 0 : b * one), one);
+    h->u_pending = true;
+    h->u_zero = false;
+  }
+  return MI_ILQR_OK;
+}
+
 int mi_ilqr_set_initial(mi_ilqr_t* h, const double* x0, const double* u_guess) {
   if (!h) return MI_ILQR_E_BAD_ARG;
   HIPCHK(hipSetDevice(h->d.device_id));
+  if (h->host_inputs) return host_inputs_write(h, x0, u_guess, false);
   if (x0) { const int rc = stage_h2d(h, h->x0, x0, (size_t)h->B * h->n * 8); if (rc != MI_ILQR_OK) return rc; }
   if (u_guess) {
     const size_t cnt = (size_t)h->B * h->m * (h->N - 1);
@@ -866,6 +921,7 @@ int mi_ilqr_set_initial(mi_ilqr_t* h, const double* x0, const double* u_guess) {
 int mi_ilqr_set_initial_shared(mi_ilqr_t* h, const double* x0, const double* u_guess_one) {
   if (!h) return MI_ILQR_E_BAD_ARG;
   HIPCHK(hipSetDevice(h->d.device_id));
+  if (h->host_inputs) return host_inputs_write(h, x0, u_guess_one, true);
   if (x0) { const int rc = stage_h2d(h, h->x0, x0, (size_t)h->B * h->n * 8); if (rc != MI_ILQR_OK) return rc; }
   if (u_guess_one) {
     const size_t one = (size_t)h->m * (h->N - 1);
@@ -906,6 +962,43 @@ int mi_ilqr_set_result_sink(mi_ilqr_t* h, double* x_bar_host, double* u_bar_host
   }
   h->sink_x = static_cast<double*>(dx); h->sink_u = static_cast<double*>(du); h->sink_cost = static_cast<double*>(dc);
   return MI_ILQR_OK;
+}
+
+int mi_ilqr_solve_into(mi_ilqr_t* h, double* x_bar, double* u_bar, double* cost, int32_t page_locked, int32_t n_extra,
+                       const int32_t* which, void* const* dst, const size_t* bytes, mi_ilqr_stats* stats, int32_t* sink_used) {
+  if (!h || !x_bar || !u_bar || !cost || n_extra < 0 || (n_extra > 0 && (!which || !dst || !bytes))) return MI_ILQR_E_BAD_ARG;
+  if (sink_used) *sink_used = 0;
+  int rc;
+  bool sink = false;
+  if (page_locked && !h->large && !h->batch_minor) {
+    rc = mi_ilqr_set_result_sink(h, x_bar, u_bar, cost);
+    if (rc == MI_ILQR_OK) sink = true;
+    else if (rc != MI_ILQR_E_BAD_ARG) return rc;                      // (BAD_ARG: not page-locked after all - copy out instead)
+  }
+  auto clear = [&]() { h->sink_x = h->sink_u = h->sink_cost = nullptr; };
+  if ((rc = mi_ilqr_solve_async(h)) != MI_ILQR_OK) { clear(); return rc; }
+  if (!sink) {
+    const int f3[3] = {MI_F_X_BAR, MI_F_U_BAR, MI_F_COST};
+    void* const d3[3] = {x_bar, u_bar, cost};
+    for (int i = 0; i < 3; ++i)
+      if ((rc = mi_ilqr_get_async(h, f3[i], d3[i], field_of(h, f3[i]).bytes)) != MI_ILQR_OK) return rc;
+  }
+  // records the kernel writes straight into host memory (tiny batches, host.hpp: host_records): a memcpy after the synchronization
+  auto host_side = [&](int w) -> const char* {
+    if (!h->host_records || !(w == MI_F_HIST || w == MI_F_ITER_CYCLES || w == MI_I64_STAGE_CYCLES || w == MI_I_ITERS || w == MI_I_STATUS)) return nullptr;
+    return h->host_records + (static_cast<const char*>(field_of(h, w).ptr) - h->host_records_dev);
+  };
+  for (int i = 0; i < n_extra; ++i) {
+    if (host_side(which[i])) { if (bytes[i] != field_of(h, which[i]).bytes) { clear(); return MI_ILQR_E_BAD_SHAPE; } continue; }
+    if ((rc = mi_ilqr_get_async(h, which[i], dst[i], bytes[i])) != MI_ILQR_OK) { clear(); return rc; }
+  }
+  rc = stats ? mi_ilqr_collect_stats_n(h, 1, stats) : mi_ilqr_synchronize(h);
+  clear();                                                             // (the stream is idle: no later kernel of the handle writes the caller's arrays)
+  if (rc == MI_ILQR_OK)
+    for (int i = 0; i < n_extra; ++i)
+      if (const char* src = host_side(which[i])) std::memcpy(dst[i], src, bytes[i]);
+  if (sink_used) *sink_used = sink ? 1 : 0;
+  return rc;
 }
 
 int mi_ilqr_host_free(void* p) {
@@ -1062,16 +1155,19 @@ int mi_ilqr_mpc_shift(mi_ilqr_t* h, int32_t replan_steps) {
   return MI_ILQR_OK;
 }
 
-// host-loop form of the receding-horizon loop: the record the single-launch kernels write themselves (x0 | cost | iterations)
+// host-loop form of the receding-horizon loop: the record the single-launch kernels write themselves (x0 | cost | iterations).
+// Same policy as theirs: a problem whose re-solve fails (line search, internal, NOT_PD) gets that re-solve's row and none after
+// it (`dead`: one flag per problem behind the log; the rows stay the zeros mi_ilqr_mpc_run fills the log with).
 __global__ void __launch_bounds__(256) mpc_log_fill_kernel(const double* __restrict__ x0, const double* __restrict__ cost,
-                                                           const int32_t* __restrict__ iters, double* __restrict__ log, int B, int n,
-                                                           int resolves, int r) {
+                                                           const int32_t* __restrict__ iters, const int32_t* __restrict__ status,
+                                                           double* __restrict__ log, double* __restrict__ dead, int B, int n, int resolves, int r) {
   const int b = blockIdx.x * 256 + threadIdx.x;
-  if (b >= B) return;
+  if (b >= B || dead[b] != 0.0) return;
   double* lg = log + ((size_t)b * resolves + r) * (n + 2);
   for (int i = 0; i < n; ++i) lg[i] = x0[(size_t)b * n + i];
   lg[n] = cost[b];
   lg[n + 1] = (double)iters[b];
+  if ((status[b] & ~MI_STATUS_FLAG_INDEFINITE) >= MI_STATUS_LINESEARCH_FAILED) dead[b] = 1.0;
 }
 
 int mi_ilqr_mpc_run(mi_ilqr_t* h, int32_t num_resolves, int32_t replan_steps, const double* target_step, mi_ilqr_stats* stats) {
@@ -1083,9 +1179,13 @@ int mi_ilqr_mpc_run(mi_ilqr_t* h, int32_t num_resolves, int32_t replan_steps, co
     HIPCHK(hipStreamSynchronize(h->stream));
     if (h->mpc_log) HIPCHK(hipFree(h->mpc_log));
     h->mpc_log = nullptr;
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(&h->mpc_log), (size_t)h->B * num_resolves * (h->n + 2) * 8));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&h->mpc_log), ((size_t)h->B * num_resolves * (h->n + 2) + h->B) * 8));
     h->mpc_log_resolves = num_resolves;
   }
+  // rows a problem never reaches (it failed in an earlier re-solve: both forms of the loop stop logging it there) read as zeros
+  double* const mpc_dead = h->mpc_log + (size_t)h->B * h->mpc_log_resolves * (h->n + 2);
+  HIPCHK(hipMemsetAsync(h->mpc_log, 0, ((size_t)h->B * h->mpc_log_resolves * (h->n + 2) + h->B) * 8, h->stream));
+  h->mpc_resolves = num_resolves; h->mpc_replan = replan_steps;     // (up front: a failing re-solve must not leave the log's shape stale)
   const bool large_on_device = h->large && (size_t)h->m * (h->N - 1) <= 8 * (size_t)kLargeThreads;
   if ((h->large && !large_on_device) || h->batch_minor || (!h->large && (h->N > 512 || h->n > 8))) {
     // lane-per-problem path (and horizons the in-kernel shift does not cover): loop shift + solve on the host
@@ -1102,8 +1202,8 @@ int mi_ilqr_mpc_run(mi_ilqr_t* h, int32_t num_resolves, int32_t replan_steps, co
       }
       mi_ilqr_stats st;
       if ((rc = mi_ilqr_solve(h, &st)) != MI_ILQR_OK) return rc;
-      hipLaunchKernelGGL(mpc_log_fill_kernel, dim3((h->B + 255) / 256), dim3(256), 0, h->stream, h->x0, h->cost, h->iters, h->mpc_log,
-                         h->B, h->n, num_resolves, r);
+      hipLaunchKernelGGL(mpc_log_fill_kernel, dim3((h->B + 255) / 256), dim3(256), 0, h->stream, h->x0, h->cost, h->iters, h->status, h->mpc_log,
+                         mpc_dead, h->B, h->n, num_resolves, r);
       HIPCHK(hipGetLastError());
       acc.total_iters += st.total_iters; acc.total_ls_trials += st.total_ls_trials; acc.kernel_ms += st.kernel_ms;
       acc.algorithmic_bytes += st.algorithmic_bytes;
@@ -1167,7 +1267,7 @@ int mi_ilqr_get(mi_ilqr_t* h, int which, double* dst, size_t bytes) {
     HIPCHK(hipMemcpy(dst, h->scratch, bytes, hipMemcpyDeviceToHost));
     return MI_ILQR_OK;
   }
-  HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDefault));            // (tiny batches keep some fields in mapped host memory: host.hpp)
   return MI_ILQR_OK;
 }
 
@@ -1186,7 +1286,7 @@ int mi_ilqr_get_async(mi_ilqr_t* h, int which, void* dst, size_t bytes) {
       return mi_ilqr_get(h, which, static_cast<double*>(dst), bytes);
   }
   const void* src = (!f.is_int && h->u_pending && which == MI_F_U_BAR) ? h->u_guess : f.ptr;
-  HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, h->stream));
   return MI_ILQR_OK;
 }
 
@@ -1197,7 +1297,7 @@ int mi_ilqr_get_int(mi_ilqr_t* h, int which, int32_t* dst, size_t bytes) {
   if (bytes != f.bytes) return MI_ILQR_E_BAD_SHAPE;
   HIPCHK(hipSetDevice(h->d.device_id));
   HIPCHK(hipStreamSynchronize(h->stream));
-  HIPCHK(hipMemcpy(dst, f.ptr, bytes, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(dst, f.ptr, bytes, hipMemcpyDefault));
   return MI_ILQR_OK;
 }
 
@@ -1218,7 +1318,7 @@ int mi_ilqr_set(mi_ilqr_t* h, int which, const double* src, size_t bytes) {
     if ((rc = relayout(h, h->scratch, static_cast<double*>(f.ptr), rows, len, true)) != MI_ILQR_OK) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));
   } else {
-    HIPCHK(hipMemcpy(f.ptr, src, bytes, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(f.ptr, src, bytes, hipMemcpyDefault));
   }
   if (which == MI_F_U_BAR) { h->u_pending = false; h->u_zero = false; }
   return MI_ILQR_OK;
@@ -1254,7 +1354,7 @@ int mi_ilqr_get_cycles(mi_ilqr_t* h, int64_t* dst, size_t bytes) {
   if (bytes != (size_t)h->B * 4 * 8) return MI_ILQR_E_BAD_SHAPE;
   HIPCHK(hipSetDevice(h->d.device_id));
   HIPCHK(hipStreamSynchronize(h->stream));
-  HIPCHK(hipMemcpy(dst, h->prof, bytes, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(dst, h->prof, bytes, hipMemcpyDefault));
   return MI_ILQR_OK;
 }
 

@@ -30,12 +30,13 @@ from .dist import shard_range, allreduce_min, allreduce_min_async  # noqa: E402,
 
 class _PinnedBlock:
     """One page-locked allocation of a solver's result pool and whether an array handed out over it is still alive."""
-    __slots__ = ("raw", "nbytes", "busy", "__weakref__")
+    __slots__ = ("raw", "addr", "ctype", "count", "busy", "ref", "__weakref__")
 
-    def __init__(self, raw, nbytes):
-        self.raw, self.nbytes, self.busy = raw, nbytes, False
+    def __init__(self, raw, nbytes, count):
+        self.raw, self.addr, self.count, self.busy, self.ref = raw, raw.value, count, False, None
+        self.ctype = C.c_char * nbytes
 
-    def release(self):
+    def _released(self, _ref):
         self.busy = False
 
 
@@ -103,6 +104,8 @@ class BatchedIterativeLQR:
         # dropped every reference to the array it got (a small pool per attribute; `x, u, t, L = ilqr.Solve()` in a loop
         # alternates between two blocks), otherwise a new block is taken.  False: plain pageable arrays and blocking copies.
         self._pinned = {} if pinned_results else None
+        self._into = None
+        self._result_fields = ((_capi.F_X_BAR, (self.B, self.n, self.N)), (_capi.F_U_BAR, (self.B, self._md, self.N - 1)), (_capi.F_COST, (self.B,)))
         self._sink = None              # pinned_results: whether the kernels of this handle can write the results into host buffers themselves
         # reference defaults (ilqr.py:61-67); NOTE x_nom is undefined until SetTargetState (F12)
         self.x0 = np.zeros((self.B, self.n))
@@ -148,8 +151,8 @@ class BatchedIterativeLQR:
         xn = _capi.as_f64(x_nom, (self.n,))
         _capi.check(self._lib.mi_ilqr_set_cost(self._h, _capi.ptr(Q), _capi.ptr(R), _capi.ptr(Qf), _capi.ptr(xn)),
                     "mi_ilqr_set_cost")
-        x0 = np.broadcast_to(np.asarray(self.x0, dtype=np.float64).reshape(-1, self.n), (self.B, self.n))
-        x0 = np.ascontiguousarray(x0)
+        x0 = np.asarray(self.x0, dtype=np.float64).reshape(-1, self.n)
+        x0 = np.ascontiguousarray(x0 if len(x0) == self.B else np.broadcast_to(x0, (self.B, self.n)))
         ug = None
         shared = False
         if self._u_guess is not None:
@@ -172,33 +175,45 @@ class BatchedIterativeLQR:
     _POOL_CAP = 4
 
     def _out(self, which, shape, dtype):
-        """Destination of a field read: a fresh array, or (pinned_results) a page-locked block nobody else holds.
+        return self._out_addr(which, shape, dtype)[0]
+
+    def _out_addr(self, which, shape, dtype):
+        """Destination of a field read and its address: a fresh array, or (pinned_results) a page-locked block nobody else holds.
 
         Every hand-out wraps the block in a NEW owner array (np.frombuffer); every view a caller derives from what it got has
-        that owner as its base, so the owner dies exactly when the last of them does - its finalizer marks the block free.  No
-        reference counts are read (a debugger, a profiler or another interpreter may hold extra ones): a block whose owner has
-        not been collected yet simply is not reused."""
+        that owner as its base, so the owner dies exactly when the last of them does - a weak reference's callback then marks
+        the block free.  No reference counts are read (a debugger, a profiler or another interpreter may hold extra ones): a
+        block whose owner has not been collected yet simply is not reused."""
         if self._pinned is None:
-            return np.empty(shape, dtype=dtype)
-        key = (which, tuple(shape), np.dtype(dtype).str)
-        pool = self._pinned.setdefault(key, [])
-        blk = next((b for b in pool if not b.busy), None)
+            a = np.empty(shape, dtype=dtype)
+            return a, _capi.ptr(a)
+        key = (which, shape if type(shape) is tuple else tuple(shape), dtype)
+        pool = self._pinned.get(key)
+        if pool is None:
+            pool = self._pinned[key] = []
+        blk = None
+        for b_ in pool:
+            if not b_.busy:
+                blk = b_
+                break
         if blk is None:
             if len(pool) >= self._POOL_CAP:         # the caller keeps many results alive: those stay theirs, this one is pageable
-                return np.empty(shape, dtype=dtype)
-            nbytes = max(int(np.prod(shape)) * np.dtype(dtype).itemsize, 8)
+                a = np.empty(shape, dtype=dtype)
+                return a, _capi.ptr(a)
+            count = int(np.prod(shape))
+            nbytes = max(count * np.dtype(dtype).itemsize, 8)
             raw = C.c_void_p()
             _capi.check(self._lib.mi_ilqr_host_alloc(nbytes, C.byref(raw)), "mi_ilqr_host_alloc")
-            blk = _PinnedBlock(raw, nbytes)
+            blk = _PinnedBlock(raw, nbytes, count)
             # the memory lives as long as the block object does: the pool's reference, or a buffer a caller's array still wraps
             weakref.finalize(blk, self._lib.mi_ilqr_host_free, raw).atexit = False
             pool.append(blk)
-        buf = (C.c_char * blk.nbytes).from_address(blk.raw.value)
-        buf._block = blk
-        owner = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape)))
+        buf = blk.ctype.from_address(blk.addr)
+        buf._block = blk                            # (an array over the buffer keeps the buffer, the buffer keeps the block - and its memory)
+        owner = np.frombuffer(buf, dtype=dtype, count=blk.count)
         blk.busy = True
-        weakref.finalize(owner, blk.release).atexit = False
-        return owner.reshape(shape)
+        blk.ref = weakref.ref(owner, blk._released)
+        return owner.reshape(shape), blk.addr
 
     # axis (from the end) along which a field carries the controls
     _U_AXIS = {_capi.F_U_BAR: -2, _capi.F_KAPPA: -2, _capi.F_U_TRIAL: -2, _capi.F_K: -3, _capi.F_FU: -2}
@@ -334,27 +349,24 @@ class BatchedIterativeLQR:
         synchronization.  Wave-per-problem kernels write them themselves as each problem finishes (mi_ilqr_set_result_sink:
         the copy-out overlaps the launch's stragglers) - the sink is set for THIS solve only, so no later kernel of the
         handle (pipelined solves, MPCRun, stage calls) touches arrays a caller holds; the other kernel families enqueue
-        three copy-outs behind the solve.  `extra`: (field, destination) pairs copied out behind the solve as well."""
-        res = [self._out(which, shp, np.float64) for which, shp in
-               ((_capi.F_X_BAR, (self.B, self.n, self.N)), (_capi.F_U_BAR, (self.B, self._md, self.N - 1)), (_capi.F_COST, (self.B,)))]
-        pinned = all(r.base is not None for r in res)
-        sink = False
-        if pinned and self._sink is not False:
-            rc = self._lib.mi_ilqr_set_result_sink(self._h, _capi.ptr(res[0]), _capi.ptr(res[1]), _capi.ptr(res[2]))
-            if rc not in (_capi.OK, _capi.E_UNSUPPORTED):
-                _capi.check(rc, "mi_ilqr_set_result_sink")
-            sink = self._sink = rc == _capi.OK
-        try:
-            _capi.check(self._lib.mi_ilqr_solve_async(self._h), "mi_ilqr_solve_async")
-            if not sink:
-                for out, which in zip(res, (_capi.F_X_BAR, _capi.F_U_BAR, _capi.F_COST)):
-                    _capi.check(self._lib.mi_ilqr_get_async(self._h, which, _capi.ptr(out), out.nbytes), "mi_ilqr_get_async")
-            for which, out in extra:               # further fields of this solve, behind it on the stream: defined after collect
-                _capi.check(self._lib.mi_ilqr_get_async(self._h, which, _capi.ptr(out), out.nbytes), "mi_ilqr_get_async")
-            self.collect(1)
-        finally:
-            if sink:
-                _capi.check(self._lib.mi_ilqr_set_result_sink(self._h, None, None, None), "mi_ilqr_set_result_sink")
+        three copy-outs behind the solve.  `extra`: (field, destination, its address) triples copied out behind the solve as
+        well.  ONE call across the boundary (mi_ilqr_solve_into)."""
+        (x, ax), (u, au), (c, ac) = (self._out_addr(which, shp, np.float64) for which, shp in self._result_fields)
+        res = [x, u, c]
+        pinned = self._sink is not False and x.base is not None and u.base is not None and c.base is not None
+        k = len(extra)
+        if self._into is None or len(self._into[0]) != k:
+            self._into = ((C.c_int32 * k)(), (C.c_void_p * k)(), (C.c_size_t * k)())
+        wh, ds, by = self._into
+        for i, (which, out, addr) in enumerate(extra):     # further fields of this solve, behind it on the stream
+            wh[i], ds[i], by[i] = which, addr, out.nbytes
+        stats, used = _capi.Stats(), C.c_int32()
+        rc = self._lib.mi_ilqr_solve_into(self._h, ax, au, ac, 1 if pinned else 0, k, wh, ds, by, C.byref(stats), C.byref(used))
+        if rc != _capi.OK:
+            _capi.check(rc, "mi_ilqr_solve_into")
+        self.stats = stats
+        if pinned:
+            self._sink = bool(used.value)
         if self._md != self.m:
             res[1] = res[1][:, :self.m, :]
         return res
@@ -468,6 +480,10 @@ class IterativeLinearQuadraticRegulator(BatchedIterativeLQR):
         # the reference inverts every Quu with np.linalg.inv and never looks at its definiteness (ilqr.py:655): so does the drop-in.
         # `status` then carries STATUS_FLAG_INDEFINITE; on_indefinite="stop" raises RuntimeError at the first such Quu instead.
         device_options.setdefault("on_indefinite", "continue")
+        hc = int(device_options.get("hist_cap", 64))
+        # what Solve() copies out behind the solve besides x_bar / u_bar / cost (field, shape, dtype)
+        self._single_extra = ((_capi.I_ITERS, (1,), np.int32), (_capi.I_STATUS, (1,), np.int32), (_capi.F_HIST, (1, hc, 4), np.float64),
+                              (_capi.F_ITER_CYCLES, (1, hc, 4), np.float64), (_capi.I64_STAGE_CYCLES, (1, 4), np.int64))
         super().__init__(system, num_timesteps, 1, input_port_index=input_port_index, delta=delta, beta=beta,
                          gamma=gamma, derivs_keypoint_method=derivs_keypoint_method, **device_options)
         self.x0 = np.zeros(self.n)
@@ -494,24 +510,22 @@ class IterativeLinearQuadraticRegulator(BatchedIterativeLQR):
         res = None
         if self._pinned is not None:
             # ONE host synchronization for the whole call: results into page-locked arrays (by the kernel itself where it
-            # can), the iteration log copied out behind the solve on the same stream
-            small = {k: self._out(k, shp, dt) for k, shp, dt in ((_capi.I_ITERS, (1,), np.int32), (_capi.I_STATUS, (1,), np.int32),
-                                                                 (_capi.F_HIST, (1, self.hist_cap, 4), np.float64),
-                                                                 (_capi.F_ITER_CYCLES, (1, self.hist_cap, 4), np.float64))}
-            res = self._solve_into_pinned(extra=list(small.items()))
+            # can), the iteration log and the stopwatches copied out behind the solve on the same stream
+            small = [(k,) + self._out_addr(k, shp, dt) for k, shp, dt in self._single_extra]
+            res = self._solve_into_pinned(extra=small)
             stats = self.stats
-            iters, status, hist, iter_cyc = int(small[_capi.I_ITERS][0]), int(small[_capi.I_STATUS][0]), small[_capi.F_HIST][0], small[_capi.F_ITER_CYCLES][0]
+            iters, status, hist, iter_cyc, loop_cycles = int(small[0][1][0]), int(small[1][1][0]), small[2][1][0], small[3][1][0], float(small[4][1][0, 3])
         else:
             stats = _capi.Stats()
             _capi.check(self._lib.mi_ilqr_solve(self._h, C.byref(stats)), "mi_ilqr_solve")
             self.stats = stats
             iters, status, hist, iter_cyc = int(self.iterations[0]), int(self.status[0]), self.history[0], self.iteration_cycles[0]
+            loop_cycles = float(self.stage_cycles[0, 3])
         total_time = time.time() - st
         self.solve_wall_s = total_time
         # the reference's stopwatches (ilqr.py:364-372,696-702) from the in-kernel cycle counters, PER ITERATION:
         # cycles of the whole solve loop (stage_cycles[3]) span the kernel's HIP-event time
-        cyc = self.stage_cycles[0].astype(np.float64)
-        sec_per_cycle = stats.kernel_ms * 1e-3 / max(cyc[3], 1.0)
+        sec_per_cycle = stats.kernel_ms * 1e-3 / max(loop_cycles, 1.0)
         rows = min(iters, self.hist_cap)
         t_iter = iter_cyc[:rows] * sec_per_cycle                      # columns: fp (line search), derivs, bp, iteration
         if rows:                                                      # like the reference: the LAST iteration's stopwatches

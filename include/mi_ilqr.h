@@ -118,7 +118,8 @@ enum {
   MI_I_STATUS = 101,    /* (B,)                                                         */
   MI_I_LS_TRIALS = 102, /* (B,) reference-equivalent line-search trials, summed         */
   MI_I_KP_COUNT = 103,  /* (B,) key-points used by the last linearization               */
-  MI_I_KP_LIST = 104    /* (B,N-1) the key-point indices, first KP_COUNT valid          */
+  MI_I_KP_LIST = 104,   /* (B,N-1) the key-point indices, first KP_COUNT valid          */
+  MI_I64_STAGE_CYCLES = 200 /* (B,4) int64: what mi_ilqr_get_cycles returns - here so that mi_ilqr_get_async can queue it behind a solve */
 };
 
 typedef struct mi_ilqr mi_ilqr_t;
@@ -290,7 +291,11 @@ int mi_ilqr_mpc_shift(mi_ilqr_t* h, int32_t replan_steps);
  * Limits of the single-launch form: wave-per-problem kernels N <= 512 (the in-kernel shift holds eight
  * controls per lane), workgroup-per-problem kernel m*(N-1) <= 2048.  Beyond them, and for the
  * lane-per-problem "throughput" kernels, the same loop runs as shift + solve launches from the host:
- * same results, same log (filled after each re-solve). */
+ * same results, same log (filled after each re-solve).
+ * A problem whose re-solve r FAILS (line search, MI_STATUS_NOT_PD, internal) gets row r of the log and none after it:
+ * the log is zero-filled at every call and both forms stop logging the problem there (rows r+1.. read as zeros).  The
+ * single-launch forms also stop RE-SOLVING it (its status is that of re-solve r); the host-loop form's batched launches
+ * cannot leave a problem out - it is shifted and solved on, and its final status is the last re-solve's. */
 int mi_ilqr_mpc_run(mi_ilqr_t* h, int32_t num_resolves, int32_t replan_steps, const double* target_step, mi_ilqr_stats* stats);
 int mi_ilqr_get_mpc_log(mi_ilqr_t* h, double* dst, size_t bytes);
 
@@ -313,6 +318,15 @@ int mi_ilqr_get_async(mi_ilqr_t* h, int which, void* dst, size_t bytes);
  * 0.32 -> 0.2x ms at B = 1024).  The arrays must stay allocated while the sink is set; three NULLs clear it.
  * The persistent state in HBM is written as always (warm starts, mi_ilqr_get). */
 int mi_ilqr_set_result_sink(mi_ilqr_t* h, double* x_bar_host, double* u_bar_host, double* cost_host);
+
+/* One blocking solve whose results land in caller memory, ONE host synchronization, one call across the boundary (the
+ * single-problem Solve() of the drop-in class: C1's latency is host overhead as much as kernel time): x_bar (B,n,N), u_bar
+ * (B,m,N-1), cost (B,) - written by the kernel itself as each problem finishes when `page_locked` is non-zero, the three come
+ * from mi_ilqr_host_alloc and the kernel family has a result sink (set for THIS solve only), copied out behind the solve
+ * otherwise - plus `n_extra` further fields (double or int selectors: which[i] -> dst[i], bytes[i] as for mi_ilqr_get_async)
+ * queued behind it.  stats and sink_used (1: the kernel wrote the three arrays itself) may be NULL. */
+int mi_ilqr_solve_into(mi_ilqr_t* h, double* x_bar, double* u_bar, double* cost, int32_t page_locked, int32_t n_extra,
+                       const int32_t* which, void* const* dst, const size_t* bytes, mi_ilqr_stats* stats, int32_t* sink_used);
 
 /* Raw device pointer of a double field (for zero-copy consumers, e.g. a torch tensor
  * view feeding the RCCL best-cost reduction), and the handle's stream.  The per-problem result scalars

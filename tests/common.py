@@ -51,7 +51,7 @@ FLIP_BUDGET = {
     "arm27_batch": 0, "arm27_mpc_full": 0,
     "c4_full_leading8": 0,
     # C4 (stiff contact, N = 200): the C oracle itself takes different decisions in 8-9 of the 256 problems when x0 moves by
-    # one ulp (tests/test_gpu_round3.py::test_c4_full_size_vs_c_oracle measures that beside this budget)
+    # one ulp (tests/test_gpu_keypoints_quad3d_fullsize.py::test_c4_full_size_vs_c_oracle measures that beside this budget)
     "c4_full_history": 8,
 }
 

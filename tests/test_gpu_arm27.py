@@ -173,7 +173,24 @@ def test_arm27_keypoint_methods_vs_reference_golden(name):
     assert np.array_equal(s.keypoint_list[0][:nk], g["kp_last"]) and 5 < nk < 30
     assert abs(L - g["L"]) <= 1e-8 * abs(g["L"]) and rel_err(h[:, 0], g["hist"][:, 0]) < 1e-8
     assert rel_err(s.fx, g["fx"]) < 1e-7 and rel_err(s.fu, g["fu"]) < 1e-7
-    assert np.max(np.abs(x - g["x_bar"])) < 1e-6 and rel_err(s.K, g["K"]) < 1e-4
+    # converged arrays: SURVEY 8(c)'s figures for exact Jacobians (x_bar 1e-8, K 1e-7) or, where the problem itself moves more than
+    # that, 10 x the reference algorithm's own sensitivity - the C oracle (same key-point method) re-solved with two entries of x0
+    # one ulp away (observed on MI355X, round 5: adaptiveJerk device 3.0e-8 / 4.0e-6 for x / K against the oracle's own 2.3e-8 /
+    # 2.5e-6; iterativeError 2.6e-8 / 2.0e-6 against 1.5e-8 / 1.3e-6 - recorded by the print below)
+    from oracle import c_oracle, models_np as M
+    model = M.Model(prob["model_id"], prob["dt"], prob.get("params"))
+    kp = golden_keypoint(g)
+    r0 = c_oracle.solve_batch(model, prob, g["x0"][None], g["u_guess"], keypoint=kp)
+    own_x = own_K = 0.0
+    for d in (np.inf, -np.inf):
+        xq = g["x0"][None].copy()
+        xq[:, 0], xq[:, 12] = np.nextafter(xq[:, 0], d), np.nextafter(xq[:, 12], d)
+        rq = c_oracle.solve_batch(model, prob, xq, g["u_guess"], keypoint=kp)
+        if rq["iters"][0] == r0["iters"][0]:
+            own_x, own_K = max(own_x, float(np.max(np.abs(rq["x_bar"] - r0["x_bar"])))), max(own_K, rel_err(rq["K"], r0["K"]))
+    e_x, e_K = float(np.max(np.abs(x - g["x_bar"]))), rel_err(s.K, g["K"])
+    print(f"{name}: |x - x_golden| {e_x:.2e} (the oracle one ulp away from itself: {own_x:.2e}), K {e_K:.2e} ({own_K:.2e})")
+    assert e_x < max(1e-8, 10 * own_x) and e_K < max(1e-7, 10 * own_K)
 
 
 @pytest.mark.parametrize("B", [1, 64])
@@ -197,7 +214,14 @@ def test_arm27_batch_fd_vs_c_oracle(B):
     print(f"arm27 B={B}: iterations {int(s.iterations.sum())}, trials {int(s.ls_trials.sum())}, worst cost error {rel[same].max():.2e}, "
           f"worst |x - x_oracle| {np.max(np.abs(x[same] - r['x_bar'][same])):.2e}")
     assert np.max(rel[same]) < 5e-8 and np.max(np.abs(x[same] - r["x_bar"][same])) < 1e-6      # (observed 1.2e-8, 2.3e-7)
-    assert rel_err(s.K[same], r["K"][same]) < 1e-5
+    # K: SURVEY 8(c)'s 1e-6 (central differences) or 10 x the oracle's own movement when two entries of x0 move by one ulp
+    xq = x0.copy()
+    xq[:, 0], xq[:, 12] = np.nextafter(xq[:, 0], np.inf), np.nextafter(xq[:, 12], -np.inf)
+    rq = c_oracle.solve_batch(M.Model(prob["model_id"], prob["dt"]), prob, xq, ug)
+    keep = same & (rq["iters"] == r["iters"]) & (rq["ls"] == r["ls"])
+    own_K, e_K = rel_err(rq["K"][keep], r["K"][keep]), rel_err(s.K[keep], r["K"][keep])
+    print(f"arm27 B={B}: K device vs oracle {e_K:.2e}, oracle vs itself one ulp away {own_K:.2e} ({int(keep.sum())} problems)")
+    assert e_K < max(1e-6, 10 * own_K)
 
 
 def test_arm27_mpc_run_vs_c_oracle():
@@ -223,7 +247,7 @@ def test_arm27_mpc_run_vs_c_oracle():
     assert np.array_equal(first_it, r["first"][:, 1].astype(int))
     assert np.max(np.abs(first_L - r["first"][:, 0]) / r["first"][:, 0]) < 5e-8
     assert (s.status == 0).all() and (r["status"] == 0).all() and st.n_converged == B
-    own_flips, own_dev = 0, np.zeros(R)
+    own_flips, own_dev, own_dev_flipped, own_state = 0, np.zeros(R), 0.0, 0.0
     for d in (np.inf, -np.inf):
         xq = x0.copy()
         xq[:, 0], xq[:, 12] = np.nextafter(xq[:, 0], d), np.nextafter(xq[:, 12], d)
@@ -232,14 +256,22 @@ def test_arm27_mpc_run_vs_c_oracle():
         own_flips = max(own_flips, int((~keep).sum()))
         dq = np.abs(rq["log"][:, :, -2] - r["log"][:, :, -2]) / r["log"][:, :, -2]
         own_dev = np.maximum(own_dev, dq[keep].max(axis=0))
+        if (~keep).any():
+            own_dev_flipped = max(own_dev_flipped, float(dq[~keep].max()))
+        own_state = max(own_state, float(np.max(np.abs(rq["log"][keep][:, :, :27] - r["log"][keep][:, :, :27]))))
     full = (log[:, :, -1] == r["log"][:, :, -1]).all(axis=1)
     dev = (np.abs(log[:, :, -2] - r["log"][:, :, -2]) / r["log"][:, :, -2])
     print(f"arm27 MPC x{R}: device takes other iteration counts in {int((~full).sum())} of {B} problems (the oracle one ulp away from itself: {own_flips}); "
           f"worst re-solve cost deviation {dev[full].max():.2e} (the oracle's own: {own_dev.max():.2e})")
     assert int((~full).sum()) <= own_flips + 2
     assert np.all(dev[full].max(axis=0) < np.maximum(1e-7, 10 * own_dev))
-    assert np.all(dev[~full] < 1e-2) if (~full).any() else True          # a problem that took another path still tracks the same closed loop
-    assert np.max(np.abs(log[full][:, :, :27] - r["log"][full][:, :, :27])) < 1e-4
+    # a problem that took another path still tracks the same closed loop: no further off than 10 x the oracle's own flipped problems
+    # (or 1e-3 when none of the oracle's flipped); the re-solves' start states: 10 x the oracle's own movement (or SURVEY's 1e-6)
+    e_flip = float(dev[~full].max()) if (~full).any() else 0.0
+    e_state = float(np.max(np.abs(log[full][:, :, :27] - r["log"][full][:, :, :27])))
+    print(f"arm27 MPC: cost deviation of problems on another path {e_flip:.2e} (the oracle's own: {own_dev_flipped:.2e}); re-solve start states {e_state:.2e} (own {own_state:.2e})")
+    assert e_flip <= max(1e-3, 10 * own_dev_flipped)
+    assert e_state < max(1e-6, 10 * own_state)
 
 
 def test_arm27_through_the_reference_class_surface(tmp_path):

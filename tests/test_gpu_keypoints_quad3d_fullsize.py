@@ -277,7 +277,7 @@ def test_quad3d_full_size_mpc_run_vs_oracle():
     every problem and re-solve against the C oracle's receding-horizon loop (mini_cheetah.py:186-213)."""
     from drake_ddp_amd import workloads as W
     from oracle import c_oracle, models_np as M
-    from test_gpu_round2 import _check_mpc_against_oracle
+    from test_gpu_mpc_quadrupeds_boundary import _check_mpc_against_oracle
     q = W.quad3d_problem()
     B = 64
     x0, ug = W.quad3d_batch_x0(B), W.quad3d_u_guess(q["N"])

@@ -1,4 +1,4 @@
-"""Diagnostic behind tests/test_gpu_round3.py::test_c4_full_size_vs_c_oracle: C4 at its benchmarked size (B = 256, N = 200,
+"""Diagnostic behind tests/test_gpu_keypoints_quad3d_fullsize.py::test_c4_full_size_vs_c_oracle: C4 at its benchmarked size (B = 256, N = 200,
 central differences) on the device against the C oracle, per problem: status, iterations, trials, the per-iteration
 (eps, trials) history, and the final-cost deviation next to what a one-ulp change of x0 does to the oracle itself."""
 import os, sys
