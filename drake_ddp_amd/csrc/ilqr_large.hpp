@@ -1214,8 +1214,12 @@ __device__ __forceinline__ bool gj_row_positive(double s) { return s > 0.0; }
 // owns row i (eliminations, triangular solves) or column i (row exchanges).  Ties take the lowest row like idamax; a NaN
 // candidate wins (the result is NaN like the reference's).  ~m^2 dependent LDS round trips.
 template <int m>
-__device__ __forceinline__ void quu_inverse_pivoted(double* W, int ws, int lane) {
+__device__ __forceinline__ void quu_inverse_pivoted(double* W_, int ws, int lane) {
   static_assert(m <= 16, "one row per lane of a 16-lane row; the permutation packs 4 bits per step");
+  // W_ points into LDS: say so.  Left generic, one instantiation ((34, 12) plugin) kept a flat access and this hipcc then fails in
+  // instruction selection on the aperture it needs ("Illegal instruction detected: Operand has incorrect register class").
+  typedef __attribute__((address_space(3))) double lds_double_t;
+  lds_double_t* const W = (lds_double_t*)W_;
   auto fence = [&]() __attribute__((always_inline)) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
@@ -1303,7 +1307,7 @@ __device__ __forceinline__ void quu_inverse_pivoted(double* W, int ws, int lane)
 // OPERAND DELIVERY: two 8-byte operands per lane feed 1024 FMAs, where a VALU formulation needs a (broadcast) LDS
 // read per 1-2 FMAs and is LDS-issue-bound at one wave per SIMD (tools/ubench/t1.hip: 4.5-10.7 k cycles for T1
 // alone) - and since round 3 most operands do not even come from LDS: see "Fused chain" below.
-template <class M>
+template <class M, bool PIV = true>
 __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, long long* bp_acc = nullptr, bool lx_ready = false) {
   constexpr int n = M::n, m = M::m, nm = n + m;
   using Ly = LLay<n, m>;
@@ -1808,7 +1812,10 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
       double sc = 1.0;
       GjOuter<m, 0>::run(arow, sc, si);                      // Quu^{-1}[si][j] = sc * arow[j]
       if (!gj_row_positive(sc)) lds[Ly::oRed + kPdFlag] = 1.0;   // Quu not positive definite (read by the kernel after the pass: MI_STATUS_NOT_PD)
-      if (v.pd_continue && __any(!gj_row_positive(sc))) {    // cold path: the reference's inverse of an indefinite Quu
+      // (PIV: kernels instantiated WITH the cold path - on_indefinite = 1 or cost matrices that are not symmetric.  The default
+      //  kernels do not carry it: ~150 instructions on a path that never runs cost the n = 36 / 37 solves 2 - 5 % through the
+      //  register allocation of the phases around them - same-box A/B)
+      if (PIV && v.pd_continue && __any(!gj_row_positive(sc))) {    // cold path: the reference's inverse of an indefinite Quu
         const double* p0 = Pq + (QO + si) * SS + QO;
         if (lane < m) {
 #pragma unroll
@@ -1892,7 +1899,7 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
 // column and K stay in registers; Vxx is read and written in full (every entry of Vxx' is computed once, by the wave that owns
 // its column, like the reference's dense update); only Quu is formed from the transposed column tiles (= the transpose of a
 // matrix that is symmetric up to round-off), which takes it off the step's critical path.  Two barriers per step.
-template <class M>
+template <class M, bool PIV = true>
 __device__ inline void mid_backward(const LView<M::n, M::m>& v, double* lds, bool lx_ready = false, bool xu_staged = false) {
   constexpr int n = M::n, m = M::m, nm = n + m;
   using Ly = LLay<n, m>;
@@ -2198,7 +2205,7 @@ __device__ inline void mid_backward(const LView<M::n, M::m>& v, double* lds, boo
       // cold path: the reference's inverse (LU with partial pivoting) of an indefinite Quu - and of EVERY Quu when the cost matrices
       // are not symmetric: positive pivots say nothing about the growth of an unpivoted elimination of a matrix that is not
       // symmetric (measured: 5e-8 / 4e-5 from the oracle on the (27, 7) plugin / the arm at N = 24 next to steps that tripped the check)
-      if (v.asym || (v.pd_continue && __any(!gj_row_positive(sc)))) {
+      if (PIV && (v.asym || (v.pd_continue && __any(!gj_row_positive(sc))))) {
         load_quu(arow);
         if (lane < m) {
 #pragma unroll
@@ -2265,10 +2272,10 @@ __device__ inline void mid_backward(const LView<M::n, M::m>& v, double* lds, boo
 }
 
 // The backward pass of a model's size class.
-template <class M>
+template <class M, bool PIV>
 __device__ __forceinline__ void backward_pass(const LView<M::n, M::m>& v, double* lds, long long* bp_acc, bool lx_ready, bool xu_staged = false) {
-  if constexpr (LLay<M::n, M::m>::kMid) mid_backward<M>(v, lds, lx_ready, xu_staged);
-  else large_backward<M>(v, lds, bp_acc, lx_ready);
+  if constexpr (LLay<M::n, M::m>::kMid) mid_backward<M, PIV>(v, lds, lx_ready, xu_staged);
+  else large_backward<M, PIV>(v, lds, bp_acc, lx_ready);
 }
 
 #ifndef MI_MID_MINBLOCKS
@@ -2276,7 +2283,9 @@ __device__ __forceinline__ void backward_pass(const LView<M::n, M::m>& v, double
 #endif
 template <class M>
 constexpr int kMinBlocks = LLay<M::n, M::m>::kMid ? MI_MID_MINBLOCKS : 1;
-template <class M, int JAC, int MODE>
+// PIV: the backward passes carry the pivoted-inverse cold path (quu_inverse_pivoted) - launched for on_indefinite = 1 and for cost
+// matrices that are not symmetric; modes without a backward pass exist as PIV = false only.
+template <class M, int JAC, int MODE, bool PIV = false>
 __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kernel(const KArgs a) {
   constexpr int n = M::n, m = M::m;
   using Ly = LLay<n, m>;
@@ -2482,7 +2491,7 @@ __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kerne
     return;
   }
   if (MODE == MODE_BACKWARD) {
-    backward_pass<M>(v, lds, nullptr, false);
+    backward_pass<M, PIV>(v, lds, nullptr, false);
     __syncthreads();
     if (tid == 0) a.status[b] = lds[Ly::oRed + kPdFlag] == 0.0 ? MI_STATUS_CONVERGED : (a.pd_continue ? MI_STATUS_FLAG_INDEFINITE : MI_STATUS_NOT_PD);
     return;
@@ -2591,7 +2600,7 @@ __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kerne
       // profiling build only: 16 phase accumulators of thread 0 (a matrix-core wave) and of thread
       // 192 (the spare wave) land in the last 8 rows of the history buffer (tools/bp_prof.py)
       long long bpa[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-      if (MODE != MODE_FORWARD) { backward_pass<M>(v, lds, bpa, kLxFromRollout<M> && !v.asym); __syncthreads(); }
+      if (MODE != MODE_FORWARD) { backward_pass<M, PIV>(v, lds, bpa, kLxFromRollout<M> && !v.asym); __syncthreads(); }
       if ((tid == 0 || tid == 192) && iters == 0 && it_this == 0) {
         double* hp = a.hist + (size_t)b * a.hist_cap * 4 + 4 * (a.hist_cap - (tid == 0 ? 4 : 8));
         for (int q_ = 0; q_ < 16; ++q_) hp[q_] = (double)bpa[q_];
@@ -2599,7 +2608,7 @@ __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kerne
 #else
       // (a four-candidate pass leaves no cost gradients behind: the backward pass forms them itself)
       // (nor does any rollout when Q is not symmetric: its cost rows hold 2 Q (x - x_nom), the reference's lx is 2 Q x - 2 Q^T x_nom, :180)
-      if (MODE != MODE_FORWARD) { backward_pass<M>(v, lds, nullptr, kLxFromRollout<M> && !used_spec && !v.asym, lin_staged && !IsChainModel<M>::value); __syncthreads(); }      // :697
+      if (MODE != MODE_FORWARD) { backward_pass<M, PIV>(v, lds, nullptr, kLxFromRollout<M> && !used_spec && !v.asym, lin_staged && !IsChainModel<M>::value); __syncthreads(); }      // :697
 #endif
       const long long c3 = clock64();
       const bool not_pd = MODE != MODE_FORWARD && lds[Ly::oRed + kPdFlag] != 0.0;     // a Quu of this backward pass was not positive definite

@@ -4,9 +4,9 @@
 #include "ilqr_large.hpp"
 
 namespace mi_host {
-template <class M, int JAC, int MODE>
+template <class M, int JAC, int MODE, bool PIV = false>
 int launch_one_large(mi_ilqr* h, const KArgs& a) {
-  auto kern = ilqr_large_kernel<M, JAC, MODE>;
+  auto kern = ilqr_large_kernel<M, JAC, MODE, PIV>;
   static bool lds_ok[kMaxDevices] = {};
   { const int rc = allow_max_lds(kern, lds_ok, h->d.device_id); if (rc != MI_ILQR_OK) return rc; }
   const int cluster = (MODE == MODE_SOLVE || MODE == MODE_MPC) ? a.cluster : 1;
@@ -14,15 +14,47 @@ int launch_one_large(mi_ilqr* h, const KArgs& a) {
   return launch_timed(h, kern, dim3(h->B * cluster), dim3(kLargeThreads), h->lds, a);
 }
 
+// Which models get BOTH forms of the kernels with a backward pass (ilqr_large.hpp: PIV) - with and without the pivoted-inverse cold
+// path: those that declare kPivSplit (models.hpp: Synth36, Quad3D).  Same-box A/B, cycles per iteration of the bench's MPC loops
+// without | with the ~150 cold instructions in the kernel: 36-state chain 429 k | 451 k (its LINE SEARCH 74 k | 85 k - the register
+// allocation of the phases around the backward pass, not the pass), 3-D quadruped 682 k | 695 k.  The default (on_indefinite = 0,
+// symmetric costs) is what the benchmarks run, so these two get the lean form for it.  Every other model keeps the ONE form that
+// carries the path: the arm + ball is no faster without it (130 k | 134 k cycles per trial the other way round), plugin models
+// would pay twice the kernels per build - the (34, 12) chain's lean form does not even compile with this hipcc ("Illegal
+// instruction detected: V_CMP_NE_U32 0, $src_shared_base") - and the planar quadruped's lean MPC kernel is MISCOMPILED by it: built
+// and run in round 5, its first rollout step returns another x_1 than every other instantiation does from bitwise the same x_0, u_0
+// (non-deterministically across runs), the line search then fails in every problem; tools/diag/quad_mpc_first_rollout.py shows it,
+// eight tests of the GPU suite catch it.  (what is known about this compiler hazard and what guards against it.)
+template <class M, class = void>
+struct HasPivSplit { static constexpr bool value = false; };
+template <class M>
+struct HasPivSplit<M, decltype((void)M::kPivSplit)> { static constexpr bool value = M::kPivSplit; };
+template <class M>
+constexpr bool kPivSplit = HasPivSplit<M>::value;
+
 template <class M, int JAC>
 int launch_mode_large(mi_ilqr* h, int mode, const KArgs& a) {
+  if (a.pd_continue || a.cost_asym || !kPivSplit<M>) {
+    switch (mode) {
+      case MODE_SOLVE: return launch_one_large<M, JAC, MODE_SOLVE, true>(h, a);
+      case MODE_BACKWARD: return launch_one_large<M, JAC, MODE_BACKWARD, true>(h, a);
+      case MODE_MPC: return launch_one_large<M, JAC, MODE_MPC, true>(h, a);
+      default: break;
+    }
+  }
+  if constexpr (kPivSplit<M>) {
+    switch (mode) {
+      case MODE_SOLVE: return launch_one_large<M, JAC, MODE_SOLVE>(h, a);
+      case MODE_BACKWARD: return launch_one_large<M, JAC, MODE_BACKWARD>(h, a);
+      case MODE_MPC: return launch_one_large<M, JAC, MODE_MPC>(h, a);
+      default: break;
+    }
+  }
   switch (mode) {
-    case MODE_SOLVE: return launch_one_large<M, JAC, MODE_SOLVE>(h, a);
     case MODE_ROLLOUT: return launch_one_large<M, JAC, MODE_ROLLOUT>(h, a);
     case MODE_FORWARD: return launch_one_large<M, JAC, MODE_FORWARD>(h, a);
     case MODE_LINEARIZE: return launch_one_large<M, JAC, MODE_LINEARIZE>(h, a);
-    case MODE_BACKWARD: return launch_one_large<M, JAC, MODE_BACKWARD>(h, a);
-    case MODE_MPC: return launch_one_large<M, JAC, MODE_MPC>(h, a);
+    default: break;
   }
   return MI_ILQR_E_BAD_ARG;
 }

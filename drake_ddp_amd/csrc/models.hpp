@@ -103,6 +103,7 @@ using CartPole = CartPoleT<false>;
 using CartPoleWall = CartPoleT<true>;
 
 struct Synth36 {             // params [ks, c, kc, bu]; 18 coupled pendula, dofs 6..17 actuated
+  static constexpr bool kPivSplit = true;     // (launch_large.hpp: two forms of the kernels with a backward pass)
   static constexpr int n = 36, m = 12, n_params = 4, nq = 18;
   // One dof of the chain: usable dof-parallel (one lane per dof) by the large-n kernels.  x and u
   // are anything indexable (pointers, or accessors that perturb / seed one entry on the fly).
@@ -356,6 +357,7 @@ struct PlanarQuad {
 // lane per leg produces in the rollout, and the order step() uses, so both give the same bits.
 // The model can FAIL like PlanarQuad: a velocity outside [-v_max, v_max] makes the step infeasible (ilqr.py:315-323).
 struct Quad3D {
+  static constexpr bool kPivSplit = true;     // (launch_large.hpp)
   static constexpr int n = 37, m = 12, n_params = 14, nq = 19, nv = 18, kLegs = 4;
   static constexpr bool kLegCooperative = true;
   static constexpr bool kCanFail = true;
