@@ -18,8 +18,9 @@ rec = {
     "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python bench.py "
                "--no-cpu-baseline --steps 5 --warmup 1 (two separate passes; MI_BENCH_NESTED=1: headline only)",
     **raw,
-    "gfx950_read_correction": "FETCH_SIZE x2 per MI355X_MICROARCH.md (wide coalesced reads are tallied at 64 B per "
-                              "128-B request); 8 B/lane loads are not separately calibrated, so x2 is an upper bound",
+    "gfx950_read_correction": "FETCH_SIZE x2 per MI355X_MICROARCH.md (wide coalesced reads are tallied at 64 B per 128-B request); "
+                              "round 5 calibrated 8 B/lane streams too (tools/ubench/stream8, profiles/r05_pmc_throughput.json: 2048 B read per "
+                              "counted KB, WRITE_SIZE 1024 B per KB)",
     "expected_bytes_per_launch": {"read": B * 8 * (m * (N - 1) + n) + 8 * 11,
                                   "write": B * 8 * (n * N + (m + m * n + m + 1 + n * n + n * m) * (N - 1))},
     "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
