@@ -8,6 +8,8 @@ import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
+import torch
+torch.cuda.init()               # (before the library touches the device: torch's lazy initialization fails after it)
 import bench
 from drake_ddp_amd import workloads as W
 from drake_ddp_amd.dist import shard_range
