@@ -358,6 +358,10 @@ def all_configs(rk, dev_index):
     out.append(run_config(rk, dev_index, "C6 arm + ball (7-joint arm pushing a free body: kinova_gen3.py's shape) n=27 m=7 N=50 MPC: "
                           "1 + 20 re-solves x batch 64, device loop, mid-size kernels", a27,
                           W.arm27_batch_x0(64), W.arm27_u_guess(a27["N"]), reps=2, mpc=(20, 5, None)))
+    a27c = W.arm27c_problem()
+    out.append(run_config(rk, dev_index, "C6b arm + ball, coupled joint dynamics (M(q) qdd = tau - ...: dense 7x7 mass matrix per step) n=27 m=7 N=50 MPC: "
+                          "cold solve + 20 warm re-solves in one launch B=64 (fd)", a27c,
+                          W.arm27_batch_x0(64), W.arm27c_u_guess(a27c["N"]), reps=2, mpc=(20, 5, None)))
     if rk.world == 1:
         out.append(throughput_entry(dev_index))
         out.append(run_config(rk, dev_index, "C5 shard of an 8-GPU run: batch 8 on this GPU", q,

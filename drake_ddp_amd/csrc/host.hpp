@@ -159,4 +159,5 @@ MI_INTERNAL int launch_synth36(mi_ilqr* h, int mode, const mi::KArgs& a);
 MI_INTERNAL int launch_planar_quad(mi_ilqr* h, int mode, const mi::KArgs& a);
 MI_INTERNAL int launch_quad3d(mi_ilqr* h, int mode, const mi::KArgs& a);
 MI_INTERNAL int launch_arm27(mi_ilqr* h, int mode, const mi::KArgs& a);
+MI_INTERNAL int launch_arm27c(mi_ilqr* h, int mode, const mi::KArgs& a);
 MI_INTERNAL int launch_batch_minor(mi_ilqr* h, int mode, const mi::KArgs& a);

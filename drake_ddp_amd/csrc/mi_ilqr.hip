@@ -61,8 +61,9 @@ const ModelInfo* model_info(int id) {
       {36, 12, 9, {9.81, 4000.0, 0.004, 0.3, 0.15, 0.05, 0.02, 2.0, 60.0}},
       {37, 12, 14, {9.81, 4000.0, 0.004, 0.3, 0.15, 0.3, 60.0, 9.0, 0.07, 0.26, 0.28, 0.06, 0.06, 0.04}},
       {27, 7, 15, {9.81, 1500.0, 0.005, 0.5, 1.0, 0.5, 0.2, 0.1, 0.05, 1.0, 0.8, 0.6, 0.3, 0.1, 0.04}},
+      {27, 7, 16, {9.81, 1500.0, 0.005, 0.5, 1.0, 0.5, 0.2, 0.1, 0.05, 1.0, 0.8, 0.3, 0.15, 0.05, 0.04, 0.6}},
   };
-  if (id < 0 || id > 7) return nullptr;
+  if (id < 0 || id > 8) return nullptr;
   return &table[id];
 }
 
@@ -83,7 +84,7 @@ size_t large_lds(int model_id, int N) {
     case MI_MODEL_SYNTH36: return large_lds_bytes<Synth36::n, Synth36::m>(N);
     case MI_MODEL_PLANAR_QUAD: return large_lds_bytes<PlanarQuad::n, PlanarQuad::m>(N);
     case MI_MODEL_QUAD3D: return large_lds_bytes<Quad3D::n, Quad3D::m>(N);
-    case MI_MODEL_ARM27: return large_lds_bytes<Arm27::n, Arm27::m>(N);
+    case MI_MODEL_ARM27: case MI_MODEL_ARM27C: return large_lds_bytes<Arm27::n, Arm27::m>(N);
     default: return 0;
   }
 }
@@ -95,7 +96,7 @@ size_t large_lds_hbm(int model_id, int N) {
     case MI_MODEL_SYNTH36: return large_lds_bytes_hbm<Synth36::n, Synth36::m>(N);
     case MI_MODEL_PLANAR_QUAD: return large_lds_bytes_hbm<PlanarQuad::n, PlanarQuad::m>(N);
     case MI_MODEL_QUAD3D: return large_lds_bytes_hbm<Quad3D::n, Quad3D::m>(N);
-    case MI_MODEL_ARM27: return large_lds_bytes_hbm<Arm27::n, Arm27::m>(N);
+    case MI_MODEL_ARM27: case MI_MODEL_ARM27C: return large_lds_bytes_hbm<Arm27::n, Arm27::m>(N);
     default: return 0;
   }
 }
@@ -165,7 +166,7 @@ KArgs make_args(const mi_ilqr* h) {
     if (forced <= 0) {
       const int id = h->d.model_id;
       if (id == MI_MODEL_PLANAR_QUAD || id == MI_MODEL_QUAD3D) {}
-      else if (id == MI_MODEL_ARM27) { if (h->B > 64) g = 1; }
+      else if (id == MI_MODEL_ARM27 || id == MI_MODEL_ARM27C) { if (h->B > 64) g = 1; }
       else if (plugin_of(id)) g = 1;
       else if (h->B > 16) g = 1;
     }
@@ -211,6 +212,7 @@ int launch(mi_ilqr* h, int mode) {
     case MI_MODEL_PLANAR_QUAD: rc = launch_planar_quad(h, mode, a); break;
     case MI_MODEL_QUAD3D: rc = launch_quad3d(h, mode, a); break;
     case MI_MODEL_ARM27: rc = launch_arm27(h, mode, a); break;
+    case MI_MODEL_ARM27C: rc = launch_arm27c(h, mode, a); break;
     default:
       if (const PluginSlot* ps = plugin_of(h->d.model_id)) { rc = ps->p.launch(h, mode, &a); break; }
       return MI_ILQR_E_UNSUPPORTED;

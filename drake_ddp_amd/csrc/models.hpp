@@ -612,4 +612,225 @@ struct Arm27 {
   }
 };
 
+// The arm + ball with COUPLED rigid-body joint dynamics (SURVEY (f)4: higher-fidelity articulated dynamics for the n = 27 shape;
+// kinova_gen3.py:105-213 builds the real arm from its URDF).  State, kinematics, contacts and integrator are Arm27's; the seven
+// joint accelerations solve the manipulator equation
+//     M(q) qdd = tau - b qd - J_hand^T F_contact - sum_p m_p J_p^T (a_p + g e_z),      M = diag(I_rotor) + sum_p m_p J_p^T J_p
+// over three point masses p (elbow, wrist, hand) that carry the links' inertia: J_p the points' Jacobians (3 / 5 / 7 columns), a_p
+// their velocity-product accelerations (centripetal and Coriolis terms: from the links' angular velocities and the bias part of
+// their angular accelerations, recursively along the chain), M factorized as L D L^T (no pivoting: positive definite).  params: the
+// fifteen of Arm27 (I_* = rotor inertias on M's diagonal) + m_wrist.  The same formulas in the same operation order as
+// oracle/models_np.py:arm27c_step and oracle/ilqr_oracle.c:arm27c_step.  Mid-size workgroup-per-problem kernels; the rollout takes the
+// seven sines / cosines on fourteen lanes like Arm27's (kTrigCooperative).
+struct Arm27C {
+  static constexpr int n = 27, m = 7, n_params = 16;
+  static constexpr bool kWholeStep = true;
+  static constexpr bool kTrigCooperative = true;
+  static constexpr int kJoints = 7;
+  template <class T>
+  __device__ static inline void cross(const T (&a)[3], const T (&b)[3], T (&o)[3]) {
+    o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+  }
+  template <class T>
+  __device__ static inline T dot3(const T (&a)[3], const T (&b)[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+  template <class T>
+  __device__ static inline void rot_acc(const T (&al)[3], const T (&w)[3], const T (&r)[3], T (&o)[3]) {
+    T a1[3], t[3], a2[3];
+    cross(al, r, a1); cross(w, r, t); cross(w, t, a2);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) o[k] = a1[k] + a2[k];
+  }
+  template <class T>
+  __device__ static inline void step(const T* x, const T* u, T* xn, const double* p, double dt) {
+    T S[7], C[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) { S[i] = mi_sin(x[i]); C[i] = mi_cos(x[i]); }
+    core<T>(S, C, x, u, xn, p, dt);
+  }
+  template <class T>
+  __device__ static inline void core(const T (&S)[7], const T (&C)[7], const T* x, const T* u, T* xn, const double* p, double dt) {
+    const double g = p[0], kc = p[1], sig = p[2], dn = p[3], mu = p[4], bj = p[5];
+    const double mb = p[6], rb = p[7], re = p[8], m_el = p[9], m_hd = p[10], m_wr = p[15];
+    // ---- kinematics: Arm27's, + the wrist point (origin of joints 5, 6)
+    T ex[3] = {T(1.0), T(0.0), T(0.0)}, ey[3] = {T(0.0), T(1.0), T(0.0)}, ez[3] = {T(0.0), T(0.0), T(1.0)};
+    T pos[3] = {T(0.0), T(0.0), T(Arm27::kH0)}, elbow[3], wrist[3], hand[3], axes[7][3], orgs[7][3];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const T s = S[i], c = C[i];
+      if (i % 2 == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { axes[i][k] = ez[k]; orgs[i][k] = pos[k]; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const T a = c * ex[k] + s * ey[k], b = c * ey[k] - s * ex[k]; ex[k] = a; ey[k] = b; }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { axes[i][k] = ey[k]; orgs[i][k] = pos[k]; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const T a = c * ex[k] - s * ez[k], b = c * ez[k] + s * ex[k]; ex[k] = a; ez[k] = b; }
+      }
+      if (i == 2) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { pos[k] = pos[k] + Arm27::kL1 * ez[k]; elbow[k] = pos[k]; }
+      } else if (i == 4) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { pos[k] = pos[k] + Arm27::kL2 * ez[k]; wrist[k] = pos[k]; }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) hand[k] = pos[k] + (p[14] * ex[k] + Arm27::kL3 * ez[k]);
+    T J[7][3], JW[5][3], JE[3][3];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      T r[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) r[k] = hand[k] - orgs[i][k];
+      cross(axes[i], r, J[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      T r[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) r[k] = wrist[k] - orgs[i][k];
+      cross(axes[i], r, JW[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      T r[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) r[k] = elbow[k] - orgs[i][k];
+      cross(axes[i], r, JE[i]);
+    }
+    T qd[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) qd[i] = x[14 + i];
+    T vh[3], d[3], nr[3], om[3], vb[3], pb[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      vh[k] = ((J[0][k] * qd[0] + J[1][k] * qd[1]) + (J[2][k] * qd[2] + J[3][k] * qd[3])) + ((J[4][k] * qd[4] + J[5][k] * qd[5]) + J[6][k] * qd[6]);
+      pb[k] = x[11 + k]; om[k] = x[21 + k]; vb[k] = x[24 + k];
+      d[k] = pb[k] - hand[k];
+    }
+    // ---- hand - ball and ball - ground contacts: Arm27's
+    const T dist = mi_sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    const T idist = mi_rcp(dist);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) nr[k] = d[k] * idist;
+    const T phi = dist - (rb + re);
+    const T fn0 = (kc * sig) * mi_softplus(-phi * (1.0 / sig));
+    T wxn[3], rel[3], vt[3], Fc[3], nxv[3], tc[3];
+    cross(om, nr, wxn);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) rel[k] = vb[k] - rb * wxn[k] - vh[k];
+    const T vn = rel[0] * nr[0] + rel[1] * nr[1] + rel[2] * nr[2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) vt[k] = rel[k] - vn * nr[k];
+    const T fnn = fn0 * (1.0 - dn * vn);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) Fc[k] = fnn * nr[k] - (mu * fn0) * vt[k];
+    cross(nr, vt, nxv);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) tc[k] = (rb * mu) * fn0 * nxv[k];
+    const T fg0 = (kc * sig) * mi_softplus(-(pb[2] - rb) * (1.0 / sig));
+    const T vcx = vb[0] - rb * om[1], vcy = vb[1] + rb * om[0];
+    const T Fg[3] = {-(mu * fg0) * vcx, -(mu * fg0) * vcy, fg0 * (1.0 - dn * vb[2])};
+    const T tg[3] = {rb * Fg[1], -(rb * Fg[0]), T(0.0)};
+    // ---- velocity-product accelerations of the three point masses (w_i = w_{i-1} + a_i qd_i, al_i = al_{i-1} + (w_{i-1} x a_i) qd_i)
+    T w[3] = {T(0.0), T(0.0), T(0.0)}, al[3] = {T(0.0), T(0.0), T(0.0)};
+    T w2[3], al2[3], w4[3], al4[3];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      T wxa[3];
+      cross(w, axes[i], wxa);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) al[k] = al[k] + wxa[k] * qd[i];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) w[k] = w[k] + axes[i][k] * qd[i];
+      if (i == 2) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { w2[k] = w[k]; al2[k] = al[k]; }
+      } else if (i == 4) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { w4[k] = w[k]; al4[k] = al[k]; }
+      }
+    }
+    T r2[3], r4[3], r6[3], aE[3], aW[3], aH[3], t4[3], t6[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { r2[k] = elbow[k] - orgs[2][k]; r4[k] = wrist[k] - elbow[k]; r6[k] = hand[k] - wrist[k]; }
+    rot_acc(al2, w2, r2, aE);
+    rot_acc(al4, w4, r4, t4);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) aW[k] = aE[k] + t4[k];
+    rot_acc(al, w, r6, t6);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) aH[k] = aW[k] + t6[k];
+    const T gE[3] = {aE[0], aE[1], aE[2] + g}, gW[3] = {aW[0], aW[1], aW[2] + g}, gH[3] = {aH[0], aH[1], aH[2] + g};
+    // ---- right-hand side, mass matrix (lower triangle), L D L^T, the two triangular solves
+    T rhs[7], Mm[7][7], L[7][7], dd[7], idd[7], y[7], acc[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      T h = m_hd * dot3(J[i], gH);
+      if (i < 5) h = h + m_wr * dot3(JW[i < 5 ? i : 0], gW);
+      if (i < 3) h = h + m_el * dot3(JE[i < 3 ? i : 0], gE);
+      rhs[i] = u[i] - bj * qd[i] - h - dot3(J[i], Fc);
+    }
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+#pragma unroll
+      for (int j = 0; j <= i; ++j) {
+        T v = m_hd * dot3(J[i], J[j]);
+        if (i < 5) v = v + m_wr * dot3(JW[i < 5 ? i : 0], JW[j < 5 ? j : 0]);
+        if (i < 3) v = v + m_el * dot3(JE[i < 3 ? i : 0], JE[j < 3 ? j : 0]);
+        if (i == j) v = v + (i < 2 ? p[11] : (i < 4 ? p[12] : p[13]));
+        Mm[i][j] = v;
+      }
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      T v = Mm[j][j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) v = v - (L[j][k] * L[j][k]) * dd[k];
+      dd[j] = v; idd[j] = mi_rcp(v);
+#pragma unroll
+      for (int i = j + 1; i < 7; ++i) {
+        T v2 = Mm[i][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) v2 = v2 - (L[i][k] * L[j][k]) * dd[k];
+        L[i][j] = v2 * idd[j];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      T v = rhs[i];
+#pragma unroll
+      for (int k = 0; k < i; ++k) v = v - L[i][k] * y[k];
+      y[i] = v;
+    }
+#pragma unroll
+    for (int i = 6; i >= 0; --i) {
+      T v = y[i] * idd[i];
+#pragma unroll
+      for (int k = i + 1; k < 7; ++k) v = v - L[k][i] * acc[k];
+      acc[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < 7; ++i) { const T qdn = qd[i] + dt * acc[i]; xn[14 + i] = qdn; xn[i] = x[i] + dt * qdn; }
+    // ---- ball: Arm27's
+    const double ib = 1.0 / (0.4 * mb * rb * rb), imb = 1.0 / mb;
+    T omn[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      omn[k] = om[k] + dt * ((tc[k] + tg[k]) * ib);
+      T alb = (Fc[k] + Fg[k]) * imb;
+      if (k == 2) alb = alb - g;
+      const T vbn = vb[k] + dt * alb;
+      xn[11 + k] = pb[k] + dt * vbn; xn[21 + k] = omn[k]; xn[24 + k] = vbn;
+    }
+    const double hd = 0.5 * dt;
+    const T qw = x[7], qx = x[8], qy = x[9], qz = x[10];
+    xn[7] = qw + hd * (-(omn[0] * qx) - omn[1] * qy - omn[2] * qz);
+    xn[8] = qx + hd * (qw * omn[0] + (omn[1] * qz - omn[2] * qy));
+    xn[9] = qy + hd * (qw * omn[1] + (omn[2] * qx - omn[0] * qz));
+    xn[10] = qz + hd * (qw * omn[2] + (omn[0] * qy - omn[1] * qx));
+  }
+};
+
 }  // namespace mi

@@ -8,9 +8,9 @@ import numpy as np
 
 from . import _capi
 
-PENDULUM, ACROBOT, CARTPOLE, CARTPOLE_WALL, SYNTH36, PLANAR_QUAD, QUAD3D, ARM27 = 0, 1, 2, 3, 4, 5, 6, 7
+PENDULUM, ACROBOT, CARTPOLE, CARTPOLE_WALL, SYNTH36, PLANAR_QUAD, QUAD3D, ARM27, ARM27C = 0, 1, 2, 3, 4, 5, 6, 7, 8
 _DIMS = {PENDULUM: (2, 1), ACROBOT: (4, 1), CARTPOLE: (4, 1), CARTPOLE_WALL: (4, 1), SYNTH36: (36, 12), PLANAR_QUAD: (36, 12), QUAD3D: (37, 12),
-         ARM27: (27, 7)}
+         ARM27: (27, 7), ARM27C: (27, 7)}
 _DEFAULTS = {
     PENDULUM: [0.25, 0.1, 4.905],
     ACROBOT: [1.0, 1.0, 1.0, 0.5, 1.0, 0.083, 0.33, 0.1, 0.1, 9.81],
@@ -20,10 +20,11 @@ _DEFAULTS = {
     PLANAR_QUAD: [9.81, 4000.0, 0.004, 0.3, 0.15, 0.05, 0.02, 2.0, 60.0],
     QUAD3D: [9.81, 4000.0, 0.004, 0.3, 0.15, 0.3, 60.0, 9.0, 0.07, 0.26, 0.28, 0.06, 0.06, 0.04],
     ARM27: [9.81, 1500.0, 0.005, 0.5, 1.0, 0.5, 0.2, 0.1, 0.05, 1.0, 0.8, 0.6, 0.3, 0.1, 0.04],
+    ARM27C: [9.81, 1500.0, 0.005, 0.5, 1.0, 0.5, 0.2, 0.1, 0.05, 1.0, 0.8, 0.3, 0.15, 0.05, 0.04, 0.6],
 }
 _NAMES = {"pendulum": PENDULUM, "acrobot": ACROBOT, "cart_pole": CARTPOLE,
           "cart_pole_with_wall": CARTPOLE_WALL, "synth36": SYNTH36, "planar_quadruped": PLANAR_QUAD,
-          "quadruped_3d": QUAD3D, "arm_and_ball": ARM27}
+          "quadruped_3d": QUAD3D, "arm_and_ball": ARM27, "arm_and_ball_coupled": ARM27C}
 
 
 class _InputPort:
@@ -118,3 +119,9 @@ def ArmAndBall(dt=1e-2, **kw):
     """7-joint arm pushing a free ball: the state kinova_gen3.py:52-70 / panda_fr3.py stack (7 joint angles | the ball's unit
     quaternion and position | 13 velocities; n = 27, m = 7), served by the mid-size workgroup-per-problem kernels."""
     return ModelSystem(ARM27, dt, **kw)
+
+
+def ArmAndBallCoupled(dt=1e-2, **kw):
+    """The arm + ball with COUPLED rigid-body joint dynamics (joint-space mass matrix of three point masses + rotor inertias,
+    centripetal / Coriolis and gravity terms; csrc/models.hpp: Arm27C) - same state, contacts and kernels as ArmAndBall."""
+    return ModelSystem(ARM27C, dt, **kw)

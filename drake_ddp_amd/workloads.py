@@ -8,7 +8,7 @@ Pure NumPy, importable without a GPU.
 """
 import numpy as np
 
-PENDULUM, ACROBOT, CARTPOLE, CARTPOLE_WALL, SYNTH36, PLANAR_QUAD, QUAD3D, ARM27 = 0, 1, 2, 3, 4, 5, 6, 7
+PENDULUM, ACROBOT, CARTPOLE, CARTPOLE_WALL, SYNTH36, PLANAR_QUAD, QUAD3D, ARM27, ARM27C = 0, 1, 2, 3, 4, 5, 6, 7, 8
 SYNTH_TARGET_VEL = 1.0
 
 
@@ -244,6 +244,22 @@ def arm27_u_guess(N):
     the build's point contact has no force (hence no gradient) at a distance, unlike the reference's hydroelastic bodies,
     and pure gravity compensation leaves iLQR in the local optimum that never touches the ball."""
     u = _A27_U_GRAV.copy()
+    u[0] += ARM27_PUSH_TORQUE
+    return np.repeat(u[:, None], N - 1, axis=1)
+
+
+# ---- the same problem on the arm with coupled rigid-body joint dynamics (csrc/models.hpp: Arm27C; oracle/models_np.py: arm27c_step)
+_A27C_U_GRAV = np.array([0.0, -11.521967177552286, 0.0, -3.933396455272099, 0.0, -0.37867887819099333, 0.0])   # g(q_start) of the three point masses
+
+
+def arm27c_problem(N=50):
+    """arm27_problem on MI_MODEL_ARM27C: kinova_gen3.py's horizon, cost, target, delta and beta."""
+    return dict(arm27_problem(N), name="arm_and_ball_coupled", model_id=ARM27C)
+
+
+def arm27c_u_guess(N):
+    """Gravity compensation of the coupled arm at the start configuration (kinova_gen3.py:268-275) + the push torque of arm27_u_guess."""
+    u = _A27C_U_GRAV.copy()
     u[0] += ARM27_PUSH_TORQUE
     return np.repeat(u[:, None], N - 1, axis=1)
 

@@ -65,9 +65,12 @@ enum {
   MI_MODEL_QUAD3D = 6,         /* n=37 m=12: 3-D floating-base quadruped with mini_cheetah.py:41-52's state layout
                                   (unit quaternion | position | 12 joints | 18 velocities), feet contact; can declare a
                                   step infeasible like the planar one */
-  MI_MODEL_ARM27 = 7           /* n=27 m=7: 7-joint arm pushing a free ball - the state kinova_gen3.py:52-70 / panda_fr3.py
+  MI_MODEL_ARM27 = 7,          /* n=27 m=7: 7-joint arm pushing a free ball - the state kinova_gen3.py:52-70 / panda_fr3.py
                                   stack (7 joint angles | the ball's unit quaternion, position | 13 velocities); served by
                                   the mid-size workgroup-per-problem kernels */
+  MI_MODEL_ARM27C = 8          /* n=27 m=7: the same arm, ball and contacts with COUPLED rigid-body joint dynamics - the joint-space
+                                  mass matrix of three point masses + rotor inertias, centripetal / Coriolis and gravity terms,
+                                  M(q) qdd = tau - ... solved per step (L D L^T); 16 parameters (Arm27's + m_wrist) */
 };
 
 /* utils_derivs_interpolation.derivs_interpolation.keypoint_method

@@ -266,5 +266,17 @@ def main():
     single_solve("arm27_kp_adaptivejerk", ca, xa[3], ua, keypoint=("adaptiveJerk", 5, 40, 1e-4, 0.0))
     single_solve("arm27_kp_iterativeerror", ca, xa[3], ua, keypoint=("iterativeError", 5, 0, 0.0, 1e-2))
 
+    # (f)4 widened (round 5): the same arm, ball, cost and horizon with COUPLED rigid-body joint dynamics (model 8: joint-space mass
+    # matrix, centripetal / Coriolis and gravity terms of three point masses + rotor inertias) - the manipulator kinova_gen3.py:105-213
+    # builds from its URDF is a coupled chain, ARM27's joints are not
+    cc = P.arm27c_problem()
+    uc = P.arm27c_u_guess(cc["N"])
+    stage_level("arm27c_stage", cc, P.arm27_start(), uc, n_iters=3)
+    single_solve("arm27c_solve_0", cc, P.arm27_start(), uc)
+    single_solve("arm27c_solve_1", cc, xa[1], uc)
+    mpc("arm27c_mpc_0", cc, xa[2], uc, resolves=2, replan=5)
+    single_solve("arm27c_kp_adaptivejerk", cc, xa[3], uc, keypoint=("adaptiveJerk", 5, 40, 1e-4, 0.0))
+    single_solve("arm27c_kp_iterativeerror", cc, xa[3], uc, keypoint=("iterativeError", 5, 0, 0.0, 1e-2))
+
 if __name__ == "__main__":
     main()

@@ -277,6 +277,116 @@ static void arm27_step(const double* x, const double* u, const double* p, double
   xn[10] = qz + hd * (qw * omn[2] + (omn[0] * qy - omn[1] * qx));
 }
 
+/* ---- arm + ball with coupled rigid-body joint dynamics (model 8): oracle/models_np.py:arm27c_step, same formulas, same order ---- */
+static double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static void rot_acc(const double* al, const double* w, const double* r, double* out) {
+  double a1[3], t[3], a2[3];
+  cross3(al, r, a1); cross3(w, r, t); cross3(w, t, a2);
+  for (int k = 0; k < 3; ++k) out[k] = a1[k] + a2[k];
+}
+static void arm27c_step(const double* x, const double* u, const double* p, double dt, double* xn) {
+  const double g = p[0], kc = p[1], sig = p[2], dn = p[3], mu = p[4], bj = p[5];
+  const double mb = p[6], rb = p[7], re = p[8], m_el = p[9], m_hd = p[10], m_wr = p[15];
+  const double Ia[7] = {p[11], p[11], p[12], p[12], p[13], p[13], p[13]};
+  const double *q = x, *qd = x + 14, *pb = x + 11, *om = x + 21, *vb = x + 24;
+  const double qw = x[7], qx = x[8], qy = x[9], qz = x[10];
+  double hand[3], wrist[3], elbow[3], axes[7][3], orgs[7][3], J[7][3], JW[5][3], JE[3][3], r[3];
+  {                                                                   /* arm27c_kinematics */
+    double ex[3] = {1.0, 0.0, 0.0}, ey[3] = {0.0, 1.0, 0.0}, ez[3] = {0.0, 0.0, 1.0}, pos[3] = {0.0, 0.0, A27_H0};
+    for (int i = 0; i < 7; ++i) {
+      const double s = sin(q[i]), c = cos(q[i]);
+      if (i % 2 == 0) {
+        for (int k = 0; k < 3; ++k) { axes[i][k] = ez[k]; orgs[i][k] = pos[k]; }
+        for (int k = 0; k < 3; ++k) { const double a = c * ex[k] + s * ey[k], b = c * ey[k] - s * ex[k]; ex[k] = a; ey[k] = b; }
+      } else {
+        for (int k = 0; k < 3; ++k) { axes[i][k] = ey[k]; orgs[i][k] = pos[k]; }
+        for (int k = 0; k < 3; ++k) { const double a = c * ex[k] - s * ez[k], b = c * ez[k] + s * ex[k]; ex[k] = a; ez[k] = b; }
+      }
+      if (i == 2) { for (int k = 0; k < 3; ++k) { pos[k] = pos[k] + A27_L1 * ez[k]; elbow[k] = pos[k]; } }
+      else if (i == 4) { for (int k = 0; k < 3; ++k) { pos[k] = pos[k] + A27_L2 * ez[k]; wrist[k] = pos[k]; } }
+    }
+    for (int k = 0; k < 3; ++k) hand[k] = pos[k] + (p[14] * ex[k] + A27_L3 * ez[k]);
+  }
+  for (int i = 0; i < 7; ++i) { for (int k = 0; k < 3; ++k) r[k] = hand[k] - orgs[i][k]; cross3(axes[i], r, J[i]); }
+  for (int i = 0; i < 5; ++i) { for (int k = 0; k < 3; ++k) r[k] = wrist[k] - orgs[i][k]; cross3(axes[i], r, JW[i]); }
+  for (int i = 0; i < 3; ++i) { for (int k = 0; k < 3; ++k) r[k] = elbow[k] - orgs[i][k]; cross3(axes[i], r, JE[i]); }
+  double vh[3], d[3], nr[3], wxn[3], rel[3], vt[3], Fc[3], nxv[3], tc[3];
+  for (int k = 0; k < 3; ++k)
+    vh[k] = ((J[0][k] * qd[0] + J[1][k] * qd[1]) + (J[2][k] * qd[2] + J[3][k] * qd[3])) + ((J[4][k] * qd[4] + J[5][k] * qd[5]) + J[6][k] * qd[6]);
+  for (int k = 0; k < 3; ++k) d[k] = pb[k] - hand[k];
+  const double dist = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  const double idist = 1.0 / dist;
+  for (int k = 0; k < 3; ++k) nr[k] = d[k] * idist;
+  const double phi = dist - (rb + re);
+  const double fn0 = (kc * sig) * softplus(-phi / sig);
+  cross3(om, nr, wxn);
+  for (int k = 0; k < 3; ++k) rel[k] = vb[k] - rb * wxn[k] - vh[k];
+  const double vn = rel[0] * nr[0] + rel[1] * nr[1] + rel[2] * nr[2];
+  for (int k = 0; k < 3; ++k) vt[k] = rel[k] - vn * nr[k];
+  const double fnn = fn0 * (1.0 - dn * vn);
+  for (int k = 0; k < 3; ++k) Fc[k] = fnn * nr[k] - (mu * fn0) * vt[k];
+  cross3(nr, vt, nxv);
+  for (int k = 0; k < 3; ++k) tc[k] = (rb * mu) * fn0 * nxv[k];
+  const double fg0 = (kc * sig) * softplus(-(pb[2] - rb) / sig);
+  const double vcx = vb[0] - rb * om[1], vcy = vb[1] + rb * om[0];
+  const double Fg[3] = {-(mu * fg0) * vcx, -(mu * fg0) * vcy, fg0 * (1.0 - dn * vb[2])};
+  const double tg[3] = {rb * Fg[1], -(rb * Fg[0]), 0.0};
+  /* velocity-product accelerations of the point masses */
+  double w[3] = {0.0, 0.0, 0.0}, al[3] = {0.0, 0.0, 0.0}, wl[7][3], all_[7][3], wxa[3];
+  for (int i = 0; i < 7; ++i) {
+    cross3(w, axes[i], wxa);
+    for (int k = 0; k < 3; ++k) al[k] = al[k] + wxa[k] * qd[i];
+    for (int k = 0; k < 3; ++k) w[k] = w[k] + axes[i][k] * qd[i];
+    for (int k = 0; k < 3; ++k) { wl[i][k] = w[k]; all_[i][k] = al[k]; }
+  }
+  double r2[3], r4[3], r6[3], aE[3], aW[3], aH[3], t4[3], t6[3];
+  for (int k = 0; k < 3; ++k) { r2[k] = elbow[k] - orgs[2][k]; r4[k] = wrist[k] - elbow[k]; r6[k] = hand[k] - wrist[k]; }
+  rot_acc(all_[2], wl[2], r2, aE);
+  rot_acc(all_[4], wl[4], r4, t4);
+  for (int k = 0; k < 3; ++k) aW[k] = aE[k] + t4[k];
+  rot_acc(all_[6], wl[6], r6, t6);
+  for (int k = 0; k < 3; ++k) aH[k] = aW[k] + t6[k];
+  const double gE[3] = {aE[0], aE[1], aE[2] + g}, gW[3] = {aW[0], aW[1], aW[2] + g}, gH[3] = {aH[0], aH[1], aH[2] + g};
+  double rhs[7], M[7][7], L[7][7], dd[7], idd[7], y[7], acc[7];
+  for (int i = 0; i < 7; ++i) {
+    double h = m_hd * dot3(J[i], gH);
+    if (i < 5) h = h + m_wr * dot3(JW[i], gW);
+    if (i < 3) h = h + m_el * dot3(JE[i], gE);
+    rhs[i] = u[i] - bj * qd[i] - h - dot3(J[i], Fc);
+  }
+  for (int i = 0; i < 7; ++i)
+    for (int j = 0; j <= i; ++j) {
+      double v = m_hd * dot3(J[i], J[j]);
+      if (i < 5) v = v + m_wr * dot3(JW[i], JW[j]);
+      if (i < 3) v = v + m_el * dot3(JE[i], JE[j]);
+      if (i == j) v = v + Ia[i];
+      M[i][j] = v;
+    }
+  for (int j = 0; j < 7; ++j) {
+    double v = M[j][j];
+    for (int k = 0; k < j; ++k) v = v - (L[j][k] * L[j][k]) * dd[k];
+    dd[j] = v; idd[j] = 1.0 / v;
+    for (int i = j + 1; i < 7; ++i) {
+      v = M[i][j];
+      for (int k = 0; k < j; ++k) v = v - (L[i][k] * L[j][k]) * dd[k];
+      L[i][j] = v * idd[j];
+    }
+  }
+  for (int i = 0; i < 7; ++i) { double v = rhs[i]; for (int k = 0; k < i; ++k) v = v - L[i][k] * y[k]; y[i] = v; }
+  for (int i = 6; i >= 0; --i) { double v = y[i] * idd[i]; for (int k = i + 1; k < 7; ++k) v = v - L[k][i] * acc[k]; acc[i] = v; }
+  for (int i = 0; i < 7; ++i) { const double qdn = qd[i] + dt * acc[i]; xn[14 + i] = qdn; xn[i] = q[i] + dt * qdn; }
+  const double ib = 1.0 / (0.4 * mb * rb * rb);
+  double omn[3], vbn[3];
+  for (int k = 0; k < 3; ++k) omn[k] = om[k] + dt * ((tc[k] + tg[k]) * ib);
+  const double alb[3] = {(Fc[0] + Fg[0]) / mb, (Fc[1] + Fg[1]) / mb, (Fc[2] + Fg[2]) / mb - g};
+  for (int k = 0; k < 3; ++k) { vbn[k] = vb[k] + dt * alb[k]; xn[11 + k] = pb[k] + dt * vbn[k]; xn[21 + k] = omn[k]; xn[24 + k] = vbn[k]; }
+  const double hd = 0.5 * dt;
+  xn[7] = qw + hd * (-(omn[0] * qx) - omn[1] * qy - omn[2] * qz);
+  xn[8] = qx + hd * (qw * omn[0] + (omn[1] * qz - omn[2] * qy));
+  xn[9] = qy + hd * (qw * omn[1] + (omn[2] * qx - omn[0] * qz));
+  xn[10] = qz + hd * (qw * omn[2] + (omn[0] * qy - omn[1] * qx));
+}
+
 /* A model may declare a step infeasible (Drake's discrete update throwing, caught at ilqr.py:315-323). */
 static int step_infeasible(const oracle_cfg* c, const double* xn) {
   if (c->model_id == 5) { for (int i = 18; i < 36; ++i) if (!(fabs(xn[i]) <= c->params[8])) return 1; }
@@ -334,6 +444,7 @@ static void step(const oracle_cfg* c, const double* x, const double* u, double* 
     }
     case 6: quad3d_step(x, u, p, dt, xn); break;    /* 3-D quadruped */
     case 7: arm27_step(x, u, p, dt, xn); break;     /* 7-joint arm + free ball */
+    case 8: arm27c_step(x, u, p, dt, xn); break;    /* the same with coupled rigid-body joint dynamics */
     default: { /* synth36 */
       const double ks = p[0], cd = p[1], kc = p[2], bu = p[3];
       const int nq = 18;

@@ -23,6 +23,8 @@ Model ids / parameter vectors (must match include/mi_ilqr.h and models.hpp):
                               (3-D floating base with a unit-quaternion attitude, contact at four feet, can FAIL)
   7 ARM27          n=27 m=7   [g, k, sigma, dn, mu, b_joint, m_ball, r_ball, r_ee, m_elbow, m_hand, I_shoulder, I_elbow, I_wrist, ee_off]
                               (7-joint arm + a free ball with a unit-quaternion attitude: the state kinova_gen3.py:52-70 stacks)
+  8 ARM27C         n=27 m=7   the same arm, ball and contacts with COUPLED rigid-body joint dynamics: M(q) qdd + c(q, qd) + g(q) = tau - b qd - J^T F
+                              [..the 15 of ARM27 (I_* = rotor inertias on M's diagonal).., m_wrist]
 
 A model may declare a step INFEASIBLE (the analogue of Drake's discrete update throwing): ``Model.step``
 then raises RuntimeError, which the reference's line search catches (ilqr.py:315-323).
@@ -31,14 +33,14 @@ import numpy as np
 
 from . import dual as D
 
-PENDULUM, ACROBOT, CARTPOLE, CARTPOLE_WALL, SYNTH36, PLANAR_QUAD, QUAD3D, ARM27 = 0, 1, 2, 3, 4, 5, 6, 7
+PENDULUM, ACROBOT, CARTPOLE, CARTPOLE_WALL, SYNTH36, PLANAR_QUAD, QUAD3D, ARM27, ARM27C = 0, 1, 2, 3, 4, 5, 6, 7, 8
 
 MODEL_DIMS = {PENDULUM: (2, 1), ACROBOT: (4, 1), CARTPOLE: (4, 1),
-              CARTPOLE_WALL: (4, 1), SYNTH36: (36, 12), PLANAR_QUAD: (36, 12), QUAD3D: (37, 12), ARM27: (27, 7)}
+              CARTPOLE_WALL: (4, 1), SYNTH36: (36, 12), PLANAR_QUAD: (36, 12), QUAD3D: (37, 12), ARM27: (27, 7), ARM27C: (27, 7)}
 
 MODEL_NAMES = {PENDULUM: "pendulum", ACROBOT: "acrobot", CARTPOLE: "cart_pole",
                CARTPOLE_WALL: "cart_pole_with_wall", SYNTH36: "synth36", PLANAR_QUAD: "planar_quadruped",
-               QUAD3D: "quadruped_3d", ARM27: "arm_and_ball"}
+               QUAD3D: "quadruped_3d", ARM27: "arm_and_ball", ARM27C: "arm_and_ball_coupled"}
 
 DEFAULT_PARAMS = {
     # m=1, l=0.5, b=0.1, g=9.81 (the shape of pendulum.py's plant; SURVEY.md §8c anchor)
@@ -63,6 +65,9 @@ DEFAULT_PARAMS = {
     # carry the links' weight (elbow, hand); reflected actuator inertias of the joint pairs (0,1), (2,3), (4,5,6); lateral
     # offset of the hand point from the last joint's axis
     ARM27: [9.81, 1500.0, 0.005, 0.5, 1.0, 0.5, 0.2, 0.1, 0.05, 1.0, 0.8, 0.6, 0.3, 0.1, 0.04],
+    # the same, with the links' inertia carried by three point masses (elbow, wrist, hand) through the joint-space mass matrix and the
+    # I_* entries as rotor (armature) inertias on its diagonal; m_wrist is the sixteenth parameter
+    ARM27C: [9.81, 1500.0, 0.005, 0.5, 1.0, 0.5, 0.2, 0.1, 0.05, 1.0, 0.8, 0.3, 0.15, 0.05, 0.04, 0.6],
 }
 
 
@@ -529,6 +534,173 @@ def arm27_step(x, u, p, dt):
     return qn + quatn + pbn + qdn + omn + vbn
 
 
+# ARM27C: the arm + ball with COUPLED rigid-body joint dynamics (SURVEY (f)4: "higher-fidelity articulated-body" dynamics for the n = 27
+# shape; kinova_gen3.py:105-213 builds the real arm from its URDF).  Same kinematics, state, contacts and integrator as ARM27; the
+# seven joint accelerations now solve the manipulator equation
+#     M(q) qdd = tau - b qd - J_hand^T F_contact - sum_p m_p J_p^T (a_p + g e_z),      M = diag(I_rotor) + sum_p m_p J_p^T J_p,
+# over three point masses p (elbow, wrist, hand) that carry the links' inertia: J_p the points' Jacobians (3 / 5 / 7 columns),
+# a_p their velocity-product accelerations (Jdot_p qd: centripetal and Coriolis terms, from the links' angular velocities and the
+# bias part of their angular accelerations, recursively along the chain), M factorized as L D L^T (7 x 7, no pivoting: M is
+# positive definite).  The same formulas in the same operation order in models.hpp (Arm27C) and ilqr_oracle.c.
+def _dot3(a, b):
+    return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]
+
+
+def arm27c_kinematics(q, p):
+    """arm27_kinematics + the wrist point (origin of joints 5, 6)."""
+    ex, ey, ez = [1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0]
+    pos = [0.0, 0.0, A27_H0]
+    axes, orgs = [], []
+    elbow = wrist = None
+    for i in range(7):
+        s, c = D.sin(q[i]), D.cos(q[i])
+        if i % 2 == 0:
+            axes.append(list(ez)); orgs.append(list(pos))
+            ex, ey = [c * ex[k] + s * ey[k] for k in range(3)], [c * ey[k] - s * ex[k] for k in range(3)]
+        else:
+            axes.append(list(ey)); orgs.append(list(pos))
+            ex, ez = [c * ex[k] - s * ez[k] for k in range(3)], [c * ez[k] + s * ex[k] for k in range(3)]
+        if i == 2:
+            pos = [pos[k] + A27_L1 * ez[k] for k in range(3)]
+            elbow = list(pos)
+        elif i == 4:
+            pos = [pos[k] + A27_L2 * ez[k] for k in range(3)]
+            wrist = list(pos)
+    hand = [pos[k] + (p[14] * ex[k] + A27_L3 * ez[k]) for k in range(3)]
+    return hand, wrist, elbow, axes, orgs
+
+
+def arm27c_step(x, u, p, dt):
+    g, kc, sig, dn, mu, bj = p[0], p[1], p[2], p[3], p[4], p[5]
+    mb, rb, re, m_el, m_hd, m_wr = p[6], p[7], p[8], p[9], p[10], p[15]
+    Ia = [p[11], p[11], p[12], p[12], p[13], p[13], p[13]]
+    q, qd = x[0:7], x[14:21]
+    qw, qx, qy, qz = x[7], x[8], x[9], x[10]
+    pb, om, vb = x[11:14], x[21:24], x[24:27]
+    hand, wrist, elbow, axes, orgs = arm27c_kinematics(q, p)
+    J = [_cross(axes[i], [hand[k] - orgs[i][k] for k in range(3)]) for i in range(7)]
+    JW = [_cross(axes[i], [wrist[k] - orgs[i][k] for k in range(3)]) for i in range(5)]
+    JE = [_cross(axes[i], [elbow[k] - orgs[i][k] for k in range(3)]) for i in range(3)]
+    vh = [((J[0][k] * qd[0] + J[1][k] * qd[1]) + (J[2][k] * qd[2] + J[3][k] * qd[3])) + ((J[4][k] * qd[4] + J[5][k] * qd[5]) + J[6][k] * qd[6])
+          for k in range(3)]
+    # hand - ball and ball - ground contacts: ARM27's
+    d = [pb[k] - hand[k] for k in range(3)]
+    dist = D.sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2])
+    idist = 1.0 / dist
+    nr = [d[k] * idist for k in range(3)]
+    phi = dist - (rb + re)
+    fn0 = (kc * sig) * D.softplus(-phi / sig)
+    wxn = _cross(om, nr)
+    rel = [vb[k] - rb * wxn[k] - vh[k] for k in range(3)]
+    vn = rel[0] * nr[0] + rel[1] * nr[1] + rel[2] * nr[2]
+    vt = [rel[k] - vn * nr[k] for k in range(3)]
+    fnn = fn0 * (1.0 - dn * vn)
+    Fc = [fnn * nr[k] - (mu * fn0) * vt[k] for k in range(3)]
+    nxv = _cross(nr, vt)
+    tc = [(rb * mu) * fn0 * nxv[k] for k in range(3)]
+    fg0 = (kc * sig) * D.softplus(-(pb[2] - rb) / sig)
+    vcx, vcy = vb[0] - rb * om[1], vb[1] + rb * om[0]
+    Fg = [-(mu * fg0) * vcx, -(mu * fg0) * vcy, fg0 * (1.0 - dn * vb[2])]
+    tg = [rb * Fg[1], -(rb * Fg[0]), 0.0]
+    # ---- velocity-product accelerations of the three point masses: angular velocity w and bias angular acceleration al of the
+    #      links along the chain (w_i = w_{i-1} + a_i qd_i, al_i = al_{i-1} + (w_{i-1} x a_i) qd_i); the points sit on links 2, 4, 6
+    w = [0.0, 0.0, 0.0]
+    al = [0.0, 0.0, 0.0]
+    wl, all_ = [], []
+    for i in range(7):
+        wxa = _cross(w, axes[i])
+        al = [al[k] + wxa[k] * qd[i] for k in range(3)]
+        w = [w[k] + axes[i][k] * qd[i] for k in range(3)]
+        wl.append(w); all_.append(al)
+
+    def rot_acc(al_, w_, r):
+        a1, a2 = _cross(al_, r), _cross(w_, _cross(w_, r))
+        return [a1[k] + a2[k] for k in range(3)]
+    r2 = [elbow[k] - orgs[2][k] for k in range(3)]
+    r4 = [wrist[k] - elbow[k] for k in range(3)]
+    r6 = [hand[k] - wrist[k] for k in range(3)]
+    aE = rot_acc(all_[2], wl[2], r2)
+    t4 = rot_acc(all_[4], wl[4], r4)
+    aW = [aE[k] + t4[k] for k in range(3)]
+    t6 = rot_acc(all_[6], wl[6], r6)
+    aH = [aW[k] + t6[k] for k in range(3)]
+    gE, gW, gH = [aE[0], aE[1], aE[2] + g], [aW[0], aW[1], aW[2] + g], [aH[0], aH[1], aH[2] + g]
+    # ---- right-hand side and mass matrix (lower triangle)
+    rhs = []
+    for i in range(7):
+        h = m_hd * _dot3(J[i], gH)
+        if i < 5:
+            h = h + m_wr * _dot3(JW[i], gW)
+        if i < 3:
+            h = h + m_el * _dot3(JE[i], gE)
+        rhs.append(u[i] - bj * qd[i] - h - _dot3(J[i], Fc))
+    M = [[None] * 7 for _ in range(7)]
+    for i in range(7):
+        for j in range(i + 1):
+            v = m_hd * _dot3(J[i], J[j])
+            if i < 5:
+                v = v + m_wr * _dot3(JW[i], JW[j])
+            if i < 3:
+                v = v + m_el * _dot3(JE[i], JE[j])
+            if i == j:
+                v = v + Ia[i]
+            M[i][j] = v
+    # ---- L D L^T and the two triangular solves
+    L = [[None] * 7 for _ in range(7)]
+    dd, idd = [None] * 7, [None] * 7
+    for j in range(7):
+        v = M[j][j]
+        for k in range(j):
+            v = v - (L[j][k] * L[j][k]) * dd[k]
+        dd[j] = v
+        idd[j] = 1.0 / v
+        for i in range(j + 1, 7):
+            v = M[i][j]
+            for k in range(j):
+                v = v - (L[i][k] * L[j][k]) * dd[k]
+            L[i][j] = v * idd[j]
+    y = [None] * 7
+    for i in range(7):
+        v = rhs[i]
+        for k in range(i):
+            v = v - L[i][k] * y[k]
+        y[i] = v
+    acc = [None] * 7
+    for i in range(6, -1, -1):
+        v = y[i] * idd[i]
+        for k in range(i + 1, 7):
+            v = v - L[k][i] * acc[k]
+        acc[i] = v
+    qdn = [qd[i] + dt * acc[i] for i in range(7)]
+    qn = [q[i] + dt * qdn[i] for i in range(7)]
+    # ---- ball: ARM27's
+    ib = 1.0 / (0.4 * mb * rb * rb)
+    omn = [om[k] + dt * ((tc[k] + tg[k]) * ib) for k in range(3)]
+    alb = [(Fc[0] + Fg[0]) / mb, (Fc[1] + Fg[1]) / mb, (Fc[2] + Fg[2]) / mb - g]
+    vbn = [vb[k] + dt * alb[k] for k in range(3)]
+    pbn = [pb[k] + dt * vbn[k] for k in range(3)]
+    hd = 0.5 * dt
+    quatn = [qw + hd * (-(omn[0] * qx) - omn[1] * qy - omn[2] * qz),
+             qx + hd * (qw * omn[0] + (omn[1] * qz - omn[2] * qy)),
+             qy + hd * (qw * omn[1] + (omn[2] * qx - omn[0] * qz)),
+             qz + hd * (qw * omn[2] + (omn[0] * qy - omn[1] * qx))]
+    return qn + quatn + pbn + qdn + omn + vbn
+
+
+def arm27c_gravity_torques(q, p):
+    """Joint torques that hold the coupled arm still away from the ball: g(q) = g sum_p m_p J_p[:, z]."""
+    hand, wrist, elbow, axes, orgs = arm27c_kinematics(list(q), p)
+    out = []
+    for i in range(7):
+        v = p[10] * _cross(axes[i], [hand[k] - orgs[i][k] for k in range(3)])[2]
+        if i < 5:
+            v += p[15] * _cross(axes[i], [wrist[k] - orgs[i][k] for k in range(3)])[2]
+        if i < 3:
+            v += p[9] * _cross(axes[i], [elbow[k] - orgs[i][k] for k in range(3)])[2]
+        out.append(p[0] * v)
+    return np.array(out, dtype=float)
+
+
 def arm27_gravity_torques(q, p):
     """Joint torques that hold the arm still away from the ball (kinova_gen3.py:268-275: the initial guess)."""
     hand, elbow, axes, orgs = arm27_kinematics(list(q), p)
@@ -542,7 +714,7 @@ def arm27_gravity_torques(q, p):
 
 STEP_FUNCS = {PENDULUM: pendulum_step, ACROBOT: acrobot_step, CARTPOLE: cartpole_step,
               CARTPOLE_WALL: cartpole_wall_step, SYNTH36: synth36_step, PLANAR_QUAD: planar_quad_step, QUAD3D: quad3d_step,
-              ARM27: arm27_step}
+              ARM27: arm27_step, ARM27C: arm27c_step}
 INFEASIBLE_FUNCS = {PLANAR_QUAD: planar_quad_infeasible, QUAD3D: quad3d_infeasible}
 
 

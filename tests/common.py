@@ -48,7 +48,7 @@ FLIP_BUDGET = {
     "short_horizons": 0, "pendulum_mpc_par_vs_seq": 0, "scan_vs_seq_backward": 0,
     "quad_batch_free": 0, "quad_batch_tight": 0, "quad_batch_free_unconverged": 0, "quad_batch_tight_unconverged": 0,
     "quad3d_batch_free": 0, "quad3d_batch_tight": 0, "quad3d_mpc_full": 0,
-    "arm27_batch": 0, "arm27_mpc_full": 0,
+    "arm27_batch": 0, "arm27_mpc_full": 0, "arm27c_batch": 0, "arm27c_mpc_first": 0,
     "c4_full_leading8": 0,
     # C4 (stiff contact, N = 200): the C oracle itself takes different decisions in 8-9 of the 256 problems when x0 moves by
     # one ulp (tests/test_gpu_keypoints_quad3d_fullsize.py::test_c4_full_size_vs_c_oracle measures that beside this budget)

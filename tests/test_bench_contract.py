@@ -93,7 +93,7 @@ def _one_rank_configs():
 @pytest.mark.gpu
 @pytest.mark.parametrize("world", [2, 8])
 def test_bench_sharded_configs_do_exactly_the_whole_batchs_work(world):
-    """`bench.py --gpus N` WITH every config (C1, C3 ... C6 through run_config's shard path: C3 at 512 / N problems per rank, C5 at
+    """`bench.py --gpus N` WITH every config (C1, C3 ... C6b through run_config's shard path: C3 at 512 / N problems per rank, C5 at
     64 / N, C1's single problem on rank 0 alone), N ranks over gloo sharing this box's GPU - the form of the run the driver's
     8-GPU node executes over RCCL.  Problems are independent and every kernel's result is independent of its batch,
     so the ranks together must do EXACTLY the single-rank run's work: the same iterations per config (rank-summed), every problem
@@ -106,7 +106,7 @@ def test_bench_sharded_configs_do_exactly_the_whole_batchs_work(world):
     assert d["config"]["parallelism"] == f"batch-shard x{world}" and "all_reduce(MIN)" in d["config"]["collective"]
     ref = {c["name"]: c for c in one["configs"]}
     names = [c["name"] for c in d["configs"]]
-    assert [n[:3].strip() for n in names] == ["C1", "C3", "C4", "C5", "C5q", "C5q", "C6"], names     # (the B = 8 shard line is a 1-rank entry)
+    assert [n[:3].strip() for n in names] == ["C1", "C3", "C4", "C5", "C5q", "C5q", "C6", "C6b"], names     # (the B = 8 shard line is a 1-rank entry)
     for c in d["configs"]:
         o = ref[c["name"]]
         assert c["batch"] == o["batch"] and c["batch_per_gpu"] == -(-c["batch"] // world), c["name"]

@@ -44,7 +44,7 @@ def test_c_oracle_vs_reference_golden_and_threads():
         assert rel_err(r1["K"][b], g["K"]) < 1e-5
 
 
-@pytest.mark.parametrize("name", ["acrobot_mpc_0", "acrobot_mpc_1", "synth36_mpc_0", "quad_mpc_0", "quad3d_mpc_0", "quad3d_mpc_1", "arm27_mpc_0"])
+@pytest.mark.parametrize("name", ["acrobot_mpc_0", "acrobot_mpc_1", "synth36_mpc_0", "quad_mpc_0", "quad3d_mpc_0", "quad3d_mpc_1", "arm27_mpc_0", "arm27c_mpc_0"])
 def test_c_oracle_mpc_loop_vs_reference_golden(name):
     """oracle_mpc_batch (shift warm start, moving target, gains persisting across solves - SURVEY F10)
     against MPC sequences recorded from the unmodified reference (exact Jacobians there, central FD here:
@@ -60,12 +60,12 @@ def test_c_oracle_mpc_loop_vs_reference_golden(name):
         step = np.zeros(n)
         step[int(g["move_target"][0])] = g["move_target"][1]
     if prob["model_id"] >= 4:
-        ug = {4: P.synth36_u_guess, 5: P.planar_quad_u_guess, 6: P.quad3d_u_guess, 7: P.arm27_u_guess}[prob["model_id"]](N)
+        ug = {4: P.synth36_u_guess, 5: P.planar_quad_u_guess, 6: P.quad3d_u_guess, 7: P.arm27_u_guess, 8: P.arm27c_u_guess}[prob["model_id"]](N)
     r = c_oracle.mpc_batch(M.Model(prob["model_id"], prob["dt"]), prob, g["x0"][None], ug, R, replan, target_step=step)
     assert r["status"][0] == 0
     # (arm + ball: the hand-ball contact's curvature k / sigma^2 = 6e7 on a 0.2 kg ball makes the h^2 truncation term of the
     #  central differences visible in the cost: 1.0e-7 relative observed against the reference's exact Jacobians)
-    tolL = 5e-7 if prob["model_id"] == 7 else 1e-8
+    tolL = 5e-7 if prob["model_id"] in (7, 8) else 1e-8
     assert int(r["first"][0, 1]) == g["iters"][0] and abs(r["first"][0, 0] - g["Ls"][0]) < tolL * abs(g["Ls"][0])
     log = r["log"][0]
     assert np.array_equal(log[:, -1].astype(int), g["iters"][1:])
@@ -78,7 +78,8 @@ def test_c_oracle_mpc_loop_vs_reference_golden(name):
 
 
 @pytest.mark.parametrize("name", ["quad_solve_0", "quad_infeasible_0", "quad_infeasible_1",
-                                  "quad3d_solve_0", "quad3d_solve_1", "quad3d_infeasible_0", "arm27_solve_0", "arm27_solve_1"])
+                                  "quad3d_solve_0", "quad3d_solve_1", "quad3d_infeasible_0", "arm27_solve_0", "arm27_solve_1",
+                                  "arm27c_solve_0", "arm27c_solve_1"])
 def test_c_oracle_planar_quadruped_vs_reference_golden(name):
     """The C restatement of the articulated-body model, of the 3-D quadruped, of the arm + ball and of the infeasible-step rule
     (L = inf, ilqr.py:315-323) against solves recorded from the reference (exact Jacobians there, central FD here)."""
@@ -92,7 +93,7 @@ def test_c_oracle_planar_quadruped_vs_reference_golden(name):
 
 @pytest.mark.parametrize("name", ["pendulum_kp_setinterval5", "pendulum_kp_adaptivejerk", "pendulum_kp_iterativeerror",
                                   "acrobot_kp_adaptivejerk", "acrobot_kp_iterativeerror",
-                                  "arm27_kp_adaptivejerk", "arm27_kp_iterativeerror"])
+                                  "arm27_kp_adaptivejerk", "arm27_kp_iterativeerror", "arm27c_kp_adaptivejerk", "arm27c_kp_iterativeerror"])
 def test_c_oracle_keypoint_methods_vs_numpy_oracle_and_golden(name):
     """setInterval / adaptiveJerk / iterativeError (ilqr.py:417-593) in the C restatement: against the NumPy oracle with
     the same central differences (per-iteration trials, step sizes and key-point counts exact, the last key-point

@@ -66,7 +66,7 @@ def mfma_small_fraction(kernel_name):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import isa_mix
     m = re.search(r"ilqr_\w+_kernel<mi::(\w+)", kernel_name)
-    model = {"Synth36": "synth36", "PlanarQuad": "planar_quad", "Quad3D": "quad3d", "Arm27": "arm27", "Acrobot": "acrobot",
+    model = {"Synth36": "synth36", "PlanarQuad": "planar_quad", "Quad3D": "quad3d", "Arm27": "arm27", "Arm27C": "arm27c", "Acrobot": "acrobot",
              "CartPoleT": "cartpole_wall", "Pendulum": "pendulum"}.get(m.group(1) if m else "", None)
     obj = os.path.join(ROOT, "drake_ddp_amd", "lib", "obj", "k_%s.o" % model) if model else None
     if not obj or not os.path.exists(obj):
@@ -93,7 +93,7 @@ lines = [json.loads(l) for l in r.stdout.decode().splitlines() if l.startswith("
 iters = {l["config"].split()[0] + ("/8" if "shard" in l["config"] else ""): l.get("iters_total", l.get("iters_per_solve")) for l in lines}
 KERNELS = {   # config -> (model substring, workgroups of the launch); every kernel mode of that model and grid is the config's
     "C1": ("Pendulum", 1), "C2": ("Pendulum", 1024), "C3": ("Acrobot", 512), "C4": ("CartPoleT<true>", 256),
-    "C5": ("Synth36", 64), "C5q": ("PlanarQuad", None), "C5q3d": ("Quad3D", None), "C6": ("Arm27", None)}
+    "C5": ("Synth36", 64), "C5q": ("PlanarQuad", None), "C5q3d": ("Quad3D", None), "C6": ("Arm27,", None), "C6b": ("Arm27C,", None)}
 per_config = {}
 for cfg, (model, grid) in KERNELS.items():
     ks = [k for k in acc if model in k and (grid is None or ("grid=%d x" % grid) in k)]

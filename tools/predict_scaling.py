@@ -37,6 +37,8 @@ def configs():
     yield "C5q", pq, W.planar_quad_batch_x0(64), W.planar_quad_u_guess(pq["N"]), 2, (100, 4, (0, W.QUAD_TARGET_VEL * pq["dt"] * 4)), False
     yield "C5q3d", q3, W.quad3d_batch_x0(64), W.quad3d_u_guess(q3["N"]), 2, (100, 4, (4, W.QUAD3D_TARGET_VEL * q3["dt"] * 4)), False
     yield "C6", a27, W.arm27_batch_x0(64), W.arm27_u_guess(a27["N"]), 2, (20, 5, None), False
+    a27c = W.arm27c_problem()
+    yield "C6b", a27c, W.arm27_batch_x0(64), W.arm27c_u_guess(a27c["N"]), 2, (20, 5, None), False
 
 
 rk, out = One(), {}

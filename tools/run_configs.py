@@ -73,3 +73,5 @@ mpc("C6 arm + ball MPC B=64 x 21 solves", a27, W.arm27_batch_x0(64), W.arm27_u_g
 if os.environ.get("MI_RUN_SHARD") == "1":     # (same grid as C5 - 8 problems x 8 workgroups: kept out of the counter passes)
     mpc("C5/8GPU shard: synth36 MPC B=8 x 101 solves", q, W.synth36_batch_x0(64)[:8], W.synth36_u_guess(q["N"]), 100, 4,
         move=(0, W.SYNTH_TARGET_VEL * q["dt"] * 4))
+a27c = W.arm27c_problem()
+mpc("C6b coupled arm + ball MPC B=64 x 21 solves", a27c, W.arm27_batch_x0(64), W.arm27c_u_guess(a27c["N"]), 20, 5)
