@@ -34,6 +34,9 @@ namespace mi {
 constexpr int kLargeThreads = 256;
 constexpr int kPdFlag = 8;          // slot of the reduction scratch (LLay::oRed) where a backward pass leaves "a Quu was not positive definite"
 
+// The thread index of a STAGE (a backward pass, a rollout, a linearization): see stage_lane (ilqr_small.hpp).
+__device__ __forceinline__ int stage_tid() { return stage_lane(); }
+
 template <int n, int m>
 struct LLay {
   static constexpr int nm = n + m;
@@ -224,7 +227,7 @@ __device__ inline double large_rollout(const LView<M::n, M::m>& v, double* lds, 
   constexpr int n = M::n, m = M::m;
   using Ly = LLay<n, m>;
   constexpr int JR = (n + 15) / 16;    // K-row elements per lane
-  const int tid = threadIdx.x, N = v.N;
+  const int tid = stage_tid(), N = v.N;
   double* xs = lds + Ly::oXs;
   double* us = lds + Ly::oUs;
   const double* xnom = lds + Ly::oXnom;
@@ -544,7 +547,7 @@ __device__ inline void mid_rollout4(const LView<M::n, M::m>& v, double* xsp, dou
   using Ly = LLay<n, m>;
   constexpr int JR = (n + 15) / 16;
   constexpr int XS = 34;               // candidate stride of the state buffers: the candidates' copies of an entry on different banks
-  const int tid = threadIdx.x, N = v.N;
+  const int tid = stage_tid(), N = v.N;
   // state (two buffers), controls and x - x_nom of the four candidates: the backward pass's H area is idle
   double* xc = lds + Ly::oH;           // [4][XS] current
   double* xn_ = xc + kSpec * XS;       // [4][XS] next
@@ -770,7 +773,7 @@ __device__ __forceinline__ void large_jac_at_sparse(const LView<M::n, M::m>& v, 
   constexpr int n = M::n, m = M::m, nc = n + m, nq = M::nq;
   const ModelScalars<M> ms(a);
   const double h = ms.fd_h, inv2h = 1.0 / (2.0 * h);
-  for (int it = first * kLargeThreads + threadIdx.x; it < count * nc; it += stride * kLargeThreads) {
+  for (int it = first * kLargeThreads + stage_tid(); it < count * nc; it += stride * kLargeThreads) {
     const int ki = it / nc, col = it - ki * nc;
     const int t = list[ki];
     const double* xg = Xsrc + (size_t)t * n;
@@ -828,7 +831,7 @@ __device__ __forceinline__ void large_jac_at_tree(const LView<M::n, M::m>& v, co
   const double h = ms.fd_h, inv2h = 1.0 / (2.0 * h), dt = ms.dt;
   using AggD = typename M::template Agg<double>;
   if (JAC == MI_JAC_FD_CENTRAL) {
-    for (int it = threadIdx.x; it < count * NCH; it += kLargeThreads) {
+    for (int it = stage_tid(); it < count * NCH; it += kLargeThreads) {
       const int ki = it / NCH, c = it - ki * NCH;
       const int t = list[ki];
       const double* xg = Xsrc + (size_t)t * xstride;
@@ -846,7 +849,7 @@ __device__ __forceinline__ void large_jac_at_tree(const LView<M::n, M::m>& v, co
   // items are dealt key-point fastest, columns in the order "chain by chain, then the trunk's": the lanes of a
   // wavefront then share the owner of their column (two owners at most), so the per-chain branches below are
   // wave-uniform - dealt column-fastest they diverge and every wave runs both sides of every branch
-  for (int it = first * kLargeThreads + threadIdx.x; it < count * nc; it += stride * kLargeThreads) {
+  for (int it = first * kLargeThreads + stage_tid(); it < count * nc; it += stride * kLargeThreads) {
     const int rank = it / count, ki = it - rank * count;
     const int col = M::input_by_owner(rank);
     const int t = list[ki];
@@ -956,7 +959,7 @@ __device__ __forceinline__ void large_jac_at_legs(const LView<M::n, M::m>& v, co
   constexpr int n = M::n, m = M::m, nc = n + m;
   const ModelScalars<M> ms(a);
   const double h = ms.fd_h, inv2h = 1.0 / (2.0 * h), dt = ms.dt;
-  for (int it = first * kLargeThreads + threadIdx.x; it < count * nc; it += cstride * kLargeThreads) {
+  for (int it = first * kLargeThreads + stage_tid(); it < count * nc; it += cstride * kLargeThreads) {
     const int rank = it / count, ki = it - rank * count;
     const int col = M::input_by_owner(rank);
     const int owner = M::leg_of_input(col);                    // -1: the trunk's own coordinates
@@ -1056,7 +1059,7 @@ __device__ __forceinline__ void large_jac_at(const LView<M::n, M::m>& v, const K
   constexpr int n = M::n, m = M::m, nc = n + m;
   const ModelScalars<M> ms(a);
   const double h = ms.fd_h, inv2h = 1.0 / (2.0 * h);
-  for (int it = first * kLargeThreads + threadIdx.x; it < count * nc; it += cstride * kLargeThreads) {
+  for (int it = first * kLargeThreads + stage_tid(); it < count * nc; it += cstride * kLargeThreads) {
     const int ki = it / nc, col = it - ki * nc;
     const int t = list[ki];
     const double* xg = Xsrc + (size_t)t * xstride;
@@ -1136,12 +1139,28 @@ struct TileOps {
 // The serial part is pivot -> reciprocal (16-cycle v_rcp_f64 + four dependent FMAs) -> multiplier -> next pivot, and the
 // wave issues in order: each step updates the column of the next pivot first, starts that pivot's reciprocal and places
 // the other column updates between its dependent instructions (sched_barrier pins the order).  Columns are visited in the order K+1, K+2, ..., K-1 (mod m).
+// One column update  a[J] -= g * (lane K's a[J])  is ONE instruction: v_fmac_f64 is a VOP2 opcode on gfx90a+ and takes a DPP64
+// row_newbcast source - v_fmac_f64_dpp a, -a(row_newbcast:K), g - where the compiler emits v_mov_b64_dpp + v_fma_f64 for
+// fma(-g, row_share<K>(a), a): half the elimination's instructions (m (m - 1) updates).  (-x) * g + a and fma(-g, x, a) are the
+// same bits.  Inline assembly is invisible to the compiler's hazard recognizer (a DPP read needs two wait states after a VALU
+// write of the same register), so the order is fixed where it matters: the s_nop at the top of every pivot covers the
+// compiler's own writes before it (the rows' assembly, the previous pivot's a[K] = select), the pivot read sits inside the block
+// that updates its column, and a column written in pivot K is read again no earlier than m - 2 + 8 instructions later.
+// (m < 4: the compiler's form - the elimination is bound by its serial chain there and the fixed s_nops only add to it.  Measured,
+// cycles per inverse, tools/ubench/gj_fmac.hip: m = 7 845 -> 829, m = 12 2 053 -> 1 609, m = 16 3 435 -> 2 416; same bits.)
+#ifndef MI_GJ_MOV_FMA
+template <int m> constexpr bool kGjAsm = m >= 4;
+#else
+template <int m> constexpr bool kGjAsm = false;
+#endif
+template <int K, bool ASM>
+__device__ __forceinline__ void fmac_row_share(double& a, double g) {
+  if constexpr (ASM) asm("v_fmac_f64_dpp %0, -%0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(a) : "v"(g), "n"(K));
+  else a = fma(-g, row_share<K>(a), a);
+}
 template <int m, int K, int NTH>
 __device__ __forceinline__ void gj_update(double (&a)[m], double g) {
-  if constexpr (NTH < m) {
-    constexpr int J = (K + NTH) % m;
-    a[J] = fma(-g, row_share<K>(a[J]), a[J]);
-  }
+  if constexpr (NTH < m) fmac_row_share<K, kGjAsm<m>>(a[(K + NTH) % m], g);
 }
 template <int m, int K, int NTH>
 struct GjRest {
@@ -1154,6 +1173,18 @@ template <int m, int K>
 struct GjRest<m, K, m> {
   static __device__ __forceinline__ void run(double (&)[m], double) {}
 };
+// the head of pivot K: the first three column updates and the read of the NEXT pivot out of the first of them, in one block
+template <int m, int K>
+__device__ __forceinline__ double gj_head(double (&a)[m], double g) {
+  static_assert(kGjAsm<m> && m >= 4, "three columns besides the pivot's");
+  double d;
+  asm("s_nop 1\n\tv_fmac_f64_dpp %1, -%1, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %2, -%2, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+      "v_fmac_f64_dpp %3, -%3, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b64_dpp %0, %1 row_newbcast:%6 row_mask:0xf bank_mask:0xf"
+      : "=&v"(d), "+v"(a[(K + 1) % m]), "+v"(a[(K + 2) % m]), "+v"(a[(K + 3) % m]) : "v"(g), "n"(K), "n"(K + 1));
+  return d;
+}
 template <int m, int K>
 struct GjOuter {
   // `inv` = 1 / pivot K, already computed; `i` = this lane's row
@@ -1162,12 +1193,19 @@ struct GjOuter {
     const double g = piv ? 0.0 : a[K] * inv;
     double r = 0.0;
     if constexpr (K + 1 < m) {
-      gj_update<m, K, 1>(a, g);                         // column K+1: the next pivot is in it
-      gj_update<m, K, 2>(a, g);                         // (also covers the DPP-after-VALU wait states of the pivot read)
-      __builtin_amdgcn_sched_barrier(0);
-      const double d = row_share<K + 1>(a[K + 1]);
-      r = __builtin_amdgcn_rcp(d);
-      gj_update<m, K, 3>(a, g);
+      double d;
+      if constexpr (kGjAsm<m>) {
+        d = gj_head<m, K>(a, g);                        // columns K+1 (the next pivot is in it), K+2, K+3 and the pivot read
+        __builtin_amdgcn_sched_barrier(0);
+        r = __builtin_amdgcn_rcp(d);
+      } else {
+        gj_update<m, K, 1>(a, g);                       // column K+1: the next pivot is in it
+        gj_update<m, K, 2>(a, g);                       // (also covers the DPP-after-VALU wait states of the pivot read)
+        __builtin_amdgcn_sched_barrier(0);
+        d = row_share<K + 1>(a[K + 1]);
+        r = __builtin_amdgcn_rcp(d);
+        gj_update<m, K, 3>(a, g);
+      }
       gj_update<m, K, 4>(a, g);
       __builtin_amdgcn_sched_barrier(0);
       double e = fma(-d, r, 1.0);
@@ -1182,6 +1220,10 @@ struct GjOuter {
       r = fma(r, e, r);                                 // == fast_rcp(d)
       GjRest<m, K, (8 < m ? 8 : m)>::run(a, g);
     } else {
+      if constexpr (kGjAsm<m>) {
+        asm volatile("s_nop 1");
+        __builtin_amdgcn_sched_barrier(0);
+      }
       GjRest<m, K, 1>::run(a, g);
     }
     a[K] = piv ? 1.0 : -g;
@@ -1307,8 +1349,13 @@ __device__ __forceinline__ void quu_inverse_pivoted(double* W_, int ws, int lane
 // OPERAND DELIVERY: two 8-byte operands per lane feed 1024 FMAs, where a VALU formulation needs a (broadcast) LDS
 // read per 1-2 FMAs and is LDS-issue-bound at one wave per SIMD (tools/ubench/t1.hip: 4.5-10.7 k cycles for T1
 // alone) - and since round 3 most operands do not even come from LDS: see "Fused chain" below.
+#ifdef MI_BACKWARD_NOINLINE
+#define MI_BP_INLINE __attribute__((noinline))
+#else
+#define MI_BP_INLINE inline
+#endif
 template <class M, bool PIV = true>
-__device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, long long* bp_acc = nullptr, bool lx_ready = false) {
+__device__ MI_BP_INLINE void large_backward(const LView<M::n, M::m>& v, double* lds, long long* bp_acc = nullptr, bool lx_ready = false) {
   constexpr int n = M::n, m = M::m, nm = n + m;
   using Ly = LLay<n, m>;
   constexpr int TS = Ly::TS, VS = Ly::VS, FS = Ly::NMP, NP = Ly::NP;
@@ -1317,7 +1364,7 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
   constexpr int UC = Ly::UC, KN = Ly::KN, NK = Ly::NK;
   constexpr int CX = SPLIT ? RT : CT;                  // column tiles the three matrix-core waves own
   static_assert(m % 4 == 0, "k-steps of 4 over m");
-  const int tid = threadIdx.x, N = v.N, wave = tid >> 6, lane = tid & 63;
+  const int tid = stage_tid(), N = v.N, wave = tid >> 6, lane = tid & 63;
   const int lr = lane & 15, lk = lane >> 4;
   const double* Q = lds + Ly::oQ;
   const double* R = lds + Ly::oR;
@@ -1900,7 +1947,7 @@ __device__ inline void large_backward(const LView<M::n, M::m>& v, double* lds, l
 // its column, like the reference's dense update); only Quu is formed from the transposed column tiles (= the transpose of a
 // matrix that is symmetric up to round-off), which takes it off the step's critical path.  Two barriers per step.
 template <class M, bool PIV = true>
-__device__ inline void mid_backward(const LView<M::n, M::m>& v, double* lds, bool lx_ready = false, bool xu_staged = false) {
+__device__ MI_BP_INLINE void mid_backward(const LView<M::n, M::m>& v, double* lds, bool lx_ready = false, bool xu_staged = false) {
   constexpr int n = M::n, m = M::m, nm = n + m;
   using Ly = LLay<n, m>;
   static_assert(Ly::kMid && Ly::kSplit && m >= 1 && m <= 16, "mid-size family: n <= 32, m <= 16");
@@ -1908,7 +1955,7 @@ __device__ inline void mid_backward(const LView<M::n, M::m>& v, double* lds, boo
   constexpr int MK = (m + 3) / 4;                            // k-steps over the controls
   constexpr int WU = RT, WP = RT + 1;                        // the u-wave and the pipeline wave
   static_assert(RT >= 1 && RT <= 2 && WP <= 3, "one or two x-waves + the u-wave + the pipeline wave");
-  const int tid = threadIdx.x, N = v.N, wave = tid >> 6, lane = tid & 63;
+  const int tid = stage_tid(), N = v.N, wave = tid >> 6, lane = tid & 63;
   const int lr = lane & 15, lk = lane >> 4;
   const double* Q = lds + Ly::oQ;
   const double* R = lds + Ly::oR;

@@ -101,6 +101,20 @@ struct KArgs {
   int cost_asym;                  // workgroup-per-problem kernels, n <= 32: Q, R or Qf is not symmetric (mi_ilqr_set_cost)
 };
 
+// threadIdx.x behind an empty asm, for the STAGES of a solve kernel (a rollout, a linearization, a backward pass): what a stage
+// derives from its lane index is loop-invariant for the solve loop around the stages, the compiler hoists it out of that loop,
+// and the hoisted values - dozens of lane-dependent addresses per stage - then live across every other stage and get spilled in
+// whichever inner loop is tightest.  Opaque per call, they are formed at the top of the stage and die with it (measured on the
+// workgroup-per-problem kernels, round 5: backward pass of the arm 6.2 k -> 5.5 k cycles per step, of the coupled arm 7.4 k -> 5.5 k;
+// on the wave-per-problem kernels of this file it changes nothing - C2 43.19 M it/s either way - and they keep threadIdx.x).
+__device__ __forceinline__ int stage_lane() {
+  int t = threadIdx.x;
+#ifndef MI_NO_STAGE_TID
+  asm volatile("" : "+v"(t));
+#endif
+  return t;
+}
+
 __device__ __forceinline__ double bcast_lane0(double v) {
   union { double d; int i[2]; } u;
   u.d = v;

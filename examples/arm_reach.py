@@ -4,7 +4,10 @@ model: the same state layout (7 joint angles | the ball's quaternion and positio
 (T = 0.5 s, dt = 1e-2), cost ("side" scenario: move the ball 15 cm along +y), delta = 1e-3, beta = 0.5, gravity-compensation
 initial guess, Solve() and SaveSolution() - then the same problem as a BATCH of perturbed starts with a receding-horizon
 loop on the device.  Drake's plant is replaced by drake_ddp_amd.models.ArmAndBall (Drake cannot run on the GPU); the
-kernels are the mid-size workgroup-per-problem family (n <= 32, any m <= 16)."""
+kernels are the mid-size workgroup-per-problem family (n <= 32, any m <= 16).
+
+    python examples/arm_reach.py [--coupled]     --coupled: the arm with coupled joint dynamics (ArmAndBallCoupled, MI_MODEL_ARM27C:
+                                                 dense mass matrix, velocity-product terms) instead of per-joint inertias"""
 import os
 import sys
 import tempfile
@@ -15,11 +18,13 @@ import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from drake_ddp_amd import workloads as W  # noqa: E402
 from drake_ddp_amd.ilqr import BatchedIterativeLQR, IterativeLinearQuadraticRegulator  # noqa: E402
-from drake_ddp_amd.models import ArmAndBall  # noqa: E402
+from drake_ddp_amd.models import ArmAndBall, ArmAndBallCoupled  # noqa: E402
 
-p = W.arm27_problem()
+coupled = "--coupled" in sys.argv
+p = W.arm27c_problem() if coupled else W.arm27_problem()
 num_steps, dt = p["N"], p["dt"]
-system_ = ArmAndBall(dt)
+system_ = (ArmAndBallCoupled if coupled else ArmAndBall)(dt)
+u_guess = (W.arm27c_u_guess if coupled else W.arm27_u_guess)(num_steps)
 
 # ---- kinova_gen3.py:254-284
 ilqr = IterativeLinearQuadraticRegulator(system_, num_steps, beta=0.5, delta=1e-3, gamma=0, derivs_keypoint_method=None)
@@ -27,7 +32,7 @@ ilqr.SetInitialState(W.arm27_start())
 ilqr.SetTargetState(p["x_nom"])
 ilqr.SetRunningCost(p["Q"], p["R"])
 ilqr.SetTerminalCost(p["Qf"])
-ilqr.SetInitialGuess(W.arm27_u_guess(num_steps))        # gravity compensation (+ a push on the base joint: workloads.py)
+ilqr.SetInitialGuess(u_guess)                           # gravity compensation (+ a push on the base joint: workloads.py)
 states, inputs, solve_time, optimal_cost = ilqr.Solve()
 print(f"Solved in {solve_time} seconds using iLQR")
 print(f"Optimal cost: {optimal_cost}")
@@ -44,7 +49,7 @@ batch.SetTargetState(p["x_nom"])
 batch.SetRunningCost(p["Q"], p["R"])
 batch.SetTerminalCost(p["Qf"])
 batch.SetInitialState(W.arm27_batch_x0(B))
-batch.SetInitialGuess(W.arm27_u_guess(num_steps))
+batch.SetInitialGuess(u_guess)
 st = time.time()
 x, u, _, cost = batch.Solve()
 it0 = int(batch.iterations.sum())

@@ -134,3 +134,23 @@ def test_struct_sizes_match_the_ctypes_mirror(lib):
     lib.mi_ilqr_struct_sizes(C.byref(d), C.byref(s), C.byref(p))
     assert (d.value, s.value, p.value) == (C.sizeof(_capi.Desc), C.sizeof(_capi.Stats), C.sizeof(plugin._Plugin))
     lib.mi_ilqr_struct_sizes(None, None, None)            # (any pointer may be NULL)
+
+
+def test_no_dpp_read_after_write_hazard_in_the_built_kernels(lib):
+    """The Gauss-Jordan elimination's column update is inline assembly (v_fmac_f64_dpp with a row_newbcast source,
+    csrc/ilqr_large.hpp) - invisible to the compiler's hazard recognizer, which otherwise guarantees two wait states between a
+    VALU write of a register and a DPP read of it.  tools/check_dpp_hazard.py walks the ISA of every kernel object of the build
+    the library was linked from and must find the elimination's instructions and no violation."""
+    import glob
+    import subprocess
+    import sys
+    objs = sorted(o for o in glob.glob(os.path.join(ROOT, "drake_ddp_amd", "lib", "obj", "k_*.o")) if "-" not in os.path.basename(o))
+    assert len(objs) >= 10, objs                                           # (the fixture built them)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_dpp_hazard.py")] + objs, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    m = re.search(r"(\d+) DPP instructions in (\d+) objects: 0 hazard violation", r.stdout)
+    assert m and int(m.group(1)) > 5000, r.stdout[-500:]
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_mix
+    text = isa_mix.device_asm(os.path.join(ROOT, "drake_ddp_amd", "lib", "obj", "k_synth36.o"))
+    assert text.count("v_fmac_f64_dpp") >= 12 * 11                          # (the 12 x 12 elimination, at least once)

@@ -182,15 +182,16 @@ def test_c3_c4_c5_configs_converge_at_full_size():
 
 @pytest.mark.parametrize("script", ["swingup_pendulum.py", "mpc_acrobot.py", "wall_cartpole.py", "mpc_many_legs.py",
                                     "mpc_planar_quadruped.py", "mpc_mini_cheetah_3d.py", "arm_reach.py", "swingup_cartpole.py",
-                                    "arm_push_scenarios.py"])
+                                    "arm_push_scenarios.py", "arm_reach.py --coupled"])
 def test_example_scripts_run(script):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "examples", script)], capture_output=True, text=True, timeout=300)
+    script, *flags = script.split()
+    out = subprocess.run([sys.executable, os.path.join(root, "examples", script)] + flags, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert any(k in out.stdout for k in ("Optimal cost: 0.23997", "device loop", "derivatives evaluated at", "iLQR iterations in the re-solves",
-                                         "Optimal cost: 1.15064"))
+                                         "Optimal cost: 1.15064", "Optimal cost: 3.49189"))
     assert "all converged: False" not in out.stdout
 
 

@@ -25,6 +25,14 @@ for jac in jacs:
         s.SetInitialState(W.arm27_batch_x0(B)); s.SetInitialGuess(W.arm27_u_guess(p["N"]))
         s.Solve(); s.Reset(); s.SetInitialGuess(W.arm27_u_guess(p["N"])); s.Solve()
         report(f"arm27 {jac}", s, p["N"])
+    pc = W.arm27c_problem()
+    for B in (1, 64, 1024):
+        s = make_solver(pc, B=B, jac=jac)
+        s.SetInitialState(W.arm27_batch_x0(B)); s.SetInitialGuess(W.arm27c_u_guess(pc["N"]))
+        s.Solve(); s.Reset(); s.SetInitialGuess(W.arm27c_u_guess(pc["N"])); s.Solve()
+        report(f"arm27c {jac}", s, pc["N"])
+    if os.environ.get("MI_CYC_ARMS_ONLY") == "1":
+        continue
     for nq, m, ne in ((6, 4, 0), (7, 7, 0), (16, 16, 0), (8, 1, 0)):
         n = 2 * nq + ne
         dt, N = 0.02, 50
