@@ -20,8 +20,12 @@ OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libmi_ilqr.so")
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# -amdgpu-mfma-vgpr-form: MFMA accumulators / results in the architectural VGPRs (gfx90a+ has one register file) instead of the
+# AGPRs the compiler's heuristic picks - in the backward passes every MFMA result feeds VALU work (Vxx' = H + 2Q - ..., stores)
+# and 29 % of the arm's hottest MFMA loop were v_accvgpr moves.  Same-box A/B, round 5: backward step of the arm 5.5 k -> 5.15 k
+# cycles, C5 350 k -> 359 k, C6 166 k -> 171 k, C3 18.7 M -> 19.1 M it/s; results bitwise unchanged (same instructions, other registers).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math",
-         "-ffp-contract=fast", "-Wall", "-Wno-unused-function"]
+         "-ffp-contract=fast", "-Wall", "-Wno-unused-function", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
 
 
 def sources():
