@@ -416,7 +416,7 @@ __device__ inline double large_rollout(const LView<M::n, M::m>& v, double* lds, 
         double S_[M::kJoints], C_[M::kJoints];
         trig_gather<M::kJoints, 0>(sc_, S_, C_);
         double xt[n];
-        M::template core<double>(S_, C_, xr, us, xt, prm, dt_);
+        M::template core<double, true>(S_, C_, xr, us, xt, prm, dt_);
 #pragma unroll
         for (int i = 0; i < n; ++i) xr[i] = xt[i];
         if (tid == 0) {
@@ -644,7 +644,7 @@ __device__ inline void mid_rollout4(const LView<M::n, M::m>& v, double* xsp, dou
         double S_[M::kJoints], C_[M::kJoints];
         trig_gather<M::kJoints, 0>(sc_, S_, C_);
         double xt[n];
-        M::template core<double>(S_, C_, xr, usc, xt, prm, dt_);
+        M::template core<double, true>(S_, C_, xr, usc, xt, prm, dt_);
 #pragma unroll
         for (int i = 0; i < n; ++i) xr[i] = xt[i];
         if (l == 0) {

@@ -479,6 +479,22 @@ struct Quad3D {
 // rigid sphere with compliant contacts against the ground and against the hand's sphere (smooth penalty, normal damping,
 // load-proportional viscous friction at the contact point); the hand receives the opposite force through J^T.
 // Served by the mid-size workgroup-per-problem kernels (ilqr_large.hpp: mid_backward).
+// The two contacts' softplus values (hand - ball, ball - ground).  ROW (the workgroup-per-problem rollouts: every lane of a 16-lane
+// row runs the step on the same values): even lanes evaluate the first argument, odd lanes the second - ONE evaluation in the
+// instruction stream instead of two (~90 of a step's ~750 instructions) - and lanes 0 / 1 share their results with the row;
+// softplus is branch-free, so each value has the bits the scalar form gives.
+template <bool ROW, class T>
+__device__ __forceinline__ void softplus_pair(const T& za, const T& zb, T& sa, T& sb) {
+  if constexpr (ROW && std::is_same<T, double>::value) {
+    const double s_ = mi_softplus((threadIdx.x & 1) ? zb : za);
+    sa = __builtin_amdgcn_update_dpp(s_, s_, 0x150, 0xF, 0xF, true);        // row_newbcast:0 / :1 (one v_mov_b64_dpp each)
+    sb = __builtin_amdgcn_update_dpp(s_, s_, 0x151, 0xF, 0xF, true);
+  } else {
+    sa = mi_softplus(za);
+    sb = mi_softplus(zb);
+  }
+}
+
 struct Arm27 {
   static constexpr int n = 27, m = 7, n_params = 15;
   static constexpr bool kWholeStep = true;
@@ -500,7 +516,7 @@ struct Arm27 {
     for (int i = 0; i < 7; ++i) { S[i] = mi_sin(x[i]); C[i] = mi_cos(x[i]); }
     core<T>(S, C, x, u, xn, p, dt);
   }
-  template <class T>
+  template <class T, bool ROW = false>
   __device__ static inline void core(const T (&S)[7], const T (&C)[7], const T* x, const T* u, T* xn, const double* p, double dt) {
     const double g = p[0], kc = p[1], sig = p[2], dn = p[3], mu = p[4], bj = p[5];
     const double mb = p[6], rb = p[7], re = p[8], m_el = p[9], m_hd = p[10];
@@ -561,7 +577,9 @@ struct Arm27 {
 #pragma unroll
     for (int k = 0; k < 3; ++k) nr[k] = d[k] * idist;
     const T phi = dist - (rb + re);
-    const T fn0 = (kc * sig) * mi_softplus(-phi * (1.0 / sig));
+    T sp_c, sp_g;
+    softplus_pair<ROW>(-phi * (1.0 / sig), -(pb[2] - rb) * (1.0 / sig), sp_c, sp_g);
+    const T fn0 = (kc * sig) * sp_c;
     T wxn[3], rel[3], vt[3], Fc[3], nxv[3], tc[3];
     cross(om, nr, wxn);
 #pragma unroll
@@ -576,7 +594,7 @@ struct Arm27 {
 #pragma unroll
     for (int k = 0; k < 3; ++k) tc[k] = (rb * mu) * fn0 * nxv[k];
     // ---- ball - ground contact
-    const T fg0 = (kc * sig) * mi_softplus(-(pb[2] - rb) * (1.0 / sig));
+    const T fg0 = (kc * sig) * sp_g;
     const T vcx = vb[0] - rb * om[1], vcy = vb[1] + rb * om[0];
     const T Fg[3] = {-(mu * fg0) * vcx, -(mu * fg0) * vcy, fg0 * (1.0 - dn * vb[2])};
     const T tg[3] = {rb * Fg[1], -(rb * Fg[0]), T(0.0)};
@@ -647,7 +665,7 @@ struct Arm27C {
     for (int i = 0; i < 7; ++i) { S[i] = mi_sin(x[i]); C[i] = mi_cos(x[i]); }
     core<T>(S, C, x, u, xn, p, dt);
   }
-  template <class T>
+  template <class T, bool ROW = false>
   __device__ static inline void core(const T (&S)[7], const T (&C)[7], const T* x, const T* u, T* xn, const double* p, double dt) {
     const double g = p[0], kc = p[1], sig = p[2], dn = p[3], mu = p[4], bj = p[5];
     const double mb = p[6], rb = p[7], re = p[8], m_el = p[9], m_hd = p[10], m_wr = p[15];
@@ -716,7 +734,9 @@ struct Arm27C {
 #pragma unroll
     for (int k = 0; k < 3; ++k) nr[k] = d[k] * idist;
     const T phi = dist - (rb + re);
-    const T fn0 = (kc * sig) * mi_softplus(-phi * (1.0 / sig));
+    T sp_c, sp_g;
+    softplus_pair<ROW>(-phi * (1.0 / sig), -(pb[2] - rb) * (1.0 / sig), sp_c, sp_g);
+    const T fn0 = (kc * sig) * sp_c;
     T wxn[3], rel[3], vt[3], Fc[3], nxv[3], tc[3];
     cross(om, nr, wxn);
 #pragma unroll
@@ -730,7 +750,7 @@ struct Arm27C {
     cross(nr, vt, nxv);
 #pragma unroll
     for (int k = 0; k < 3; ++k) tc[k] = (rb * mu) * fn0 * nxv[k];
-    const T fg0 = (kc * sig) * mi_softplus(-(pb[2] - rb) * (1.0 / sig));
+    const T fg0 = (kc * sig) * sp_g;
     const T vcx = vb[0] - rb * om[1], vcy = vb[1] + rb * om[0];
     const T Fg[3] = {-(mu * fg0) * vcx, -(mu * fg0) * vcy, fg0 * (1.0 - dn * vb[2])};
     const T tg[3] = {rb * Fg[1], -(rb * Fg[0]), T(0.0)};
