@@ -27,6 +27,7 @@ STATUS_FLAG_INDEFINITE = 16     # OR-ed onto the outcome: on_indefinite="continu
 F_X_BAR, F_U_BAR, F_K, F_KAPPA, F_DV, F_FX, F_FU, F_COST, F_X0, F_HIST, F_X_TRIAL, F_U_TRIAL, F_TRIAL_COST, F_ITER_CYCLES = range(14)
 I_ITERS, I_STATUS, I_LS_TRIALS, I_KP_COUNT, I_KP_LIST = 100, 101, 102, 103, 104
 I64_STAGE_CYCLES = 200
+I64_CLUSTER_WORDS = 201
 
 EXPORTS = [
     "mi_ilqr_abi_version", "mi_ilqr_struct_sizes", "mi_ilqr_strerror", "mi_ilqr_model_info", "mi_ilqr_register_model", "mi_ilqr_create", "mi_ilqr_destroy",

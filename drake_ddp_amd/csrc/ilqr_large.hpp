@@ -144,6 +144,29 @@ __device__ __forceinline__ double ld_shared(const double* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void wait_stores() { __builtin_amdgcn_s_waitcnt(0x0F70); }   // vmcnt(0): this thread's stores acknowledged
+// Publishing write-through (device-scope) stores to another workgroup: each thread waits until its own are acknowledged - a
+// device-scope store is acknowledged when it is complete at that scope - and the barrier collects the threads; the flag store /
+// atomic that follows it may then be relaxed.  What a device-scope RELEASE FENCE would add is buffer_wbl2 sc1: a write-back of
+// every dirty line in the XCD's L2 - the gains, trial trajectories and own Jacobian shares of every leader that lives there,
+// none of which any other workgroup reads.
+// That holds for a reader behind the SAME L2 (one XCD).  For a reader on another XCD it does not: measured in round 5 - with
+// the fence dropped and the cluster spread over XCDs, the coupled arm's cold solves took 1009 iterations instead of 1002 - an
+// acknowledged write-through store has reached the XCD's L2, not yet the memory the other XCD reads.  one_l2 = false: the fence.
+__device__ __forceinline__ void cluster_publish_barrier(bool one_l2) {
+  if (one_l2) { wait_stores(); asm volatile("" ::: "memory"); }
+  else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __syncthreads();
+}
+// XCC (= XCD) this wave runs on
+__device__ __forceinline__ int xcc_id() {
+#ifdef MI_NO_XCC
+  return 0;
+#else
+  unsigned x;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+  return (int)(x & 15u);
+#endif
+}
 
 // Models whose step is an articulated-body algorithm cut into chains (models.hpp: PlanarQuad): cooperative
 // step in the rollout, accessor-driven whole-tree evaluation in the linearization.
@@ -221,9 +244,19 @@ __device__ __forceinline__ void trig_gather(double v, double (&S)[NJ], double (&
 // u_bar_t, kappa_t come from HBM/L2 and are prefetched one step ahead into registers;
 // (2) one lane per degree of freedom advances the dynamics while other waves add the
 // stage-cost rows (their Q/R rows live in registers); (3) the new state is published.
+// prog != nullptr: the rollout PUBLISHES the trial as it goes, for helper workgroups that linearize it while it is still being
+// rolled out (ilqr_large_kernel: early linearization).  x_t, u_t then leave as write-through stores - all from the fourth wave,
+// which issues no other vector-memory operation in this loop, so its counter of outstanding operations counts exactly them -
+// and lane 192 stores `tag | s` into *prog once the steps 0 .. s-1 are complete at device scope: kPubLag steps behind the
+// rollout, waiting for nothing that a step's time has not long delivered.
+constexpr int kPubLag = 3;
+constexpr unsigned long long kPubAbort = 0x80000000ull;      // *prog = tag | kPubAbort: the trial was rejected, stop linearizing it
+template <class M>
+constexpr bool kEarlyLin = M::m * 16 <= 192;                 // (the fourth wave holds no control-law lanes: no prefetch loads on it)
 template <class M>
 __device__ inline double large_rollout(const LView<M::n, M::m>& v, double* lds, const KArgs& a,
-                                       const double* x0g, double eps, double& expd_out) {
+                                       const double* x0g, double eps, double& expd_out,
+                                       unsigned long long* prog = nullptr, unsigned long long tag = 0ull) {
   constexpr int n = M::n, m = M::m;
   using Ly = LLay<n, m>;
   constexpr int JR = (n + 15) / 16;    // K-row elements per lane
@@ -237,6 +270,8 @@ __device__ inline double large_rollout(const LView<M::n, M::m>& v, double* lds, 
   const bool q2role = tid >= 192 && tid < 192 + n;   // cost row i = tid-192, second half (the fourth wave)
   constexpr int nh = n / 2;
   const bool rrole = tid >= 128 && tid < 128 + m;    // control-cost row k = tid-128
+  static_assert(n + m <= 64, "u_t leaves from the fourth wave's lanes behind the n state lanes");
+  const bool uorole = tid >= 192 + n && tid < 192 + n + m;   // u_t -> HBM (the fourth wave: with x_t, every trajectory store of the step)
   // cost rows -> registers (one-off)
   double qrow[n], rrow[m];
   if (qrole || q2role) {
@@ -323,7 +358,18 @@ __device__ inline double large_rollout(const LView<M::n, M::m>& v, double* lds, 
     if (drole) {
       const double xv_ = xc[tid - 192];
       dxc[tid - 192] = xv_ - xnr;
-      v.Xn[(size_t)t * n + (tid - 192)] = xv_;
+      if (prog) {
+        if (tid == 192 && t >= 1) {
+          // every step from the second on publishes (a count of zero claims nothing), so the wave has issued exactly
+          // (publish, x, u) x kPubLag operations since u_{t-1-kPubLag}: all but that many complete = steps 0 .. t-1-kPubLag out
+          if (t > kPubLag) __builtin_amdgcn_s_waitcnt(0x0F70 | (3 * kPubLag));
+          asm volatile("" ::: "memory");
+          __hip_atomic_store(prog, tag | (unsigned long long)(t > kPubLag ? t - kPubLag : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        st_shared<true>(v.Xn + (size_t)t * n + (tid - 192), xv_);
+      } else {
+        v.Xn[(size_t)t * n + (tid - 192)] = xv_;
+      }
     }
     if (t + 2 < N - 1) prefetch(f, t + 2);       // this set is free again
     lds_barrier();
@@ -466,7 +512,13 @@ __device__ inline double large_rollout(const LView<M::n, M::m>& v, double* lds, 
       for (int j = 0; j < m; ++j) r += rrow[j] * us[j];
       acc += us[k] * r;
       if constexpr (kLx) lxu_store(v, Lxu, t * (n + m) + n + k, 2.0 * r);
+#ifdef MI_UN_RROLE
       v.Un[(size_t)t * m + k] = us[k];
+#endif
+    } else if (uorole) {
+      const int k = tid - 192 - n;
+      if (prog) st_shared<true>(v.Un + (size_t)t * m + k, us[k]);
+      else v.Un[(size_t)t * m + k] = us[k];
     }
     lds_barrier();
     double* tmp_ = xc; xc = xn_; xn_ = tmp_;
@@ -480,6 +532,11 @@ __device__ inline double large_rollout(const LView<M::n, M::m>& v, double* lds, 
   }
   xs = xc;                             // final state x_{N-1}
   if (tid < n) v.Xn[(size_t)(N - 1) * n + tid] = xs[tid];
+  if (prog && tid == 192) {            // every step of the trial is out
+    wait_stores();
+    asm volatile("" ::: "memory");
+    __hip_atomic_store(prog, tag | (unsigned long long)(N - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   if constexpr (kLx) {
     if (qrole && N >= 2) lxu_store(v, Lxu, (N - 2) * (n + m) + (tid - 64), 2.0 * (r1_prev + r2buf[((N - 2) & 1) * 64 + (tid - 64)]));
   }
@@ -509,15 +566,18 @@ __device__ inline double large_rollout(const LView<M::n, M::m>& v, double* lds, 
 
 // Sequential line search (ilqr.py:300-337); on accept Xn/Un hold the trajectory.
 template <class M>
+// prog: the FIRST trial is published step by step (large_rollout); a rejected first trial is called off at once.
 __device__ inline bool large_linesearch(const LView<M::n, M::m>& v, double* lds, const KArgs& a, const double* x0g,
-                                        double L_last, double& L_out, double& eps_out, int& trials) {
+                                        double L_last, double& L_out, double& eps_out, int& trials,
+                                        unsigned long long* prog = nullptr, unsigned long long tag = 0ull) {
   double eps = 1.0;
   trials = 0;
   while (eps >= 1e-8) {
     trials += 1;
     double ex;
-    const double L = large_rollout<M>(v, lds, a, x0g, eps, ex);
+    const double L = large_rollout<M>(v, lds, a, x0g, eps, ex, trials == 1 ? prog : nullptr, tag);
     if ((L_last - L) > a.gamma * ex) { L_out = L; eps_out = eps; return true; }
+    if (prog && trials == 1 && threadIdx.x == 192) __hip_atomic_store(prog, tag | kPubAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     eps *= a.beta;
     __syncthreads();
   }
@@ -2341,8 +2401,25 @@ __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kerne
   int* ilds = reinterpret_cast<int*>(lds + Ly::doubles + (a.lxu ? (size_t)0 : (size_t)a.N * (n + m)));
   // `cluster` workgroups per problem (MODE_SOLVE / MODE_MPC): workgroup 0 of a cluster is the leader and runs the
   // solve, the others only help with its linearizations (cluster handshake below)
-  const int G = ((MODE == MODE_SOLVE || MODE == MODE_MPC) && a.cluster > 1) ? a.cluster : 1;
-  const int b = blockIdx.x / G, role = blockIdx.x - b * G, tid = threadIdx.x, N = a.N;
+  const int G = ((MODE == MODE_SOLVE || MODE == MODE_MPC) && (a.cluster & 0xff) > 1) ? (a.cluster & 0xff) : 1;
+  const int corder = (a.cluster >> 8) & 3;                  // placement of a cluster's members (mi_ilqr.hip: launch arguments)
+  const bool early_lin = ((a.cluster >> 10) & 1) != 0;      // early linearization (below)
+  constexpr int kEarlyBlock = (kLargeThreads / (n + m)) > 0 ? kLargeThreads / (n + m) : 1;   // steps per block: one pass of the workgroup
+  // XCD-aware placement of a cluster: the dispatcher deals workgroups to the 8 XCDs round-robin by blockIdx.x, so the members of
+  // one cluster take block indices that are congruent mod 8 - one XCD, ONE L2: the helpers' Jacobians reach the leader through the
+  // cache they share, and the leaders spread over all eight L2s (with b = blockIdx.x / G the leaders of clusters of 4 all sat on
+  // XCDs 0 and 4).  The grid is 8 G ceil(B / 8) workgroups (launch_large.hpp); those beyond the batch leave at once.  Nothing
+  // below RELIES on the placement: every member reads its XCC id from the hardware register and the leader takes the same-L2
+  // path of the handshake only when all the helpers it counts on reported its own id.
+  const int xslot = (int)blockIdx.x >> 3, xP = (a.B + 7) >> 3;       // slot on its XCD; problems per XCD
+  const int tid = threadIdx.x, N = a.N;
+  int b = (int)blockIdx.x, role = 0;
+  if (G > 1) {
+    if (corder == 0) { b = (int)blockIdx.x / G; role = (int)blockIdx.x - b * G; }                     // consecutive blocks: a cluster spans G XCDs
+    else if (corder == 1) { b = ((int)blockIdx.x & 7) + 8 * (xslot / G); role = xslot % G; }         // one XCD, members in consecutive slots
+    else { b = ((int)blockIdx.x & 7) + 8 * (xslot % xP); role = xslot / xP; }                         // one XCD, the XCD's leaders first, then its helpers
+    if (b >= a.B) return;
+  }
   LView<n, m> v;
   v.N = N;
   v.X = a.x_bar + (size_t)b * n * N;
@@ -2417,24 +2494,26 @@ __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kerne
   // ---- cluster handshake (G > 1; every step a key-point, models with an LDS-staged linearization) -------------
   // The linearization is the one stage of an iteration whose (step, column) items are independent, and with few
   // problems per GPU most CUs idle: the leader of a problem's cluster shares them with its helper workgroups.
-  //   sync words (global, zero at launch): [0] command = round << 32 | participants, [1] done (chunk shares
-  //   finished, monotonic), [2] alive (helpers that have started), [3] exit.
+  //   sync words (global, zero at launch, kSyncWords per problem): [0] command = round << 32 | early << 16 | participants,
+  //   [1] done (shares finished, monotonic), [2] alive (helpers that have started; per XCC id above bit 16), [3] exit,
+  //   [4] progress of the trial being rolled out (early linearization: round << 32 | steps out, or | kPubAbort),
+  //   [5] early rounds opened << 32 | early rounds whose trial was accepted (written at exit, diagnostic).
   // A helper registers when it starts running (role by arrival); the leader snapshots `alive` when it publishes a
   // round and only counts on those helpers - a workgroup that is not resident yet is never waited for, so the
   // scheme cannot deadlock on an oversubscribed device.  Items are dealt in chunks of 256 to the participants
   // round-robin (static: every Jacobian entry is written by exactly one workgroup, with the arithmetic of the
   // single-workgroup path - bitwise the same fx, fu).  Trajectory and Jacobians cross workgroups through global
   // memory under device-scope release / acquire fences.
-  unsigned long long* csync = a.cluster_sync + (size_t)4 * b;
+  //
+  // EARLY LINEARIZATION (round 5).  The first trial of a line search is accepted almost always (the receding-horizon
+  // configs: 1.00 - 1.03 trials per iteration), and while the leader rolls it out - N - 1 dependent steps on a handful of lanes -
+  // its helpers idle.  So the leader opens an `early` round before the line search: the rollout publishes its progress
+  // (large_rollout), the helpers - the leader takes no share - linearize the trial block by block of kEarlyBlock steps as the
+  // steps come out, and an accepted trial finds its Jacobians all but finished: what is left of the linearization stage is the
+  // wait for the last block.  A rejected first trial is called off (the helpers stop at their next block boundary and report
+  // in), and the accepted trial is linearized the usual way.  Same items, same arithmetic: bitwise the same fx, fu.
+  unsigned long long* csync = a.cluster_sync + (size_t)kSyncWords * b;
   const bool clustered = G > 1 && lin_staged && a.kp_method == MI_KP_SET_INTERVAL && a.minN == 1;
-  auto stage_trajectory = [&]() __attribute__((always_inline)) {          // helper: the leader's x_bar / u_bar -> LDS
-    double* xs_ = lds + Ly::oT1;
-    double* us_ = lds + Ly::oF;
-    for (int e = tid; e < n * N; e += kLargeThreads) xs_[(e / n) * kXS + e % n] = ld_shared(v.X + e);
-    for (int e = tid; e < m * (N - 1); e += kLargeThreads) us_[(e / m) * kUS + e % m] = ld_shared(v.U + e);
-    for (int i = tid; i < N - 1; i += kLargeThreads) acc.kp[i] = i;          // keypoints_set_interval(minN = 1)
-    __syncthreads();
-  };
   auto jac_share = [&](int first, int stride, auto coherent) __attribute__((always_inline)) {
     constexpr bool COH = decltype(coherent)::value;
     if constexpr (HasSparsity<M>::value) large_jac_at_sparse<M, JAC, COH>(v, a, acc.kp, N - 1, lin_X, lin_U, first, stride);
@@ -2442,19 +2521,35 @@ __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kerne
     else if constexpr (IsLegModel<M>::value) large_jac_at_legs<M, JAC, COH>(v, a, acc.kp, N - 1, lin_X, lin_U, lin_xs, lin_us, first, stride);
     else large_jac_at<M, JAC, COH>(v, a, acc.kp, N - 1, lin_X, lin_U, lin_xs, lin_us, first, stride);
   };
-  constexpr long long kSpinCap = 1ll << 22;                 // x s_sleep(4) ~ 1 s: a lost partner ends the wait, not the device
+  // helper workgroups: a list of key-points (a block of time steps), write-through stores
+  auto jac_list = [&](const int* list, int count, int first, int stride) __attribute__((always_inline)) {
+    if constexpr (HasSparsity<M>::value) large_jac_at_sparse<M, JAC, true>(v, a, list, count, lin_X, lin_U, first, stride);
+    else if constexpr (IsChainModel<M>::value) large_jac_at_tree<M, JAC, true>(v, a, list, count, lin_X, lin_U, lin_xs, lin_us, lds + Ly::doubles, first, stride);
+    else if constexpr (IsLegModel<M>::value) large_jac_at_legs<M, JAC, true>(v, a, list, count, lin_X, lin_U, lin_xs, lin_us, first, stride);
+    else large_jac_at<M, JAC, true>(v, a, list, count, lin_X, lin_U, lin_xs, lin_us, first, stride);
+  };
+#ifndef MI_SPIN_CAP_SHIFT
+#define MI_SPIN_CAP_SHIFT 22
+#endif
+  constexpr long long kSpinCap = 1ll << MI_SPIN_CAP_SHIFT;                 // x s_sleep(4) ~ 1 s: a lost partner ends the wait, not the device
   if (role > 0) {
     // ---- helper workgroup
     if (!clustered) return;
-    if (tid == 0) acc.aux[1] = (int)__hip_atomic_fetch_add(csync + 2, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+    if (tid == 0) acc.aux[1] = (int)(__hip_atomic_fetch_add(csync + 2, 1ull | (1ull << (16 + 6 * xcc_id())), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xffffull) + 1;
     __syncthreads();
     const int my = acc.aux[1];                              // 1, 2, ...: order of arrival
-    unsigned last_round = 0;
+    // The last round served lives in LDS, not in a register of the loop: this hipcc placed the register's spill copy
+    // (v_accvgpr_write_b32) of ilqr_large_kernel<Arm27C, 0, MODE_MPC> at the top of a join block BEFORE the s_or_b64 that
+    // re-activates the lanes - executed with EXEC = 0 it saved nothing, the reload returned the round before, and the helpers
+    // repeated a finished round for ever.  tools/check_exec_spill.py looks for that pattern in every built kernel (CPU test).
+    int* const last_round_p = acc.need;
+    if (tid == 0) *last_round_p = 0;
     for (;;) {
       if (tid == 0) {
         unsigned long long cmd = 0;
         long long spins = 0;
         int go = -1;
+        const unsigned last_round = (unsigned)*last_round_p;
         for (; spins < 16 * kSpinCap; ++spins) {           // (a helper may be resident long before its leader speaks)
           cmd = __hip_atomic_load(csync + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if ((unsigned)(cmd >> 32) != last_round) { go = 1; break; }
@@ -2464,40 +2559,86 @@ __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kerne
         acc.aux[0] = go;
         acc.aux[2] = (int)(unsigned)(cmd >> 32);
         acc.aux[3] = (int)(unsigned)(cmd & 0xffffffffull);
+        if (go > 0) *last_round_p = (int)(unsigned)(cmd >> 32);
       }
       __syncthreads();
-      const int go = acc.aux[0], parts = acc.aux[3];
-      last_round = (unsigned)acc.aux[2];
+      const int go = acc.aux[0], parts = acc.aux[3] & 0xffff;
+      const bool early = ((acc.aux[3] >> 16) & 1) != 0;
+      const bool one_l2 = ((acc.aux[3] >> 17) & 1) != 0;    // the leader found every helper of this round on its own XCD
+      const unsigned last_round = (unsigned)acc.aux[2];     // (the round being served: the tag of its progress word)
       __syncthreads();
       if (go < 0) return;                                   // exit flag (or nobody spoke for a second)
       if (my >= parts) continue;                            // arrived after this round's snapshot: not counted on
-      stage_trajectory();                                   // (cache-bypassing loads: no acquire fence)
-      jac_share(my, parts, std::true_type{});               // this share of fx / fu: write-through stores ...
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");    // ... and a release: nothing of it is left dirty, so the
-      __syncthreads();                                      //     write-back it implies finds next to nothing to do
+      // a regular round is ONE block: every key-point, this workgroup's chunks of it; an early round: the blocks of kEarlyBlock
+      // steps dealt to the parts - 1 helpers in turn, each linearized whole once the rollout has put its steps out
+      const int nblk = early ? (N - 1 + kEarlyBlock - 1) / kEarlyBlock : 1;
+      for (int j = early ? my - 1 : 0; j < nblk; j += early ? parts - 1 : 1) {
+        const int t0 = early ? j * kEarlyBlock : 0, t1 = early ? (t0 + kEarlyBlock < N - 1 ? t0 + kEarlyBlock : N - 1) : N - 1;
+        if (early) {
+          if (tid == 0) {
+            int st = -1;                                    // -1: called off (or the leader is gone); 1: steps t0 .. t1-1 are out
+            for (long long spins = 0; spins < 16 * kSpinCap; ++spins) {
+              const unsigned long long pw = __hip_atomic_load(csync + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if ((unsigned)(pw >> 32) == last_round) {
+                if (pw & kPubAbort) break;
+                if ((int)(pw & 0x7fffffffull) >= t1) { st = 1; break; }
+              }
+              if (__hip_atomic_load(csync + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) break;
+              __builtin_amdgcn_s_sleep(2);
+            }
+            acc.aux[0] = st;
+          }
+          __syncthreads();
+          const int st = acc.aux[0];
+          __syncthreads();
+          if (st < 0) break;
+        }
+        {                                                   // the leader's trajectory -> LDS (cache-bypassing loads: no acquire fence)
+          const double* Xg = early ? v.Xn : v.X;            // (early: the trial as the rollout publishes it)
+          const double* Ug = early ? v.Un : v.U;
+          double* xs_ = lds + Ly::oT1;
+          double* us_ = lds + Ly::oF;
+          const int xe = early ? t1 * n : n * N;            // (a regular round stages x_{N-1} too, as it always has)
+          for (int e = t0 * n + tid; e < xe; e += kLargeThreads) xs_[(e / n) * kXS + e % n] = ld_shared(Xg + e);
+          for (int e = t0 * m + tid; e < t1 * m; e += kLargeThreads) us_[(e / m) * kUS + e % m] = ld_shared(Ug + e);
+          for (int i = t0 + tid; i < t1; i += kLargeThreads) acc.kp[i] = i;      // keypoints_set_interval(minN = 1)
+          __syncthreads();
+        }
+        jac_list(acc.kp + t0, t1 - t0, early ? 0 : my, early ? 1 : parts);       // this share of fx / fu: write-through stores
+        __syncthreads();                                    // (the next block's staging reuses what this one read)
+      }
+      cluster_publish_barrier(one_l2);                      // (one L2: no cache-wide write-back - see there)
       if (tid == 0) __hip_atomic_fetch_add(csync + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
-  unsigned cl_round = 0;
-  unsigned long long cl_expected = 0;                       // done-counter value after the helpers of all rounds so far
+  // The leader's handshake state lives in LDS (the integer scratch of the key-point methods, idle when every step is a key-point),
+  // thread 0 only: [0] rounds, [1] rounds on the same-L2 path, [2] early rounds opened, [3] ... accepted, [4] done-counter value
+  // after the helpers of all rounds so far.  (As loop-carried registers of the solve loop they were what tipped the coupled arm's
+  // receding-horizon kernel into scratch spills.)
+  int* const cst = acc.need;
+  if (G > 1 && tid == 0) { cst[0] = 0; cst[1] = 0; cst[2] = 0; cst[3] = 0; cst[4] = 0; }
+  __syncthreads();
   // leader: one clustered linearization of the committed trajectory (LDS copy in place).  Returns false on a lost helper.
   auto linearize_clustered = [&]() __attribute__((always_inline)) -> bool {
     for (int i = tid; i < N - 1; i += kLargeThreads) acc.kp[i] = i;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // the write-through x_bar / u_bar stores of the commit
-    __syncthreads();
     if (tid == 0) {
-      const unsigned long long alive = __hip_atomic_load(csync + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long word = __hip_atomic_load(csync + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long alive = word & 0xffffull;   // (at most G - 1 <= 7 helpers exist; bits 16 + 6 x ..: how many of them per XCC id)
       const unsigned parts = 1u + (unsigned)(alive < (unsigned long long)(G - 1) ? alive : (unsigned long long)(G - 1));
-      cl_round += 1;
       acc.aux[3] = (int)parts;
-      __hip_atomic_store(csync + 0, ((unsigned long long)cl_round << 32) | parts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      acc.aux[1] = ((word >> (16 + 6 * xcc_id())) & 63ull) == alive ? 1 : 0;   // every helper counted on shares this workgroup's L2
     }
     __syncthreads();
     const int parts = acc.aux[3];
+    cluster_publish_barrier(acc.aux[1] != 0);               // the write-through x_bar / u_bar stores of the commit
+    if (tid == 0) {
+      const unsigned cl_round = (unsigned)(cst[0] += 1);
+      __hip_atomic_store(csync + 0, ((unsigned long long)cl_round << 32) | ((unsigned long long)(acc.aux[1] != 0 ? 1 : 0) << 17) | (unsigned)parts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     jac_share(0, parts, std::false_type{});                 // (own share: read back by this workgroup only)
     __syncthreads();
     if (tid == 0) {
-      cl_expected += (unsigned long long)(parts - 1);
+      const unsigned long long cl_expected = (unsigned long long)(cst[4] += parts - 1);
       long long spins = 0;
       int ok = 1;
       while (__hip_atomic_load(csync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < cl_expected) {
@@ -2508,9 +2649,64 @@ __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kerne
     }
     __syncthreads();
     const bool ok = acc.aux[0] != 0;
-    // the helpers' shares of fx / fu are in memory; drop this XCD's cached copies of last iteration's (invalidate
-    // only - nothing of this workgroup needs writing back for anybody)
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    // The helpers' shares of fx / fu are complete at device scope.  Helpers on this XCD wrote them THROUGH the L2 this workgroup
+    // reads from: only this CU's vector cache can hold last iteration's lines - drop those (buffer_inv sc0: what a workgroup-scope
+    // acquire is in threadgroup-split mode) and leave the L2 alone.  A helper elsewhere: a device-scope acquire, which invalidates
+    // this XCD's L2 for every workgroup on it (invalidate only - nothing of this workgroup needs writing back for anybody).
+    const bool same_l2 = acc.aux[1] != 0;
+    if (same_l2) asm volatile("buffer_inv sc0" ::: "memory");
+    else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (tid == 0 && same_l2) cst[1] += 1;
+    __syncthreads();
+    return ok;
+  };
+  // leader, early linearization: open a round for the trial the line search is about to roll out (false: no helper is there yet)
+  auto open_early = [&]() __attribute__((always_inline)) -> bool {
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned long long word = __hip_atomic_load(csync + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long alive = word & 0xffffull;
+      const unsigned parts = 1u + (unsigned)(alive < (unsigned long long)(G - 1) ? alive : (unsigned long long)(G - 1));
+      const bool same = ((word >> (16 + 6 * xcc_id())) & 63ull) == alive;
+      // Only with every helper on this workgroup's own XCD.  The helpers of an early round write ALL of fx, fu - through the L2
+      // they share with the leader; from another XCD they would write past lines this L2 still holds DIRTY (the leader's own
+      // share of the last regular round, plain stores), and the stale line would win.  (Seen, not imagined: forced onto other
+      // XCDs - MI_ILQR_CLUSTER_ORDER=0 - the arm's solves took other iteration counts until this test was in.)
+      acc.aux[3] = same ? (int)parts : 1;
+      acc.aux[1] = 1;
+      if (same && parts > 1) {
+        const unsigned cl_round = (unsigned)(cst[0] += 1);
+        cst[4] += (int)parts - 1;
+        cst[2] += 1;
+        __hip_atomic_store(csync + 4, (unsigned long long)cl_round << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(csync + 0, ((unsigned long long)cl_round << 32) | (3ull << 16) | parts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      acc.aux[2] = cst[0];
+    }
+    __syncthreads();
+    return acc.aux[3] > 1;
+  };
+  // ... and close it: every helper of the round has reported in (its blocks finished, or called off).  False on a lost helper.
+  auto close_early = [&](bool use) __attribute__((always_inline)) -> bool {
+    __syncthreads();
+    const bool same_l2 = acc.aux[1] != 0;
+    if (tid == 0) {
+      const unsigned long long cl_expected = (unsigned long long)cst[4];
+      long long spins = 0;
+      int ok = 1;
+      while (__hip_atomic_load(csync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < cl_expected) {
+        if (++spins >= kSpinCap) { ok = 0; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      acc.aux[0] = ok;
+      if (use) { cst[3] += 1; cst[1] += same_l2 ? 1 : 0; }
+    }
+    __syncthreads();
+    const bool ok = acc.aux[0] != 0;
+    if (use) {                                              // the Jacobians are the helpers': as after a regular round
+      if (same_l2) asm volatile("buffer_inv sc0" ::: "memory");
+      else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
     __syncthreads();
     return ok;
   };
@@ -2604,25 +2800,29 @@ __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kerne
       if (it_this >= a.max_iters) { status = MI_STATUS_MAX_ITERS; break; }
       double L_new, eps; int trials;
       const long long c0 = clock64();
-      bool ok, used_spec = false;
+      bool ok, used_spec = false, early = false;
       int win = 0;
       if constexpr (kSpecRollout<M>) {
         if ((a.spec_policy == 2 || (a.spec_policy == 1 && backtracked)) && L < __builtin_inf()) {
           used_spec = true;
           ok = mid_linesearch4<M>(v, xsp, usp, sx_, su_, lds, a, x0g, L, L_new, eps, trials, win);
         } else {
-          ok = large_linesearch<M>(v, lds, a, x0g, L, L_new, eps, trials);
+          if constexpr (kEarlyLin<M>) { if (clustered && early_lin) early = open_early(); }
+          ok = large_linesearch<M>(v, lds, a, x0g, L, L_new, eps, trials, early ? csync + 4 : nullptr, (unsigned long long)(unsigned)acc.aux[2] << 32);
         }
         backtracked = backtracked || trials > 1;
       } else {
-        ok = large_linesearch<M>(v, lds, a, x0g, L, L_new, eps, trials);
+        if constexpr (kEarlyLin<M>) { if (clustered && early_lin) early = open_early(); }
+        ok = large_linesearch<M>(v, lds, a, x0g, L, L_new, eps, trials, early ? csync + 4 : nullptr, (unsigned long long)(unsigned)acc.aux[2] << 32);
       }
       ls_total += trials;
-      if (!ok) { status = MI_STATUS_LINESEARCH_FAILED; break; }
+      // (a failed search after an early round: its helpers have written a rejected trial's Jacobians over fx, fu - the stage below
+      //  runs once more, on the nominal trajectory, before the solve stops; the reference's fx, fu are the last linearization's)
+      if (!ok && !early) { status = MI_STATUS_LINESEARCH_FAILED; break; }
       __syncthreads();
       const long long c1 = clock64();
-      const double* const Xw = win == 0 ? v.Xn : xsp + (size_t)(win - 1) * sx_;      // the accepted trial
-      const double* const Uw = win == 0 ? v.Un : usp + (size_t)(win - 1) * su_;
+      const double* const Xw = !ok ? v.X : (win == 0 ? v.Xn : xsp + (size_t)(win - 1) * sx_);      // the accepted trial
+      const double* const Uw = !ok ? v.U : (win == 0 ? v.Un : usp + (size_t)(win - 1) * su_);
       {                                                                              // :375-376 (+ the LDS copy the
         double* xs_ = lds + Ly::oT1;                                                 //  linearization reads)
         double* us_ = lds + Ly::oF;
@@ -2635,12 +2835,17 @@ __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kerne
         }
       }
       __syncthreads();
-      if (clustered) {                                                               // :370, shared with the helper workgroups
+      const bool early_hit = early && ok && trials == 1;                             // the helpers have linearized THIS trajectory
+      if (early && !close_early(early_hit)) { status = MI_STATUS_INTERNAL; break; }
+      if (early_hit) {
+        nk = N - 1;
+      } else if (clustered) {                                                        // :370, shared with the helper workgroups
         nk = N - 1;
         if (!linearize_clustered()) { status = MI_STATUS_INTERNAL; break; }
       } else {
         nk = do_linearize(true);                                                     // :370
       }
+      if (!ok) { status = MI_STATUS_LINESEARCH_FAILED; break; }
       __syncthreads();
       const long long c2 = clock64();
 #ifdef MI_PROF_BACKWARD
@@ -2681,7 +2886,9 @@ __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kerne
       if (status >= MI_STATUS_LINESEARCH_FAILED) break;
     }
   }
-  if (G > 1 && tid == 0) __hip_atomic_store(csync + 3, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // helpers: go home
+  if (G > 1 && tid == 0) __hip_atomic_store(csync + 5, ((unsigned long long)(unsigned)cst[2] << 32) | (unsigned)cst[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // helpers: go home (any non-zero value; the rest of the word is for MI_I64_CLUSTER_WORDS: rounds << 32 | same-L2 rounds << 8 | 1)
+  if (G > 1 && tid == 0) __hip_atomic_store(csync + 3, ((unsigned long long)(unsigned)cst[0] << 32) | ((unsigned long long)((unsigned)cst[1] & 0xffffffu) << 8) | 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   for (int i = tid; i < nk; i += kLargeThreads) a.kp_list[(size_t)b * (N - 1) + i] = acc.kp[i];
   if (tid == 0) {
     a.cost[b] = L; a.iters[b] = iters; a.status[b] = status | (met_indefinite ? MI_STATUS_FLAG_INDEFINITE : 0); a.ls_trials[b] = ls_total; a.kp_count[b] = nk;

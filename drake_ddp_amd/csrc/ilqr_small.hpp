@@ -49,6 +49,7 @@ struct DevStats {
   double best_cost;
 };
 
+constexpr int kSyncWords = 8;       // 64-bit handshake words per problem (KArgs::cluster_sync)
 struct KArgs {
   // persistent per-problem solver state, reference layout with a leading batch axis
   double *x_bar, *u_bar, *K, *kappa, *dV, *fx, *fu;
@@ -81,7 +82,9 @@ struct KArgs {
   int32_t* done_counter;       // zero between launches
   // workgroup-per-problem kernels, MODE_SOLVE / MODE_MPC with every step a key-point: `cluster` workgroups per
   // problem - one leader that runs the solve and cluster-1 helpers that share its linearizations
-  // (ilqr_large.hpp: cluster handshake).  cluster_sync: 4 x 64-bit words per problem, zero at launch.
+  // (ilqr_large.hpp: cluster handshake).  cluster_sync: kSyncWords 64-bit words per problem, zero at launch.
+  // cluster: bits 0-7 workgroups per problem, bits 8-9 their placement (0: consecutive blocks, a cluster spans XCDs; 1, 2: all on
+  // one XCD), bit 10: early linearization (the helpers linearize the line search's first trial while it is being rolled out).
   int32_t cluster;
   unsigned long long* cluster_sync;
   // wave-per-problem kernels: optional RESULT SINK (mi_ilqr_set_result_sink) - device-visible, page-locked HOST arrays

@@ -157,16 +157,16 @@ KArgs make_args(const mi_ilqr* h) {
   if (h->large && h->cluster_sync && h->d.keypoint_method == MI_KP_SET_INTERVAL && h->d.minN == 1) {
     static const int forced = [] { const char* e = std::getenv("MI_ILQR_CLUSTER"); return e ? std::atoi(e) : 0; }();
     int g = forced > 0 ? forced : (h->n_cus > 0 ? h->n_cus / h->B : 1);
-    // a handshake costs ~40 k cycles when a few hundred workgroups fence at once: worth it for the articulated
-    // model at any batch (its linearization is 450 k cycles), for the sparse chain model (75 k) only while the
-    // launch stays small
-    // (the arm + ball's dense linearization is 100 k: 38 k with a cluster of 8 at B = 1, 62 k with 4 at B = 64 where the
-    // helpers' Jacobians cost the backward pass 12 k in L2 misses - worth it up to there; plugin models: the library
-    // cannot know what their step costs - a cheap one loses to the handshake, so they are not clustered unless forced)
+    // Which models: those whose linearization is worth a handshake (round 5: ~20 k cycles - six memory round trips - since the
+    // cache-wide write-backs are gone; with the helpers linearizing the line search's first trial WHILE it is rolled out - early
+    // linearization, ilqr_large.hpp - the stage shrinks to the wait for the last block: 36-state chain 74 k -> 12 k cycles at
+    // B = 64, 3-D quadruped 92 k -> 30 k, planar quadruped 164 k -> 132 k (its helpers cannot keep up with the rollout)).  The arm
+    // + ball's dense linearization (100 k single) up to B = 64; plugin models: the library cannot know what their step costs - a
+    // cheap one loses to the handshake, so they are not clustered unless forced.
     if (forced <= 0) {
       const int id = h->d.model_id;
       if (id == MI_MODEL_PLANAR_QUAD || id == MI_MODEL_QUAD3D) {}
-      else if (id == MI_MODEL_ARM27 || id == MI_MODEL_ARM27C) { if (h->B > 64) g = 1; }
+      else if (id == MI_MODEL_ARM27 || id == MI_MODEL_ARM27C || id == MI_MODEL_SYNTH36) { if (h->B > 64) g = 1; }
       else if (plugin_of(id)) g = 1;
       else if (h->B > 16) g = 1;
     }
@@ -182,7 +182,13 @@ KArgs make_args(const mi_ilqr* h) {
     if (forced <= 0 && h->d.jacobian_mode == MI_JAC_AUTODIFF) g = 1;
     if (g > 8) g = 8;
     if (g < 1) g = 1;
-    a.cluster = g;
+    // placement (MI_ILQR_CLUSTER_ORDER, A/B runs): 2 = a cluster on ONE XCD, the XCD's leaders in its first slots (default: measured
+    // best or level for every model once early linearization is on); 1 = one XCD, members in consecutive slots (the quadrupeds'
+    // helpers run 40 - 70 % slower next to leaders: neighbouring CUs share an instruction cache, and their linearization loops are
+    // 50 - 90 KB of code); 0 = consecutive blocks, a cluster spans XCDs (what rounds 2 - 4 did; no early linearization there)
+    static const int order = [] { const char* e = std::getenv("MI_ILQR_CLUSTER_ORDER"); return e ? std::atoi(e) : 2; }();
+    static const int early = [] { const char* e = std::getenv("MI_ILQR_EARLY"); return e ? std::atoi(e) : 1; }();
+    a.cluster = g | ((order & 3) << 8) | ((early ? 1 : 0) << 10);
   }
   return a;
 }
@@ -493,6 +499,7 @@ Field field_of(mi_ilqr* h, int which) {
     case MI_I_KP_COUNT: return {h->kp_count, B * 4, true};
     case MI_I_KP_LIST: return {h->kp_list, B * (N - 1) * 4, true};
     case MI_I64_STAGE_CYCLES: return {h->prof, B * 4 * 8, true};
+    case MI_I64_CLUSTER_WORDS: return {h->cluster_sync, B * kSyncWords * 8, true};
   }
   return {nullptr, 0, false};
 }
@@ -705,7 +712,7 @@ int mi_ilqr_create(const mi_ilqr_desc* desc, mi_ilqr_t** out) {
   ALLOC(h->kp_count, B, int32_t);
   ALLOC(h->kp_list, B * (N - 1), int32_t);
   ALLOC(h->done_counter, 1, int32_t);
-  if (large) ALLOC(h->cluster_sync, B * 4, unsigned long long);
+  if (large) ALLOC(h->cluster_sync, B * kSyncWords, unsigned long long);
   if (lxu_hbm) ALLOC(h->lxu, B * (N - 1) * (n + m), double);
   if (large && n <= 32) {
     // mid-size kernels: four line-search candidates per pass - an optimization, so a batch too large for three more

@@ -644,6 +644,9 @@ struct Arm27C {
   static constexpr int n = 27, m = 7, n_params = 16;
   static constexpr bool kWholeStep = true;
   static constexpr bool kTrigCooperative = true;
+#ifdef MI_ARM27C_PIVSPLIT
+  static constexpr bool kPivSplit = true;
+#endif
   static constexpr int kJoints = 7;
   template <class T>
   __device__ static inline void cross(const T (&a)[3], const T (&b)[3], T (&o)[3]) {

@@ -602,17 +602,39 @@ s.SetInitialState(x0); s.SetInitialGuess(ug)
 x, u, _, L = s.Solve()
 fx0, it0 = s.fx.copy(), s.iterations.copy()
 s.MPCRun(6, 4, target_step=step)
-np.savez(sys.argv[1], x=x, u=u, L=L, fx0=fx0, it0=it0, log=s.mpc_log, xm=s.x_bar, K=s.K, fx=s.fx, fu=s.fu, it=s.iterations, st=s.status)
+cs = s.cluster_stats
+np.savez(sys.argv[1], x=x, u=u, L=L, fx0=fx0, it0=it0, log=s.mpc_log, xm=s.x_bar, K=s.K, fx=s.fx, fu=s.fu, it=s.iterations, st=s.status, cs=cs)
 """
-    outs = []
-    for tag, env in (("cluster", {} if forced is None else {"MI_ILQR_CLUSTER": forced}), ("single", {"MI_ILQR_CLUSTER": "1"})):
+    # Round 5: the default launch places a cluster on ONE XCD and lets the helpers linearize the line search's first trial while the
+    # leader is still rolling it out (early linearization); the variants switch that off, put the members in consecutive slots of
+    # the XCD, or spread them over XCDs like rounds 2 - 4 did (where no early round may open: another L2 could hold a stale line).
+    variants = [("cluster", {}), ("single", {"MI_ILQR_CLUSTER": "1"})]
+    if (cfg, B) in (("quad", 8), ("quad3d", 64), ("arm27", 48), ("synth36", 8), ("quad3d", 5)):
+        variants += [("early0", {"MI_ILQR_EARLY": "0"}), ("order0", {"MI_ILQR_CLUSTER_ORDER": "0"}), ("order1", {"MI_ILQR_CLUSTER_ORDER": "1"})]
+    outs = {}
+    for tag, env in variants:
+        env = dict(env)
+        if forced is not None and tag != "single": env["MI_ILQR_CLUSTER"] = forced
         f = str(tmp_path / f"{tag}.npz")
         r = subprocess.run([sys.executable, "-c", script, f], capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
         assert r.returncode == 0, r.stderr[-2000:]
-        outs.append(np.load(f))
-    assert (outs[0]["st"] == 0).all()
-    for k in outs[0].files:
-        assert np.array_equal(outs[0][k], outs[1][k]), k
+        outs[tag] = np.load(f)
+    assert (outs["cluster"]["st"] == 0).all()
+    for tag in outs:
+        for k in outs["single"].files:
+            if k != "cs": assert np.array_equal(outs[tag][k], outs["single"][k]), (tag, k)
+    # columns of cluster_stats: helpers, regular rounds, rounds with every helper on the leader's XCD, early rounds opened, ... accepted
+    cs = outs["cluster"]["cs"]
+    assert (outs["single"]["cs"] == 0).all()
+    resident = cs[:, 0] > 0                                  # (oversubscribed launches: a problem's helpers may never have been resident)
+    if resident.any():
+        c = cs[resident]
+        assert (c[:, 2] == c[:, 1] + c[:, 4]).all()          # every round that used the helpers' Jacobians found the whole cluster on one XCD
+        assert c[:, 3].sum() > 0 and c[:, 4].sum() > 0.5 * c[:, 3].sum()      # early rounds ran, and mostly hit
+        print(cfg, B, "helpers", c[:, 0].min(), "-", c[:, 0].max(), "regular rounds", c[:, 1].sum(), "early opened / accepted", c[:, 3].sum(), c[:, 4].sum())
+    if "order0" in outs:
+        assert (outs["order0"]["cs"][:, 3] == 0).all() and (outs["order0"]["cs"][:, 2] == 0).all() and outs["order0"]["cs"][:, 1].sum() > 0
+        assert (outs["early0"]["cs"][:, 3] == 0).all() and outs["early0"]["cs"][:, 1].sum() > 0
 
 
 @pytest.mark.gpu
