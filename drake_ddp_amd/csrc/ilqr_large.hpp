@@ -251,6 +251,13 @@ __device__ __forceinline__ void trig_gather(double v, double (&S)[NJ], double (&
 // rollout, waiting for nothing that a step's time has not long delivered.
 constexpr int kPubLag = 3;
 constexpr unsigned long long kPubAbort = 0x80000000ull;      // *prog = tag | kPubAbort: the trial was rejected, stop linearizing it
+// Blocks at the END of the horizon that the leader linearizes itself once the trial is accepted (early rounds): models whose
+// helpers cannot keep up with the rollout (planar quadruped: an item is two passes over the tree, ~78 k cycles) - the last
+// block comes out last anyway, and the leader's hands are free by then.
+template <class M, class = void>
+struct EarlyLeaderBlocks { static constexpr int value = 0; };
+template <class M>
+struct EarlyLeaderBlocks<M, decltype((void)M::kEarlyLeaderBlocks)> { static constexpr int value = M::kEarlyLeaderBlocks; };
 template <class M>
 constexpr bool kEarlyLin = M::m * 16 <= 192;                 // (the fourth wave holds no control-law lanes: no prefetch loads on it)
 template <class M>
@@ -2405,6 +2412,8 @@ __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kerne
   const int corder = (a.cluster >> 8) & 3;                  // placement of a cluster's members (mi_ilqr.hip: launch arguments)
   const bool early_lin = ((a.cluster >> 10) & 1) != 0;      // early linearization (below)
   constexpr int kEarlyBlock = (kLargeThreads / (n + m)) > 0 ? kLargeThreads / (n + m) : 1;   // steps per block: one pass of the workgroup
+  const int early_blocks = (a.N - 1 + kEarlyBlock - 1) / kEarlyBlock;                          // blocks of an early round ...
+  const int early_helper_blocks = early_blocks - (EarlyLeaderBlocks<M>::value < early_blocks ? EarlyLeaderBlocks<M>::value : early_blocks - 1);   // ... the first of them the helpers'
   // XCD-aware placement of a cluster: the dispatcher deals workgroups to the 8 XCDs round-robin by blockIdx.x, so the members of
   // one cluster take block indices that are congruent mod 8 - one XCD, ONE L2: the helpers' Jacobians reach the leader through the
   // cache they share, and the leaders spread over all eight L2s (with b = blockIdx.x / G the leaders of clusters of 4 all sat on
@@ -2514,12 +2523,12 @@ __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kerne
   // in), and the accepted trial is linearized the usual way.  Same items, same arithmetic: bitwise the same fx, fu.
   unsigned long long* csync = a.cluster_sync + (size_t)kSyncWords * b;
   const bool clustered = G > 1 && lin_staged && a.kp_method == MI_KP_SET_INTERVAL && a.minN == 1;
-  auto jac_share = [&](int first, int stride, auto coherent) __attribute__((always_inline)) {
-    constexpr bool COH = decltype(coherent)::value;
-    if constexpr (HasSparsity<M>::value) large_jac_at_sparse<M, JAC, COH>(v, a, acc.kp, N - 1, lin_X, lin_U, first, stride);
-    else if constexpr (IsChainModel<M>::value) large_jac_at_tree<M, JAC, COH>(v, a, acc.kp, N - 1, lin_X, lin_U, lin_xs, lin_us, lds + Ly::doubles, first, stride);
-    else if constexpr (IsLegModel<M>::value) large_jac_at_legs<M, JAC, COH>(v, a, acc.kp, N - 1, lin_X, lin_U, lin_xs, lin_us, first, stride);
-    else large_jac_at<M, JAC, COH>(v, a, acc.kp, N - 1, lin_X, lin_U, lin_xs, lin_us, first, stride);
+  // the leader's own share: a list of key-points, plain stores (read back by this workgroup only)
+  auto jac_own = [&](const int* list, int count, int first, int stride) __attribute__((always_inline)) {
+    if constexpr (HasSparsity<M>::value) large_jac_at_sparse<M, JAC, false>(v, a, list, count, lin_X, lin_U, first, stride);
+    else if constexpr (IsChainModel<M>::value) large_jac_at_tree<M, JAC, false>(v, a, list, count, lin_X, lin_U, lin_xs, lin_us, lds + Ly::doubles, first, stride);
+    else if constexpr (IsLegModel<M>::value) large_jac_at_legs<M, JAC, false>(v, a, list, count, lin_X, lin_U, lin_xs, lin_us, first, stride);
+    else large_jac_at<M, JAC, false>(v, a, list, count, lin_X, lin_U, lin_xs, lin_us, first, stride);
   };
   // helper workgroups: a list of key-points (a block of time steps), write-through stores
   auto jac_list = [&](const int* list, int count, int first, int stride) __attribute__((always_inline)) {
@@ -2571,7 +2580,7 @@ __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kerne
       if (my >= parts) continue;                            // arrived after this round's snapshot: not counted on
       // a regular round is ONE block: every key-point, this workgroup's chunks of it; an early round: the blocks of kEarlyBlock
       // steps dealt to the parts - 1 helpers in turn, each linearized whole once the rollout has put its steps out
-      const int nblk = early ? (N - 1 + kEarlyBlock - 1) / kEarlyBlock : 1;
+      const int nblk = early ? early_helper_blocks : 1;
       for (int j = early ? my - 1 : 0; j < nblk; j += early ? parts - 1 : 1) {
         const int t0 = early ? j * kEarlyBlock : 0, t1 = early ? (t0 + kEarlyBlock < N - 1 ? t0 + kEarlyBlock : N - 1) : N - 1;
         if (early) {
@@ -2619,24 +2628,32 @@ __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kerne
   if (G > 1 && tid == 0) { cst[0] = 0; cst[1] = 0; cst[2] = 0; cst[3] = 0; cst[4] = 0; }
   __syncthreads();
   // leader: one clustered linearization of the committed trajectory (LDS copy in place).  Returns false on a lost helper.
-  auto linearize_clustered = [&]() __attribute__((always_inline)) -> bool {
+  // (own_only: just the key-points own_t0 .. N-2, every item of them, no handshake - the tail of an accepted early round)
+  auto linearize_clustered = [&](bool own_only, int own_t0) __attribute__((always_inline)) -> bool {
     for (int i = tid; i < N - 1; i += kLargeThreads) acc.kp[i] = i;
-    if (tid == 0) {
-      const unsigned long long word = __hip_atomic_load(csync + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned long long alive = word & 0xffffull;   // (at most G - 1 <= 7 helpers exist; bits 16 + 6 x ..: how many of them per XCC id)
-      const unsigned parts = 1u + (unsigned)(alive < (unsigned long long)(G - 1) ? alive : (unsigned long long)(G - 1));
-      acc.aux[3] = (int)parts;
-      acc.aux[1] = ((word >> (16 + 6 * xcc_id())) & 63ull) == alive ? 1 : 0;   // every helper counted on shares this workgroup's L2
+    int parts = 1;
+    if (!own_only) {
+      if (tid == 0) {
+        const unsigned long long word = __hip_atomic_load(csync + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long alive = word & 0xffffull; // (at most G - 1 <= 7 helpers exist; bits 16 + 6 x ..: how many of them per XCC id)
+        const unsigned parts_ = 1u + (unsigned)(alive < (unsigned long long)(G - 1) ? alive : (unsigned long long)(G - 1));
+        acc.aux[3] = (int)parts_;
+        acc.aux[1] = ((word >> (16 + 6 * xcc_id())) & 63ull) == alive ? 1 : 0;   // every helper counted on shares this workgroup's L2
+      }
+      __syncthreads();
+      parts = acc.aux[3];
+      cluster_publish_barrier(acc.aux[1] != 0);             // the write-through x_bar / u_bar stores of the commit
+      if (tid == 0) {
+        const unsigned cl_round = (unsigned)(cst[0] += 1);
+        __hip_atomic_store(csync + 0, ((unsigned long long)cl_round << 32) | ((unsigned long long)(acc.aux[1] != 0 ? 1 : 0) << 17) | (unsigned)parts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    } else {
+      __syncthreads();
     }
+    const int t_first = own_only ? own_t0 : 0;
+    jac_own(acc.kp + t_first, N - 1 - t_first, 0, parts);
     __syncthreads();
-    const int parts = acc.aux[3];
-    cluster_publish_barrier(acc.aux[1] != 0);               // the write-through x_bar / u_bar stores of the commit
-    if (tid == 0) {
-      const unsigned cl_round = (unsigned)(cst[0] += 1);
-      __hip_atomic_store(csync + 0, ((unsigned long long)cl_round << 32) | ((unsigned long long)(acc.aux[1] != 0 ? 1 : 0) << 17) | (unsigned)parts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    jac_share(0, parts, std::false_type{});                 // (own share: read back by this workgroup only)
-    __syncthreads();
+    if (own_only) return true;                              // (the tail of an accepted early round: close_early does the rest)
     if (tid == 0) {
       const unsigned long long cl_expected = (unsigned long long)(cst[4] += parts - 1);
       long long spins = 0;
@@ -2836,12 +2853,15 @@ __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kerne
       }
       __syncthreads();
       const bool early_hit = early && ok && trials == 1;                             // the helpers have linearized THIS trajectory
+      if constexpr (EarlyLeaderBlocks<M>::value > 0) {                               // ... but for the last block(s), which are the leader's
+        if (early_hit && early_helper_blocks < early_blocks) linearize_clustered(true, early_helper_blocks * kEarlyBlock);
+      }
       if (early && !close_early(early_hit)) { status = MI_STATUS_INTERNAL; break; }
       if (early_hit) {
         nk = N - 1;
       } else if (clustered) {                                                        // :370, shared with the helper workgroups
         nk = N - 1;
-        if (!linearize_clustered()) { status = MI_STATUS_INTERNAL; break; }
+        if (!linearize_clustered(false, 0)) { status = MI_STATUS_INTERNAL; break; }
       } else {
         nk = do_linearize(true);                                                     // :370
       }
