@@ -33,7 +33,8 @@ extern "C" {
 #endif
 
 #define MI_ILQR_ABI_VERSION 8   /* 7: mi_ilqr_desc.on_indefinite, mi_ilqr_model_plugin.m_user, 256 plugin slots;
-                                   8: MI_STATUS_FLAG_INDEFINITE, on_indefinite = 1 inverts with partial pivoting, asymmetric costs for n <= 32 */
+                                   8: MI_STATUS_FLAG_INDEFINITE, on_indefinite = 1 inverts with partial pivoting, asymmetric costs for n <= 32,
+                                      the diagnostic field MI_I64_CLUSTER_WORDS */
 #define MI_ILQR_MAX_PARAMS 16
 
 /* Error codes (0 = OK).  The Python wrapper maps them onto the exception types
