@@ -17,16 +17,18 @@ int launch_one_large(mi_ilqr* h, const KArgs& a) {
 }
 
 // Which models get BOTH forms of the kernels with a backward pass (ilqr_large.hpp: PIV) - with and without the pivoted-inverse cold
-// path: those that declare kPivSplit (models.hpp: Synth36, Quad3D).  Same-box A/B, cycles per iteration of the bench's MPC loops
-// without | with the ~150 cold instructions in the kernel: 36-state chain 429 k | 451 k (its LINE SEARCH 74 k | 85 k - the register
-// allocation of the phases around the backward pass, not the pass), 3-D quadruped 682 k | 695 k.  The default (on_indefinite = 0,
-// symmetric costs) is what the benchmarks run, so these two get the lean form for it.  Every other model keeps the ONE form that
-// carries the path: the arm + ball is no faster without it (130 k | 134 k cycles per trial the other way round), plugin models
-// would pay twice the kernels per build - the (34, 12) chain's lean form does not even compile with this hipcc ("Illegal
-// instruction detected: V_CMP_NE_U32 0, $src_shared_base") - and the planar quadruped's lean MPC kernel is MISCOMPILED by it: built
-// and run in round 5, its first rollout step returns another x_1 than every other instantiation does from bitwise the same x_0, u_0
-// (non-deterministically across runs), the line search then fails in every problem; tools/diag/quad_mpc_first_rollout.py shows it,
-// eight tests of the GPU suite catch it.  (what is known about this compiler hazard and what guards against it.)
+// path: those that declare kPivSplit (models.hpp: Synth36, Quad3D, PlanarQuad).  Same-box A/B, cycles per iteration of the bench's
+// MPC loops without | with the ~150 cold instructions in the kernel: 36-state chain 429 k | 451 k (its LINE SEARCH 74 k | 85 k - the
+// register allocation of the phases around the backward pass, not the pass), 3-D quadruped 682 k | 695 k, planar quadruped + 2.5 %
+// it/s without.  The default (on_indefinite = 0, symmetric costs) is what the benchmarks run, so these get the lean form for it.
+// Every other model keeps the ONE form that carries the path: the arm + ball is no faster without it (130 k | 134 k cycles per
+// trial the other way round), plugin models would pay twice the kernels per build - the (34, 12) chain's lean form does not even
+// compile with this hipcc ("Illegal instruction detected: V_CMP_NE_U32 0, $src_shared_base").
+// The planar quadruped's lean MPC kernel was MISCOMPILED when it was first built (round 5, first session: another x_1 from bitwise
+// the same x_0, u_0, non-deterministically; eight tests of the GPU suite caught it) and left out; the round's last session found
+// the mechanism of this hipcc's miscompiles of these kernels (a VGPR spill copy placed in a zero-EXEC block prologue: DESIGN
+// section 8, tools/check_exec_spill.py), rebuilt the form on the current sources - the checker finds no such site in it, the
+// 50 planar-quadruped tests of the GPU suite pass on it - and adopted it.
 template <class M, class = void>
 struct HasPivSplit { static constexpr bool value = false; };
 template <class M>

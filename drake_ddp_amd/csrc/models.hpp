@@ -160,6 +160,7 @@ struct Synth36 {             // params [ks, c, kc, bu]; 18 coupled pendula, dofs
 struct PlanarQuad {
   static constexpr int n = 36, m = 12, n_params = 9, nq = 18, kChains = 5;
   static constexpr bool kChainCooperative = true;
+  static constexpr bool kPivSplit = true;     // (launch_large.hpp: two forms of the kernels with a backward pass; C5q + 2.5 %)
   static constexpr int kEarlyLeaderBlocks = 1;   // (ilqr_large.hpp: early linearization - the last block of the horizon is the leader's)
   static constexpr bool kCanFail = true;
   template <class T> struct Trunk { T sn, cs, om, pz, vx, vz; };
