@@ -56,7 +56,9 @@ def sites(body):
             if EXEC_RESTORE.match(t):
                 out += pending
                 break
-            if BRANCH.match(t) or re.match(r"^s_(and|andn2|or|xor|mov)\w*_b64 exec", t) or t.startswith("s_barrier") or t.startswith("s_endpgm"):
+            # (anything else that writes EXEC ends the prologue: the arms of a structured if / else set their own lane masks - a copy
+            #  there is a per-lane phi, executed by exactly the lanes that own the value)
+            if BRANCH.match(t) or "saveexec" in t or re.match(r"^s_(and|andn2|or|xor|mov)\w*_b64 exec", t) or t.startswith("s_barrier") or t.startswith("s_endpgm"):
                 break
             if SPILL.match(t):
                 pending.append((a, t))
