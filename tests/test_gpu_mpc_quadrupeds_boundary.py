@@ -637,6 +637,52 @@ np.savez(sys.argv[1], x=x, u=u, L=L, fx0=fx0, it0=it0, log=s.mpc_log, xm=s.x_bar
         assert (outs["early0"]["cs"][:, 3] == 0).all() and outs["early0"]["cs"][:, 1].sum() > 0
 
 
+@pytest.mark.parametrize("cfg", ["arm27", "quad3d"])
+def test_a_failed_search_after_an_early_round_leaves_the_last_linearization(cfg, tmp_path):
+    """Early linearization (ilqr_large.hpp): the helpers of a cluster linearize the line search's FIRST trial while the leader
+    rolls it out - over fx, fu.  When that trial is rejected and the whole search then runs out of step sizes (ilqr.py:337), the
+    reference's fx, fu are still the last accepted trajectory's: the device re-linearizes the nominal trajectory before it
+    stops.  With beta = 1e-9 a search has ONE step size (the next is below 1e-8, ilqr.py:302): the first iteration whose full
+    step is rejected fails its search.  State, Jacobians, gains, counts and status bitwise those of one workgroup per problem
+    (MI_ILQR_CLUSTER=1), with one early round opened and not hit per failed problem."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = f"""
+import sys, warnings, numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, 'tests')!r})
+from drake_ddp_amd import workloads as W
+from test_gpu_parity import make_solver
+if {cfg!r} == 'arm27':
+    prob, x0, ug = dict(W.arm27_problem(), beta=1e-9), W.arm27_batch_x0(64)[:6], W.arm27_u_guess(50)
+else:
+    prob, x0, ug = dict(W.quad3d_problem(), beta=1e-9), W.quad3d_batch_x0(64)[:6], W.quad3d_u_guess(40)
+s = make_solver(prob, B=6, jac='fd')
+s.SetInitialState(x0); s.SetInitialGuess(ug)
+with warnings.catch_warnings():
+    warnings.simplefilter('ignore')
+    x, u, _, L = s.Solve()
+np.savez(sys.argv[1], x=x, u=u, L=L, K=s.K, fx=s.fx, fu=s.fu, it=s.iterations, st=s.status, ls=s.ls_trials, cs=s.cluster_stats)
+"""
+    outs = {}
+    for tag, env in (("cluster", {}), ("single", {"MI_ILQR_CLUSTER": "1"}), ("early0", {"MI_ILQR_EARLY": "0"})):
+        f = str(tmp_path / f"{tag}.npz")
+        r = subprocess.run([sys.executable, "-c", script, f], capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[tag] = np.load(f)
+    st, it = outs["single"]["st"], outs["single"]["it"]
+    failed = st == 2
+    assert failed.any() and (it[failed] >= 1).all(), (st, it)                       # (the first search has no cost to beat)
+    for tag in ("cluster", "early0"):
+        for k in outs["single"].files:
+            if k != "cs": assert np.array_equal(outs[tag][k], outs["single"][k]), (tag, k)
+    cs = outs["cluster"]["cs"]
+    # an early round per search that found helpers there (the very first may come before they are), all hit but a failing one
+    assert (cs[:, 0] > 0).all() and (cs[:, 3] >= 1).all() and ((cs[:, 3] - cs[:, 4]) == failed).all(), (cs, st)
+    print(cfg, "status", st, "iterations", it, "early rounds opened / hit", cs[:, 3], cs[:, 4])
+    assert (outs["early0"]["cs"][:, 3] == 0).all()
+
+
 @pytest.mark.gpu
 def test_pipelined_solves_defer_their_statistics_and_sample_their_events():
     """mi_ilqr_solve_async is ONE dispatch: each solve leaves its per-problem results in its own ring slot and the
