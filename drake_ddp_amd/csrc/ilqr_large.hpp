@@ -249,7 +249,10 @@ __device__ __forceinline__ void trig_gather(double v, double (&S)[NJ], double (&
 // which issues no other vector-memory operation in this loop, so its counter of outstanding operations counts exactly them -
 // and lane 192 stores `tag | s` into *prog once the steps 0 .. s-1 are complete at device scope: kPubLag steps behind the
 // rollout, waiting for nothing that a step's time has not long delivered.
-constexpr int kPubLag = 3;
+#ifndef MI_PUB_LAG
+#define MI_PUB_LAG 3
+#endif
+constexpr int kPubLag = MI_PUB_LAG;
 constexpr unsigned long long kPubAbort = 0x80000000ull;      // *prog = tag | kPubAbort: the trial was rejected, stop linearizing it
 // Blocks at the END of the horizon that the leader linearizes itself once the trial is accepted (early rounds): models whose
 // helpers cannot keep up with the rollout (planar quadruped: an item is two passes over the tree, ~78 k cycles) - the last
