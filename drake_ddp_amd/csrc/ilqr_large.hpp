@@ -246,9 +246,11 @@ __device__ __forceinline__ void trig_gather(double v, double (&S)[NJ], double (&
 // stage-cost rows (their Q/R rows live in registers); (3) the new state is published.
 // prog != nullptr: the rollout PUBLISHES the trial as it goes, for helper workgroups that linearize it while it is still being
 // rolled out (ilqr_large_kernel: early linearization).  x_t, u_t then leave as write-through stores - all from the fourth wave,
-// which issues no other vector-memory operation in this loop, so its counter of outstanding operations counts exactly them -
-// and lane 192 stores `tag | s` into *prog once the steps 0 .. s-1 are complete at device scope: kPubLag steps behind the
-// rollout, waiting for nothing that a step's time has not long delivered.
+// whose vector-memory operations complete in the order issued: it issues AT LEAST (progress word, x_t, u_t) per step, so "all but
+// the youngest 3 kPubLag operations are complete" (s_waitcnt vmcnt) covers every x, u store older than kPubLag steps - anything
+// else the wave might issue in the loop only moves that horizon closer - and lane 192 stores `tag | s` into *prog once the steps
+// 0 .. s-1 are complete at device scope: kPubLag steps behind the rollout, waiting for nothing that a step's time has not long
+// delivered.
 #ifndef MI_PUB_LAG
 #define MI_PUB_LAG 3
 #endif
