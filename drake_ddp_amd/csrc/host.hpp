@@ -81,6 +81,7 @@ struct mi_ilqr {
   int n_store = 1;         // line-search candidate trajectories kept in LDS
   bool batch_minor = false; // lane-per-problem path: state arrays are [t][row][b] in HBM
   double* lxu = nullptr;             // workgroup-per-problem kernels, long horizons: cost gradients in HBM
+  int spec_slots = 0;              // trial trajectories x_spec / u_spec hold per problem (3: one workgroup's four candidates; 31: candidate groups)
   double *x_spec = nullptr, *u_spec = nullptr;   // mid-size kernels: trial trajectories of three more line-search candidates
   int32_t* bm_scratch = nullptr;   // lane-per-problem kernels with key-points: integer scratch (ilqr_batch.hpp)
   double *sink_x = nullptr, *sink_u = nullptr, *sink_cost = nullptr;   // result sink (device aliases of host arrays), optional

@@ -795,13 +795,19 @@ __device__ inline void mid_rollout4(const LView<M::n, M::m>& v, double* xsp, dou
 }
 
 // The line search of ilqr.py:300-337, four candidates per pass; `win` = which candidate's buffers hold the accepted trial.
-template <class M>
+// groups > 1 (ilqr_large_kernel: candidate groups): while this workgroup rolls out the candidates 0 .. 3 of the FIRST pass, the
+// helper workgroups g = 1 .. groups - 1 of its cluster roll out the candidates 4 g .. 4 g + 3 (same arithmetic, their own trial
+// buffers); collect() waits for them, their costs are then at Lh[4 (g - 1) + c] and the scan simply goes on in order - the first
+// candidate that passes is the one the sequential search returns.  Later passes (the step sizes below beta^(4 groups)) are this
+// workgroup's alone.
+template <class M, class Collect>
 __device__ inline bool mid_linesearch4(const LView<M::n, M::m>& v, double* xsp, double* usp, size_t sx, size_t su, double* lds,
                                        const KArgs& a, const double* x0g, double L_last, double& L_out, double& eps_out,
-                                       int& trials, int& win) {
+                                       int& trials, int& win, int groups, const unsigned long long* Lh, Collect&& collect) {
   double eps = 1.0;
   trials = 0;
   win = 0;
+  bool first = true;
   while (eps >= 1e-8) {
     double e4[kSpec], L4[kSpec], dvs;
     e4[0] = eps;
@@ -815,7 +821,20 @@ __device__ inline bool mid_linesearch4(const LView<M::n, M::m>& v, double* xsp, 
       const double ex = -e4[c] * (1.0 - e4[c] / 2.0) * dvs;                   // :326
       if ((L_last - L4[c]) > a.gamma * ex) { L_out = L4[c]; eps_out = e4[c]; win = c; return true; }
     }
-    eps = e4[kSpec - 1] * a.beta;
+    double e = e4[kSpec - 1];
+    if (first && groups > 1) {
+      collect();
+      for (int q = 0; q < kSpec * (groups - 1); ++q) {
+        e *= a.beta;
+        if (!(e >= 1e-8)) return false;
+        trials += 1;
+        const double Lq = __longlong_as_double((long long)__hip_atomic_load(Lh + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        const double ex = -e * (1.0 - e / 2.0) * dvs;
+        if ((L_last - Lq) > a.gamma * ex) { L_out = Lq; eps_out = e; win = kSpec + q; return true; }
+      }
+    }
+    first = false;
+    eps = e * a.beta;
     __syncthreads();
   }
   return false;
@@ -2416,6 +2435,7 @@ __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kerne
   const int G = ((MODE == MODE_SOLVE || MODE == MODE_MPC) && (a.cluster & 0xff) > 1) ? (a.cluster & 0xff) : 1;
   const int corder = (a.cluster >> 8) & 3;                  // placement of a cluster's members (mi_ilqr.hip: launch arguments)
   const bool early_lin = ((a.cluster >> 10) & 1) != 0;      // early linearization (below)
+  const bool ls_groups = ((a.cluster >> 11) & 1) != 0;      // candidate groups on the helper workgroups (mid_linesearch4)
   constexpr int kEarlyBlock = (kLargeThreads / (n + m)) > 0 ? kLargeThreads / (n + m) : 1;   // steps per block: one pass of the workgroup
   const int early_blocks = (a.N - 1 + kEarlyBlock - 1) / kEarlyBlock;                          // blocks of an early round ...
   const int early_helper_blocks = early_blocks - (EarlyLeaderBlocks<M>::value < early_blocks ? EarlyLeaderBlocks<M>::value : early_blocks - 1);   // ... the first of them the helpers'
@@ -2583,6 +2603,33 @@ __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kerne
       __syncthreads();
       if (go < 0) return;                                   // exit flag (or nobody spoke for a second)
       if (my >= parts) continue;                            // arrived after this round's snapshot: not counted on
+      if constexpr (kSpecRollout<M>) {
+        if (((acc.aux[3] >> 18) & 1) != 0) {
+          // a candidate-group round: the leader's gains, nominal trajectory and x0 are in the L2 this workgroup shares with it
+          // (such rounds open only then) - drop this CU's vector cache and roll out the candidates 4 my .. 4 my + 3 of the pass
+          asm volatile("buffer_inv sc0" ::: "memory");
+          double e4[kSpec], L4[kSpec], dvs;
+          double e = 1.0;
+          for (int q = 0; q < kSpec * my; ++q) e *= a.beta;              // (the sequence eps *= beta produces, ilqr.py:335)
+          e4[0] = e;
+#pragma unroll
+          for (int c = 1; c < kSpec; ++c) e4[c] = e4[c - 1] * a.beta;
+          const size_t sxh = (size_t)a.B * n * N, suh = (size_t)a.B * m * (N - 1);
+          double* const xh = a.x_spec + (size_t)b * n * N + (size_t)(kSpec * my - 1) * sxh;     // slot of candidate 4 my; the next three follow
+          double* const uh = a.u_spec + (size_t)b * m * (N - 1) + (size_t)(kSpec * my - 1) * suh;
+          LView<n, m> vh = v;
+          vh.Xn = xh; vh.Un = uh;
+          mid_rollout4<M>(vh, xh + sxh, uh + suh, sxh, suh, lds, a, x0g, e4, L4, dvs);
+          if (tid == 0) {
+#pragma unroll
+            for (int c = 0; c < kSpec; ++c)
+              __hip_atomic_store(csync + 8 + kSpec * (my - 1) + c, (unsigned long long)__double_as_longlong(L4[c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          cluster_publish_barrier(true);
+          if (tid == 0) __hip_atomic_fetch_add(csync + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          continue;
+        }
+      }
       // a regular round is ONE block: every key-point, this workgroup's chunks of it; an early round: the blocks of kEarlyBlock
       // steps dealt to the parts - 1 helpers in turn, each linearized whole once the rollout has put its steps out
       const int nblk = early ? early_helper_blocks : 1;
@@ -2630,7 +2677,8 @@ __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kerne
   // after the helpers of all rounds so far.  (As loop-carried registers of the solve loop they were what tipped the coupled arm's
   // receding-horizon kernel into scratch spills.)
   int* const cst = acc.need;
-  if (G > 1 && tid == 0) { cst[0] = 0; cst[1] = 0; cst[2] = 0; cst[3] = 0; cst[4] = 0; }
+  if (G > 1 && tid == 0) { cst[0] = 0; cst[1] = 0; cst[2] = 0; cst[3] = 0; cst[4] = 0; cst[5] = 0; }   // ([5]: candidate-group rounds)
+  bool groups_round = false;                                 // the round close_early is closing is a candidate-group round
   __syncthreads();
   // leader: one clustered linearization of the committed trajectory (LDS copy in place).  Returns false on a lost helper.
   // (own_only: just the key-points own_t0 .. N-2, every item of them, no handshake - the tail of an accepted early round)
@@ -2708,6 +2756,28 @@ __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kerne
     __syncthreads();
     return acc.aux[3] > 1;
   };
+  // leader, candidate groups: the helpers roll out the candidates 4 .. 4 parts - 1 of the line search's first pass (false: no helper
+  // there, or not all on this XCD - the gains and the nominal trajectory reach them through the shared L2 only)
+  auto open_groups = [&]() __attribute__((always_inline)) -> bool {
+    wait_stores();
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned long long word = __hip_atomic_load(csync + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long alive = word & 0xffffull;
+      const unsigned parts = 1u + (unsigned)(alive < (unsigned long long)(G - 1) ? alive : (unsigned long long)(G - 1));
+      const bool same = ((word >> (16 + 6 * xcc_id())) & 63ull) == alive;
+      acc.aux[3] = same ? (int)parts : 1;
+      acc.aux[1] = 1;
+      if (same && parts > 1) {
+        const unsigned cl_round = (unsigned)(cst[0] += 1);
+        cst[4] += (int)parts - 1;
+        cst[5] += 1;
+        __hip_atomic_store(csync + 0, ((unsigned long long)cl_round << 32) | (6ull << 16) | parts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    __syncthreads();
+    return acc.aux[3] > 1;
+  };
   // ... and close it: every helper of the round has reported in (its blocks finished, or called off).  False on a lost helper.
   auto close_early = [&](bool use) __attribute__((always_inline)) -> bool {
     __syncthreads();
@@ -2721,7 +2791,7 @@ __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kerne
         __builtin_amdgcn_s_sleep(1);
       }
       acc.aux[0] = ok;
-      if (use) { cst[3] += 1; cst[1] += same_l2 ? 1 : 0; }
+      if (use && !groups_round) { cst[3] += 1; cst[1] += same_l2 ? 1 : 0; }
     }
     __syncthreads();
     const bool ok = acc.aux[0] != 0;
@@ -2822,12 +2892,18 @@ __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kerne
       if (it_this >= a.max_iters) { status = MI_STATUS_MAX_ITERS; break; }
       double L_new, eps; int trials;
       const long long c0 = clock64();
-      bool ok, used_spec = false, early = false;
+      bool ok, used_spec = false, early = false, lost = false;
       int win = 0;
       if constexpr (kSpecRollout<M>) {
         if ((a.spec_policy == 2 || (a.spec_policy == 1 && backtracked)) && L < __builtin_inf()) {
           used_spec = true;
-          ok = mid_linesearch4<M>(v, xsp, usp, sx_, su_, lds, a, x0g, L, L_new, eps, trials, win);
+          bool par = false, collected = false;
+          if (clustered && ls_groups) par = open_groups();
+          const int groups = par ? acc.aux[3] : 1;
+          auto collect = [&]() __attribute__((always_inline)) { groups_round = true; lost = !close_early(true); groups_round = false; collected = true; };
+          ok = mid_linesearch4<M>(v, xsp, usp, sx_, su_, lds, a, x0g, L, L_new, eps, trials, win, groups, csync + 8, collect);
+          if (par && !collected) collect();                                           // (an accepted candidate of the leader's own four)
+          if (lost) { status = MI_STATUS_INTERNAL; break; }
         } else {
           if constexpr (kEarlyLin<M>) { if (clustered && early_lin) early = open_early(); }
           ok = large_linesearch<M>(v, lds, a, x0g, L, L_new, eps, trials, early ? csync + 4 : nullptr, (unsigned long long)(unsigned)acc.aux[2] << 32);
@@ -2912,6 +2988,7 @@ __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kerne
     }
   }
   if (G > 1 && tid == 0) __hip_atomic_store(csync + 5, ((unsigned long long)(unsigned)cst[2] << 32) | (unsigned)cst[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (G > 1 && tid == 0) __hip_atomic_store(csync + 7, (unsigned long long)(unsigned)cst[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // helpers: go home (any non-zero value; the rest of the word is for MI_I64_CLUSTER_WORDS: rounds << 32 | same-L2 rounds << 8 | 1)
   if (G > 1 && tid == 0) __hip_atomic_store(csync + 3, ((unsigned long long)(unsigned)cst[0] << 32) | ((unsigned long long)((unsigned)cst[1] & 0xffffffu) << 8) | 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   for (int i = tid; i < nk; i += kLargeThreads) a.kp_list[(size_t)b * (N - 1) + i] = acc.kp[i];

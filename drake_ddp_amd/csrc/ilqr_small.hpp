@@ -49,7 +49,7 @@ struct DevStats {
   double best_cost;
 };
 
-constexpr int kSyncWords = 8;       // 64-bit handshake words per problem (KArgs::cluster_sync)
+constexpr int kSyncWords = 40;      // 64-bit handshake words per problem (KArgs::cluster_sync): 8 + the costs of 4 x 7 line-search candidates
 struct KArgs {
   // persistent per-problem solver state, reference layout with a leading batch axis
   double *x_bar, *u_bar, *K, *kappa, *dV, *fx, *fu;
@@ -84,7 +84,8 @@ struct KArgs {
   // problem - one leader that runs the solve and cluster-1 helpers that share its linearizations
   // (ilqr_large.hpp: cluster handshake).  cluster_sync: kSyncWords 64-bit words per problem, zero at launch.
   // cluster: bits 0-7 workgroups per problem, bits 8-9 their placement (0: consecutive blocks, a cluster spans XCDs; 1, 2: all on
-  // one XCD), bit 10: early linearization (the helpers linearize the line search's first trial while it is being rolled out).
+  // one XCD), bit 10: early linearization (the helpers linearize the line search's first trial while it is being rolled out),
+  // bit 11: candidate groups (mid-size kernels: the helpers roll out line-search candidates 4 .. beside the leader's four).
   int32_t cluster;
   unsigned long long* cluster_sync;
   // wave-per-problem kernels: optional RESULT SINK (mi_ilqr_set_result_sink) - device-visible, page-locked HOST arrays

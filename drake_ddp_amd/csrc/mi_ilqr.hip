@@ -188,7 +188,13 @@ KArgs make_args(const mi_ilqr* h) {
     // 50 - 90 KB of code); 0 = consecutive blocks, a cluster spans XCDs (what rounds 2 - 4 did; no early linearization there)
     static const int order = [] { const char* e = std::getenv("MI_ILQR_CLUSTER_ORDER"); return e ? std::atoi(e) : 2; }();
     static const int early = [] { const char* e = std::getenv("MI_ILQR_EARLY"); return e ? std::atoi(e) : 1; }();
-    a.cluster = g | ((order & 3) << 8) | ((early ? 1 : 0) << 10);
+    // candidate groups (MI_ILQR_LS_GROUPS=0|1): the helpers need trial buffers of their own, and - they keep their own LDS copy of
+    // the cost constants - a target that does not move inside the launch
+    static const int groups = [] { const char* e = std::getenv("MI_ILQR_LS_GROUPS"); return e ? std::atoi(e) : 1; }();
+    bool still = true;
+    for (int i = 0; i < h->n; ++i) still = still && h->mpc_target_step[i] == 0.0;
+    const bool lsg = groups && still && h->spec_slots >= 4 * g - 1 && g > 1;
+    a.cluster = g | ((order & 3) << 8) | ((early ? 1 : 0) << 10) | ((lsg ? 1 : 0) << 11);
   }
   return a;
 }
@@ -717,11 +723,17 @@ int mi_ilqr_create(const mi_ilqr_desc* desc, mi_ilqr_t** out) {
   if (large && n <= 32) {
     // mid-size kernels: four line-search candidates per pass - an optimization, so a batch too large for three more
     // trial buffers simply searches one candidate at a time (make_args: spec_policy = 0 without them)
-    const size_t xb = 3 * B * n * N * sizeof(double), ub = 3 * B * m * (N - 1) * sizeof(double);
-    if (hipMalloc(reinterpret_cast<void**>(&h->x_spec), xb) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&h->u_spec), ub) != hipSuccess) {
+    // (batches small enough for clusters: 31 slots - the candidates 1 .. 31 of a first pass that the leader and up to seven helper
+    //  workgroups roll out together, ilqr_large.hpp: candidate groups)
+    h->spec_slots = B <= 64 ? 31 : 3;
+    for (;;) {
+      const size_t xb = (size_t)h->spec_slots * B * n * N * sizeof(double), ub = (size_t)h->spec_slots * B * m * (N - 1) * sizeof(double);
+      if (hipMalloc(reinterpret_cast<void**>(&h->x_spec), xb) == hipSuccess && hipMalloc(reinterpret_cast<void**>(&h->u_spec), ub) == hipSuccess) break;
       (void)hipGetLastError();
       if (h->x_spec) (void)hipFree(h->x_spec);
       h->x_spec = nullptr; h->u_spec = nullptr;
+      if (h->spec_slots == 3) { h->spec_slots = 0; break; }
+      h->spec_slots = 3;
     }
   }
   if (batch_minor && !(desc->keypoint_method == MI_KP_SET_INTERVAL && desc->minN == 1)) ALLOC(h->bm_scratch, B * 6 * (N - 1), int32_t);

@@ -304,13 +304,14 @@ class BatchedIterativeLQR:
     def cluster_stats(self):
         """Workgroup-per-problem kernels, diagnostic: per problem of the last launch - helpers that took part, linearizations shared
         with them the regular way, rounds in which every helper sat on the leader's own XCD, early rounds opened (the helpers
-        linearize the line search's first trial while it is rolled out), early rounds whose trial was accepted - (B,5) int64;
+        linearize the line search's first trial while it is rolled out), early rounds whose trial was accepted, candidate-group rounds
+        (mid-size kernels: the helpers roll out line-search candidates 4 .. beside the leader's four) - (B,6) int64;
         zeros when the launch was not clustered (mi_ilqr.h: MI_I64_CLUSTER_WORDS)."""
-        w = np.empty((self.B, 8), dtype=np.uint64)
+        w = np.empty((self.B, 40), dtype=np.uint64)
         _capi.check(self._lib.mi_ilqr_get_int(self._h, _capi.I64_CLUSTER_WORDS, _capi.ptr(w), w.nbytes), "mi_ilqr_get_int")
         u = np.uint64
-        ea_open, ea_hit = w[:, 5] >> u(32), w[:, 5] & u(0xffffffff)
-        return np.stack([w[:, 2] & u(0xffff), (w[:, 3] >> u(32)) - ea_open, (w[:, 3] >> u(8)) & u(0xffffff), ea_open, ea_hit], axis=1).astype(np.int64)
+        ea_open, ea_hit, groups = w[:, 5] >> u(32), w[:, 5] & u(0xffffffff), w[:, 7]
+        return np.stack([w[:, 2] & u(0xffff), (w[:, 3] >> u(32)) - ea_open - groups, (w[:, 3] >> u(8)) & u(0xffffff), ea_open, ea_hit, groups], axis=1).astype(np.int64)
 
     def last_kernel_ms(self):
         ms = C.c_float()

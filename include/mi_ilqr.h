@@ -124,13 +124,14 @@ enum {
   MI_I_KP_COUNT = 103,  /* (B,) key-points used by the last linearization               */
   MI_I_KP_LIST = 104,   /* (B,N-1) the key-point indices, first KP_COUNT valid          */
   MI_I64_STAGE_CYCLES = 200, /* (B,4) int64: what mi_ilqr_get_cycles returns - here so that mi_ilqr_get_async can queue it behind a solve */
-  MI_I64_CLUSTER_WORDS = 201 /* (B,8) uint64, workgroup-per-problem kernels only (mi_ilqr_get_int / _get_async; diagnostic): the handshake
+  MI_I64_CLUSTER_WORDS = 201 /* (B,40) uint64, workgroup-per-problem kernels only (mi_ilqr_get_int / _get_async; diagnostic): the handshake
                                 words of the last launch that shared its linearizations among a cluster of workgroups - [1] helper shares
                                 finished, [2] & 0xffff helpers that took part, [2] >> (16 + 6 x) & 63 how many of them ran on XCD x,
                                 [3] >> 32 rounds (regular + early), [3] >> 8 & 0xffffff rounds that found every helper on the leader's
                                 own XCD (one L2: no cache-wide invalidate), [4] progress word of the last early round, [5] >> 32 early
                                 rounds opened (the helpers linearize the line search's first trial while it is being rolled out),
-                                [5] & 0xffffffff early rounds whose trial was accepted */
+                                [5] & 0xffffffff early rounds whose trial was accepted, [7] candidate-group rounds (mid-size kernels: the
+                                helpers roll out the line-search candidates 4 .. beside the leader's four), [8 ..] the costs of those */
 };
 
 typedef struct mi_ilqr mi_ilqr_t;

@@ -600,10 +600,10 @@ else:
     s = make_solver(prob, B={B}, jac='fd')
 s.SetInitialState(x0); s.SetInitialGuess(ug)
 x, u, _, L = s.Solve()
-fx0, it0 = s.fx.copy(), s.iterations.copy()
+fx0, it0, cs0 = s.fx.copy(), s.iterations.copy(), s.cluster_stats
 s.MPCRun(6, 4, target_step=step)
 cs = s.cluster_stats
-np.savez(sys.argv[1], x=x, u=u, L=L, fx0=fx0, it0=it0, log=s.mpc_log, xm=s.x_bar, K=s.K, fx=s.fx, fu=s.fu, it=s.iterations, st=s.status, cs=cs)
+np.savez(sys.argv[1], x=x, u=u, L=L, fx0=fx0, it0=it0, log=s.mpc_log, xm=s.x_bar, K=s.K, fx=s.fx, fu=s.fu, it=s.iterations, st=s.status, cs=cs, cs0=cs0)
 """
     # Round 5: the default launch places a cluster on ONE XCD and lets the helpers linearize the line search's first trial while the
     # leader is still rolling it out (early linearization); the variants switch that off, put the members in consecutive slots of
@@ -611,6 +611,8 @@ np.savez(sys.argv[1], x=x, u=u, L=L, fx0=fx0, it0=it0, log=s.mpc_log, xm=s.x_bar
     variants = [("cluster", {}), ("single", {"MI_ILQR_CLUSTER": "1"})]
     if (cfg, B) in (("quad", 8), ("quad3d", 64), ("arm27", 48), ("synth36", 8), ("quad3d", 5)):
         variants += [("early0", {"MI_ILQR_EARLY": "0"}), ("order0", {"MI_ILQR_CLUSTER_ORDER": "0"}), ("order1", {"MI_ILQR_CLUSTER_ORDER": "1"})]
+    if cfg == "arm27":       # mid-size kernels: the helpers also roll out line-search candidates 4 .. beside the leader's four (candidate groups)
+        variants += [("groups0", {"MI_ILQR_LS_GROUPS": "0"})]
     outs = {}
     for tag, env in variants:
         env = dict(env)
@@ -622,8 +624,9 @@ np.savez(sys.argv[1], x=x, u=u, L=L, fx0=fx0, it0=it0, log=s.mpc_log, xm=s.x_bar
     assert (outs["cluster"]["st"] == 0).all()
     for tag in outs:
         for k in outs["single"].files:
-            if k != "cs": assert np.array_equal(outs[tag][k], outs["single"][k]), (tag, k)
-    # columns of cluster_stats: helpers, regular rounds, rounds with every helper on the leader's XCD, early rounds opened, ... accepted
+            if k not in ("cs", "cs0"): assert np.array_equal(outs[tag][k], outs["single"][k]), (tag, k)
+    # columns of cluster_stats: helpers, regular rounds, rounds with every helper on the leader's XCD, early rounds opened, ... accepted,
+    # candidate-group rounds
     cs = outs["cluster"]["cs"]
     assert (outs["single"]["cs"] == 0).all()
     resident = cs[:, 0] > 0                                  # (oversubscribed launches: a problem's helpers may never have been resident)
@@ -632,6 +635,12 @@ np.savez(sys.argv[1], x=x, u=u, L=L, fx0=fx0, it0=it0, log=s.mpc_log, xm=s.x_bar
         assert (c[:, 2] == c[:, 1] + c[:, 4]).all()          # every round that used the helpers' Jacobians found the whole cluster on one XCD
         assert c[:, 3].sum() > 0 and c[:, 4].sum() > 0.5 * c[:, 3].sum()      # early rounds ran, and mostly hit
         print(cfg, B, "helpers", c[:, 0].min(), "-", c[:, 0].max(), "regular rounds", c[:, 1].sum(), "early opened / accepted", c[:, 3].sum(), c[:, 4].sum())
+    if cfg == "arm27":
+        # candidate groups: in the cold solve (48 problems: some backtrack) - not in the receding-horizon loop, whose target MOVES
+        # (the helpers keep their own LDS copy of x_nom); and they can be switched off
+        assert (outs["groups0"]["cs0"][:, 5] == 0).all() and (cs[:, 5] == 0).all()
+        if B == 48: assert outs["cluster"]["cs0"][:, 5].sum() > 0
+        print("candidate-group rounds of the cold solve", outs["cluster"]["cs0"][:, 5].sum())
     if "order0" in outs:
         assert (outs["order0"]["cs"][:, 3] == 0).all() and (outs["order0"]["cs"][:, 2] == 0).all() and outs["order0"]["cs"][:, 1].sum() > 0
         assert (outs["early0"]["cs"][:, 3] == 0).all() and outs["early0"]["cs"][:, 1].sum() > 0

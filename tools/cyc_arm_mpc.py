@@ -18,4 +18,4 @@ for name, p, ug in (("C6 arm27", W.arm27_problem(), W.arm27_u_guess(50)), ("C6b 
     cs = s.cluster_stats
     print(f"{name:11s} B {B}: MPC launch {s.stats.kernel_ms:7.2f} ms, iterations {int(it.sum())} (max {int(it.max())}, min {int(it.min())}), trials {int(ls.sum())} | cycles per iteration: "
           f"line search {(cyc[:, 0] / it).mean():8.0f} linearize {(cyc[:, 1] / it).mean():8.0f} backward {(cyc[:, 2] / it).mean():8.0f} (per step {(cyc[:, 2] / it).mean() / (N - 1):6.0f}) "
-          f"all {(cyc[:, 3] / it).mean():8.0f} | loop cycles max {cyc[:, 3].max():.0f} mean {cyc[:, 3].mean():.0f} | regular rounds {cs[:, 1].sum()} early opened {cs[:, 3].sum()} hit {cs[:, 4].sum()}", flush=True)
+          f"all {(cyc[:, 3] / it).mean():8.0f} | loop cycles max {cyc[:, 3].max():.0f} mean {cyc[:, 3].mean():.0f} | regular rounds {cs[:, 1].sum()} early opened {cs[:, 3].sum()} hit {cs[:, 4].sum()} candidate-group rounds {cs[:, 5].sum()} | reference trials in the loop {int(s.ls_trials.sum())}", flush=True)
