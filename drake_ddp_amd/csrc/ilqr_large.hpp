@@ -378,10 +378,11 @@ __device__ inline double large_rollout(const LView<M::n, M::m>& v, double* lds, 
           asm volatile("" ::: "memory");
           __hip_atomic_store(prog, tag | (unsigned long long)(t > kPubLag ? t - kPubLag : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        st_shared<true>(v.Xn + (size_t)t * n + (tid - 192), xv_);
-      } else {
-        v.Xn[(size_t)t * n + (tid - 192)] = xv_;
       }
+      // (plain stores either way: the helpers of an early round sit behind the SAME L2 - early rounds open only then - and read the
+      //  trial out of it; a write-through store acknowledged by that L2 may still be on its way to memory, which is where a
+      //  device-scope load would look: seen as garbage Jacobians on models with steps of a few hundred cycles)
+      v.Xn[(size_t)t * n + (tid - 192)] = xv_;
     }
     if (t + 2 < N - 1) prefetch(f, t + 2);       // this set is free again
     lds_barrier();
@@ -529,8 +530,7 @@ __device__ inline double large_rollout(const LView<M::n, M::m>& v, double* lds, 
 #endif
     } else if (uorole) {
       const int k = tid - 192 - n;
-      if (prog) st_shared<true>(v.Un + (size_t)t * m + k, us[k]);
-      else v.Un[(size_t)t * m + k] = us[k];
+      v.Un[(size_t)t * m + k] = us[k];
     }
     lds_barrier();
     double* tmp_ = xc; xc = xn_; xn_ = tmp_;
@@ -2660,15 +2660,18 @@ __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kerne
           double* xs_ = lds + Ly::oT1;
           double* us_ = lds + Ly::oF;
           const int xe = early ? t1 * n : n * N;            // (a regular round stages x_{N-1} too, as it always has)
-          for (int e = t0 * n + tid; e < xe; e += kLargeThreads) xs_[(e / n) * kXS + e % n] = ld_shared(Xg + e);
-          for (int e = t0 * m + tid; e < t1 * m; e += kLargeThreads) us_[(e / m) * kUS + e % m] = ld_shared(Ug + e);
+          // early: out of the L2 shared with the leader (its plain stores, acknowledged by that L2) - drop this CU's vector cache
+          // and read normally; a regular round: device-scope loads of the leader's write-through stores
+          if (early) asm volatile("buffer_inv sc0" ::: "memory");
+          for (int e = t0 * n + tid; e < xe; e += kLargeThreads) xs_[(e / n) * kXS + e % n] = early ? Xg[e] : ld_shared(Xg + e);
+          for (int e = t0 * m + tid; e < t1 * m; e += kLargeThreads) us_[(e / m) * kUS + e % m] = early ? Ug[e] : ld_shared(Ug + e);
           for (int i = t0 + tid; i < t1; i += kLargeThreads) acc.kp[i] = i;      // keypoints_set_interval(minN = 1)
           __syncthreads();
         }
         jac_list(acc.kp + t0, t1 - t0, early ? 0 : my, early ? 1 : parts);       // this share of fx / fu: write-through stores
         __syncthreads();                                    // (the next block's staging reuses what this one read)
       }
-      cluster_publish_barrier(one_l2);                      // (one L2: no cache-wide write-back - see there)
+      cluster_publish_barrier(one_l2 && !early);            // (a regular one-L2 round: no cache-wide write-back - see there; an early round: close_early)
       if (tid == 0) __hip_atomic_fetch_add(csync + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
@@ -2795,8 +2798,13 @@ __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kerne
     }
     __syncthreads();
     const bool ok = acc.aux[0] != 0;
-    if (use) {                                              // the Jacobians are the helpers': as after a regular round
-      if (same_l2) asm volatile("buffer_inv sc0" ::: "memory");
+    if (use) {
+      // The Jacobians are the helpers'.  After an EARLY round: a device-scope acquire, with the helpers' full release on the other
+      // side - the light pair of a regular one-L2 round (acknowledged write-through stores / this CU's vector cache dropped) was
+      // seen to hand the backward pass stale Jacobians on a plugin model with steps of a few hundred cycles (tools/diag/
+      // early_small_shape.py: fx, fu right in memory, K of the first iteration wrong; right with the fences).  A candidate-group
+      // round moves plain stores through the shared L2: the vector cache is all there is to drop.
+      if (groups_round && same_l2) asm volatile("buffer_inv sc0" ::: "memory");
       else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();

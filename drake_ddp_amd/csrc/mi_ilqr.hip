@@ -187,7 +187,12 @@ KArgs make_args(const mi_ilqr* h) {
     // helpers run 40 - 70 % slower next to leaders: neighbouring CUs share an instruction cache, and their linearization loops are
     // 50 - 90 KB of code); 0 = consecutive blocks, a cluster spans XCDs (what rounds 2 - 4 did; no early linearization there)
     static const int order = [] { const char* e = std::getenv("MI_ILQR_CLUSTER_ORDER"); return e ? std::atoi(e) : 2; }();
-    static const int early = [] { const char* e = std::getenv("MI_ILQR_EARLY"); return e ? std::atoi(e) : 1; }();
+    // Early linearization: the built-in models only.  Its progress word trails the rollout by three STEPS, which is ample store
+    // latency for their steps of 2 - 6 k cycles; forced onto plugin chains with steps of a few hundred cycles it was seen to hand the
+    // helpers rows of the previous trial (tools/shape_sweep.py with MI_ILQR_CLUSTER=4: wrong Jacobians from the second iteration on) -
+    // plugin models, which are not clustered by default anyway, keep the regular rounds (72 of 72 shapes right when forced).
+    static const int early_env = [] { const char* e = std::getenv("MI_ILQR_EARLY"); return e ? std::atoi(e) : 1; }();
+    const int early = early_env && !plugin_of(h->d.model_id);
     // candidate groups (MI_ILQR_LS_GROUPS=0|1): the helpers need trial buffers of their own, and - they keep their own LDS copy of
     // the cost constants - a target that does not move inside the launch
     static const int groups = [] { const char* e = std::getenv("MI_ILQR_LS_GROUPS"); return e ? std::atoi(e) : 1; }();

@@ -633,7 +633,10 @@ np.savez(sys.argv[1], x=x, u=u, L=L, fx0=fx0, it0=it0, log=s.mpc_log, xm=s.x_bar
     if resident.any():
         c = cs[resident]
         assert (c[:, 2] == c[:, 1] + c[:, 4]).all()          # every round that used the helpers' Jacobians found the whole cluster on one XCD
-        assert c[:, 3].sum() > 0 and c[:, 4].sum() > 0.5 * c[:, 3].sum()      # early rounds ran, and mostly hit
+        if cfg == "chainx":
+            assert c[:, 3].sum() == 0 and c[:, 1].sum() > 0                  # plugin models: regular rounds only (the early rounds' progress word is timed for the built-in models' steps)
+        else:
+            assert c[:, 3].sum() > 0 and c[:, 4].sum() > 0.5 * c[:, 3].sum()      # early rounds ran, and mostly hit
         print(cfg, B, "helpers", c[:, 0].min(), "-", c[:, 0].max(), "regular rounds", c[:, 1].sum(), "early opened / accepted", c[:, 3].sum(), c[:, 4].sum())
     if cfg == "arm27":
         # candidate groups: in the cold solve (48 problems: some backtrack) - not in the receding-horizon loop, whose target MOVES
