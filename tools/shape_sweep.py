@@ -2,7 +2,9 @@
 iterations each with forward-mode duals and with central differences - x_bar, K, kappa against oracle/ilqr_np.py.  The sweep
 that found the wrong gains of (36, 4), (36, 8), (40, 4) and m = 16 above 32 states in round 4.
     python tools/shape_sweep.py build      compile the plugins (CPU, in parallel)
-    python tools/shape_sweep.py            run (GPU)"""
+    python tools/shape_sweep.py            run (GPU)
+MI_ILQR_CLUSTER=k forces clusters of k workgroups per problem onto every workgroup-per-problem shape (plugin models are not clustered by
+default): the sweep that, in round 5, showed where the early rounds of ilqr_large.hpp are not safe."""
 import sys, os, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "examples", "plugins"))
