@@ -187,7 +187,22 @@ def cpu_baseline(prob, x0, sample, budget_s=8.0):
     return out
 
 
-FP64_PEAK_TFLOPS = 78.6  # /opt/skills/guides/MI355X_MICROARCH.md: dense fp64 vector / matrix peak
+def measured_fp64_peak():
+    """The dense fp64 rate of an MI355X as MEASURED by tools/ubench/fp64_peak.hip (every SIMD busy with independent
+    v_fma_f64 chains / v_mfma_f64_16x16x4; kernel time from HIP events) and committed as profiles/rNN_fp64_peak.json - the
+    guide has no fp64 figure.  Falls back to 16 FMA / clk / SIMD (tools/ubench/mfma_cu.hip) x 1024 SIMDs x 2.4 GHz."""
+    import glob
+    for f in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_fp64_peak.json")))):
+        try:
+            with open(f) as fh:
+                d = json.load(fh)
+            return float(d["fp64_peak_TFLOPs"]), "measured: profiles/" + os.path.basename(f) + " (tools/ubench/fp64_peak.hip)"
+        except Exception:
+            pass
+    return 78.6, "16 FMA/clk/SIMD (tools/ubench/mfma_cu.hip) x 1024 SIMDs x 2.4 GHz; no profiles/r*_fp64_peak.json found"
+
+
+FP64_PEAK_TFLOPS, FP64_PEAK_SOURCE = measured_fp64_peak()
 
 
 def backward_flops_per_iteration(n, m, N):
@@ -318,7 +333,10 @@ def run_config(rk, dev_index, name, prob, x0_all, u_guess, reps, mpc=None):
         out["roofline_compute"] = {"bound": "fp64", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS,
                                    "fp64_flops_per_iteration": cc[key]["fp64_flops_per_iteration"],
                                    "wave_slots_occupied": None if "shard" in name else cc[key]["wave_slots_occupied"],
-                                   "counters": "committed " + src}
+                                   "counters": "committed " + src, "peak_source": FP64_PEAK_SOURCE}
+    elif kms_max > 0:
+        # no silent omission (round 5 lost C5's entry that way): say in the line that this config has no counter record
+        out["roofline_compute"] = {"error": "no entry for %r in %s (tools/pmc_issue.py writes it; its `missing` key says why)" % (key, src or "profiles/r*_pmc_issue.json")}
     if n >= 16:                                      # C5: the backward pass is matrix-core work
         tf = backward_flops_per_iteration(n, m, N) * it / (kms_max * 1e-3) / 1e12 / max(rk.world, 1)
         out["backward_fp64_TFLOPs_per_gpu"] = tf
@@ -703,7 +721,7 @@ def main():
         if flops is not None:
             tf = flops / (k_ms * 1e-3) / 1e12
             compute = {"bound": "fp64", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS,
-                       "fp64_flops_per_launch": flops, "source": flops_src, "wave_slots_occupied": slots, "wave_slots_source": slots_src,
+                       "peak_source": FP64_PEAK_SOURCE, "fp64_flops_per_launch": flops, "source": flops_src, "wave_slots_occupied": slots, "wave_slots_source": slots_src,
                        "valu_busy_of_resident_wave_time": (ctr["SQ_ACTIVE_INST_VALU"] / ctr["SQ_WAVE_CYCLES"]) if ("SQ_ACTIVE_INST_VALU" in ctr and ctr.get("SQ_WAVE_CYCLES")) else None,
                        "note": "what binds this kernel: one wave per SIMD issues an fp64 instruction every ~5.3 cycles, and the launch lasts as long "
                                "as its slowest problem (12 iterations against a mean of 6), so about half of the wave slots idle"}

@@ -91,14 +91,20 @@ for k, c in acc.items():
 r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "run_configs.py")], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600)
 lines = [json.loads(l) for l in r.stdout.decode().splitlines() if l.startswith("{")]
 iters = {l["config"].split()[0] + ("/8" if "shard" in l["config"] else ""): l.get("iters_total", l.get("iters_per_solve")) for l in lines}
-KERNELS = {   # config -> (model substring, workgroups of the launch); every kernel mode of that model and grid is the config's
-    "C1": ("Pendulum", 1), "C2": ("Pendulum", 1024), "C3": ("Acrobot", 512), "C4": ("CartPoleT<true>", 256),
-    "C5": ("Synth36", 64), "C5q": ("PlanarQuad", None), "C5q3d": ("Quad3D", None), "C6": ("Arm27,", None), "C6b": ("Arm27C,", None)}
+KERNELS = {   # config -> (model substring, workgroups of the launch or None); every kernel mode of that model (and grid) is the
+    # config's.  Only the two pendulum configs share a model and need the grid to tell them apart; the workgroup-per-problem
+    # kernels are matched by MODEL alone - their grid depends on the cluster size the launch picks (round 5 lost C5's entry to
+    # a "grid=64" filter when its launch became 256 workgroups; run_configs.py keeps the B = 8 shard out of these passes).
+    "C1": ("Pendulum", 1), "C2": ("Pendulum", 1024), "C3": ("Acrobot", None), "C4": ("CartPoleT<true>", None),
+    "C5": ("Synth36", None), "C5q": ("PlanarQuad", None), "C5q3d": ("Quad3D", None), "C6": ("Arm27,", None), "C6b": ("Arm27C,", None)}
 per_config = {}
+missing = {}
 for cfg, (model, grid) in KERNELS.items():
     ks = [k for k in acc if model in k and (grid is None or ("grid=%d x" % grid) in k)]
     key = cfg
     if not ks or key not in iters:
+        missing[cfg] = "no kernel matching %r%s among the profiled launches" % (model, "" if grid is None else " with grid=%d" % grid) if not ks \
+            else "tools/run_configs.py printed no line for %s" % cfg
         continue
     fl = sum(acc[k]["fp64_flops_per_launch"] for k in ks)
     wc = sum(acc[k].get("SQ_WAVE_CYCLES", 0) for k in ks)
@@ -109,10 +115,14 @@ for cfg, (model, grid) in KERNELS.items():
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 path = os.path.join(ROOT, "gpurun_out", tag + "_pmc_issue.json")
 json.dump({"command": "rocprofv3 --pmc <group> --kernel-trace --output-format csv -- python tools/run_configs.py (one pass per group)",
-           "groups": GROUPS, "kernels": acc, "configs": per_config}, open(path, "w"), indent=1)
+           "groups": GROUPS, "kernels": acc, "configs": per_config, "missing": missing}, open(path, "w"), indent=1)
+for k, why in missing.items():
+    print("MISSING %-10s %s" % (k, why))
 for k, c in per_config.items():
     print("%-10s fp64 flops/iteration %.4g   wave slots %.3f" % (k, c["fp64_flops_per_iteration"], c["wave_slots_occupied"]))
 for k, c in acc.items():
     print(k)
     for name, v in c.get("derived", {}).items():
         print("   %-120s %.4f" % (name, v))
+if missing:
+    sys.exit("pmc_issue: no counter entry for " + ", ".join(sorted(missing)))
