@@ -611,25 +611,50 @@ def main():
                 concurrent = concurrent_batches(prob, x0, dev_index)
         rk.fence()
 
-    s = make_solver(prob, B, dev_index)
+    s = s_weak = make_solver(prob, B, dev_index)
     s.SetInitialState(x0)
     s.SetInitialGuess(np.zeros((1, N - 1)))
     s._push_problem()                                      # inputs resident in HBM from here on
 
     pending = []
-    # MI_BENCH_NATIVE_RCCL=1: the collective goes through the library's own RCCL communicator
-    # (mi_ilqr_allreduce_min_start/_wait, the C caller's path) instead of torch.distributed
-    native = None
-    if world > 1 and os.environ.get("MI_BENCH_NATIVE_RCCL") == "1":     # (any torch backend: it only ships the communicator's id)
+    # The path's one collective.  By default through the LIBRARY's own RCCL communicator (mi_ilqr_allreduce_min_start / _wait: the C
+    # caller's path, torch.distributed only ships the 128-byte id) - after it has proved itself on this run's ranks: every rank
+    # creates it, the communicator's own rank count (ncclCommCount) must be the world size and a reduction of rank-dependent
+    # values must return their minimum, on EVERY rank (agreed through torch.distributed); anything else falls back to
+    # torch.distributed's all_reduce(MIN) with the reason in config.collective.  MI_BENCH_NATIVE_RCCL=1 insists (no fall-back: a
+    # failure ends the run with the library's message), =0 skips the attempt.
+    native, native_why, comm_ranks = None, None, (world if world > 1 else None)
+    want_native = os.environ.get("MI_BENCH_NATIVE_RCCL", "auto")
+    if world > 1 and want_native == "1":                                 # (any torch backend: it only ships the communicator's id)
         from drake_ddp_amd.dist import NativeComm
         native = NativeComm.from_torch(dev_index)
+        comm_ranks = native.count()[0]
+    elif world > 1 and want_native != "0":
+        if backend != "nccl":
+            native_why = f"backend {backend}: the ranks share a device, and RCCL refuses two ranks on one device"
+        else:
+            from drake_ddp_amd.dist import NativeComm
+            ok, err = 1.0, ""
+            try:
+                native = NativeComm.from_torch(dev_index)
+                n_, r_ = native.count()
+                got = native.allreduce_min([float(rank + 1), -float(rank), 7.0])
+                if n_ != world or r_ != rank or list(got) != [1.0, -float(world - 1), 7.0]:
+                    ok, err = 0.0, f"self-check: count {n_}, rank {r_}, min {list(got)}"
+            except Exception as e:                                       # noqa: BLE001 - any failure means "use torch.distributed"
+                ok, err = 0.0, f"{type(e).__name__}: {e}"
+            all_ok = -rk.reduce([-ok], "max")[0]                          # min over ranks
+            if all_ok < 1.0:
+                native, native_why = None, ("library communicator not usable on every rank" + (f" (this rank: {err})" if err else ""))
+            else:
+                comm_ranks = native.count()[0]
     RING = 32      # solves the library lets us keep in flight (per-launch events + statistics records)
     # HIP events ride on one launch in TIME_EVERY: a profiled dispatch serializes the pipelined stream by ~5 us
     # (tools/ubench/gap.hip); roofline.kernel_ms is the average over the timed launches of the timed region
     TIME_EVERY = 4
     s.set_timing(TIME_EVERY)
 
-    def run_steps(count):
+    def run_steps(count, s=None):
         """`count` cold-start solves of the whole (per-rank) batch, enqueued back to back on the handle's
         stream in groups of RING: launch latency overlaps the previous solve; every solve still runs in
         full and leaves its own statistics record.  With N > 1 ranks the path's one collective - the
@@ -637,6 +662,7 @@ def main():
         reduction of the group's best costs, asynchronously (it overlaps the next group) and completed
         inside the timed region."""
         from drake_ddp_amd.dist import allreduce_min_vec_async
+        s = s if s is not None else s_weak
         out = []
         done = 0
         while done < count:
@@ -692,7 +718,40 @@ def main():
     last = per_step[-1]
     elapsed = rk.reduce([elapsed], "max")[0]
     iters_all = rk.reduce([iters], "sum")[0]
-    del s
+    onehot = [0.0] * world
+    onehot[rank] = float(iters)
+    iters_per_rank = rk.reduce(onehot, "sum")              # every rank's own iteration sum over the K timed steps
+    del s, s_weak
+
+    # N > 1: the STRONG-scaling figure beside the weak one - north_star's "a batch of 1024 ... at 1/2/4/8 GPUs": the single-GPU run's
+    # own 1024 problems (the same draw), a contiguous shard per rank, the same K steps between the same fences.  A launch lasts
+    # as long as its slowest problem at any batch size, so this is expected to stay near the single-GPU value: it is reported
+    # so that a scaling record shows it, not because the path has anything to gain from it.
+    strong = None
+    if world > 1:
+        from drake_ddp_amd.dist import shard_range
+        lo, hi = shard_range(B, rank, world)
+        ss = make_solver(prob, hi - lo, dev_index)
+        ss.SetInitialState(W.pendulum_batch_x0(B, seed=0)[lo:hi])
+        ss.SetInitialGuess(np.zeros((1, N - 1)))
+        ss._push_problem()
+        ss.set_timing(TIME_EVERY)
+        run_steps(args.warmup + 8, ss)
+        drain()
+        rk.fence()
+        ts0 = time.perf_counter()
+        st_steps = run_steps(args.steps, ss)
+        drain()
+        rk.fence()
+        s_el = rk.reduce([time.perf_counter() - ts0], "max")[0]
+        s_it = sum(st.total_iters for st in st_steps)
+        onehot = [0.0] * world
+        onehot[rank] = float(s_it)
+        s_per_rank = rk.reduce(onehot, "sum")
+        strong = {"value": sum(s_per_rank) / s_el, "unit": "iterations/s", "global_batch": B, "batch_per_gpu": hi - lo if rank == 0 else None,
+                  "ms_per_step": 1e3 * s_el / args.steps, "iterations_per_rank": s_per_rank,
+                  "note": "C2's 1024 problems (the single-GPU run's own draw) sharded contiguously over the ranks; same K steps, same fences"}
+        del ss
 
     if rank == 0:
         k_ms = kernel_ms / n_timed                          # avg launch duration of the dominant kernel (HIP events)
@@ -738,6 +797,10 @@ def main():
             "us_per_solve_per_problem": 1e6 * elapsed / args.steps / B,
             "higher_is_better": True,
             "scaling": "weak",
+            "value_strong": None if strong is None else strong["value"],
+            "strong_scaling": strong,
+            "iterations_per_rank": iters_per_rank,
+            "communicator_ranks": comm_ranks,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
@@ -745,8 +808,9 @@ def main():
                                    "(rng seed 0), fp64, central-FD Jacobians h=1e-5, cold-start Solve per step",
                        "batch_per_gpu": B, "global_batch": B * world, "N": N, "n": 2, "m": 1,
                        "parallelism": f"batch-shard x{world}",
-                       "collective": None if world == 1 else ("librccl all-reduce(min) via mi_ilqr_allreduce_min_start" if native is not None
-                                                              else f"torch.distributed all_reduce(MIN), backend {backend}")},
+                       "collective": None if world == 1 else ("librccl all-reduce(min) via mi_ilqr_allreduce_min_start (the library's own communicator; ncclCommCount = %d)" % comm_ranks
+                                                              if native is not None else f"torch.distributed all_reduce(MIN), backend {backend}"),
+                       "collective_fallback_reason": native_why},
             "value_cold_clock": cold_iters / cold_elapsed,
             "ms_per_step_cold_clock": 1e3 * cold_elapsed / args.steps,
             "iterations_per_step_rank0": iters / args.steps,

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MI_ILQR_LIB") or os.path.join(_HERE, "lib", "libmi_ilqr.so")
 
 MAX_PARAMS = 16
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 # enums (include/mi_ilqr.h)
 OK, E_BAD_SHAPE, E_BAD_METHOD, E_LINESEARCH, E_HIP, E_NO_DEVICE, E_BAD_ARG, E_UNSUPPORTED, E_RCCL = 0, -1, -2, -3, -4, -5, -6, -7, -8
@@ -28,6 +28,7 @@ F_X_BAR, F_U_BAR, F_K, F_KAPPA, F_DV, F_FX, F_FU, F_COST, F_X0, F_HIST, F_X_TRIA
 I_ITERS, I_STATUS, I_LS_TRIALS, I_KP_COUNT, I_KP_LIST = 100, 101, 102, 103, 104
 I64_STAGE_CYCLES = 200
 I64_CLUSTER_WORDS = 201
+CLUSTER_WORDS = 40          # MI_ILQR_CLUSTER_WORDS
 
 EXPORTS = [
     "mi_ilqr_abi_version", "mi_ilqr_struct_sizes", "mi_ilqr_strerror", "mi_ilqr_model_info", "mi_ilqr_register_model", "mi_ilqr_create", "mi_ilqr_destroy",
@@ -37,7 +38,7 @@ EXPORTS = [
     "mi_ilqr_mpc_run", "mi_ilqr_get_mpc_log",
     "mi_ilqr_get", "mi_ilqr_get_int", "mi_ilqr_get_async", "mi_ilqr_set", "mi_ilqr_device_ptr", "mi_ilqr_get_stream",
     "mi_ilqr_synchronize", "mi_ilqr_last_kernel_ms", "mi_ilqr_set_timing", "mi_ilqr_get_cycles", "mi_ilqr_bytes_per_iteration", "mi_ilqr_lds_bytes",
-    "mi_ilqr_comm_unique_id", "mi_ilqr_comm_create", "mi_ilqr_comm_destroy", "mi_ilqr_allreduce_min",
+    "mi_ilqr_comm_unique_id", "mi_ilqr_comm_create", "mi_ilqr_comm_destroy", "mi_ilqr_comm_count", "mi_ilqr_allreduce_min",
     "mi_ilqr_allreduce_min_start", "mi_ilqr_allreduce_min_wait",
 ]
 
@@ -125,6 +126,7 @@ def load():
     lib.mi_ilqr_comm_create.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(H)]
     lib.mi_ilqr_comm_destroy.argtypes = [H]
     lib.mi_ilqr_comm_destroy.restype = None
+    lib.mi_ilqr_comm_count.argtypes = [H, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.mi_ilqr_allreduce_min.argtypes = [H, C.c_void_p, C.c_int32]
     lib.mi_ilqr_allreduce_min_start.argtypes = [H, C.c_void_p, C.c_int32]
     lib.mi_ilqr_allreduce_min_wait.argtypes = [H, C.c_void_p, C.c_int32]

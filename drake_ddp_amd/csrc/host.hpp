@@ -72,7 +72,8 @@ struct mi_ilqr {
   int cost_asym = 0;       // workgroup-per-problem kernels, n <= 32: Q, R or Qf is not symmetric (mid_backward then uses no symmetry at all)
   std::vector<double> h_costmat;   // host mirror of costmat (Q | R | Qf | x_nom)
   bool costmat_synced = false;     // the device copy equals the mirror
-  unsigned long long* cluster_sync = nullptr;   // workgroup-per-problem kernels: 4 handshake words per problem
+  unsigned long long* cluster_sync = nullptr;   // workgroup-per-problem kernels: kSyncWords handshake words per problem
+  bool last_clustered = false;     // the last MODE_SOLVE / MODE_MPC launch shared its linearizations among clusters (else MI_I64_CLUSTER_WORDS reads as zeros)
   int n_cus = 0;                   // compute units of the device
   double* scratch = nullptr;       // device staging area of the boundary's layout conversions (grow-only)
   size_t scratch_bytes = 0;

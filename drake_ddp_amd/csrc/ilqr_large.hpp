@@ -131,10 +131,27 @@ __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-// Data that crosses workgroups of one launch (cluster handshake): write-through stores / cache-bypassing loads at
-// device scope - coherent across the XCDs' L2 caches access by access, so no cache-wide write-back is needed to
-// publish them (a device-scope release fence writes back the whole L2 of the XCD: measured ~130 k cycles per
-// handshake with 256 workgroups doing it).
+// ---- Data that crosses workgroups of one launch (cluster hand-shake): the memory-model argument --------------------------------
+// What the hardware does was MEASURED before this was written (round 6, tools/ubench/l1_probe.hip, profiles/r06_l1_probe.txt:
+// a consumer workgroup that keeps a 4 KB block L1-warm, a producer on the same / another XCD rewriting it, every word checked):
+//   * a CU's vector L1 is never refreshed by another CU's stores: without an acquire every re-read is stale (100 %);
+//   * `buffer_inv sc0` - the workgroup-scope invalidate rounds 5 used on the one-XCD path - has NO effect on such lines outside
+//     threadgroup-split mode: 100 % stale, same XCD or not.  That hand-shake passed its tests only where the 32 KB L1 had been
+//     thrashed in between (large models), and failed on small plugin shapes - both stale-data failures of round 5 were this;
+//   * an agent-scope acquire fence (`buffer_inv sc1`) followed by plain loads, or agent-scope (sc1) loads without any fence,
+//     read fresh data - from a same-XCD producer after `s_waitcnt vmcnt(0)` alone, from a producer on ANOTHER XCD only if its
+//     stores were agent-scope (sc1, write-through) stores or were followed by an agent-scope release fence (`buffer_wbl2 sc1`).
+// So every hand-off below takes one of the two forms that are correct for ANY placement of the workgroups (LLVM's AMDGPU memory
+// model for gfx942 / gfx950: an agent-scope atomic store is `global_store sc1`, complete at agent scope when the vector-memory
+// counter has counted it; an agent-scope atomic load is `global_load sc1`; an agent-scope acquire fence is `buffer_inv sc1`):
+//   (A) payload in agent-scope stores (st_shared<true>), every wave drains its own (drain_stores), a barrier collects the waves,
+//       ONE thread then raises the flag (relaxed agent-scope atomic); the reader polls the flag (relaxed), and either reads the
+//       payload with agent-scope loads (ld_shared) or executes ONE agent-scope acquire fence + barrier and reads it normally;
+//   (B) payload in plain stores (the gains a backward pass leaves, a candidate group's trial trajectories): every wave drains, a
+//       barrier, ONE thread executes an agent-scope release fence (cluster_release) and then raises the flag; the reader: poll,
+//       agent-scope acquire fence, barrier, plain loads.
+// Nothing depends on which XCD a workgroup runs on, on the size of a cache or on how long a step takes; the one-XCD placement of a
+// cluster (launch_large.hpp) is a speed choice (the leaders spread over the eight L2s).
 template <bool COHERENT>
 __device__ __forceinline__ void st_shared(double* p, double v) {
   if constexpr (COHERENT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -144,19 +161,26 @@ __device__ __forceinline__ double ld_shared(const double* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void wait_stores() { __builtin_amdgcn_s_waitcnt(0x0F70); }   // vmcnt(0): this thread's stores acknowledged
-// Publishing write-through (device-scope) stores to another workgroup: each thread waits until its own are acknowledged - a
-// device-scope store is acknowledged when it is complete at that scope - and the barrier collects the threads; the flag store /
-// atomic that follows it may then be relaxed.  What a device-scope RELEASE FENCE would add is buffer_wbl2 sc1: a write-back of
-// every dirty line in the XCD's L2 - the gains, trial trajectories and own Jacobian shares of every leader that lives there,
-// none of which any other workgroup reads.
-// That holds for a reader behind the SAME L2 (one XCD).  For a reader on another XCD it does not: measured in round 5 - with
-// the fence dropped and the cluster spread over XCDs, the coupled arm's cold solves took 1009 iterations instead of 1002 - an
-// acknowledged write-through store has reached the XCD's L2, not yet the memory the other XCD reads.  one_l2 = false: the fence.
-__device__ __forceinline__ void cluster_publish_barrier(bool one_l2) {
-  if (one_l2) { wait_stores(); asm volatile("" ::: "memory"); }
-  else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+// This wave's vector-memory operations are complete (inline assembly: the compiler's wait-count pass cannot drop or move it -
+// ROCm 7.2 drops the wait behind a release fence when its own scoreboard believes the counter is empty).
+__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// Form (A): the agent-scope stores of EVERY thread of the workgroup are complete once this returns; the flag store that follows
+// may be relaxed.
+__device__ __forceinline__ void cluster_publish_barrier() {
+  drain_stores();
   __syncthreads();
 }
+// Form (B), after cluster_publish_barrier(), by the ONE thread that raises the flag next: writes back the dirty lines of this XCD's
+// L2 (the plain stores of every wave of the workgroup have reached it: drained + barrier) so that a reader behind another L2 finds
+// them; a reader behind the same L2 needs only the drain.
+__device__ __forceinline__ void cluster_release() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  drain_stores();
+}
+// The reader's side of either form, by ONE thread after it has seen the flag, followed by a barrier: drops this CU's vector L1
+// (and whatever of this XCD's L2 may be stale with respect to another XCD's write-through stores); later plain loads of the
+// workgroup read what the writer published.
+__device__ __forceinline__ void cluster_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
 // XCC (= XCD) this wave runs on
 __device__ __forceinline__ int xcc_id() {
 #ifdef MI_NO_XCC
@@ -245,16 +269,21 @@ __device__ __forceinline__ void trig_gather(double v, double (&S)[NJ], double (&
 // (2) one lane per degree of freedom advances the dynamics while other waves add the
 // stage-cost rows (their Q/R rows live in registers); (3) the new state is published.
 // prog != nullptr: the rollout PUBLISHES the trial as it goes, for helper workgroups that linearize it while it is still being
-// rolled out (ilqr_large_kernel: early linearization).  x_t, u_t then leave as write-through stores - all from the fourth wave,
-// whose vector-memory operations complete in the order issued: it issues AT LEAST (progress word, x_t, u_t) per step, so "all but
-// the youngest 3 kPubLag operations are complete" (s_waitcnt vmcnt) covers every x, u store older than kPubLag steps - anything
-// else the wave might issue in the loop only moves that horizon closer - and lane 192 stores `tag | s` into *prog once the steps
-// 0 .. s-1 are complete at device scope: kPubLag steps behind the rollout, waiting for nothing that a step's time has not long
-// delivered.
+// rolled out (ilqr_large_kernel: early linearization).  x_t, u_t then leave as agent-scope (write-through) stores - all from the
+// fourth wave - and lane 192 stores `tag | s` into *prog once the steps 0 .. s-1 are complete at agent scope (form (A) of the
+// hand-shake above; the helpers read the rows with agent-scope loads).  How it knows:
+//   MI_PUB_LAG = 0 (default): at the top of step t, BEFORE this step's stores are issued, the wave drains its vector-memory counter
+//     - s_waitcnt vmcnt(0): every store it has issued (steps 0 .. t-1) is complete - and publishes s = t.  No assumption about the
+//     order in which operations complete, none about how long a step takes (round 5's form rested on both, and was opened for the
+//     built-in models only).  What the wave waits for is at least half a step old (u_{t-1} left in the middle of step t-1).
+//   MI_PUB_LAG = k > 0 (A/B builds): the counted form - s_waitcnt vmcnt(3 k) "all but the youngest 3 k operations are complete" and
+//     s = t - k.  Right only while the wave has nothing but stores in flight (operations of one kind complete in the order issued;
+//     a load - a register spill's reload, say - would not be ordered with them).
 #ifndef MI_PUB_LAG
-#define MI_PUB_LAG 3
+#define MI_PUB_LAG 0
 #endif
 constexpr int kPubLag = MI_PUB_LAG;
+static_assert(kPubLag >= 0 && 3 * kPubLag <= 15, "the counted wait of large_rollout's publisher sits in the 4-bit low field of s_waitcnt's vmcnt");
 constexpr unsigned long long kPubAbort = 0x80000000ull;      // *prog = tag | kPubAbort: the trial was rejected, stop linearizing it
 // Blocks at the END of the horizon that the leader linearizes itself once the trial is accepted (early rounds): models whose
 // helpers cannot keep up with the rollout (planar quadruped: an item is two passes over the tree, ~78 k cycles) - the last
@@ -372,17 +401,21 @@ __device__ inline double large_rollout(const LView<M::n, M::m>& v, double* lds, 
       dxc[tid - 192] = xv_ - xnr;
       if (prog) {
         if (tid == 192 && t >= 1) {
-          // every step from the second on publishes (a count of zero claims nothing), so the wave has issued exactly
-          // (publish, x, u) x kPubLag operations since u_{t-1-kPubLag}: all but that many complete = steps 0 .. t-1-kPubLag out
-          if (t > kPubLag) __builtin_amdgcn_s_waitcnt(0x0F70 | (3 * kPubLag));
-          asm volatile("" ::: "memory");
-          __hip_atomic_store(prog, tag | (unsigned long long)(t > kPubLag ? t - kPubLag : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if constexpr (kPubLag == 0) {
+            drain_stores();                                  // steps 0 .. t-1: every store this wave has issued is complete
+            __hip_atomic_store(prog, tag | (unsigned long long)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          } else {
+            // every step from the second on publishes (a count of zero claims nothing), so the wave has issued exactly
+            // (publish, x, u) x kPubLag operations since u_{t-1-kPubLag}: all but that many complete = steps 0 .. t-1-kPubLag out
+            if (t > kPubLag) __builtin_amdgcn_s_waitcnt(0x0F70 | (3 * kPubLag));
+            asm volatile("" ::: "memory");
+            __hip_atomic_store(prog, tag | (unsigned long long)(t > kPubLag ? t - kPubLag : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
         }
       }
-      // (plain stores either way: the helpers of an early round sit behind the SAME L2 - early rounds open only then - and read the
-      //  trial out of it; a write-through store acknowledged by that L2 may still be on its way to memory, which is where a
-      //  device-scope load would look: seen as garbage Jacobians on models with steps of a few hundred cycles)
-      v.Xn[(size_t)t * n + (tid - 192)] = xv_;
+      // a published trial leaves in agent-scope stores (form (A) of the hand-shake: the helpers read it with agent-scope loads)
+      if (prog) st_shared<true>(v.Xn + (size_t)t * n + (tid - 192), xv_);
+      else v.Xn[(size_t)t * n + (tid - 192)] = xv_;
     }
     if (t + 2 < N - 1) prefetch(f, t + 2);       // this set is free again
     lds_barrier();
@@ -530,7 +563,8 @@ __device__ inline double large_rollout(const LView<M::n, M::m>& v, double* lds, 
 #endif
     } else if (uorole) {
       const int k = tid - 192 - n;
-      v.Un[(size_t)t * m + k] = us[k];
+      if (prog) st_shared<true>(v.Un + (size_t)t * m + k, us[k]);
+      else v.Un[(size_t)t * m + k] = us[k];
     }
     lds_barrier();
     double* tmp_ = xc; xc = xn_; xn_ = tmp_;
@@ -545,8 +579,7 @@ __device__ inline double large_rollout(const LView<M::n, M::m>& v, double* lds, 
   xs = xc;                             // final state x_{N-1}
   if (tid < n) v.Xn[(size_t)(N - 1) * n + tid] = xs[tid];
   if (prog && tid == 192) {            // every step of the trial is out
-    wait_stores();
-    asm volatile("" ::: "memory");
+    drain_stores();
     __hip_atomic_store(prog, tag | (unsigned long long)(N - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if constexpr (kLx) {
@@ -2495,8 +2528,14 @@ __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kerne
     for (int e = tid; e < m * n * (N - 1); e += kLargeThreads) v.K[e] = 0.0;
     for (int e = tid; e < m * (N - 1); e += kLargeThreads) v.kap[e] = 0.0;
     for (int e = tid; e < N - 1; e += kLargeThreads) v.dV[e] = 0.0;
-    for (int e = tid; e < n * n * (N - 1); e += kLargeThreads) v.Fx[e] = 0.0;
-    for (int e = tid; e < n * m * (N - 1); e += kLargeThreads) v.Fu[e] = 0.0;
+    // (a clustered launch: no dirty line of fx / fu may stay in this XCD's L2 - see open_early)
+    if (G > 1) {
+      for (int e = tid; e < n * n * (N - 1); e += kLargeThreads) st_shared<true>(v.Fx + e, 0.0);
+      for (int e = tid; e < n * m * (N - 1); e += kLargeThreads) st_shared<true>(v.Fu + e, 0.0);
+    } else {
+      for (int e = tid; e < n * n * (N - 1); e += kLargeThreads) v.Fx[e] = 0.0;
+      for (int e = tid; e < n * m * (N - 1); e += kLargeThreads) v.Fu[e] = 0.0;
+    }
   }
   if (a.u_pending && role == 0) {
     const double* ug = a.u_guess + (size_t)b * m * (N - 1);
@@ -2548,14 +2587,10 @@ __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kerne
   // in), and the accepted trial is linearized the usual way.  Same items, same arithmetic: bitwise the same fx, fu.
   unsigned long long* csync = a.cluster_sync + (size_t)kSyncWords * b;
   const bool clustered = G > 1 && lin_staged && a.kp_method == MI_KP_SET_INTERVAL && a.minN == 1;
-  // the leader's own share: a list of key-points, plain stores (read back by this workgroup only)
-  auto jac_own = [&](const int* list, int count, int first, int stride) __attribute__((always_inline)) {
-    if constexpr (HasSparsity<M>::value) large_jac_at_sparse<M, JAC, false>(v, a, list, count, lin_X, lin_U, first, stride);
-    else if constexpr (IsChainModel<M>::value) large_jac_at_tree<M, JAC, false>(v, a, list, count, lin_X, lin_U, lin_xs, lin_us, lds + Ly::doubles, first, stride);
-    else if constexpr (IsLegModel<M>::value) large_jac_at_legs<M, JAC, false>(v, a, list, count, lin_X, lin_U, lin_xs, lin_us, first, stride);
-    else large_jac_at<M, JAC, false>(v, a, list, count, lin_X, lin_U, lin_xs, lin_us, first, stride);
-  };
-  // helper workgroups: a list of key-points (a block of time steps), write-through stores
+  // a share of a clustered linearization - the leader's own as well as a helper's: a list of key-points (a block of time steps),
+  // agent-scope write-through stores.  (The leader's own share too, although only the leader reads it back: plain stores would
+  // leave dirty lines of fx / fu in this XCD's L2, and in a later round - the shares move when a helper arrives late, and an early
+  // round's helpers write everything - a helper behind ANOTHER L2 may own those entries.)
   auto jac_list = [&](const int* list, int count, int first, int stride) __attribute__((always_inline)) {
     if constexpr (HasSparsity<M>::value) large_jac_at_sparse<M, JAC, true>(v, a, list, count, lin_X, lin_U, first, stride);
     else if constexpr (IsChainModel<M>::value) large_jac_at_tree<M, JAC, true>(v, a, list, count, lin_X, lin_U, lin_xs, lin_us, lds + Ly::doubles, first, stride);
@@ -2594,20 +2629,20 @@ __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kerne
         acc.aux[2] = (int)(unsigned)(cmd >> 32);
         acc.aux[3] = (int)(unsigned)(cmd & 0xffffffffull);
         if (go > 0) *last_round_p = (int)(unsigned)(cmd >> 32);
+        // a candidate-group round reads the leader's gains, nominal trajectory and x0 with plain loads (mid_rollout4): form (B),
+        // the reader's side - this thread has seen the flag; the barrier below hands the acquire to the workgroup
+        if (go > 0 && ((cmd >> 18) & 1ull) != 0ull) cluster_acquire();
       }
       __syncthreads();
       const int go = acc.aux[0], parts = acc.aux[3] & 0xffff;
       const bool early = ((acc.aux[3] >> 16) & 1) != 0;
-      const bool one_l2 = ((acc.aux[3] >> 17) & 1) != 0;    // the leader found every helper of this round on its own XCD
       const unsigned last_round = (unsigned)acc.aux[2];     // (the round being served: the tag of its progress word)
       __syncthreads();
       if (go < 0) return;                                   // exit flag (or nobody spoke for a second)
       if (my >= parts) continue;                            // arrived after this round's snapshot: not counted on
       if constexpr (kSpecRollout<M>) {
         if (((acc.aux[3] >> 18) & 1) != 0) {
-          // a candidate-group round: the leader's gains, nominal trajectory and x0 are in the L2 this workgroup shares with it
-          // (such rounds open only then) - drop this CU's vector cache and roll out the candidates 4 my .. 4 my + 3 of the pass
-          asm volatile("buffer_inv sc0" ::: "memory");
+          // a candidate-group round (acquired above): roll out the candidates 4 my .. 4 my + 3 of the pass
           double e4[kSpec], L4[kSpec], dvs;
           double e = 1.0;
           for (int q = 0; q < kSpec * my; ++q) e *= a.beta;              // (the sequence eps *= beta produces, ilqr.py:335)
@@ -2625,8 +2660,8 @@ __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kerne
             for (int c = 0; c < kSpec; ++c)
               __hip_atomic_store(csync + 8 + kSpec * (my - 1) + c, (unsigned long long)__double_as_longlong(L4[c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
-          cluster_publish_barrier(true);
-          if (tid == 0) __hip_atomic_fetch_add(csync + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          cluster_publish_barrier();                        // form (B): the trial trajectories are mid_rollout4's plain stores
+          if (tid == 0) { cluster_release(); __hip_atomic_fetch_add(csync + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
           continue;
         }
       }
@@ -2654,24 +2689,21 @@ __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kerne
           __syncthreads();
           if (st < 0) break;
         }
-        {                                                   // the leader's trajectory -> LDS (cache-bypassing loads: no acquire fence)
-          const double* Xg = early ? v.Xn : v.X;            // (early: the trial as the rollout publishes it)
+        {                                                   // the leader's trajectory -> LDS: form (A), agent-scope loads of its agent-scope stores
+          const double* Xg = early ? v.Xn : v.X;            // (early: the trial as the rollout publishes it, large_rollout)
           const double* Ug = early ? v.Un : v.U;
           double* xs_ = lds + Ly::oT1;
           double* us_ = lds + Ly::oF;
           const int xe = early ? t1 * n : n * N;            // (a regular round stages x_{N-1} too, as it always has)
-          // early: out of the L2 shared with the leader (its plain stores, acknowledged by that L2) - drop this CU's vector cache
-          // and read normally; a regular round: device-scope loads of the leader's write-through stores
-          if (early) asm volatile("buffer_inv sc0" ::: "memory");
-          for (int e = t0 * n + tid; e < xe; e += kLargeThreads) xs_[(e / n) * kXS + e % n] = early ? Xg[e] : ld_shared(Xg + e);
-          for (int e = t0 * m + tid; e < t1 * m; e += kLargeThreads) us_[(e / m) * kUS + e % m] = early ? Ug[e] : ld_shared(Ug + e);
+          for (int e = t0 * n + tid; e < xe; e += kLargeThreads) xs_[(e / n) * kXS + e % n] = ld_shared(Xg + e);
+          for (int e = t0 * m + tid; e < t1 * m; e += kLargeThreads) us_[(e / m) * kUS + e % m] = ld_shared(Ug + e);
           for (int i = t0 + tid; i < t1; i += kLargeThreads) acc.kp[i] = i;      // keypoints_set_interval(minN = 1)
           __syncthreads();
         }
         jac_list(acc.kp + t0, t1 - t0, early ? 0 : my, early ? 1 : parts);       // this share of fx / fu: write-through stores
         __syncthreads();                                    // (the next block's staging reuses what this one read)
       }
-      cluster_publish_barrier(one_l2 && !early);            // (a regular one-L2 round: no cache-wide write-back - see there; an early round: close_early)
+      cluster_publish_barrier();                            // form (A): this share of fx / fu is agent-scope stores, complete now
       if (tid == 0) __hip_atomic_fetch_add(csync + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
@@ -2698,7 +2730,7 @@ __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kerne
       }
       __syncthreads();
       parts = acc.aux[3];
-      cluster_publish_barrier(acc.aux[1] != 0);             // the write-through x_bar / u_bar stores of the commit
+      cluster_publish_barrier();                            // form (A): the agent-scope x_bar / u_bar stores of the commit are complete
       if (tid == 0) {
         const unsigned cl_round = (unsigned)(cst[0] += 1);
         __hip_atomic_store(csync + 0, ((unsigned long long)cl_round << 32) | ((unsigned long long)(acc.aux[1] != 0 ? 1 : 0) << 17) | (unsigned)parts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2707,8 +2739,8 @@ __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kerne
       __syncthreads();
     }
     const int t_first = own_only ? own_t0 : 0;
-    jac_own(acc.kp + t_first, N - 1 - t_first, 0, parts);
-    __syncthreads();
+    jac_list(acc.kp + t_first, N - 1 - t_first, 0, parts);
+    cluster_publish_barrier();                              // (this workgroup's own share is complete before anybody's acquire)
     if (own_only) return true;                              // (the tail of an accepted early round: close_early does the rest)
     if (tid == 0) {
       const unsigned long long cl_expected = (unsigned long long)(cst[4] += parts - 1);
@@ -2719,19 +2751,14 @@ __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kerne
         __builtin_amdgcn_s_sleep(1);
       }
       acc.aux[0] = ok;
+      // Form (A), the reader's side: the helpers' shares of fx / fu are complete at agent scope; the backward pass reads them with
+      // plain loads, so this CU's vector L1 - which may hold last iteration's lines of fx / fu - is dropped here, once, by the
+      // thread that saw the counter (tools/ubench/l1_probe.hip: ~1.7 us; `buffer_inv sc0`, which stood here in round 5, drops nothing)
+      cluster_acquire();
+      if (acc.aux[1] != 0) cst[1] += 1;                     // (diagnostic: rounds whose helpers all sat on this workgroup's XCD)
     }
     __syncthreads();
-    const bool ok = acc.aux[0] != 0;
-    // The helpers' shares of fx / fu are complete at device scope.  Helpers on this XCD wrote them THROUGH the L2 this workgroup
-    // reads from: only this CU's vector cache can hold last iteration's lines - drop those (buffer_inv sc0: what a workgroup-scope
-    // acquire is in threadgroup-split mode) and leave the L2 alone.  A helper elsewhere: a device-scope acquire, which invalidates
-    // this XCD's L2 for every workgroup on it (invalidate only - nothing of this workgroup needs writing back for anybody).
-    const bool same_l2 = acc.aux[1] != 0;
-    if (same_l2) asm volatile("buffer_inv sc0" ::: "memory");
-    else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    if (tid == 0 && same_l2) cst[1] += 1;
-    __syncthreads();
-    return ok;
+    return acc.aux[0] != 0;
   };
   // leader, early linearization: open a round for the trial the line search is about to roll out (false: no helper is there yet)
   auto open_early = [&]() __attribute__((always_inline)) -> bool {
@@ -2741,18 +2768,21 @@ __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kerne
       const unsigned long long alive = word & 0xffffull;
       const unsigned parts = 1u + (unsigned)(alive < (unsigned long long)(G - 1) ? alive : (unsigned long long)(G - 1));
       const bool same = ((word >> (16 + 6 * xcc_id())) & 63ull) == alive;
-      // Only with every helper on this workgroup's own XCD.  The helpers of an early round write ALL of fx, fu - through the L2
-      // they share with the leader; from another XCD they would write past lines this L2 still holds DIRTY (the leader's own
-      // share of the last regular round, plain stores), and the stale line would win.  (Seen, not imagined: forced onto other
-      // XCDs - MI_ILQR_CLUSTER_ORDER=0 - the arm's solves took other iteration counts until this test was in.)
-      acc.aux[3] = same ? (int)parts : 1;
-      acc.aux[1] = 1;
-      if (same && parts > 1) {
+      // Any placement (round 6).  The helpers of an early round write ALL of fx, fu, so no byte of fx / fu may sit dirty in this
+      // XCD's L2 when a helper behind another L2 writes it: every writer of fx / fu in a clustered launch - the helpers, the leader's
+      // own share (jac_own), the lazy zero-fill - uses agent-scope write-through stores, which leave no dirty line behind.  (Round 5
+      // had the leader's share in plain stores and therefore refused early rounds across XCDs: "the stale line wins" was seen.)
+      acc.aux[3] = (int)parts;
+      acc.aux[1] = same ? 1 : 0;                            // (diagnostic only)
+      if (parts > 1) {
         const unsigned cl_round = (unsigned)(cst[0] += 1);
         cst[4] += (int)parts - 1;
         cst[2] += 1;
+        // the progress word first: a helper that sees the command must not take last round's final count for this round's
+        // (both are agent-scope stores of ONE thread to different addresses: drained in between)
         __hip_atomic_store(csync + 4, (unsigned long long)cl_round << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(csync + 0, ((unsigned long long)cl_round << 32) | (3ull << 16) | parts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        drain_stores();
+        __hip_atomic_store(csync + 0, ((unsigned long long)cl_round << 32) | (1ull << 16) | ((unsigned long long)(same ? 1 : 0) << 17) | parts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       acc.aux[2] = cst[0];
     }
@@ -2760,22 +2790,23 @@ __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kerne
     return acc.aux[3] > 1;
   };
   // leader, candidate groups: the helpers roll out the candidates 4 .. 4 parts - 1 of the line search's first pass (false: no helper
-  // there, or not all on this XCD - the gains and the nominal trajectory reach them through the shared L2 only)
+  // there).  Form (B): the gains (K, kappa, dV: the backward pass's plain stores), the nominal trajectory and x0 are read by the
+  // helpers with plain loads - every wave drains, ONE release fence, then the command.
   auto open_groups = [&]() __attribute__((always_inline)) -> bool {
-    wait_stores();
-    __syncthreads();
+    cluster_publish_barrier();
     if (tid == 0) {
       const unsigned long long word = __hip_atomic_load(csync + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const unsigned long long alive = word & 0xffffull;
       const unsigned parts = 1u + (unsigned)(alive < (unsigned long long)(G - 1) ? alive : (unsigned long long)(G - 1));
       const bool same = ((word >> (16 + 6 * xcc_id())) & 63ull) == alive;
-      acc.aux[3] = same ? (int)parts : 1;
-      acc.aux[1] = 1;
-      if (same && parts > 1) {
+      acc.aux[3] = (int)parts;
+      acc.aux[1] = same ? 1 : 0;                            // (diagnostic only)
+      if (parts > 1) {
         const unsigned cl_round = (unsigned)(cst[0] += 1);
         cst[4] += (int)parts - 1;
         cst[5] += 1;
-        __hip_atomic_store(csync + 0, ((unsigned long long)cl_round << 32) | (6ull << 16) | parts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        cluster_release();
+        __hip_atomic_store(csync + 0, ((unsigned long long)cl_round << 32) | (4ull << 16) | ((unsigned long long)(same ? 1 : 0) << 17) | parts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     __syncthreads();
@@ -2795,20 +2826,13 @@ __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kerne
       }
       acc.aux[0] = ok;
       if (use && !groups_round) { cst[3] += 1; cst[1] += same_l2 ? 1 : 0; }
+      // The reader's side of form (A) (an early round: fx, fu are the helpers' agent-scope stores) and of form (B) (a candidate-group
+      // round: the winner's trial trajectory is a helper's plain stores behind its release fence): ONE agent-scope acquire by the
+      // thread that saw the counter, the barrier below hands it to the workgroup.
+      if (use) cluster_acquire();
     }
     __syncthreads();
-    const bool ok = acc.aux[0] != 0;
-    if (use) {
-      // The Jacobians are the helpers'.  After an EARLY round: a device-scope acquire, with the helpers' full release on the other
-      // side - the light pair of a regular one-L2 round (acknowledged write-through stores / this CU's vector cache dropped) was
-      // seen to hand the backward pass stale Jacobians on a plugin model with steps of a few hundred cycles (tools/diag/
-      // early_small_shape.py: fx, fu right in memory, K of the first iteration wrong; right with the fences).  A candidate-group
-      // round moves plain stores through the shared L2: the vector cache is all there is to drop.
-      if (groups_round && same_l2) asm volatile("buffer_inv sc0" ::: "memory");
-      else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    __syncthreads();
-    return ok;
+    return acc.aux[0] != 0;
   };
   auto do_linearize = [&](bool have_copy) __attribute__((always_inline)) {
     if (lin_staged && !have_copy) {

@@ -49,7 +49,7 @@ struct DevStats {
   double best_cost;
 };
 
-constexpr int kSyncWords = 40;      // 64-bit handshake words per problem (KArgs::cluster_sync): 8 + the costs of 4 x 7 line-search candidates
+constexpr int kSyncWords = MI_ILQR_CLUSTER_WORDS;      // (= 40) 64-bit handshake words per problem (KArgs::cluster_sync): 8 + the costs of 4 x 7 line-search candidates
 struct KArgs {
   // persistent per-problem solver state, reference layout with a leading batch axis
   double *x_bar, *u_bar, *K, *kappa, *dV, *fx, *fu;

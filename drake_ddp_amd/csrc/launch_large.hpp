@@ -10,6 +10,7 @@ int launch_one_large(mi_ilqr* h, const KArgs& a) {
   static bool lds_ok[kMaxDevices] = {};
   { const int rc = allow_max_lds(kern, lds_ok, h->d.device_id); if (rc != MI_ILQR_OK) return rc; }
   const int cluster = (MODE == MODE_SOLVE || MODE == MODE_MPC) ? (a.cluster & 0xff) : 1;
+  if (MODE == MODE_SOLVE || MODE == MODE_MPC) h->last_clustered = cluster > 1;
   if (cluster > 1) HIPCHK(hipMemsetAsync(h->cluster_sync, 0, (size_t)h->B * kSyncWords * sizeof(unsigned long long), h->stream));
   // clusters: 8 G ceil(B / 8) workgroups, a cluster's members congruent mod 8 = on one XCD (ilqr_large_kernel: XCD-aware placement)
   const unsigned grid = cluster > 1 ? (((a.cluster >> 8) & 3) ? 8u * (unsigned)cluster * (unsigned)((h->B + 7) / 8) : (unsigned)(h->B * cluster)) : (unsigned)h->B;

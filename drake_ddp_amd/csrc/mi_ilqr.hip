@@ -187,12 +187,13 @@ KArgs make_args(const mi_ilqr* h) {
     // helpers run 40 - 70 % slower next to leaders: neighbouring CUs share an instruction cache, and their linearization loops are
     // 50 - 90 KB of code); 0 = consecutive blocks, a cluster spans XCDs (what rounds 2 - 4 did; no early linearization there)
     static const int order = [] { const char* e = std::getenv("MI_ILQR_CLUSTER_ORDER"); return e ? std::atoi(e) : 2; }();
-    // Early linearization: the built-in models only.  Its progress word trails the rollout by three STEPS, which is ample store
-    // latency for their steps of 2 - 6 k cycles; forced onto plugin chains with steps of a few hundred cycles it was seen to hand the
-    // helpers rows of the previous trial (tools/shape_sweep.py with MI_ILQR_CLUSTER=4: wrong Jacobians from the second iteration on) -
-    // plugin models, which are not clustered by default anyway, keep the regular rounds (72 of 72 shapes right when forced).
+    // Early linearization (MI_ILQR_EARLY=0|1): every model, built-in or plugin (round 6).  Round 5 opened it for the built-in models
+    // only: forced onto plugin chains with steps of a few hundred cycles the helpers linearized rows of the previous trial.  The cause
+    // was not the progress word's lag but the helpers' side of the hand-shake - `buffer_inv sc0` does not drop another CU's lines
+    // from the vector L1 (tools/ubench/l1_probe.hip), and a small trajectory survives there from one iteration to the next; the
+    // helpers now read the trial with agent-scope loads and the progress word follows a full drain (ilqr_large.hpp).
     static const int early_env = [] { const char* e = std::getenv("MI_ILQR_EARLY"); return e ? std::atoi(e) : 1; }();
-    const int early = early_env && !plugin_of(h->d.model_id);
+    const int early = early_env;
     // candidate groups (MI_ILQR_LS_GROUPS=0|1): the helpers need trial buffers of their own, and - they keep their own LDS copy of
     // the cost constants - a target that does not move inside the launch
     static const int groups = [] { const char* e = std::getenv("MI_ILQR_LS_GROUPS"); return e ? std::atoi(e) : 1; }();
@@ -515,6 +516,13 @@ Field field_of(mi_ilqr* h, int which) {
   return {nullptr, 0, false};
 }
 
+// The per-iteration records (MI_F_HIST, MI_F_ITER_CYCLES: hist_cap rows of 4 doubles per problem) may be read in part: any whole
+// number of LEADING rows of the first problem - what a caller with one problem and a long log capacity wants after a short solve
+// (the drop-in class keeps 4096 rows and reads the 64 first with the solve, the rest only when a solve took more iterations).
+bool prefix_ok(int which, size_t bytes, size_t field_bytes) {
+  return (which == MI_F_HIST || which == MI_F_ITER_CYCLES) && bytes > 0 && bytes < field_bytes && bytes % 32 == 0;
+}
+
 bool is_state_field(int which) {
   return which == MI_F_X_BAR || which == MI_F_K || which == MI_F_KAPPA || which == MI_F_DV || which == MI_F_FX || which == MI_F_FU;
 }
@@ -730,7 +738,19 @@ int mi_ilqr_create(const mi_ilqr_desc* desc, mi_ilqr_t** out) {
     // trial buffers simply searches one candidate at a time (make_args: spec_policy = 0 without them)
     // (batches small enough for clusters: 31 slots - the candidates 1 .. 31 of a first pass that the leader and up to seven helper
     //  workgroups roll out together, ilqr_large.hpp: candidate groups)
-    h->spec_slots = B <= 64 ? 31 : 3;
+    // ... as many as the cluster size make_args will pick asks for: 4 g - 1 (15 at B = 64 on 256 CUs), 3 when the launch will not be
+    // clustered - plugin models unless MI_ILQR_CLUSTER forces it, batches beyond 64, fewer than two CUs per problem.  (Round 5
+    // allocated 31 for every batch up to 64: 1 GB of HBM for nothing on an n = 32, N = 2000 plugin.)
+    {
+      int cus = 0;
+      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, desc->device_id);
+      const char* fe = std::getenv("MI_ILQR_CLUSTER");
+      const int forced = fe ? std::atoi(fe) : 0;
+      int g = forced > 0 ? forced : (cus > 0 ? cus / B : 1);
+      if (forced <= 0 && (plugin_of(desc->model_id) || B > 64)) g = 1;
+      if (g > 8) g = 8;
+      h->spec_slots = g > 1 ? 4 * g - 1 : 3;
+    }
     for (;;) {
       const size_t xb = (size_t)h->spec_slots * B * n * N * sizeof(double), ub = (size_t)h->spec_slots * B * m * (N - 1) * sizeof(double);
       if (hipMalloc(reinterpret_cast<void**>(&h->x_spec), xb) == hipSuccess && hipMalloc(reinterpret_cast<void**>(&h->u_spec), ub) == hipSuccess) break;
@@ -1015,7 +1035,11 @@ int mi_ilqr_solve_into(mi_ilqr_t* h, double* x_bar, double* u_bar, double* cost,
     return h->host_records + (static_cast<const char*>(field_of(h, w).ptr) - h->host_records_dev);
   };
   for (int i = 0; i < n_extra; ++i) {
-    if (host_side(which[i])) { if (bytes[i] != field_of(h, which[i]).bytes) { clear(); return MI_ILQR_E_BAD_SHAPE; } continue; }
+    if (host_side(which[i])) {
+      const size_t fb = field_of(h, which[i]).bytes;
+      if (bytes[i] != fb && !prefix_ok(which[i], bytes[i], fb)) { clear(); return MI_ILQR_E_BAD_SHAPE; }
+      continue;
+    }
     if ((rc = mi_ilqr_get_async(h, which[i], dst[i], bytes[i])) != MI_ILQR_OK) { clear(); return rc; }
   }
   rc = stats ? mi_ilqr_collect_stats_n(h, 1, stats) : mi_ilqr_synchronize(h);
@@ -1277,7 +1301,7 @@ int mi_ilqr_get(mi_ilqr_t* h, int which, double* dst, size_t bytes) {
   if (!h || !dst) return MI_ILQR_E_BAD_ARG;
   Field f = field_of(h, which);
   if (!f.ptr || f.is_int) return MI_ILQR_E_BAD_ARG;
-  if (bytes != f.bytes) return MI_ILQR_E_BAD_SHAPE;
+  if (bytes != f.bytes && !prefix_ok(which, bytes, f.bytes)) return MI_ILQR_E_BAD_SHAPE;
   HIPCHK(hipSetDevice(h->d.device_id));
   HIPCHK(hipStreamSynchronize(h->stream));
   if (h->cold && is_state_field(which)) { std::memset(dst, 0, bytes); return MI_ILQR_OK; }
@@ -1301,7 +1325,7 @@ int mi_ilqr_get_async(mi_ilqr_t* h, int which, void* dst, size_t bytes) {
   if (!h || !dst) return MI_ILQR_E_BAD_ARG;
   Field f = field_of(h, which);
   if (!f.ptr) return MI_ILQR_E_BAD_ARG;
-  if (bytes != f.bytes) return MI_ILQR_E_BAD_SHAPE;
+  if (bytes != f.bytes && !prefix_ok(which, bytes, f.bytes)) return MI_ILQR_E_BAD_SHAPE;
   HIPCHK(hipSetDevice(h->d.device_id));
   if (!f.is_int) {
     int len = 0;
@@ -1318,6 +1342,15 @@ int mi_ilqr_get_async(mi_ilqr_t* h, int which, void* dst, size_t bytes) {
 
 int mi_ilqr_get_int(mi_ilqr_t* h, int which, int32_t* dst, size_t bytes) {
   if (!h || !dst) return MI_ILQR_E_BAD_ARG;
+  if (which == MI_I64_CLUSTER_WORDS && (!h->cluster_sync || !h->last_clustered)) {
+    // the header's promise: zeros when the last solve / MPC launch was not clustered (the device words would be an older launch's),
+    // and for handles of the other kernel families, which have no such words
+    if (bytes != (size_t)h->B * MI_ILQR_CLUSTER_WORDS * 8) return MI_ILQR_E_BAD_SHAPE;
+    HIPCHK(hipSetDevice(h->d.device_id));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    std::memset(dst, 0, bytes);
+    return MI_ILQR_OK;
+  }
   Field f = field_of(h, which);
   if (!f.ptr || !f.is_int) return MI_ILQR_E_BAD_ARG;
   if (bytes != f.bytes) return MI_ILQR_E_BAD_SHAPE;
@@ -1405,6 +1438,8 @@ struct RcclApi {
   int (*GetUniqueId)(UniqueId*) = nullptr;
   int (*CommInitRank)(void**, int, UniqueId, int) = nullptr;
   int (*CommDestroy)(void*) = nullptr;
+  int (*CommCount)(void*, int*) = nullptr;
+  int (*CommUserRank)(void*, int*) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
   bool ok = false;
@@ -1428,6 +1463,8 @@ const RcclApi& rccl() {
     a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
     a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
     a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(dlsym(lib, "ncclAllReduce"));
+    a.CommCount = reinterpret_cast<decltype(a.CommCount)>(dlsym(lib, "ncclCommCount"));
+    a.CommUserRank = reinterpret_cast<decltype(a.CommUserRank)>(dlsym(lib, "ncclCommUserRank"));
     a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
     a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllReduce;
     return a;
@@ -1505,6 +1542,18 @@ void mi_ilqr_comm_destroy(mi_ilqr_comm_t* c) {
   if (c->done) (void)hipEventDestroy(c->done);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
+}
+
+int mi_ilqr_comm_count(mi_ilqr_comm_t* c, int32_t* ranks, int32_t* rank) {
+  // what the COMMUNICATOR says (ncclCommCount / ncclCommUserRank), not what the caller passed to mi_ilqr_comm_create
+  if (!c || !c->comm || !ranks) return MI_ILQR_E_BAD_ARG;
+  if (!rccl().CommCount) return MI_ILQR_E_RCCL;
+  int n = 0, r = -1;
+  RCCLCHK(rccl().CommCount(c->comm, &n));
+  if (rank && rccl().CommUserRank) RCCLCHK(rccl().CommUserRank(c->comm, &r));
+  *ranks = n;
+  if (rank) *rank = r;
+  return MI_ILQR_OK;
 }
 
 int mi_ilqr_allreduce_min_start(mi_ilqr_comm_t* c, const double* values, int32_t count) {

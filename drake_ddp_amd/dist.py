@@ -125,14 +125,18 @@ class NativeComm:
         self._capi, self._C = _capi, C
         self._lib = _capi.load()
         ident = None
+        if world > 1 and exchange is None:
+            raise ValueError("world > 1 needs an `exchange` callable to ship the communicator id")
         if rank == 0:
             buf = (C.c_char * _capi.COMM_ID_BYTES)()
-            _capi.check(self._lib.mi_ilqr_comm_unique_id(buf), "mi_ilqr_comm_unique_id")
-            ident = bytes(buf.raw)
+            rc = self._lib.mi_ilqr_comm_unique_id(buf)
+            # (a failure here still goes through the exchange - as an empty id - so that the other ranks, which are waiting in it,
+            #  fail with this rank instead of hanging)
+            ident = bytes(buf.raw) if rc == _capi.OK else b""
         if world > 1:
-            if exchange is None:
-                raise ValueError("world > 1 needs an `exchange` callable to ship the communicator id")
             ident = exchange(ident)
+        if not ident:
+            raise RuntimeError("mi_ilqr_comm_unique_id failed on rank 0 (librccl not loadable?)")
         h = C.c_void_p()
         idbuf = C.create_string_buffer(ident, _capi.COMM_ID_BYTES)
         _capi.check(self._lib.mi_ilqr_comm_create(idbuf, int(rank), int(world), int(device_id), C.byref(h)), "mi_ilqr_comm_create")
@@ -157,6 +161,13 @@ class NativeComm:
         h, self._h = getattr(self, "_h", None), None
         if h:
             self._lib.mi_ilqr_comm_destroy(h)
+
+    def count(self):
+        """(ranks, this rank) as the COMMUNICATOR reports them (ncclCommCount / ncclCommUserRank)."""
+        C = self._C
+        n, r = C.c_int32(), C.c_int32()
+        self._capi.check(self._lib.mi_ilqr_comm_count(self._h, C.byref(n), C.byref(r)), "mi_ilqr_comm_count")
+        return int(n.value), int(r.value)
 
     def allreduce_min(self, values):
         v = np.ascontiguousarray(values, dtype=np.float64).copy()

@@ -307,7 +307,7 @@ class BatchedIterativeLQR:
         linearize the line search's first trial while it is rolled out), early rounds whose trial was accepted, candidate-group rounds
         (mid-size kernels: the helpers roll out line-search candidates 4 .. beside the leader's four) - (B,6) int64;
         zeros when the launch was not clustered (mi_ilqr.h: MI_I64_CLUSTER_WORDS)."""
-        w = np.empty((self.B, 40), dtype=np.uint64)
+        w = np.empty((self.B, _capi.CLUSTER_WORDS), dtype=np.uint64)
         _capi.check(self._lib.mi_ilqr_get_int(self._h, _capi.I64_CLUSTER_WORDS, _capi.ptr(w), w.nbytes), "mi_ilqr_get_int")
         u = np.uint64
         ea_open, ea_hit, groups = w[:, 5] >> u(32), w[:, 5] & u(0xffffffff), w[:, 7]
@@ -335,6 +335,10 @@ class BatchedIterativeLQR:
         if stats is not None and stats.n_internal > 0:
             raise RuntimeError(f"{stats.n_internal} problem(s) aborted inside the device kernel (status {_capi.STATUS_INTERNAL}); "
                                "their results are not a solution")
+        if stats is not None and stats.n_max_iters > 0:
+            # (the reference's loop has no cap, ilqr.py:692: a problem stopped by this class's `max_iters` is not a converged one)
+            warnings.warn(f"{stats.n_max_iters} of {self.B} problem(s) stopped at max_iters = {int(self._desc.max_iters)} with the improvement "
+                          f"still above delta (status {_capi.STATUS_MAX_ITERS}): not converged", RuntimeWarning, stacklevel=3)
         if stats is not None and stats.n_not_pd > 0:
             how = ("stopped there (status %d): their gains are not to be used" % _capi.STATUS_NOT_PD if self.on_indefinite == "stop"
                    else "inverted it like the reference's np.linalg.inv (ilqr.py:655) and carried on (status flag %d)" % _capi.STATUS_FLAG_INDEFINITE)
@@ -493,7 +497,14 @@ class IterativeLinearQuadraticRegulator(BatchedIterativeLQR):
         # the reference inverts every Quu with np.linalg.inv and never looks at its definiteness (ilqr.py:655): so does the drop-in.
         # `status` then carries STATUS_FLAG_INDEFINITE; on_indefinite="stop" raises RuntimeError at the first such Quu instead.
         device_options.setdefault("on_indefinite", "continue")
-        hc = int(device_options.get("hist_cap", 64))
+        # The reference's loop has no iteration cap (`while improvement > delta`, ilqr.py:692) and prints a row per iteration
+        # (:704): so does the drop-in - no cap unless the caller gives `max_iters` (a solve that then runs into it RAISES: it is
+        # not a converged one), and a log of 4096 rows (128 KB; `hist_cap`), of which the first 64 ride with the solve and the
+        # rest is fetched only after a solve that took more iterations (cart_pole.py's problem takes 108).
+        self._capped = "max_iters" in device_options
+        device_options.setdefault("max_iters", 2 ** 31 - 1)
+        device_options.setdefault("hist_cap", 4096)
+        hc = min(int(device_options["hist_cap"]), self._LOG_ROWS_WITH_SOLVE)
         # what Solve() copies out behind the solve besides x_bar / u_bar / cost (field, shape, dtype)
         self._single_extra = ((_capi.I_ITERS, (1,), np.int32), (_capi.I_STATUS, (1,), np.int32), (_capi.F_HIST, (1, hc, 4), np.float64),
                               (_capi.F_ITER_CYCLES, (1, hc, 4), np.float64), (_capi.I64_STAGE_CYCLES, (1, 4), np.int64))
@@ -501,9 +512,17 @@ class IterativeLinearQuadraticRegulator(BatchedIterativeLQR):
                          gamma=gamma, derivs_keypoint_method=derivs_keypoint_method, **device_options)
         self.x0 = np.zeros(self.n)
 
+    _LOG_ROWS_WITH_SOLVE = 64
+
     def SetInitialGuess(self, u_guess):
         assert u_guess.shape == (self.m, self.N - 1)          # ilqr.py:155
         self._u_guess = u_guess
+
+    def _log_rows(self, which, rows):
+        """The leading `rows` rows of a per-iteration record of the last solve (mi_ilqr.h: partial reads of MI_F_HIST / MI_F_ITER_CYCLES)."""
+        out = np.empty((rows, 4), dtype=np.float64)
+        _capi.check(self._lib.mi_ilqr_get(self._h, which, _capi.ptr(out), out.nbytes), "mi_ilqr_get")
+        return out
 
     x_bar = property(lambda s: s._get(_capi.F_X_BAR, (s.n, s.N)))
     u_bar = property(lambda s: s._get(_capi.F_U_BAR, (s.m, s.N - 1)))
@@ -532,7 +551,9 @@ class IterativeLinearQuadraticRegulator(BatchedIterativeLQR):
             stats = _capi.Stats()
             _capi.check(self._lib.mi_ilqr_solve(self._h, C.byref(stats)), "mi_ilqr_solve")
             self.stats = stats
-            iters, status, hist, iter_cyc = int(self.iterations[0]), int(self.status[0]), self.history[0], self.iteration_cycles[0]
+            iters, status = int(self.iterations[0]), int(self.status[0])
+            r0 = max(1, min(iters, self.hist_cap))
+            hist, iter_cyc = self._log_rows(_capi.F_HIST, r0), self._log_rows(_capi.F_ITER_CYCLES, r0)
             loop_cycles = float(self.stage_cycles[0, 3])
         total_time = time.time() - st
         self.solve_wall_s = total_time
@@ -540,6 +561,8 @@ class IterativeLinearQuadraticRegulator(BatchedIterativeLQR):
         # cycles of the whole solve loop (stage_cycles[3]) span the kernel's HIP-event time
         sec_per_cycle = stats.kernel_ms * 1e-3 / max(loop_cycles, 1.0)
         rows = min(iters, self.hist_cap)
+        if rows > len(hist):                                          # a long solve: the rest of the log (the reference prints every row, ilqr.py:704)
+            hist, iter_cyc = self._log_rows(_capi.F_HIST, rows), self._log_rows(_capi.F_ITER_CYCLES, rows)
         t_iter = iter_cyc[:rows] * sec_per_cycle                      # columns: fp (line search), derivs, bp, iteration
         if rows:                                                      # like the reference: the LAST iteration's stopwatches
             self.time_fp, self.time_getDerivs, self.time_backwardsPass = (float(v) for v in t_iter[-1, :3])
@@ -555,6 +578,8 @@ class IterativeLinearQuadraticRegulator(BatchedIterativeLQR):
                 elapsed += t_it
                 print(f"{i + 1:^14}{L_new:11.4f}  {eps:^12.4f}{int(ls):^11}   {t_derivs:1.5f}         {pct:.1f}       "
                       f"{t_bp:1.5f}    {t_fp:1.5f}      {t_it:1.5f}          {elapsed:4.2f}")
+            if iters > rows:
+                print(f"note: iterations {rows + 1} .. {iters} are not in the log (hist_cap = {self.hist_cap} rows)")
         self.met_indefinite_quu = bool(status & _capi.STATUS_FLAG_INDEFINITE)
         status &= ~_capi.STATUS_FLAG_INDEFINITE
         if self.met_indefinite_quu and self.verbose:
@@ -569,6 +594,10 @@ class IterativeLinearQuadraticRegulator(BatchedIterativeLQR):
             raise RuntimeError("linesearch failed after %s iterations" % n_trials)
         if status == _capi.STATUS_INTERNAL:
             raise RuntimeError("solve aborted inside the device kernel (cluster hand-shake lost); results are not a solution")
+        if status == _capi.STATUS_MAX_ITERS:
+            # the reference has no cap (ilqr.py:692): what a capped solve returns is NOT what the reference would have returned
+            raise RuntimeError(f"no convergence after max_iters = {int(self._desc.max_iters)} iterations (improvement still above delta = {self.delta}); "
+                               "the state attributes hold the last iterate")
         if status == _capi.STATUS_NOT_PD:
             raise RuntimeError("Quu is not positive definite in the backward pass (indefinite cost expansion, or round-off) and "
                                "on_indefinite=\"stop\" was asked for; the default, \"continue\", inverts it like the reference (ilqr.py:655)")

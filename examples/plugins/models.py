@@ -117,8 +117,9 @@ def build_chainx(nq, m, ne=0, verbose=False):
     return plugin.build_model(*chainx_spec(nq, m, ne), verbose=verbose)
 
 
-# the shapes the tests and __graft_entry__.build() use: (nq, m, ne) -> (n, m) = (12, 4), (14, 7), (27, 7), (32, 16), (9, 4), (7, 3), (16, 1)
-CHAINX_SHAPES = [(6, 4, 0), (7, 7, 0), (10, 7, 7), (16, 16, 0), (4, 4, 1), (3, 3, 1), (8, 1, 0)]
+# the shapes the tests and __graft_entry__.build() use: (nq, m, ne) -> (n, m) = (12, 4), (14, 7), (27, 7), (32, 16), (9, 4), (7, 3), (16, 1),
+# (4, 1) - the last one a chain whose step is a few hundred cycles: the fast-step case of the cluster hand-shake's tests
+CHAINX_SHAPES = [(6, 4, 0), (7, 7, 0), (10, 7, 7), (16, 16, 0), (4, 4, 1), (3, 3, 1), (8, 1, 0), (2, 1, 0)]
 
 
 # n > 32 with a number of controls that is not a multiple of 4: the plugin pads the device model's controls (plugin.device_controls),

@@ -32,10 +32,12 @@
 extern "C" {
 #endif
 
-#define MI_ILQR_ABI_VERSION 8   /* 7: mi_ilqr_desc.on_indefinite, mi_ilqr_model_plugin.m_user, 256 plugin slots;
+#define MI_ILQR_ABI_VERSION 9   /* 9: mi_ilqr_comm_count; partial reads of MI_F_HIST / MI_F_ITER_CYCLES; MI_I64_CLUSTER_WORDS reads as zeros where no cluster ran;
+                                   7: mi_ilqr_desc.on_indefinite, mi_ilqr_model_plugin.m_user, 256 plugin slots;
                                    8: MI_STATUS_FLAG_INDEFINITE, on_indefinite = 1 inverts with partial pivoting, asymmetric costs for n <= 32,
                                       the diagnostic field MI_I64_CLUSTER_WORDS */
 #define MI_ILQR_MAX_PARAMS 16
+#define MI_ILQR_CLUSTER_WORDS 40 /* 64-bit words per problem of the diagnostic field MI_I64_CLUSTER_WORDS */
 
 /* Error codes (0 = OK).  The Python wrapper maps them onto the exception types
  * the reference raises (SURVEY.md §8b "Error convention"). */
@@ -124,8 +126,9 @@ enum {
   MI_I_KP_COUNT = 103,  /* (B,) key-points used by the last linearization               */
   MI_I_KP_LIST = 104,   /* (B,N-1) the key-point indices, first KP_COUNT valid          */
   MI_I64_STAGE_CYCLES = 200, /* (B,4) int64: what mi_ilqr_get_cycles returns - here so that mi_ilqr_get_async can queue it behind a solve */
-  MI_I64_CLUSTER_WORDS = 201 /* (B,40) uint64, workgroup-per-problem kernels only (mi_ilqr_get_int / _get_async; diagnostic): the handshake
-                                words of the last launch that shared its linearizations among a cluster of workgroups - [1] helper shares
+  MI_I64_CLUSTER_WORDS = 201 /* (B,MI_ILQR_CLUSTER_WORDS) uint64 (mi_ilqr_get_int; diagnostic): the handshake words of the last solve / MPC launch
+                                when it shared its linearizations among clusters of workgroups (workgroup-per-problem kernels) - zeros when it
+                                did not, and for handles of the other kernel families - [1] helper shares
                                 finished, [2] & 0xffff helpers that took part, [2] >> (16 + 6 x) & 63 how many of them ran on XCD x,
                                 [3] >> 32 rounds (regular + early), [3] >> 8 & 0xffffff rounds that found every helper on the leader's
                                 own XCD (one L2: no cache-wide invalidate), [4] progress word of the last early round, [5] >> 32 early
@@ -311,7 +314,10 @@ int mi_ilqr_mpc_shift(mi_ilqr_t* h, int32_t replan_steps);
 int mi_ilqr_mpc_run(mi_ilqr_t* h, int32_t num_resolves, int32_t replan_steps, const double* target_step, mi_ilqr_stats* stats);
 int mi_ilqr_get_mpc_log(mi_ilqr_t* h, double* dst, size_t bytes);
 
-/* Copy a field out / in (host memory; `bytes` must equal the field size). */
+/* Copy a field out / in (host memory; `bytes` must equal the field size - except that the per-iteration records MI_F_HIST and
+ * MI_F_ITER_CYCLES may be read in part: `bytes` = any whole number of 32-byte rows < the field size returns the LEADING rows of
+ * the first problem, also through mi_ilqr_get_async and mi_ilqr_solve_into; the drop-in class keeps a 4096-row log and copies 64
+ * rows with the solve, the rest only after a solve that took more iterations - the reference's table has every row, ilqr.py:704). */
 int mi_ilqr_get(mi_ilqr_t* h, int which, double* dst, size_t bytes);
 int mi_ilqr_get_int(mi_ilqr_t* h, int which, int32_t* dst, size_t bytes);
 int mi_ilqr_set(mi_ilqr_t* h, int which, const double* src, size_t bytes);
@@ -366,6 +372,9 @@ typedef struct mi_ilqr_comm mi_ilqr_comm_t;
 int mi_ilqr_comm_unique_id(void* id_bytes);
 int mi_ilqr_comm_create(const void* id_bytes, int32_t rank, int32_t world, int32_t device_id, mi_ilqr_comm_t** out);
 void mi_ilqr_comm_destroy(mi_ilqr_comm_t* c);
+/* The communicator's own answer (ncclCommCount, ncclCommUserRank): how many ranks it spans and which one this is - what a
+ * multi-GPU bench line reports so that a scaling record can be checked from the line alone (ABI 9).  `rank` may be NULL. */
+int mi_ilqr_comm_count(mi_ilqr_comm_t* c, int32_t* ranks, int32_t* rank);
 int mi_ilqr_allreduce_min(mi_ilqr_comm_t* c, double* values, int32_t count);
 int mi_ilqr_allreduce_min_start(mi_ilqr_comm_t* c, const double* values, int32_t count);
 int mi_ilqr_allreduce_min_wait(mi_ilqr_comm_t* c, double* values, int32_t count);

@@ -104,6 +104,16 @@ def test_bench_sharded_configs_do_exactly_the_whole_batchs_work(world):
     d = _json_line(r.stdout)
     assert d["n_gpus"] == world and d["scaling"] == "weak" and d["config"]["global_batch"] == 1024 * world
     assert d["config"]["parallelism"] == f"batch-shard x{world}" and "all_reduce(MIN)" in d["config"]["collective"]
+    # round 6: the N > 1 line checks itself - the communicator's rank count, every rank's own iteration sum, the strong-scaling
+    # figure (C2's 1024 problems sharded over the ranks) beside the weak one, and why the library's own communicator was not
+    # used (gloo ranks share this box's one GPU; on the driver's node it is, after a self-check)
+    assert d["communicator_ranks"] == world and "share a device" in d["config"]["collective_fallback_reason"]
+    ipr = d["iterations_per_rank"]
+    assert len(ipr) == world and all(v > 0 for v in ipr) and abs(sum(ipr) - d["value"] * d["ms_per_step"] * 1e-3 * d["steps"]) < 1e-6 * sum(ipr)
+    sg = d["strong_scaling"]
+    assert d["value_strong"] == sg["value"] > 0 and sg["global_batch"] == 1024 and len(sg["iterations_per_rank"]) == world
+    # the shards of the single-GPU run's own batch do exactly its work: K steps x the single-rank run's iterations per step
+    assert abs(sum(sg["iterations_per_rank"]) - d["steps"] * one["iterations_per_step_rank0"]) < 0.5
     ref = {c["name"]: c for c in one["configs"]}
     names = [c["name"] for c in d["configs"]]
     assert [n[:3].strip() for n in names] == ["C1", "C3", "C4", "C5", "C5q", "C5q", "C6", "C6b"], names     # (the B = 8 shard line is a 1-rank entry)

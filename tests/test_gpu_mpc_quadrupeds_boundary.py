@@ -557,7 +557,8 @@ def test_per_iteration_stopwatches_and_console_table(capsys):
 
 @pytest.mark.parametrize("cfg,B,forced", [("quad", 8, None), ("synth36", 8, None), ("quad", 64, "8"), ("quad", 3, "5"),
                                           ("quad3d", 8, None), ("quad3d", 64, None), ("quad3d", 5, "3"),
-                                          ("arm27", 1, None), ("arm27", 48, None), ("arm27", 7, "3"), ("chainx", 5, "4")])
+                                          ("arm27", 1, None), ("arm27", 48, None), ("arm27", 7, "3"), ("chainx", 5, "4"),
+                                          ("chainx4", 6, "4"), ("chainx4", 3, "8")])
 def test_cluster_linearization_is_bitwise_the_single_workgroup_one(cfg, B, forced, tmp_path):
     """With few problems per GPU the linearization of ONE problem is shared by a cluster of workgroups (leader +
     helpers, handshake through global memory, ilqr_large.hpp).  Every Jacobian entry is still computed by the
@@ -565,7 +566,11 @@ def test_cluster_linearization_is_bitwise_the_single_workgroup_one(cfg, B, force
     problem returns (MI_ILQR_CLUSTER=1) - including when the launch is oversubscribed (512 workgroups on 256 CUs:
     helpers that are not resident are never waited for) and for cluster sizes that do not divide anything.  Since round 4
     the dense (whole-step) linearization of the mid-size models is shared the same way: the arm + ball (by default up to
-    B = 64) and a plugin chain (forced: plugins are not clustered by default - the library cannot know what their step costs)."""
+    B = 64) and a plugin chain (forced: plugins are not clustered by default - the library cannot know what their step costs).
+    Round 6: `chainx4` is a (4, 1) chain, N = 24, whose step takes a few hundred cycles and whose whole trajectory, Jacobians and
+    gains fit the vector L1 several times over - the shape on which round 5's hand-shake handed out stale data twice (its
+    `buffer_inv sc0` drops nothing, tools/ubench/l1_probe.hip); early rounds now run on plugin models too, and with the cluster
+    spread over XCDs (`order0`)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -583,17 +588,18 @@ elif {cfg!r} == 'quad3d':
 elif {cfg!r} == 'arm27':
     prob, x0, ug = W.arm27_problem(), W.arm27_batch_x0(64)[:{B}], W.arm27_u_guess(50)
     step = np.zeros(27); step[12] = 0.002
-elif {cfg!r} == 'chainx':
+elif {cfg!r}.startswith('chainx'):
     sys.path.insert(0, {os.path.join(root, 'examples', 'plugins')!r})
     import models as PM
     from drake_ddp_amd.ilqr import BatchedIterativeLQR
-    n, m, N, dt = 14, 7, 30, 0.02
+    nq, m, N, dt = (7, 7, 30, 0.02) if {cfg!r} == 'chainx' else (2, 1, 24, 0.02)
+    n = 2 * nq
     step = np.zeros(n); step[0] = 0.01
 else:
     prob, x0, ug = W.synth36_problem(), W.synth36_batch_x0(64)[:{B}], W.synth36_u_guess(40)
     step = np.zeros(36); step[0] = W.SYNTH_TARGET_VEL * prob['dt'] * 4
-if {cfg!r} == 'chainx':
-    s = BatchedIterativeLQR(PM.build_chainx(7, 7, 0)(dt), N, {B}, delta=1e-3, beta=0.7, jacobian_mode='fd')
+if {cfg!r}.startswith('chainx'):
+    s = BatchedIterativeLQR(PM.build_chainx(nq, m, 0)(dt), N, {B}, delta=1e-3, beta=0.7, jacobian_mode='fd')
     s.SetTargetState(np.zeros(n)); s.SetRunningCost(dt * np.eye(n), dt * 0.05 * np.eye(m)); s.SetTerminalCost(5.0 * np.eye(n))
     x0, ug = 0.4 * np.random.default_rng(2).standard_normal(({B}, n)), np.zeros((m, N - 1))
 else:
@@ -607,9 +613,10 @@ np.savez(sys.argv[1], x=x, u=u, L=L, fx0=fx0, it0=it0, log=s.mpc_log, xm=s.x_bar
 """
     # Round 5: the default launch places a cluster on ONE XCD and lets the helpers linearize the line search's first trial while the
     # leader is still rolling it out (early linearization); the variants switch that off, put the members in consecutive slots of
-    # the XCD, or spread them over XCDs like rounds 2 - 4 did (where no early round may open: another L2 could hold a stale line).
+    # the XCD, or spread them over XCDs like rounds 2 - 4 did (round 6: early rounds and candidate groups open there too - the
+    # hand-shake no longer depends on the placement).
     variants = [("cluster", {}), ("single", {"MI_ILQR_CLUSTER": "1"})]
-    if (cfg, B) in (("quad", 8), ("quad3d", 64), ("arm27", 48), ("synth36", 8), ("quad3d", 5)):
+    if (cfg, B) in (("quad", 8), ("quad3d", 64), ("arm27", 48), ("synth36", 8), ("quad3d", 5), ("chainx4", 6), ("chainx4", 3), ("chainx", 5)):
         variants += [("early0", {"MI_ILQR_EARLY": "0"}), ("order0", {"MI_ILQR_CLUSTER_ORDER": "0"}), ("order1", {"MI_ILQR_CLUSTER_ORDER": "1"})]
     if cfg == "arm27":       # mid-size kernels: the helpers also roll out line-search candidates 4 .. beside the leader's four (candidate groups)
         variants += [("groups0", {"MI_ILQR_LS_GROUPS": "0"})]
@@ -632,11 +639,8 @@ np.savez(sys.argv[1], x=x, u=u, L=L, fx0=fx0, it0=it0, log=s.mpc_log, xm=s.x_bar
     resident = cs[:, 0] > 0                                  # (oversubscribed launches: a problem's helpers may never have been resident)
     if resident.any():
         c = cs[resident]
-        assert (c[:, 2] == c[:, 1] + c[:, 4]).all()          # every round that used the helpers' Jacobians found the whole cluster on one XCD
-        if cfg == "chainx":
-            assert c[:, 3].sum() == 0 and c[:, 1].sum() > 0                  # plugin models: regular rounds only (the early rounds' progress word is timed for the built-in models' steps)
-        else:
-            assert c[:, 3].sum() > 0 and c[:, 4].sum() > 0.5 * c[:, 3].sum()      # early rounds ran, and mostly hit
+        assert (c[:, 2] == c[:, 1] + c[:, 4]).all()          # every round that used the helpers' Jacobians found the whole cluster on one XCD (a speed matter only, since round 6)
+        assert c[:, 3].sum() > 0 and c[:, 4].sum() > 0.5 * c[:, 3].sum()      # early rounds ran - on the plugin chains too - and mostly hit
         print(cfg, B, "helpers", c[:, 0].min(), "-", c[:, 0].max(), "regular rounds", c[:, 1].sum(), "early opened / accepted", c[:, 3].sum(), c[:, 4].sum())
     if cfg == "arm27":
         # candidate groups: in the cold solve (48 problems: some backtrack) - not in the receding-horizon loop, whose target MOVES
@@ -645,7 +649,8 @@ np.savez(sys.argv[1], x=x, u=u, L=L, fx0=fx0, it0=it0, log=s.mpc_log, xm=s.x_bar
         if B == 48: assert outs["cluster"]["cs0"][:, 5].sum() > 0
         print("candidate-group rounds of the cold solve", outs["cluster"]["cs0"][:, 5].sum())
     if "order0" in outs:
-        assert (outs["order0"]["cs"][:, 3] == 0).all() and (outs["order0"]["cs"][:, 2] == 0).all() and outs["order0"]["cs"][:, 1].sum() > 0
+        o0 = outs["order0"]["cs"]
+        assert (o0[:, 2] == 0).all() and o0[:, 3].sum() > 0 and o0[:, 4].sum() > 0      # no cluster on one XCD - and early rounds all the same
         assert (outs["early0"]["cs"][:, 3] == 0).all() and outs["early0"]["cs"][:, 1].sum() > 0
 
 
@@ -932,3 +937,19 @@ def test_staged_inputs_survive_the_ring_wrapping_and_back_to_back_setters():
     t.Reset(); t.SetInitialState(base + 0.04); t.SetInitialGuess(ug + 0.004)
     xr, ur, _, Lr = t.Solve()
     assert np.array_equal(x, xr) and np.array_equal(u, ur) and np.array_equal(L, Lr)
+
+
+def test_cluster_words_read_as_zeros_where_no_cluster_ran():
+    """mi_ilqr.h, MI_I64_CLUSTER_WORDS: zeros for a handle of the wave-per-problem kernels (it has no such words; until round 6 the
+    call failed with BAD_ARG there) and for a workgroup-per-problem launch that was not clustered (B = 300 on 256 CUs)."""
+    from drake_ddp_amd import workloads as W
+    a = W.acrobot_problem()
+    s = make_solver(a, B=4, jac="fd")
+    s.SetInitialState(W.acrobot_batch_x0(4)); s.SetInitialGuess(np.zeros((1, a["N"] - 1)))
+    s.Solve()
+    assert s.cluster_stats.shape == (4, 6) and (s.cluster_stats == 0).all()
+    q = W.synth36_problem()
+    s = make_solver(dict(q, N=8), B=300, jac="fd")
+    s.SetInitialState(np.tile(W.synth36_batch_x0(64), (5, 1))[:300]); s.SetInitialGuess(W.synth36_u_guess(8))
+    s.Solve()
+    assert (s.cluster_stats == 0).all()
