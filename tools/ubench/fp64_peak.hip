@@ -12,6 +12,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 __global__ void __launch_bounds__(256) valu(double* sink, long long* clk, int iters, double y) {
   double x0 = threadIdx.x * 1e-3, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7;
   const long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+#pragma unroll 4
   for (int i = 0; i < iters; ++i) {
     x0 = __builtin_fma(x0, y, 1e-9); x1 = __builtin_fma(x1, y, 1e-9); x2 = __builtin_fma(x2, y, 1e-9); x3 = __builtin_fma(x3, y, 1e-9);
     x4 = __builtin_fma(x4, y, 1e-9); x5 = __builtin_fma(x5, y, 1e-9); x6 = __builtin_fma(x6, y, 1e-9); x7 = __builtin_fma(x7, y, 1e-9);
@@ -41,11 +42,11 @@ int main(int argc, char** argv) {
   hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
   const int cus = p.multiProcessorCount;
   double* sink; long long* clk;
-  hipMalloc(&sink, 8); hipMalloc(&clk, 2 * 8 * cus * 8 * sizeof(long long));
+  hipMalloc(&sink, 8); hipMalloc(&clk, 2 * 8 * cus * 8 * sizeof(long long));   // (room for 8 workgroups per CU)
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   double best_valu = 0, best_mfma = 0, mhz_valu = 0, mhz_mfma = 0; int wv = 0, wm = 0;
   for (int kind = 0; kind < 2; ++kind)
-    for (int wgs_per_cu : {1, 2, 4}) {              // 256 threads = one wave per SIMD per workgroup
+    for (int wgs_per_cu : {1, 2, 4, 8}) {              // 256 threads = one wave per SIMD per workgroup
       const int blocks = cus * wgs_per_cu, iters = kind == 0 ? 40000 : 6000;
       float ms = 0;
       for (int rep = 0; rep < 4; ++rep) {           // the last repetition counts: the clock has ramped by then
