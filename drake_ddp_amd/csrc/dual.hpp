@@ -77,8 +77,22 @@ __device__ inline Dual2 mi_rcp(Dual2 a) { const double r = fast_rcp(a.v), q = -(
 
 // log(1+exp(z)) = max(z,0) + log1p(exp(-|z|)), overflow-safe and branch-free; same value as the
 // two-branch form of oracle/dual.py:softplus.  d/dz = logistic(z).
+// MI_SOFTPLUS_SKIP (round 6): once t = exp(-|z|) < 2^-53, fast_log1p01(t) returns t itself, bit for bit (f = t, 2 + f rounds to 2,
+// its reciprocal is exactly 0.5, s = t / 2, and the series term s w R ~ t^3 / 12 is below half an ulp of 2 s = t), so a wave whose
+// every lane is that far from the contact leaves the logarithm - a third of the step's dependency chain - out: one compare
+// and a scalar branch; the same bits either way.  (Branch per wave, not per lane: lanes in contact keep everybody on the long path.)
+// MEASURED, and OFF by default: in the one-wave microbenchmark the step gets 7 - 11 % shorter (tools/ubench/chain_step.hip: 715 -> 666 /
+// 635 cycles), inside the fused solve kernel it gets 12 % LONGER (same-box A/B, profiles/r06_c4_ab.txt: C4's line search 178.6 k ->
+// 201.1 k cycles per iteration) - the branch splits the rollout loop's body, both arms stay resident, and the loop that held its
+// values in 293 instructions without a register move now carries 36 v_accvgpr moves in 352 (tools/isa_mix.py).
+#ifndef MI_SOFTPLUS_SKIP
+#define MI_SOFTPLUS_SKIP 0
+#endif
 __device__ inline double mi_softplus(double z, const SoftplusPool& c) {
   const double t = fast_exp_nonpos(-fabs(z), c);
+#if MI_SOFTPLUS_SKIP
+  if (__builtin_amdgcn_ballot_w64(!(t < 0x1p-53)) == 0ull) return fmax(z, 0.0) + t;
+#endif
   return fmax(z, 0.0) + fast_log1p01(t, c);
 }
 __device__ inline double mi_softplus(double z) { return mi_softplus(z, SoftplusPool::literals()); }

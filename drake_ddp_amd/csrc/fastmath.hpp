@@ -36,13 +36,52 @@ constexpr double kLn2Hi = 0x1.62e42fee00000p-1, kLn2Lo = 0x1.a39ef35793c76p-33, 
                  kLn2 = 0x1.62e42fefa39efp-1, kSqrt2m1 = 0x1.a827999fcef32p-2;
 }  // namespace fm
 
+// Polynomial evaluation.  These kernels run ONE instruction stream per problem at one wave per SIMD: a dependent fp64 operation
+// waits ~8 cycles for its operand while an independent one issues every 4, so what a rollout step costs is the DEPTH of its
+// dependency chain - or so round 6 assumed, and built Estrin's scheme (MI_POLY_ESTRIN=1: the same polynomial in
+// ceil(log2(degree + 1)) + 1 levels of independent multiply-adds for two or three more multiplications) to shorten it.  MEASURED
+// (tools/ubench/chain_step.hip, one wave, dependent steps; profiles/r06_chain_step.txt): SLOWER - cart-pole + wall 715 -> 725
+// cycles per step, acrobot 670 -> 694 - and less accurate (3 ulp against Horner's 2, tools/ubench/trig_acc.hip).  The reason is
+// in tools/ubench/fp64_peak.hip's first row: ONE wave per SIMD issues an fp64 instruction every ~9.6 cycles even from eight
+// INDEPENDENT chains (13.3 of 32 flop / clk / SIMD; two waves: 23.6) - a wave's own issue interval already covers the latency a
+// dependent operation would wait for, so what a step costs at one wave per SIMD is its instruction COUNT.  Horner stays.
+#ifndef MI_POLY_ESTRIN
+#define MI_POLY_ESTRIN 0
+#endif
+// c[0] + c[1] x + ... + c[10] x^10
+template <class C>
+__device__ __forceinline__ double poly10(const C& c, double x) {
+#if MI_POLY_ESTRIN
+  const double x2 = x * x, x4 = x2 * x2, x8 = x4 * x4;
+  const double a0 = fma(c[1], x, c[0]), a1 = fma(c[3], x, c[2]), a2 = fma(c[5], x, c[4]), a3 = fma(c[7], x, c[6]), a4 = fma(c[9], x, c[8]);
+  const double b0 = fma(a1, x2, a0), b1 = fma(a3, x2, a2), b2 = fma(c[10], x2, a4);
+  return fma(b2, x8, fma(b1, x4, b0));
+#else
+  double p = c[10];
+#pragma unroll
+  for (int k = 9; k >= 0; --k) p = fma(p, x, c[k]);
+  return p;
+#endif
+}
+// c[0] + c[1] x + ... + c[7] x^7
+template <class C>
+__device__ __forceinline__ double poly7(const C& c, double x) {
+#if MI_POLY_ESTRIN
+  const double x2 = x * x, x4 = x2 * x2;
+  const double a0 = fma(c[1], x, c[0]), a1 = fma(c[3], x, c[2]), a2 = fma(c[5], x, c[4]), a3 = fma(c[7], x, c[6]);
+  return fma(fma(a3, x2, a2), x4, fma(a1, x2, a0));
+#else
+  double p = c[7];
+#pragma unroll
+  for (int k = 6; k >= 0; --k) p = fma(p, x, c[k]);
+  return p;
+#endif
+}
+
 // sin of a reduced argument |r| <= pi/2 (+ small margin)
 __device__ __forceinline__ double sin_reduced(double r) {
   const double s = r * r;
-  double p = fm::kS[10];
-#pragma unroll
-  for (int k = 9; k >= 0; --k) p = fma(p, s, fm::kS[k]);
-  return fma(r * s, p, r);
+  return fma(r * s, poly10(fm::kS, s), r);
 }
 
 // Round-to-nearest-even integer by the 1.5*2^52 trick: t = y + magic has ulp(t) = 1, so the
@@ -155,9 +194,7 @@ __device__ __forceinline__ double fast_exp_nonpos(double x, const SoftplusPool& 
   const double nd = kn.n;
   double r = fma(-nd, fm::kLn2Hi, x);
   r = fma(-nd, fm::kLn2Lo, r);
-  double p = c.E[10];
-#pragma unroll
-  for (int k = 9; k >= 0; --k) p = fma(p, r, c.E[k]);
+  const double p = poly10(c.E, r);
   const double e = 1.0 + fma(r * r, p, r);
   return ldexp(e, kn.lo);
 }
@@ -169,9 +206,7 @@ __device__ __forceinline__ double fast_log1p01(double y, const SoftplusPool& c) 
   const double f = hi ? 0.5 * (y - 1.0) : y;           // 1+y = 2(1+f) resp. 1+f, both exact
   const double s = f * fast_rcp(2.0 + f);
   const double w = s * s;
-  double R = c.L[7];
-#pragma unroll
-  for (int k = 6; k >= 0; --k) R = fma(R, w, c.L[k]);
+  const double R = poly7(c.L, w);
   const double l = fma(s * w, R, 2.0 * s);
   return hi ? l + c.ln2 : l;
 }

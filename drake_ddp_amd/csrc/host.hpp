@@ -69,6 +69,7 @@ struct mi_ilqr {
   char* host_records_dev = nullptr;   // the same block as the device sees it
   size_t host_records_bytes = 0;
   bool host_inputs = false;           // x0 and u_guess live in the block too (B <= 4, wave-per-problem kernels)
+  int q_diag = 0;          // Q has no off-diagonal entry (KArgs::q_diag)
   int cost_asym = 0;       // workgroup-per-problem kernels, n <= 32: Q, R or Qf is not symmetric (mid_backward then uses no symmetry at all)
   std::vector<double> h_costmat;   // host mirror of costmat (Q | R | Qf | x_nom)
   bool costmat_synced = false;     // the device copy equals the mirror

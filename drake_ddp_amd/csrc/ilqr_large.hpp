@@ -2442,11 +2442,188 @@ __device__ MI_BP_INLINE void mid_backward(const LView<M::n, M::m>& v, double* ld
   }
 }
 
+// The backward pass for cost matrices that are NOT symmetric, 32 < n <= 40 (round 6).  The reference takes any Q, R, Qf and never
+// symmetrizes anything (ilqr.py:130-146, 180-184, 651-667); large_backward cannot follow it there - its fused chain keeps a wave's
+// column tile of Vxx as that wave's ROW tile too and mirrors three tiles of Qxx, i.e. it computes with Vxx = Vxx^T - and the
+// library refused such matrices for these sizes until round 6.  This is the recursion as the reference writes it, with no use of
+// symmetry anywhere, in plain fp64 multiply-adds out of LDS:
+//     A = F^T Vxx ((n+m) x n), F = [fx | fu];   Qx | Qu = lx | lu + F^T Vx;   [Qxx - lxx ; Qux] = A fx;   Quu = luu + A_u fu;
+//     Quu^{-1} by LU with partial pivoting (np.linalg.inv's algorithm; positive pivots of an unpivoted elimination say nothing
+//     about a matrix that is not symmetric - they only feed the MI_STATUS_NOT_PD / FLAG_INDEFINITE report, as in mid_backward);
+//     kappa = Quu^{-1} Qu, K = Quu^{-1} Qux, dV = Qu^T kappa, Vx' = Qx - Qux^T (Quu^{-T} Qu), Vxx' = Qxx - Qux^T K   (:659-667)
+// lx = 2 Q x - 2 x_nom^T Q, lu = 2 R u are formed here, step by step (a rollout's cost rows hold 2 Q (x - x_nom): not lx when Q is
+// not symmetric).  A cold path: ~4 x the cycles of the matrix-core pass per step (LDS-bound dot products, six barriers), taken
+// only by handles whose cost matrices are not symmetric - the kernels of every other handle never enter it.
+template <class M>
+__device__ inline void large_backward_asym(const LView<M::n, M::m>& v, double* lds) {
+  constexpr int n = M::n, m = M::m, nm = n + m;
+  using Ly = LLay<n, m>;
+  static_assert(!Ly::kMid && m <= 16, "32 < n <= 40, m <= 16");
+  constexpr int WS = 17;
+  const int tid = stage_tid(), N = v.N, lane = tid & 63, wave = tid >> 6;
+  const double* Q = lds + Ly::oQ;
+  const double* R = lds + Ly::oR;
+  const double* Qf = lds + Ly::oQf;
+  const double* qn = lds + Ly::oQn;
+  const double* qfn = lds + Ly::oQfn;
+  double* Vxx = lds + Ly::oVxx;      // [n][n] dense (the matrix-core layout's area: NP x VS)
+  double* Vx = lds + Ly::oVx;        // [n]
+  double* Fb = lds + Ly::oF;         // [n][nm] = [fx_t | fu_t]; after the products: scratch of the pivot check [m][WS]
+  double* A = lds + Ly::oT1;         // [nm][n] = F^T Vxx; after the products: K_t [m][n]
+  double* Hb = lds + Ly::oH;         // [nm][n]: rows < n  fx^T Vxx fx, rows >= n  Qux
+  double* Gr = Hb + nm * n;          // [nm] lx_t | lu_t
+  double* q1 = Gr + nm;              // [nm] Qx | Qu
+  double* kap = q1 + nm;             // [16] kappa_t
+  double* kapT = kap + 16;           // [16] Quu^{-T} Qu
+  double* W = lds + Ly::oS;          // [m][WS] Quu, then its inverse
+  static_assert(n * n <= Ly::NP * Ly::VS && n * nm <= Ly::NK * Ly::NMP && nm * n <= Ly::NK * Ly::TS, "dense operands inside the matrix-core layout's areas");
+  static_assert(nm * n + 2 * nm + 32 <= Ly::NMP * Ly::TS && m * WS <= 16 * 17 + 1 && m * WS <= n * nm, "products and small vectors inside the H area, Quu in the tile scratch");
+  auto wave_fence = [&]() __attribute__((always_inline)) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+  };
+  // terminal: Vx = 2 Qf x_T - 2 x_nom^T Qf ; Vxx = 2 Qf   (ilqr.py:203-204, :638)
+  __syncthreads();
+  if (tid == 0) lds[Ly::oRed + kPdFlag] = 0.0;
+  for (int e = tid; e < n * n; e += kLargeThreads) Vxx[e] = 2.0 * Qf[e];
+  if (tid < n) {
+    const double* xT = v.X + (size_t)(N - 1) * n;
+    double s_ = 0.0;
+    for (int j = 0; j < n; ++j) s_ += (2.0 * Qf[tid * n + j]) * xT[j];
+    Vx[tid] = s_ - qfn[tid];
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int t = N - 2; t >= 0; --t) {
+    // ---- F_t and the cost gradients (:180-181)
+    {
+      const double* fxg = v.Fx + (size_t)t * n * n;
+      const double* fug = v.Fu + (size_t)t * n * m;
+      for (int e = tid; e < n * nm; e += kLargeThreads) {
+        const int i = e / nm, j = e - i * nm;
+        Fb[e] = j < n ? fxg[i * n + j] : fug[i * m + (j - n)];
+      }
+      if (tid < n) {
+        const double* xg = v.X + (size_t)t * n;
+        double s_ = -qn[tid];
+        for (int j = 0; j < n; ++j) s_ += (2.0 * Q[tid * n + j]) * xg[j];
+        Gr[tid] = s_;
+      } else if (tid < nm) {
+        const double* ug = v.U + (size_t)t * m;
+        double s_ = 0.0;
+        for (int j = 0; j < m; ++j) s_ += (2.0 * R[(tid - n) * m + j]) * ug[j];
+        Gr[tid] = s_;
+      }
+    }
+    __syncthreads();
+    // ---- A = F^T Vxx ; Qx | Qu = l + F^T Vx (:651-652)
+    for (int e = tid; e < nm * n; e += kLargeThreads) {
+      const int r = e / n, j = e - r * n;
+      double s_ = 0.0;
+#pragma unroll 4
+      for (int i = 0; i < n; ++i) s_ = fma(Fb[i * nm + r], Vxx[i * n + j], s_);
+      A[e] = s_;
+    }
+    if (tid >= 192 && tid - 192 < nm) {
+      const int r = tid - 192;
+      double s_ = Gr[r];
+      for (int i = 0; i < n; ++i) s_ = fma(Fb[i * nm + r], Vx[i], s_);
+      q1[r] = s_;
+    }
+    __syncthreads();
+    // ---- [Qxx - lxx ; Qux] = A fx ; Quu = luu + A_u fu (:653-656)
+    for (int e = tid; e < nm * n; e += kLargeThreads) {
+      const int r = e / n, j = e - r * n;
+      double s_ = 0.0;
+#pragma unroll 4
+      for (int k = 0; k < n; ++k) s_ = fma(A[r * n + k], Fb[k * nm + j], s_);
+      Hb[e] = s_;
+    }
+    for (int e = tid; e < m * m; e += kLargeThreads) {
+      const int a_ = e / m, b_ = e - a_ * m;
+      double s_ = 0.0;
+      for (int k = 0; k < n; ++k) s_ = fma(A[(n + a_) * n + k], Fb[k * nm + n + b_], s_);
+      W[a_ * WS + b_] = 2.0 * R[a_ * m + b_] + s_;
+    }
+    __syncthreads();
+    // ---- Quu^{-1} (:655) on one wave; the pivots of an UNPIVOTED elimination of a copy only feed the status report
+    if (wave == 0) {
+      double* S = Fb;
+      const bool on = lane < m;
+      const int i = on ? lane : 0;
+      if (on) { for (int j = 0; j < m; ++j) S[i * WS + j] = W[i * WS + j]; }
+      bool bad = false;
+#pragma unroll 1
+      for (int k = 0; k < m; ++k) {
+        wave_fence();
+        const double piv = S[k * WS + k];
+        bad = bad || !(piv > 0.0);
+        double l_ = 0.0;
+        if (on && i > k) l_ = S[i * WS + k] / piv;
+        wave_fence();
+        if (on && i > k) { for (int j = k + 1; j < m; ++j) S[i * WS + j] = fma(-l_, S[k * WS + j], S[i * WS + j]); }
+      }
+      if (bad && lane == 0) lds[Ly::oRed + kPdFlag] = 1.0;
+      wave_fence();
+      quu_inverse_pivoted<m>(W, WS, lane);
+    }
+    __syncthreads();
+    // ---- kappa = Quu^{-1} Qu, Quu^{-T} Qu, K = Quu^{-1} Qux (:659-660)
+    if (tid < m) {
+      double s_ = 0.0;
+      for (int b_ = 0; b_ < m; ++b_) s_ = fma(W[tid * WS + b_], q1[n + b_], s_);
+      kap[tid] = s_;
+      v.kap[(size_t)t * m + tid] = s_;
+    } else if (tid >= 64 && tid - 64 < m) {
+      const int a_ = tid - 64;
+      double s_ = 0.0;
+      for (int b_ = 0; b_ < m; ++b_) s_ = fma(W[b_ * WS + a_], q1[n + b_], s_);
+      kapT[a_] = s_;
+    }
+    {
+      double* Kg = v.K + (size_t)t * m * n;
+      for (int e = tid; e < m * n; e += kLargeThreads) {
+        const int a_ = e / n, j = e - a_ * n;
+        double s_ = 0.0;
+        for (int b_ = 0; b_ < m; ++b_) s_ = fma(W[a_ * WS + b_], Hb[(n + b_) * n + j], s_);
+        A[e] = s_;
+        Kg[e] = s_;
+      }
+    }
+    __syncthreads();
+    // ---- dV = Qu^T kappa (:663), Vx' = Qx - Qux^T Quu^{-T} Qu, Vxx' = Qxx - Qux^T K (:666-667)
+    if (tid == 0) {
+      double s_ = 0.0;
+      for (int a_ = 0; a_ < m; ++a_) s_ = fma(q1[n + a_], kap[a_], s_);
+      v.dV[t] = s_;
+    }
+    if (tid >= 64 && tid - 64 < n) {
+      const int j = tid - 64;
+      double s_ = q1[j];
+      for (int b_ = 0; b_ < m; ++b_) s_ -= Hb[(n + b_) * n + j] * kapT[b_];
+      Vx[j] = s_;
+    }
+    for (int e = tid; e < n * n; e += kLargeThreads) {
+      const int i = e / n, j = e - i * n;
+      double s_ = 0.0;
+      for (int b_ = 0; b_ < m; ++b_) s_ = fma(Hb[(n + b_) * n + i], A[b_ * n + j], s_);
+      Vxx[e] = (2.0 * Q[e] + Hb[e]) - s_;
+    }
+    __syncthreads();
+  }
+}
+
 // The backward pass of a model's size class.
 template <class M, bool PIV>
 __device__ __forceinline__ void backward_pass(const LView<M::n, M::m>& v, double* lds, long long* bp_acc, bool lx_ready, bool xu_staged = false) {
   if constexpr (LLay<M::n, M::m>::kMid) mid_backward<M, PIV>(v, lds, lx_ready, xu_staged);
-  else large_backward<M, PIV>(v, lds, bp_acc, lx_ready);
+  else {
+    if constexpr (PIV) {
+      if (v.asym) { large_backward_asym<M>(v, lds); return; }   // (cost matrices that are not symmetric: launched as the PIV form, launch_large.hpp)
+    }
+    large_backward<M, PIV>(v, lds, bp_acc, lx_ready);
+  }
 }
 
 #ifndef MI_MID_MINBLOCKS
@@ -2500,7 +2677,7 @@ __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kerne
   v.Un = a.u_trial + (size_t)b * m * (N - 1);
   v.LxG = a.lxu ? a.lxu + (size_t)b * (N - 1) * (n + m) : nullptr;
   v.pd_continue = a.pd_continue;
-  v.asym = Ly::kMid ? a.cost_asym : 0;      // (the host refuses such matrices for n >= 33: large_backward mirrors tiles)
+  v.asym = a.cost_asym;                     // (n >= 33: large_backward_asym, the PIV form of the kernel)
   LargeAcc<n, m> acc;
   acc.X = v.X; acc.Fx = v.Fx; acc.Fu = v.Fu; acc.N = N;
   acc.kp = ilds; acc.aux = ilds + N; acc.need = ilds + 2 * N; acc.binA = ilds + 3 * N; acc.binB = ilds + 5 * N;

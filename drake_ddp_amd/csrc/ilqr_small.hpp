@@ -98,7 +98,8 @@ struct KArgs {
   // mid-size workgroup-per-problem kernels (ilqr_large.hpp: mid_rollout4): trial trajectories of the line-search candidates
   // rolled out beside the first, [3][B][N][n] and [3][B][N-1][m]
   double *x_spec, *u_spec;
-  int spec_policy, pad_spec_;
+  int spec_policy;
+  int q_diag;                     // Q has no off-diagonal entry (every script of the reference): the sequential rollouts' stage cost skips the n (n - 1) products with zeros
   // workgroup-per-problem kernels, long horizons: the cost gradients [B][N-1][n+m] in HBM instead of LDS (ilqr_large.hpp)
   double* lxu;
   int pd_continue;                // mi_ilqr_desc.on_indefinite
@@ -320,19 +321,36 @@ struct Consts {
 // Lane 0 stores its trajectory into the T records; the other lanes' stores go
 // to a per-lane dump slot so the loop carries no exec-mask branches.
 // ---------------------------------------------------------------------------
+// q_diag (wave-uniform: a kernel argument): Q is diagonal - the products with its zeros are left out.  Same bits: a row sum then is
+// fma(0, dx_j, s) = s for every j != i (finite states; a diverged trial's cost is NaN or inf either way, and rejected either way).
+// 12 of the 146 instructions of a cart-pole + wall rollout step - and, MEASURED in the fused kernel (same-box A/B,
+// profiles/r06_c4_ab.txt), a line search that is 26 % LONGER (178.6 k -> 224.9 k cycles per iteration): the second arm of the branch
+// lives in the same loop, and its registers push the loop's values into the accumulation file.  OFF by default (MI_STAGE_COST_DIAG).
 template <class M>
-__device__ __forceinline__ double stage_cost(const Consts<M>& c, const double (&x)[M::n], const double (&u)[M::m]) {
+__device__ __forceinline__ double stage_cost(const Consts<M>& c, const double (&x)[M::n], const double (&u)[M::m], bool q_diag = false) {
   constexpr int n = M::n, m = M::m;
   double dx[n];
 #pragma unroll
   for (int i = 0; i < n; ++i) dx[i] = x[i] - c.xnom[i];
   double q = 0.0;
+#ifndef MI_STAGE_COST_DIAG
+#define MI_STAGE_COST_DIAG 0
+#endif
+  if (MI_STAGE_COST_DIAG && n >= 4 && q_diag) {
 #pragma unroll
-  for (int i = 0; i < n; ++i) {
-    double s = 0.0;
+    for (int i = 0; i < n; ++i) {
+      double s = 0.0;
+      s += c.Q[i][i] * dx[i];                                 // (the same fma(Q_ii, dx_i, 0) the full row sum ends up with)
+      q += dx[i] * s;
+    }
+  } else {
 #pragma unroll
-    for (int j = 0; j < n; ++j) s += c.Q[i][j] * dx[j];
-    q += dx[i] * s;
+    for (int i = 0; i < n; ++i) {
+      double s = 0.0;
+#pragma unroll
+      for (int j = 0; j < n; ++j) s += c.Q[i][j] * dx[j];
+      q += dx[i] * s;
+    }
   }
   double ru = 0.0;
 #pragma unroll
@@ -410,7 +428,7 @@ __device__ __forceinline__ void rollout_step(const GRegs<M>& r, const Consts<M>&
   else M::template step<double>(x, u, xnext, a.params, a.dt);
   if (COST) {
     // stage cost (no 1/2 factor, ilqr.py:325) and expected improvement (:326)
-    L += stage_cost<M>(c, x, u);
+    L += stage_cost<M>(c, x, u, a.q_diag != 0);
     expd += ce * r.dv;
   }
   // T_t.u = u_t ; T_{t+1}.x = x_{t+1}

@@ -150,6 +150,7 @@ KArgs make_args(const mi_ilqr* h) {
   a.lxu = h->lxu;
   a.pd_continue = h->d.on_indefinite == 1 ? 1 : 0;
   a.cost_asym = h->cost_asym ? 1 : 0;
+  a.q_diag = h->q_diag ? 1 : 0;
   static const int spec = [] { const char* e = std::getenv("MI_ILQR_SPEC"); return e ? std::atoi(e) : 1; }();
   a.spec_policy = (h->x_spec && spec >= 0 && spec <= 2) ? spec : 0;
   a.cluster = 1;
@@ -865,9 +866,10 @@ int mi_ilqr_set_cost(mi_ilqr_t* h, const double* Q, const double* R, const doubl
     if (Qf) std::memcpy(cm.data() + n * n + m * m, Qf, n * n * 8);
     if (x_nom) std::memcpy(cm.data() + 2 * n * n + m * m, x_nom, n * 8);
     if (h->large && n > 32) {
-      // The n >= 33 workgroup-per-problem kernels have no form without symmetry, and matrices built as A^T A or by float
-      // arithmetic are often symmetric only to round-off: asymmetries up to a few ulps of the largest entry are
-      // averaged away here (|A - A^T| <= 8 eps max|A|); anything larger is refused below with E_UNSUPPORTED.
+      // The n >= 33 workgroup-per-problem kernels' matrix-core pass has no form without symmetry (the plain-arithmetic pass that
+      // takes over - large_backward_asym - is ~4 x slower per step), and matrices built as A^T A or by float arithmetic are often
+      // symmetric only to round-off: asymmetries up to a few ulps of the largest entry are averaged away here
+      // (|A - A^T| <= 8 eps max|A|) so that they keep the fast pass; anything larger is followed as given.
       // (n <= 32: matrices are taken as given, like the reference does.)
       auto symmetrize = [](double* A, size_t k) {
         double scale = 0.0;
@@ -887,8 +889,9 @@ int mi_ilqr_set_cost(mi_ilqr_t* h, const double* Q, const double* R, const doubl
       // Quu = 2R + fu^T Vxx fu of every backward pass (MI_STATUS_NOT_PD, or mi_ilqr_desc.on_indefinite = 1: inverted with partial
       // pivoting like the reference's np.linalg.inv, ilqr.py:655).  SYMMETRY: the mid-size kernels (n <= 32, mid_backward) follow
       // the reference on any matrices - lxx = 2Q and luu = 2R as given, lx = 2Qx - 2 x_nom^T Q, Vx' = Qx - Qu^T Quu^{-1} Qux with
-      // the inverse of a Quu that is not symmetric, Vxx stored in full (ilqr.py:180-184,651-667); the n >= 33 kernels mirror
-      // tiles of the symmetric products and take their cost gradients from the rollout's rows 2 Q (x - x_nom): they refuse.
+      // the inverse of a Quu that is not symmetric, Vxx stored in full (ilqr.py:180-184,651-667); the n >= 33 kernels, whose
+      // matrix-core pass mirrors tiles of the symmetric products, take a plain-arithmetic pass for such matrices (round 6:
+      // large_backward_asym; they refused them before).
       auto finite = [](const double* A, size_t k) {
         for (size_t i = 0; i < k * k; ++i) if (!(std::fabs(A[i]) < INFINITY)) return false;
         return true;
@@ -903,12 +906,14 @@ int mi_ilqr_set_cost(mi_ilqr_t* h, const double* Q, const double* R, const doubl
         return MI_ILQR_E_UNSUPPORTED;
       }
       asym = !(symmetric(cm.data(), n) && symmetric(cm.data() + n * n, m) && symmetric(cm.data() + n * n + m * m, n));
-      if (asym && n > 32) {
-        std::fprintf(stderr, "mi_ilqr_set_cost: the n >= 33 workgroup-per-problem kernels (n = %d, m = %d) need symmetric (to 8 ulp) Q, R, Qf\n", (int)n, (int)m);
-        return MI_ILQR_E_UNSUPPORTED;
-      }
     }
     h->cost_asym = asym ? 1 : 0;
+    {
+      bool diag = true;
+      for (size_t i = 0; i < n; ++i)
+        for (size_t j = 0; j < n; ++j) if (i != j && cm[i * n + j] != 0.0) diag = false;
+      h->q_diag = diag ? 1 : 0;
+    }
     h->exact_backward = regular ? 0 : 1;
     // the device copy mirrors h_costmat: nothing to send when the caller repeats the matrices it set before
     // (Solve() pushes them on every call, like the reference reads its attributes on every call)

@@ -231,13 +231,15 @@ void mi_ilqr_destroy(mi_ilqr_t* h);
 
 /* SetRunningCost / SetTerminalCost / SetTargetState (ilqr.py:111-146): Q (n,n), R (m,m),
  * Qf (n,n), x_nom (n), shared by the batch.  Any pointer may be NULL = keep.  ANY finite matrices are accepted, like the
- * reference (lxx = 2Q, luu = 2R, lx = 2Qx - 2 x_nom^T Q, never symmetrized - ilqr.py:180-184), by every kernel family up to
- * n = 32:  wave- and lane-per-problem kernels - symmetric positive semi-definite Q, Qf and positive definite R take the
+ * reference (lxx = 2Q, luu = 2R, lx = 2Qx - 2 x_nom^T Q, never symmetrized - ilqr.py:180-184), by every kernel family:
+ * wave- and lane-per-problem kernels - symmetric positive semi-definite Q, Qf and positive definite R take the
  * time-parallel / matrix-core backward passes, anything else the reference's recursion verbatim;  mid-size
  * workgroup-per-problem kernels (m > 2 or n > 6, n <= 32: Arm27, plugin family 1) - the matrix-core pass itself uses no
- * symmetry when a matrix is not symmetric (ABI 8).  Only the n = 33..40 kernels (n = 36 / 37 models, plugin family 1
- * above 32 states) need SYMMETRIC matrices: their chain mirrors tiles of the symmetric products (asymmetries up to 8 ulp
- * of the largest entry are averaged away, larger ones: MI_ILQR_E_UNSUPPORTED).  Definiteness is required of none - it is
+ * symmetry when a matrix is not symmetric (ABI 8);  the n = 33..40 kernels (n = 36 / 37 models, plugin family 1 above 32
+ * states) - their matrix-core chain mirrors tiles of the symmetric products, so matrices that are not symmetric take a
+ * plain-arithmetic form of the pass (ABI 9: large_backward_asym, about four times the cycles per step; MI_ILQR_E_UNSUPPORTED
+ * before), and asymmetries of up to 8 ulp of the largest entry - round-off of an A^T A - are averaged away so that such
+ * matrices keep the fast pass.  Definiteness is required of none - it is
  * checked where it matters: mi_ilqr_desc.on_indefinite says what a backward pass does with a Quu that is not positive
  * definite. */
 int mi_ilqr_set_cost(mi_ilqr_t* h, const double* Q, const double* R, const double* Qf, const double* x_nom);

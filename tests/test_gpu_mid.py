@@ -308,7 +308,8 @@ np.savez(sys.argv[1], **out)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("which", ["chainx_12_4", "chainx_27_7", "arm27_n16", "arm27_n24"])
+@pytest.mark.parametrize("which", ["chainx_12_4", "chainx_27_7", "arm27_n16", "arm27_n24",
+                                   "synth36_n16", "quad3d_n12", "chainx_40_16", "chainx_36_7", "chainx_33_16", "chainx_40_8"])
 def test_asymmetric_costs_follow_the_reference_on_the_mid_size_kernels(which):
     """The reference accepts any Q, R, Qf and never symmetrizes (ilqr.py:120-146,161-186): lxx = 2Q, luu = 2R,
     lx = 2Qx - 2 x_nom^T Q, Quu not symmetric, Vx' = Qx - Qu^T Quu^{-1} Qux, Vxx' = Qxx - Qux^T Quu^{-1} Qux.  The mid-size
@@ -319,7 +320,10 @@ def test_asymmetric_costs_follow_the_reference_on_the_mid_size_kernels(which):
     (The reference's recursion is itself fragile on such costs: the antisymmetric part of Vxx enters the symmetric part of Vxx'
     through -Qux^T Quu^{-1} Qux and takes it indefinite within a few dozen steps - on the arm + ball problem the fp64 NumPy pass
     is 1e-12 from the extended-precision one at N = 16, 1e-9 at N = 24 and has no digit left at the scripts' N = 50 (cond(Quu)
-    1e14), whatever the size of the asymmetry.  Hence the arm's short horizons here, and the extended-precision yardstick.)"""
+    1e14), whatever the size of the asymmetry.  Hence the arm's short horizons here, and the extended-precision yardstick.)
+    Round 6: the n = 33 .. 40 kernels too (they refused such matrices until then: their matrix-core chain mirrors tiles) - the
+    36-state chain, the 3-D quadruped (n = 37) and plugin chains of (40, 16), (36, 7: padded controls), (33, 16), (40, 8: the
+    compact tile layout) through large_backward_asym, the reference's recursion in plain arithmetic."""
     import models as PM
     import plugin_steps as PS
     from drake_ddp_amd import workloads as W
@@ -330,17 +334,23 @@ def test_asymmetric_costs_follow_the_reference_on_the_mid_size_kernels(which):
     rng = np.random.default_rng(23)
     B, cap = 2, 5
     from common import backward_errors
-    if which.startswith("arm27"):
-        prob = W.arm27_problem(N=int(which[-2:]))
-        n, m, N, dt = 27, 7, prob["N"], prob["dt"]
+    if not which.startswith("chainx"):
+        name, Nw = which.split("_n")
+        prob, x0f, ugf = {"arm27": (W.arm27_problem, W.arm27_batch_x0, W.arm27_u_guess), "synth36": (W.synth36_problem, W.synth36_batch_x0, W.synth36_u_guess),
+                          "quad3d": (W.quad3d_problem, W.quad3d_batch_x0, W.quad3d_u_guess)}[name]
+        prob = prob(N=int(Nw))
+        n, m, N, dt = prob["Q"].shape[0], prob["R"].shape[0], prob["N"], prob["dt"]
         sys_ = ModelSystem(prob["model_id"], dt, prob.get("params"))
         model = M.Model(prob["model_id"], dt, prob.get("params"))
         Q, R, Qf, x_nom = prob["Q"].copy(), prob["R"].copy(), prob["Qf"].copy(), prob["x_nom"]
-        x0 = W.arm27_batch_x0(B)
-        ug = np.broadcast_to(W.arm27_u_guess(N), (B, m, N - 1)).copy()
+        if name != "arm27":            # (diagonals with zeros: give the asymmetric parts something to scale with)
+            Q, Qf = Q + dt * 0.05 * np.eye(n), Qf + 0.05 * np.eye(n)
+        x0 = x0f(B)
+        ug = np.broadcast_to(ugf(N), (B, m, N - 1)).copy()
         delta, beta = prob["delta"], prob["beta"]
     else:
-        nq, m, ne = {"chainx_12_4": (6, 4, 0), "chainx_27_7": (10, 7, 7)}[which]
+        nq, m, ne = {"chainx_12_4": (6, 4, 0), "chainx_27_7": (10, 7, 7), "chainx_40_16": (20, 16, 0), "chainx_36_7": (18, 7, 0),
+                     "chainx_33_16": (16, 16, 1), "chainx_40_8": (20, 8, 0)}[which]
         n, N, dt = 2 * nq + ne, 24, 0.02
         sys_ = PM.build_chainx(nq, m, ne)(dt)
         model = M.Model.custom(n, m, PS.chainx_step(nq, m, ne), sys_.params, dt)

@@ -236,18 +236,51 @@ def test_asymmetric_and_indefinite_costs_follow_the_reference(cfg):
     assert np.all(np.isfinite(s.cost))
 
 
-def test_large_path_rejects_asymmetric_costs():
-    from drake_ddp_amd import workloads as W
-    from drake_ddp_amd._capi import MiIlqrError
-    q = dict(W.synth36_problem())
-    s = make_solver(q, B=1, jac="ad")
-    Q = q["Q"].copy()
-    Q[0, 1] += 1e-3
-    s.SetRunningCost(Q, q["R"])
-    s.SetInitialState(W.synth36_batch_x0(1))
-    s.SetInitialGuess(W.synth36_u_guess(q["N"]))
-    with pytest.raises(MiIlqrError, match="not supported"):
-        s.Solve()
+@pytest.mark.parametrize("name", ["synth36_stage", "quad3d_stage"])
+def test_large_path_follows_asymmetric_costs(name):
+    """Until round 6 the n = 36 / 37 kernels refused cost matrices that are not symmetric (this test asserted the refusal); the
+    reference takes any (ilqr.py:130-146) and never symmetrizes (:180-184, :651-667).  Stage level on the reference-generated
+    fixtures' trajectories and Jacobians with Q, R AND Qf made asymmetric: K, kappa, dV against oracle.backward() and against the
+    reference's recursion in extended precision (the device no further from it than 20 x the fp64 NumPy pass is, or 1e-10) -
+    and NOT what the symmetrized matrices give; with symmetric matrices the same handle is bitwise the matrix-core pass."""
+    from common import backward_errors
+    g, prob = load_golden(name)
+    rng = np.random.default_rng(5)
+
+    def asym(A, upper, floor):
+        d = np.sqrt(np.abs(np.diag(A)) + floor)
+        T = rng.uniform(0.5, 1.0, A.shape)
+        return A + 0.1 * (d[:, None] * (np.triu(T, 1) if upper else np.tril(T, -1)) * d[None, :])
+    Q, R, Qf = asym(prob["Q"], True, 1e-3 * prob["dt"]), asym(prob["R"], False, 0.0), asym(prob["Qf"], False, 1e-3)
+    o = make_oracle(prob)
+    o.set_problem(g["x0"], prob["x_nom"], Q, R, Qf, g["pre_u_bar"])
+    o.x_bar, o.u_bar, o.fx, o.fu = g["roll_x"], g["roll_u"], g["fx"], g["fu"]
+    o.backward()
+    s = make_solver(prob, jac="ad", on_indefinite="continue")
+    s.SetRunningCost(Q, R); s.SetTerminalCost(Qf)
+    s.SetInitialState(g["x0"][None])                         # (no SetInitialGuess: u_bar is set as state below)
+    s.set_state(x_bar=g["roll_x"][None], u_bar=g["roll_u"][None], fx=g["fx"][None], fu=g["fu"][None])
+    s.stage_backward()
+    dev = (s.K[0], s.kappa[0], s.dV_coeff[0])
+    e_dev, e_ref, cond = backward_errors(dev, o)
+    per = [rel_err(a_, b_) for a_, b_ in zip(dev, (o.K, o.kappa, o.dV))]
+    print(f"{name}: device vs NumPy K {per[0]:.1e} kappa {per[1]:.1e} dV {per[2]:.1e}; vs extended precision {e_dev:.1e} (NumPy {e_ref:.1e}), cond(Quu) {cond:.1e}")
+    # (the 3-D quadruped's fixture with these matrices: cond(Quu) 3e10 - the fp64 reference itself is 2e-5 from the extended pass,
+    #  the device 1.4e-5; the 36-state chain: both at 1e-12)
+    assert e_ref < 1e-4 and e_dev < max(1e-10, 20 * e_ref), (e_dev, e_ref, cond)
+    osym = make_oracle(prob)
+    osym.set_problem(g["x0"], prob["x_nom"], 0.5 * (Q + Q.T), 0.5 * (R + R.T), 0.5 * (Qf + Qf.T), g["pre_u_bar"])
+    osym.x_bar, osym.u_bar, osym.fx, osym.fu = g["roll_x"], g["roll_u"], g["fx"], g["fu"]
+    osym.backward()
+    assert rel_err(osym.K, o.K) > 1e-6                       # (the asymmetric parts are seen)
+    # symmetric matrices on the SAME handle: the matrix-core pass, bitwise what a fresh handle returns
+    s.SetRunningCost(prob["Q"], prob["R"]); s.SetTerminalCost(prob["Qf"])
+    s.stage_backward()
+    f = make_solver(prob, jac="ad", on_indefinite="continue")
+    f.SetInitialState(g["x0"][None])
+    f.set_state(x_bar=g["roll_x"][None], u_bar=g["roll_u"][None], fx=g["fx"][None], fu=g["fu"][None])
+    f.stage_backward()
+    assert np.array_equal(s.K, f.K) and np.array_equal(s.kappa, f.kappa) and rel_err(s.K[0], g["post_K"]) < 1e-9
 
 
 # ----------------------------------------------------------------------------------
