@@ -408,11 +408,13 @@ def throughput_entry(dev_index, B=262144, reps=5):
         it += st.total_iters; kms += st.kernel_ms; ab += st.algorithmic_bytes
     wall = time.perf_counter() - t0
     traffic = src = None
-    path = os.path.join(ROOT, "profiles", "r05_pmc_throughput.json")
-    if os.path.exists(path):
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_throughput.json")))
+    if paths:
+        path = paths[-1]                                       # the latest round's counter passes (tools/pmc_throughput.py)
         for r in json.load(open(path))["runs"]:
             if r["B"] == B and r["kp"] == "none":
-                traffic, src = r["hbm_bytes_per_launch"], "committed profiles/r05_pmc_throughput.json (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE, calibrated on tools/ubench/stream8)"
+                traffic, src = r["hbm_bytes_per_launch"], f"committed profiles/{os.path.basename(path)} (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE, calibrated on tools/ubench/stream8)"
     k_s = kms / reps * 1e-3
     achieved = ab / reps / k_s / 1e9
     out = {"name": f"throughput: acrobot N=40, batch {B}, lane-per-problem kernels (state streamed through HBM), cold-start solves",

@@ -245,7 +245,12 @@ void mi_ilqr_destroy(mi_ilqr_t* h);
 int mi_ilqr_set_cost(mi_ilqr_t* h, const double* Q, const double* R, const double* Qf, const double* x_nom);
 
 /* SetInitialState / SetInitialGuess (ilqr.py:102-109,148-156): x0 (B,n), u_guess (B,m,N-1).
- * u_guess becomes u_bar (the reference aliases it, ilqr.py:156).  NULL = keep. */
+ * u_guess becomes u_bar (the reference aliases it, ilqr.py:156).  NULL = keep.
+ * Ordering against mi_ilqr_solve_async: the new inputs are those of the NEXT solve.  Handles of more than four problems copy them
+ * on the handle's stream (the call returns at once, behind a solve that is still running); wave-per-problem handles of up to four
+ * problems keep x0 / u_guess in mapped host memory that the kernels read directly (no copy engine in front of a single-problem
+ * solve), so there the call WAITS for a solve still in flight before it overwrites them - a caller that pipelines
+ * solve_async / set_initial / collect on such a handle serializes at set_initial. */
 int mi_ilqr_set_initial(mi_ilqr_t* h, const double* x0, const double* u_guess);
 
 /* The same with ONE control sequence u_guess_one (m,N-1) for every problem of the batch - the argument the
