@@ -69,10 +69,17 @@ struct LLay {
   static constexpr size_t doubles = oEnd + 8;
 };
 
+// Integer scratch of the key-point code: five arrays of N (or 2 N) ints - and, while every step is a key-point, the home of the
+// cluster hand-shake's state (aux[0..3], the leader's six counters / a helper's last round in `need`): each array is therefore
+// at least kIntRowMin ints long.  (Round 5's last session moved that state from registers into these arrays; with N = 3 aux[3]
+// WAS need[0] - the leader's round counter - and every clustered solve of a three-step horizon ended with MI_STATUS_INTERNAL.  Found
+// in round 6 by running the GPU suite with clusters forced: test_shortest_horizons_vs_c_oracle swallowed the RuntimeError.)
+constexpr int kIntRowMin = 8;
+__host__ __device__ constexpr int int_row(int N) { return N > kIntRowMin ? N : kIntRowMin; }
 template <int n, int m>
 __host__ __device__ constexpr size_t large_lds_bytes(int N) {
   // fixed block + per-step cost gradients [N][n+m] + integer scratch of the key-point code
-  return (LLay<n, m>::doubles + (size_t)N * (n + m)) * 8 + (size_t)7 * N * 4 + 16;
+  return (LLay<n, m>::doubles + (size_t)N * (n + m)) * 8 + (size_t)7 * int_row(N) * 4 + 16;
 }
 
 // Horizons whose cost gradients do not fit next to the fixed block any more (N > 148 for (36, 12), > 319 for (27, 7)): the
@@ -80,7 +87,7 @@ __host__ __device__ constexpr size_t large_lds_bytes(int N) {
 // of lx_t | lu_t per step on the wave that forms the first-order column), but no horizon limit short of 160 KB of integers.
 template <int n, int m>
 __host__ __device__ constexpr size_t large_lds_bytes_hbm(int N) {
-  return (size_t)LLay<n, m>::doubles * 8 + (size_t)7 * N * 4 + 16;
+  return (size_t)LLay<n, m>::doubles * 8 + (size_t)7 * int_row(N) * 4 + 16;
 }
 
 // Per-problem views of the time-major HBM arrays.
@@ -2680,7 +2687,7 @@ __global__ void __launch_bounds__(kLargeThreads, kMinBlocks<M>) ilqr_large_kerne
   v.asym = a.cost_asym;                     // (n >= 33: large_backward_asym, the PIV form of the kernel)
   LargeAcc<n, m> acc;
   acc.X = v.X; acc.Fx = v.Fx; acc.Fu = v.Fu; acc.N = N;
-  acc.kp = ilds; acc.aux = ilds + N; acc.need = ilds + 2 * N; acc.binA = ilds + 3 * N; acc.binB = ilds + 5 * N;
+  { const int Nr = int_row(N); acc.kp = ilds; acc.aux = ilds + Nr; acc.need = ilds + 2 * Nr; acc.binA = ilds + 3 * Nr; acc.binB = ilds + 5 * Nr; }
   const double* x0g = a.x0 + (size_t)b * n;
 
   // cost constants -> LDS ; 2 x_nom^T Q and 2 x_nom^T Qf (ilqr.py:180,203)

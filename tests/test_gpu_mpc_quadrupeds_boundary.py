@@ -658,7 +658,8 @@ np.savez(sys.argv[1], x=x, u=u, L=L, fx0=fx0, it0=it0, log=s.mpc_log, xm=s.x_bar
         env = dict(env)
         if forced is not None and tag != "single": env["MI_ILQR_CLUSTER"] = forced
         f = str(tmp_path / f"{tag}.npz")
-        r = subprocess.run([sys.executable, "-c", script, f], capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
+        base = {k: v for k, v in os.environ.items() if not k.startswith("MI_ILQR_")}     # (a suite run with forced switches does not leak into the variants)
+        r = subprocess.run([sys.executable, "-c", script, f], capture_output=True, text=True, timeout=300, env=dict(base, **env))
         assert r.returncode == 0, r.stderr[-2000:]
         outs[tag] = np.load(f)
     assert (outs["cluster"]["st"] == 0).all()
@@ -717,7 +718,8 @@ np.savez(sys.argv[1], x=x, u=u, L=L, K=s.K, fx=s.fx, fu=s.fu, it=s.iterations, s
     outs = {}
     for tag, env in (("cluster", {}), ("single", {"MI_ILQR_CLUSTER": "1"}), ("early0", {"MI_ILQR_EARLY": "0"})):
         f = str(tmp_path / f"{tag}.npz")
-        r = subprocess.run([sys.executable, "-c", script, f], capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
+        base = {k: v for k, v in os.environ.items() if not k.startswith("MI_ILQR_")}
+        r = subprocess.run([sys.executable, "-c", script, f], capture_output=True, text=True, timeout=300, env=dict(base, **env))
         assert r.returncode == 0, r.stderr[-2000:]
         outs[tag] = np.load(f)
     st, it = outs["single"]["st"], outs["single"]["it"]
@@ -981,6 +983,8 @@ def test_cluster_words_read_as_zeros_where_no_cluster_ran():
     s.SetInitialState(W.acrobot_batch_x0(4)); s.SetInitialGuess(np.zeros((1, a["N"] - 1)))
     s.Solve()
     assert s.cluster_stats.shape == (4, 6) and (s.cluster_stats == 0).all()
+    if os.environ.get("MI_ILQR_CLUSTER", "1") not in ("", "1"):
+        return                                               # (a suite run with clusters forced: this launch WOULD be clustered)
     q = W.synth36_problem()
     s = make_solver(dict(q, N=8), B=300, jac="fd")
     s.SetInitialState(np.tile(W.synth36_batch_x0(64), (5, 1))[:300]); s.SetInitialGuess(W.synth36_u_guess(8))
