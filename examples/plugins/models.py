@@ -117,9 +117,11 @@ def build_chainx(nq, m, ne=0, verbose=False):
     return plugin.build_model(*chainx_spec(nq, m, ne), verbose=verbose)
 
 
-# the shapes the tests and __graft_entry__.build() use: (nq, m, ne) -> (n, m) = (12, 4), (14, 7), (27, 7), (32, 16), (9, 4), (7, 3), (16, 1),
-# (4, 1) - the last one a chain whose step is a few hundred cycles: the fast-step case of the cluster hand-shake's tests
-CHAINX_SHAPES = [(6, 4, 0), (7, 7, 0), (10, 7, 7), (16, 16, 0), (4, 4, 1), (3, 3, 1), (8, 1, 0), (2, 1, 0)]
+# the shapes the tests and __graft_entry__.build() use: (nq, m, ne) -> (n, m) = (12, 4), (14, 7), (27, 7), (32, 16), (9, 4), (7, 3), (16, 1)
+CHAINX_SHAPES = [(6, 4, 0), (7, 7, 0), (10, 7, 7), (16, 16, 0), (4, 4, 1), (3, 3, 1), (8, 1, 0)]
+# (4, 1): a chain whose step is a few hundred cycles and whose whole state fits a CU's vector L1 several times over - the
+# fast-step case of the cluster hand-shake's tests (tests/test_gpu_mpc_quadrupeds_boundary.py: chainx4)
+FAST_STEP_SHAPES = [(2, 1, 0)]
 
 
 # n > 32 with a number of controls that is not a multiple of 4: the plugin pads the device model's controls (plugin.device_controls),
@@ -146,7 +148,7 @@ def build_all(verbose=False):
     specs = [("vdp", 2, 1, VDP_BODY, VDP_DEFAULTS, "small"), ("kink2", 2, 1, KINK2_BODY, KINK2_DEFAULTS, "small"),
              ("chain3", 6, 2, CHAIN3_BODY, CHAIN3_DEFAULTS, "small"),
              ("synth36p", 36, 12, SYNTH36P_BODY, SYNTH36P_DEFAULTS, "large"), chain_spec(17), chain_spec(20)]
-    specs += [chainx_spec(*sh) for sh in CHAINX_SHAPES + PADDED_SHAPES + LARGE_SHAPES]
+    specs += [chainx_spec(*sh) for sh in CHAINX_SHAPES + PADDED_SHAPES + LARGE_SHAPES + FAST_STEP_SHAPES]
     return plugin.build_models(specs, verbose=verbose)
 
 
