@@ -262,7 +262,73 @@ __global__ void __launch_bounds__(64) ilqr_batch_kernel(const KArgs a) {
             }
           });
         };
+        // Key-point lists that are known BEFORE any Jacobian is needed (setInterval, adaptiveJerk): ONE forward pass over time
+        // evaluates and interpolates (round 6).  Every lane walks the same t; where t is the NEXT key-point of any lane of the wave
+        // the wave reads row t of x_bar / u_bar - a coalesced row, the same for all lanes - and differentiates the step; a lane
+        // whose key-point it is keeps the result (fE), stores it, and fills the interior of the segment it closes, rows t-1 .. s+1 -
+        // again the same rows for every lane that takes part - from fS (its previous key-point, still in registers) and fE: the
+        // expression of ilqr.py:607-621, the same bits.  Until round 6 the lanes GATHERED x, u at their own key-points (a row per
+        // distinct time step among the 64 lanes), scattered the Jacobians, and a second pass gathered both end matrices of every
+        // segment back: 1.23 - 1.29 x the algorithmic bytes and twice the reads (profiles/r05_pmc_throughput.json); now no
+        // Jacobian is read back before the backward sweep and nothing is gathered but the lane's own list (4 bytes a key-point).
+        auto eval_and_interpolate = [&](int nk_) __attribute__((always_inline)) {
+          constexpr int cnt = n * n + n * m;
+          double fS[cnt];
+#pragma unroll
+          for (int r = 0; r < cnt; ++r) fS[r] = 0.0;
+          int ptr = 0, s_ = 0;
+          int next = (ok && nk_ > 0) ? kpl[0] : -1;
+          for (int t = 0; t < N - 1; ++t) {
+            const bool act = ok && t == next;
+            if (!__any(act)) continue;
+            double xv[n], uv[m], fE[cnt];
+#pragma unroll
+            for (int i = 0; i < n; ++i) xv[i] = xb[bm(t, i, n, B)];
+#pragma unroll
+            for (int k = 0; k < m; ++k) uv[k] = ub[bm(t, k, m, B)];
+            jac_columns(xv, uv, [&](int col, const double (&d)[n]) __attribute__((always_inline)) {
+#pragma unroll
+              for (int i = 0; i < n; ++i) {
+                if (col < n) fE[i * n + col] = d[i];
+                else fE[n * n + i * m + (col - n)] = d[i];
+              }
+            });
+            {
+              double* fo = act ? Fxp : sink;
+              double* go = act ? Fup : sink;
+              const size_t wz = act ? Bz : 0;
+#pragma unroll
+              for (int r = 0; r < n * n; ++r) fo[((size_t)t * n * n + r) * wz] = fE[r];
+#pragma unroll
+              for (int r = 0; r < n * m; ++r) go[((size_t)t * n * m + r) * wz] = fE[n * n + r];
+            }
+            const int gap = (act && ptr > 0) ? t - s_ - 1 : 0;                  // interior points of the segment (s_, t)
+            int gap_max = gap;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { const int w_ = __shfl_xor(gap_max, o); gap_max = w_ > gap_max ? w_ : gap_max; }
+            const double len = (double)(t - s_);
+            for (int w = 1; w <= gap_max; ++w) {
+              const int row = t - w;
+              const bool in = w <= gap;
+              const double w_ = (double)(row - s_);
+              double* fo = in ? Fxp : sink;
+              double* go = in ? Fup : sink;
+              const size_t wz = in ? Bz : 0;
+#pragma unroll
+              for (int r = 0; r < n * n; ++r) fo[((size_t)row * n * n + r) * wz] = fS[r] + (fE[r] - fS[r]) * w_ / len;
+#pragma unroll
+              for (int r = 0; r < n * m; ++r) go[((size_t)row * n * m + r) * wz] = fS[n * n + r] + (fE[n * n + r] - fS[n * n + r]) * w_ / len;
+            }
+            if (act) {
+#pragma unroll
+              for (int r = 0; r < cnt; ++r) fS[r] = fE[r];
+              s_ = t; ptr += 1;
+              next = ptr < nk_ ? kpl[(size_t)ptr * Bz] : -1;
+            }
+          }
+        };
         int nk = 0;
+        bool fused_interp = false;
         if (a.kp_method == MI_KP_SET_INTERVAL) {
           // ilqr.py:417-432: arange(0, N-1, minN), the LAST entry overwritten with N-2 - the same list in every lane
           const int count = (N - 2) / a.minN + 1;
@@ -270,9 +336,10 @@ __global__ void __launch_bounds__(64) ilqr_batch_kernel(const KArgs a) {
             int tv = i * a.minN;
             if (i == count - 1 && tv != N - 2) tv = N - 2;
             if (ok) kpl[(size_t)i * Bz] = tv;
-            eval_store(tv, ok);
           }
           nk = count;
+          eval_and_interpolate(nk);
+          fused_interp = true;
         } else if (a.kp_method == MI_KP_ADAPTIVE_JERK) {
           // ilqr.py:434-486: signed second difference of the "velocity rows" x[dof + i], dof = int(n / 2); a key-point when the
           // counter has reached minN and a jerk exceeds the threshold, or when it reaches maxN; the last one overwritten with N-2
@@ -297,14 +364,8 @@ __global__ void __launch_bounds__(64) ilqr_batch_kernel(const KArgs a) {
             if (since >= a.maxN) { if (ok) kpl[(size_t)nk * Bz] = t; last = t; nk += 1; since = 0; }
           }
           if (last != N - 2 && ok) kpl[(size_t)(nk - 1) * Bz] = N - 2;                       // :465-466
-          int nk_max = nk;                                                                   // (lanes differ: the wave runs the longest list)
-#pragma unroll
-          for (int o = 32; o > 0; o >>= 1) { const int w_ = __shfl_xor(nk_max, o); nk_max = w_ > nk_max ? w_ : nk_max; }
-          for (int i = 0; i < nk_max; ++i) {
-            const bool act = ok && i < nk;
-            const int tv = act ? kpl[(size_t)i * Bz] : 0;
-            eval_store(tv, act);
-          }
+          eval_and_interpolate(nk);                                                          // (lanes differ in their lists: see there)
+          fused_interp = true;
         } else {
           // ilqr.py:488-593: level-synchronous bisection of [0, N-2]; a bin wider than minN is tested at its midpoint against the
           // mean of its end matrices (fx only, divisor 2n) and split when the error exceeds the threshold; every index the test
@@ -358,7 +419,9 @@ __global__ void __launch_bounds__(64) ilqr_batch_kernel(const KArgs a) {
         }
         // ---- interpolate_derivatives (ilqr.py:596-621): lock step over time, interior points only; a lane fetches its segment's
         //      end matrices when it crosses a key-point
-        if (!(a.kp_method == MI_KP_SET_INTERVAL && a.minN == 1)) {
+        //      (iterativeError only: its list is known only once the Jacobians it tests have been evaluated; the other two methods
+        //       interpolate in the pass that evaluates, above)
+        if (!fused_interp) {
           constexpr int cnt = n * n + n * m;
           double fS[cnt], fE[cnt];
           int seg = 0, s_ = 0, e_ = 0;
