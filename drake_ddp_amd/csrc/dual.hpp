@@ -71,7 +71,18 @@ __host__ __device__ inline Dual2 operator-(double a, Dual2 b) { return {a - b.v,
 __host__ __device__ inline Dual2 operator*(Dual2 a, double b) { return {a.v * b, a.d0 * b, a.d1 * b}; }
 __host__ __device__ inline Dual2 operator*(double a, Dual2 b) { return {a * b.v, a * b.d0, a * b.d1}; }
 __host__ __device__ inline double value_of(Dual2 a) { return a.v; }
+// The time-parallel rollout's Newton sweeps need cos only as the SLOPE of sin: fast_sin_slope (fastmath.hpp) - the value bit for
+// bit fast_sin, the slope to 1e-10 from the same reduction.  Same-box A/B, round 6 (tools/diag/build_variant.py cc1
+// -DMI_DUAL2_CHEAP_COS=1 against =0, three runs each): C2 43.5 -> 44.4 M it/s (kernel 0.1405 -> 0.1376 ms), the same 6193
+// iterations per step.
+#ifndef MI_DUAL2_CHEAP_COS
+#define MI_DUAL2_CHEAP_COS 1
+#endif
+#if MI_DUAL2_CHEAP_COS
+__device__ inline Dual2 mi_sin(Dual2 a) { double c_; const double s_ = fast_sin_slope(a.v, c_); return {s_, c_ * a.d0, c_ * a.d1}; }
+#else
 __device__ inline Dual2 mi_sin(Dual2 a) { const double c_ = fast_cos(a.v); return {fast_sin(a.v), c_ * a.d0, c_ * a.d1}; }
+#endif
 __device__ inline Dual2 mi_cos(Dual2 a) { const double s_ = -fast_sin(a.v); return {fast_cos(a.v), s_ * a.d0, s_ * a.d1}; }
 __device__ inline Dual2 mi_rcp(Dual2 a) { const double r = fast_rcp(a.v), q = -(r * r); return {r, q * a.d0, q * a.d1}; }
 
