@@ -26,6 +26,9 @@ import time
 
 import numpy as np
 
+# N > 1: how long the library's own RCCL communicator may take to come up and pass its self-check before the run falls back
+NATIVE_DEADLINE_S = float(os.environ.get("MI_BENCH_NATIVE_DEADLINE_S", "120"))
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -623,32 +626,52 @@ def main():
     # caller's path, torch.distributed only ships the 128-byte id) - after it has proved itself on this run's ranks: every rank
     # creates it, the communicator's own rank count (ncclCommCount) must be the world size and a reduction of rank-dependent
     # values must return their minimum, on EVERY rank (agreed through torch.distributed); anything else falls back to
-    # torch.distributed's all_reduce(MIN) with the reason in config.collective.  MI_BENCH_NATIVE_RCCL=1 insists (no fall-back: a
+    # torch.distributed's all_reduce(MIN) with the reason in config.collective_fallback_reason - a communicator that does not answer within
+    # NATIVE_DEADLINE_S included.  MI_BENCH_NATIVE_RCCL=try attempts it under any torch backend, =1 insists (no fall-back: a
     # failure ends the run with the library's message), =0 skips the attempt.
-    native, native_why, comm_ranks = None, None, (world if world > 1 else None)
+    native, native_why, comm_ranks, native_stuck = None, None, (world if world > 1 else None), False
     want_native = os.environ.get("MI_BENCH_NATIVE_RCCL", "auto")
     if world > 1 and want_native == "1":                                 # (any torch backend: it only ships the communicator's id)
         from drake_ddp_amd.dist import NativeComm
         native = NativeComm.from_torch(dev_index)
         comm_ranks = native.count()[0]
     elif world > 1 and want_native != "0":
-        if backend != "nccl":
+        if backend != "nccl" and want_native != "try":
             native_why = f"backend {backend}: the ranks share a device, and RCCL refuses two ranks on one device"
         else:
+            # (the attempt runs in a worker thread with a deadline: a communicator that never comes up - a bootstrap that
+            #  cannot reach a peer - must cost this run NATIVE_DEADLINE_S, not the whole bench; the main thread then agrees on
+            #  the fall-back with the other ranks and the run ends through os._exit, the stuck thread still inside librccl)
+            import threading
             from drake_ddp_amd.dist import NativeComm
-            ok, err = 1.0, ""
-            try:
-                native = NativeComm.from_torch(dev_index)
-                n_, r_ = native.count()
-                got = native.allreduce_min([float(rank + 1), -float(rank), 7.0])
-                if n_ != world or r_ != rank or list(got) != [1.0, -float(world - 1), 7.0]:
-                    ok, err = 0.0, f"self-check: count {n_}, rank {r_}, min {list(got)}"
-            except Exception as e:                                       # noqa: BLE001 - any failure means "use torch.distributed"
-                ok, err = 0.0, f"{type(e).__name__}: {e}"
+            box = {"ok": 0.0, "err": f"no answer from librccl within {NATIVE_DEADLINE_S} s (communicator bootstrap or the self-check's reduction)"}
+
+            def attempt():
+                try:
+                    if os.environ.get("MI_BENCH_NATIVE_TEST_STALL"):      # (the contract test's stand-in for a bootstrap that hangs)
+                        time.sleep(3600)
+                    torch.cuda.set_device(dev_index)                      # (the current device is per thread)
+                    c_ = NativeComm(rank, world, dev_index, ident=ident)
+                    n_, r_ = c_.count()
+                    got = c_.allreduce_min([float(rank + 1), -float(rank), 7.0])
+                    if n_ != world or r_ != rank or list(got) != [1.0, -float(world - 1), 7.0]:
+                        box.update(ok=0.0, err=f"self-check: count {n_}, rank {r_}, min {list(got)}")
+                    else:
+                        box.update(ok=1.0, err="", comm=c_)
+                except Exception as e:                                   # noqa: BLE001 - any failure means "use torch.distributed"
+                    box.update(ok=0.0, err=f"{type(e).__name__}: {e}")
+            # the id travels on the MAIN thread (torch.distributed collectives keep one order on every rank)
+            ident = NativeComm.torch_exchange(NativeComm.unique_id() if rank == 0 else None)
+            th = threading.Thread(target=attempt, daemon=True)
+            th.start()
+            th.join(NATIVE_DEADLINE_S)
+            native_stuck = th.is_alive()
+            ok, err = (0.0, box["err"]) if native_stuck else (box["ok"], box["err"])
             all_ok = -rk.reduce([-ok], "max")[0]                          # min over ranks
             if all_ok < 1.0:
                 native, native_why = None, ("library communicator not usable on every rank" + (f" (this rank: {err})" if err else ""))
             else:
+                native = box["comm"]
                 comm_ranks = native.count()[0]
     RING = 32      # solves the library lets us keep in flight (per-launch events + statistics records)
     # HIP events ride on one launch in TIME_EVERY: a profiled dispatch serializes the pipelined stream by ~5 us
@@ -838,6 +861,10 @@ def main():
         out["boundary_inclusive"] = boundary
         out["concurrent_batches"] = concurrent
         print(json.dumps(out), flush=True)
+    if native_stuck:                                       # a thread of this process is still inside librccl: no orderly teardown
+        rk.fence()
+        sys.stdout.flush()
+        os._exit(0)
     if world > 1:
         dist.destroy_process_group()
 

@@ -119,22 +119,19 @@ class NativeComm:
     128-byte communicator id is created on rank 0 and shipped by whatever channel the launcher has
     (`exchange`: a callable bytes-or-None -> bytes; from_torch() uses the process group's object broadcast)."""
 
-    def __init__(self, rank, world, device_id, exchange=None):
+    def __init__(self, rank, world, device_id, exchange=None, ident=None):
         import ctypes as C
         from . import _capi
         self._capi, self._C = _capi, C
         self._lib = _capi.load()
-        ident = None
-        if world > 1 and exchange is None:
-            raise ValueError("world > 1 needs an `exchange` callable to ship the communicator id")
-        if rank == 0:
-            buf = (C.c_char * _capi.COMM_ID_BYTES)()
-            rc = self._lib.mi_ilqr_comm_unique_id(buf)
-            # (a failure here still goes through the exchange - as an empty id - so that the other ranks, which are waiting in it,
-            #  fail with this rank instead of hanging)
-            ident = bytes(buf.raw) if rc == _capi.OK else b""
-        if world > 1:
-            ident = exchange(ident)
+        if ident is None:
+            if world > 1 and exchange is None:
+                raise ValueError("world > 1 needs an `exchange` callable to ship the communicator id")
+            # (a failure on rank 0 still goes through the exchange - as an empty id - so that the other ranks, which are waiting in
+            #  it, fail with this rank instead of hanging)
+            ident = self.unique_id() if rank == 0 else None
+            if world > 1:
+                ident = exchange(ident)
         if not ident:
             raise RuntimeError("mi_ilqr_comm_unique_id failed on rank 0 (librccl not loadable?)")
         h = C.c_void_p()
@@ -144,18 +141,28 @@ class NativeComm:
         self.rank, self.world = int(rank), int(world)
         self._pending = 0
 
+    @staticmethod
+    def unique_id():
+        """A fresh 128-byte communicator id (rank 0 creates it and ships it), b"" when librccl cannot make one."""
+        import ctypes as C
+        from . import _capi
+        buf = (C.c_char * _capi.COMM_ID_BYTES)()
+        return bytes(buf.raw) if _capi.load().mi_ilqr_comm_unique_id(buf) == _capi.OK else b""
+
+    @staticmethod
+    def torch_exchange(ident):
+        """rank 0's id to every rank of the initialized torch.distributed process group (any backend)."""
+        box = [ident]
+        _dist().broadcast_object_list(box, src=0)
+        return box[0]
+
     @classmethod
     def from_torch(cls, device_id):
         """Ranks and id exchange taken from the initialized torch.distributed process group (any backend)."""
         dist = _dist()
         if dist is None:
             return cls(0, 1, device_id)
-
-        def exchange(ident):
-            box = [ident]
-            dist.broadcast_object_list(box, src=0)
-            return box[0]
-        return cls(dist.get_rank(), dist.get_world_size(), device_id, exchange)
+        return cls(dist.get_rank(), dist.get_world_size(), device_id, cls.torch_exchange)
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None

@@ -143,3 +143,24 @@ def test_bench_native_rccl_communicator_two_ranks():
     else:
         assert r.returncode != 0
         assert "ncclCommInitRank failed" in r.stderr and "mi_ilqr_comm_create" in r.stderr, r.stderr[-3000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stall", [False, True])
+def test_bench_falls_back_when_the_library_communicator_fails_or_never_answers(stall):
+    """The default N > 1 run tries the library's own communicator first.  Two ranks on this box's one GPU: RCCL refuses the second
+    rank (an error), or - MI_BENCH_NATIVE_TEST_STALL - the attempt never returns (a bootstrap that hangs); either way every rank
+    agrees on torch.distributed, the reason is in the line and the run finishes."""
+    import torch
+    if torch.cuda.device_count() >= 2 and not stall:
+        pytest.skip("two GPUs: the communicator comes up (test_bench_native_rccl_communicator_two_ranks)")
+    env = {"MI_BENCH_BACKEND": "gloo", "MI_BENCH_NATIVE_RCCL": "try"}
+    if stall:
+        env.update(MI_BENCH_NATIVE_TEST_STALL="1", MI_BENCH_NATIVE_DEADLINE_S="5")
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-configs"], env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _json_line(r.stdout)
+    assert "torch.distributed all_reduce(MIN)" in d["config"]["collective"]
+    why = d["config"]["collective_fallback_reason"]
+    assert ("no answer from librccl within" in why) if stall else ("mi_ilqr_comm_create: RCCL error" in why), why
+    assert d["n_gpus"] == 2 and d["value"] > 0
