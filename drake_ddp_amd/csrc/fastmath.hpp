@@ -41,10 +41,11 @@ constexpr double kLn2Hi = 0x1.62e42fee00000p-1, kLn2Lo = 0x1.a39ef35793c76p-33, 
 // dependency chain - or so round 6 assumed, and built Estrin's scheme (MI_POLY_ESTRIN=1: the same polynomial in
 // ceil(log2(degree + 1)) + 1 levels of independent multiply-adds for two or three more multiplications) to shorten it.  MEASURED
 // (tools/ubench/chain_step.hip, one wave, dependent steps; profiles/r06_chain_step.txt): SLOWER - cart-pole + wall 715 -> 725
-// cycles per step, acrobot 670 -> 694 - and less accurate (3 ulp against Horner's 2, tools/ubench/trig_acc.hip).  The reason is
-// in tools/ubench/fp64_peak.hip's first row: ONE wave per SIMD issues an fp64 instruction every ~9.6 cycles even from eight
-// INDEPENDENT chains (13.3 of 32 flop / clk / SIMD; two waves: 23.6) - a wave's own issue interval already covers the latency a
-// dependent operation would wait for, so what a step costs at one wave per SIMD is its instruction COUNT.  Horner stays.
+// cycles per step, acrobot 670 -> 694 - and less accurate (3 ulp against Horner's 2, tools/ubench/trig_acc.hip).  The reason
+// (tools/ubench/issue_interval.hip, profiles/r06_issue_interval.txt): ONE wave issues an independent v_fma_f64 every 5.0 cycles
+// at best (a dependent one every 8.4), and the cart-pole step already runs at 715 / 146 = 4.9 cycles per instruction - the
+// scheduler finds the independent work among the step's own functions (sin, cos, exp, log1p side by side), so the step is at the
+// one-wave issue floor and what it costs is its instruction COUNT.  Horner stays.
 #ifndef MI_POLY_ESTRIN
 #define MI_POLY_ESTRIN 0
 #endif
