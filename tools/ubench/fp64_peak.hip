@@ -2,7 +2,9 @@
 // (a) VALU: every SIMD of every CU runs W waves of 8 independent v_fma_f64 chains; (b) matrix cores: the same with
 // v_mfma_f64_16x16x4_f64 (2048 flops per wave instruction).  Rate = flops / kernel time from HIP events; the shader clock the
 // waves ran at comes from s_memtime / s_memrealtime (100 MHz) inside the same launch.
-//   hipcc --offload-arch=gfx950 -O3 tools/ubench/fp64_peak.hip -o tools/ubench/fp64_peak && tools/ubench/fp64_peak [out.json]
+// (-amdgpu-mfma-vgpr-form=1, the library's own flag: without it this hipcc carries the four accumulators through 64 v_accvgpr moves
+//  per loop trip and the matrix row reads 49 TF instead of the pipe's rate - the first r06 file had that)
+//   hipcc --offload-arch=gfx950 -O3 -mllvm -amdgpu-mfma-vgpr-form=1 tools/ubench/fp64_peak.hip -o tools/ubench/fp64_peak && tools/ubench/fp64_peak [out.json]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
