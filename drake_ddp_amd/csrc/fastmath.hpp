@@ -36,16 +36,16 @@ constexpr double kLn2Hi = 0x1.62e42fee00000p-1, kLn2Lo = 0x1.a39ef35793c76p-33, 
                  kLn2 = 0x1.62e42fefa39efp-1, kSqrt2m1 = 0x1.a827999fcef32p-2;
 }  // namespace fm
 
-// Polynomial evaluation.  These kernels run ONE instruction stream per problem at one wave per SIMD: a dependent fp64 operation
-// waits ~8 cycles for its operand while an independent one issues every 4, so what a rollout step costs is the DEPTH of its
-// dependency chain - or so round 6 assumed, and built Estrin's scheme (MI_POLY_ESTRIN=1: the same polynomial in
+// Polynomial evaluation.  These kernels run ONE instruction stream per problem at one wave per SIMD: if a dependent fp64 operation
+// waited ~8 cycles for its operand while an independent one issues every 4, what a rollout step costs would be the DEPTH of its
+// dependency chain - so round 6 assumed, and built Estrin's scheme (MI_POLY_ESTRIN=1: the same polynomial in
 // ceil(log2(degree + 1)) + 1 levels of independent multiply-adds for two or three more multiplications) to shorten it.  MEASURED
 // (tools/ubench/chain_step.hip, one wave, dependent steps; profiles/r06_chain_step.txt): SLOWER - cart-pole + wall 715 -> 725
 // cycles per step, acrobot 670 -> 694 - and less accurate (3 ulp against Horner's 2, tools/ubench/trig_acc.hip).  The reason
-// (tools/ubench/issue_interval.hip, profiles/r06_issue_interval.txt): ONE wave issues an independent v_fma_f64 every 5.0 cycles
-// at best (a dependent one every 8.4), and the cart-pole step already runs at 715 / 146 = 4.9 cycles per instruction - the
-// scheduler finds the independent work among the step's own functions (sin, cos, exp, log1p side by side), so the step is at the
-// one-wave issue floor and what it costs is its instruction COUNT.  Horner stays.
+// (tools/ubench/issue_interval.hip, profiles/r06_issue_interval.txt): ONE wave issues a v_fma_f64 every 4.04 cycles from
+// independent chains and every 4.17 from a single DEPENDENT chain - a dependent fp64 operation issues back to back, there is no
+// latency for Estrin's independent multiply-adds to hide, only more instructions to issue.  What a step costs at one wave per
+// SIMD is its instruction COUNT.  Horner stays.
 #ifndef MI_POLY_ESTRIN
 #define MI_POLY_ESTRIN 0
 #endif

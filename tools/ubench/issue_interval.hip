@@ -6,6 +6,7 @@
 #include <vector>
 #include <algorithm>
 
+constexpr int kTrip = 840;     // instructions per loop trip: a multiple of every chain count below
 template <int CH>
 __global__ void __launch_bounds__(256) fma_chains(double* sink, long long* clk, int iters, double y) {
   double x[CH];
@@ -14,7 +15,7 @@ __global__ void __launch_bounds__(256) fma_chains(double* sink, long long* clk, 
   const long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
   for (int i = 0; i < iters; ++i) {
 #pragma unroll
-    for (int rep = 0; rep < 32 / CH; ++rep)
+    for (int rep = 0; rep < kTrip / CH; ++rep)
 #pragma unroll
       for (int c = 0; c < CH; ++c) x[c] = __builtin_fma(x[c], y, 1e-9);
   }
@@ -28,7 +29,7 @@ __global__ void __launch_bounds__(256) fma_chains(double* sink, long long* clk, 
 
 template <int CH>
 void run(const char* where, int blocks, int wg_per_cu, double* sink, long long* clk) {
-  const int iters = 20000;                     // x 32 instructions per trip
+  const int iters = 800;                       // x kTrip instructions per trip
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   float ms = 0;
   for (int rep = 0; rep < 4; ++rep) {
@@ -42,7 +43,7 @@ void run(const char* where, int blocks, int wg_per_cu, double* sink, long long* 
   for (int w = 0; w < blocks * 4; ++w) { cyc += double(h[2 * w]); mhz += double(h[2 * w]) / double(h[2 * w + 1]) * 100.0; }
   cyc /= blocks * 4; mhz /= blocks * 4;
   printf("%-9s %d wave(s)/SIMD  %d chain(s): %6.2f cycles per v_fma_f64 per wave (counter), clock %.0f MHz, kernel %.3f ms -> %.2f cycles by wall time\n",
-         where, wg_per_cu, CH, cyc / (double(iters) * 32), mhz, ms, ms * 1e-3 * mhz * 1e6 / (double(iters) * 32));
+         where, wg_per_cu, CH, cyc / (double(iters) * kTrip), mhz, ms, ms * 1e-3 * mhz * 1e6 / (double(iters) * kTrip));
 }
 
 int main() {
@@ -51,7 +52,8 @@ int main() {
   double* sink; long long* clk;
   hipMalloc(&sink, 8); hipMalloc(&clk, 2 * 8 * cus * 8 * 4 * sizeof(long long));
   for (int wg : {1, 2, 4}) {
-    run<1>("one CU", wg, wg, sink, clk); run<2>("one CU", wg, wg, sink, clk); run<4>("one CU", wg, wg, sink, clk); run<8>("one CU", wg, wg, sink, clk);
+    run<1>("one CU", wg, wg, sink, clk); run<2>("one CU", wg, wg, sink, clk); run<3>("one CU", wg, wg, sink, clk); run<4>("one CU", wg, wg, sink, clk);
+    run<5>("one CU", wg, wg, sink, clk); run<6>("one CU", wg, wg, sink, clk); run<7>("one CU", wg, wg, sink, clk); run<8>("one CU", wg, wg, sink, clk);
   }
   for (int wg : {1, 2, 4, 8}) {
     run<1>("all CUs", cus * wg, wg, sink, clk); run<2>("all CUs", cus * wg, wg, sink, clk); run<4>("all CUs", cus * wg, wg, sink, clk); run<8>("all CUs", cus * wg, wg, sink, clk);
