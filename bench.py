@@ -807,7 +807,7 @@ def main():
             compute = {"bound": "fp64", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS,
                        "peak_source": FP64_PEAK_SOURCE, "fp64_flops_per_launch": flops, "source": flops_src, "wave_slots_occupied": slots, "wave_slots_source": slots_src,
                        "valu_busy_of_resident_wave_time": (ctr["SQ_ACTIVE_INST_VALU"] / ctr["SQ_WAVE_CYCLES"]) if ("SQ_ACTIVE_INST_VALU" in ctr and ctr.get("SQ_WAVE_CYCLES")) else None,
-                       "note": "what binds this kernel: one wave per SIMD issues an fp64 instruction every ~5.3 cycles, and the launch lasts as long "
+                       "note": "what binds this kernel: ONE wave per SIMD (a resident wave spends ~6 cycles per VALU instruction: 4 in the VALU, the rest scalar / LDS / back edges it cannot hide - DESIGN section 8), and the launch lasts as long "
                                "as its slowest problem (12 iterations against a mean of 6), so about half of the wave slots idle"}
         out = {
             "metric": "iLQR iterations/sec (batch, whole node)",
@@ -848,9 +848,9 @@ def main():
                          "kernel_ms_source": f"HIP events carried by {n_timed} of the {args.steps} timed launches (one in {TIME_EVERY})",
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "hbm_traffic_frac": (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                         "limiter": "fp64 issue latency, NOT HBM: `bound`/`frac` are SURVEY 8(d)'s algorithmic-bytes accounting; the state is LDS-resident, the real "
+                         "limiter": "the instruction stream of one wave per SIMD, NOT HBM: `bound`/`frac` are SURVEY 8(d)'s algorithmic-bytes accounting; the state is LDS-resident, the real "
                                     "HBM traffic is `hbm_traffic_frac` of the peak and what binds is `roofline_compute` (fp64 issued / fp64 peak at one wave per SIMD)",
-                         "note": "issue-latency-bound: one wave per problem, rollout and Riccati sweep as time-parallel scans; state is LDS-resident, the launch lasts as long as its slowest problem"},
+                         "note": "instruction-count-bound: one wave per problem, rollout and Riccati sweep as time-parallel scans; state is LDS-resident, the launch lasts as long as its slowest problem"},
         }
         out["roofline_compute"] = compute
         out["cpu_baseline"] = cpu_base
